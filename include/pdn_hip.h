@@ -1,0 +1,157 @@
+/* pdn_hip.h -- C ABI of libpdnhip.so, the MI355X (gfx950) compute backend for PyDyNet's
+ * Tensor-op hot path.
+ *
+ * The reference (WeltXing/PyDyNet) has exactly one device seam: `Device.xp` returns the
+ * module `numpy` or `cupy` (pydynet/cuda.py:89-91) and every operator calls `self.xp.<fn>`
+ * or an ndarray operator on `Tensor.data`.  This header is what a HIP backend binds instead
+ * of CuPy: each entry point cites the reference call site(s) it replaces.  The host shim
+ * (pydynet_amd/_lib.py, ctypes) is the only caller.
+ *
+ * Conventions
+ *   - plain C: pointers are DEVICE pointers unless named *_host; sizes/strides are in
+ *     ELEMENTS (not bytes); `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - every function returns 0 on success, a negative PDN_E* code for a rejected argument,
+ *     or a positive hipError_t; pdn_last_error() returns a thread-local message.
+ *   - kernels never allocate and never retain pointers after the launch is enqueued;
+ *     scratch is passed in as `workspace`, sized by the matching *_workspace_bytes query.
+ *   - launches are asynchronous on `stream`; nothing synchronises except
+ *     pdn_stream_synchronize and pdn_gemm_prof_collect.
+ *   - dtype codes: 0 = float32, 1 = float64, 2 = int64, 3 = bool (uint8 0/1), 4 = int32.
+ */
+#ifndef PDN_HIP_H
+#define PDN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDN_OK 0
+#define PDN_EINVAL (-1)
+#define PDN_EUNSUPPORTED (-2)
+#define PDN_EWORKSPACE (-3)
+
+enum pdn_dtype { PDN_F32 = 0, PDN_F64 = 1, PDN_I64 = 2, PDN_BOOL = 3, PDN_I32 = 4 };
+enum pdn_binary_op { PDN_ADD = 0, PDN_SUB, PDN_MUL, PDN_DIV, PDN_POW, PDN_MAXIMUM, PDN_MINIMUM,
+                     PDN_EQ = 16, PDN_NE, PDN_LT, PDN_LE, PDN_GT, PDN_GE };
+enum pdn_unary_op { PDN_COPY = 0, PDN_NEG, PDN_EXP, PDN_LOG, PDN_ABS, PDN_SIGN, PDN_SQRT,
+                    PDN_SQUARE, PDN_RECIP, PDN_SIGMOID, PDN_TANH };
+enum pdn_reduce_op { PDN_SUM = 0, PDN_MEAN, PDN_MAX, PDN_MIN, PDN_ARGMAX, PDN_ARGMIN };
+
+/* ---- library ------------------------------------------------------------------------- */
+const char* pdn_last_error(void);
+int pdn_abi_version(void);
+/* replaces cp.cuda.runtime.getDeviceCount (pydynet/cuda.py:20-24) */
+int pdn_device_count(void);
+int pdn_device_info(int device, char* name, int cap, int* compute_units, int64_t* total_mem);
+/* replaces the implicit sync of cupy `.get()` / `.item()` (pydynet/core/tensor.py:385-393) */
+int pdn_stream_synchronize(void* stream);
+
+/* ---- matmul: `x.data @ y.data`, and `grad @ B^T`, `A^T @ grad` (tensor.py:659,670-675) ----
+ * C[b1,b2] = alpha * A[b1,b2](MxK) * B[b1,b2](KxN) + bias[N] + beta * C[b1,b2]
+ * A(m,k)=A[m*a_rs+k*a_cs], B(k,n)=B[k*b_rs+n*b_cs], C(m,n)=C[m*ldc+n]; two batch dims with
+ * independent (possibly 0) strides.  fp32 MFMA, split-K through `workspace` when given. */
+int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
+                 const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
+                 const float* bias, int nb1, int nb2, int64_t a_bs1, int64_t a_bs2,
+                 int64_t b_bs1, int64_t b_bs2, int64_t c_bs1, int64_t c_bs2, void* workspace,
+                 int64_t workspace_bytes, void* stream);
+int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
+/* per-launch HIP-event timing of the GEMM kernel for bench.py's roofline block */
+int pdn_gemm_prof_enable(int on);
+int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
+
+/* ---- broadcasting elementwise: + - * / ** maximum minimum, comparisons
+ * (tensor.py:548,564,591,612,634,811,820; 289-316).  mode 0: a op b, 1: a op scalar,
+ * 2: scalar op a.  Broadcast = stride 0.  Comparison ops write uint8. */
+int pdn_ew_binary(int dtype, int op, int mode, int ndim, const int64_t* shape, const void* a,
+                  const int64_t* sa, const void* b, const int64_t* sb, double scalar, void* out,
+                  const int64_t* so, void* stream);
+/* xp.exp/log/abs/sign, unary minus, x**0.5, sigmoid/tanh piecewise forms
+ * (tensor.py:689,786,802,829,1000-1002,1013-1015) */
+int pdn_ew_unary(int dtype, int op, int ndim, const int64_t* shape, const void* a,
+                 const int64_t* sa, void* out, const int64_t* so, void* stream);
+/* ndarray.astype / .copy() / `view[...] = array` (tensor.py:168-177, 279) */
+int pdn_cast(int src_dtype, int dst_dtype, int ndim, const int64_t* shape, const void* a,
+             const int64_t* sa, void* out, const int64_t* so, void* stream);
+/* xp.zeros / xp.ones / `grad[...] = 0.` (tensor.py:90,355,380-383) */
+int pdn_fill(int dtype, double value, int ndim, const int64_t* shape, void* out,
+             const int64_t* so, void* stream);
+/* `data[bool_mask] = value` (Tensor.__setitem__, tensor.py:279) */
+int pdn_masked_fill(int dtype, double value, int ndim, const int64_t* shape, const void* mask,
+                    const int64_t* smask, void* out, const int64_t* so, void* stream);
+
+/* ---- reductions: getattr(xp,'sum'|'mean'|'max'|'min'|'argmax'|'argmin')(x, axis, keepdims)
+ * (tensor.py:701,705) and the engine's un-broadcast sums (tensor.py:360-370).
+ * reduce_axis[k] != 0 marks a reduced dim; out is contiguous over the kept dims. */
+int pdn_reduce(int dtype, int op, int ndim, const int64_t* shape, const int64_t* strides,
+               const uint8_t* reduce_axis, const void* x, void* out, void* workspace,
+               int64_t workspace_bytes, void* stream);
+
+/* ---- fused softmax (nn/functional.py:43-49) with the attention prologue
+ * `scores / sqrt(hd) + causal_mask` (llm/llama/model.py:113-117, 199-203) folded in.
+ * causal_L = 0 disables the mask; divisor = 1 for plain softmax. */
+int pdn_softmax_fwd_f32(const float* x, float* y, int64_t rows, int cols, float divisor,
+                        int causal_L, int start_pos, void* stream);
+int pdn_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows, int cols,
+                        float divisor, void* stream);
+
+/* ---- RMSNorm (nn/modules/norm.py:245-248): y = x / sqrt(mean(x^2)+eps) * w; `rms` (rows,)
+ * is saved for backward.  bwd: dw (+)= sum_rows dy*x/rms when dw != NULL. */
+int pdn_rmsnorm_fwd_f32(const float* x, const float* w, float* y, float* rms, int64_t rows,
+                        int cols, float eps, void* stream);
+int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* rms, const float* dy,
+                        float* dx, float* dw, int accumulate_dw, int64_t rows, int cols,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pdn_rmsnorm_bwd_workspace_bytes(int64_t rows, int cols);
+
+/* ---- SiLU / SwiGLU (nn/functional.py:39-40; llm/llama/model.py:56-58):
+ * y = g/(1+exp(-g)) [* u];  u == NULL selects plain SiLU. */
+int pdn_swiglu_fwd_f32(const float* g, const float* u, float* y, int64_t n, void* stream);
+int pdn_swiglu_bwd_f32(const float* g, const float* u, const float* dy, float* dg, float* du,
+                       int64_t n, void* stream);
+/* grad of relu = maximum(0., x): (out == x) * dy (tensor.py:814-815, functional.py:31-32) */
+int pdn_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+
+/* ---- RoPE on interleaved pairs (llm/llama/model.py:23-44); x,y: (rows, heads, head_dim),
+ * cos/sin tables (L, head_dim/2) already offset by start_pos; position = row % L.
+ * backward != 0 rotates by -theta (the gradient).  In-place (y == x) is allowed. */
+int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* y, int64_t rows,
+                 int L, int heads, int head_dim, int backward, void* stream);
+
+/* ---- embedding: `weight[ids]` (nn/functional.py:14-20) and its gradient
+ * `full = zeros; full[key] = grad` (tensor.py:937-940: scatter-ASSIGN, last write wins).
+ * scatter mode 0: assign, 1: assign-last accumulated into dW, 2: atomic scatter-add. */
+int pdn_embedding_gather_f32(const float* W, int64_t V, int D, int64_t w_row_stride,
+                             const int64_t* ids, int64_t n, float* out, int* err_flag,
+                             void* stream);
+int pdn_embedding_scatter_f32(const float* g, const int64_t* ids, int64_t n, float* dW, int64_t V,
+                              int D, int mode, void* workspace, int64_t workspace_bytes,
+                              void* stream);
+int64_t pdn_embedding_scatter_workspace_bytes(int64_t V);
+/* `x[range(N), idx]` and its scatter-assign gradient (nn/functional.py:371) */
+int pdn_take_cols_f32(const float* x, int64_t n, int64_t C, int64_t x_row_stride,
+                      const int64_t* idx, float* out, int* err_flag, void* stream);
+int pdn_put_cols_f32(const float* g, const int64_t* idx, float* dx, int64_t n, int64_t C,
+                     void* stream);
+
+/* ---- cross entropy with integer targets (nn/functional.py:364-381), fused:
+ * loss_row[n] = logsumexp(x[n,:]) - x[n,t_n]; loss_out = mean or sum of loss_row.
+ * bwd: dlogits = (softmax(x) - onehot) * gscale * (upstream ? upstream[0] : 1); may alias x. */
+int pdn_cross_entropy_fwd_f32(const float* logits, const int64_t* targets, int64_t rows, int V,
+                              int mean, float* loss_row, float* lse_row, float* loss_out,
+                              int* err_flag, void* stream);
+int pdn_cross_entropy_bwd_f32(const float* logits, const int64_t* targets, const float* lse_row,
+                              const float* upstream, float gscale, float* dlogits, int64_t rows,
+                              int V, void* stream);
+
+/* ---- Adam.step for all parameters in one launch (optim/optimizer.py:185-196).
+ * chunk_table_dev: device int64[nchunks][5] = {p, g, m, v addresses, n elements}.
+ * step = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host as the reference does. */
+int pdn_adam_multi_f32(const int64_t* chunk_table_dev, int nchunks, float step, float beta1,
+                       float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
+                       float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDN_HIP_H */

@@ -1,0 +1,451 @@
+// fp32 GEMM on the CDNA4 matrix cores (v_mfma_f32_32x32x2_f32), gfx950 only.
+//
+// Replaces the reference's `x.data @ y.data` and the two products in matmul.grad_fn
+// (pydynet/core/tensor.py:657-676) which dispatch to OpenBLAS / cuBLAS through `xp`.
+//
+//   C[b1,b2] = alpha * A[b1,b2] (MxK) * B[b1,b2] (KxN)  (+ bias[N])  (+ beta * C[b1,b2])
+//
+// Operands are addressed through element strides so that transposed / head-split views
+// (q.transpose(0,2,1,3), W.T, x.T ...) are consumed in place, never copied:
+//   A(m,k) = A[m*a_rs + k*a_cs]      B(k,n) = B[k*b_rs + n*b_cs]      C(m,n) = C[m*ldc + n]
+//
+// Kernel structure (one workgroup = 4 wave64, one wave per SIMD, 2 workgroups per CU):
+//   * block tile BM x BN x 32, wave tile (WM*32) x (WN*32) of 32x32 MFMA accumulators;
+//   * global -> registers -> LDS staging, double-buffered in LDS, the loads for tile t+1
+//     are in flight while tile t is multiplied (one barrier per k-tile);
+//   * the contraction index inside an MFMA is permuted (half-wave h, step j -> k = 8t+4h+j)
+//     so a K-contiguous operand is fetched from LDS with ONE ds_read_b128 per four MFMAs
+//     and an M/N-contiguous operand with conflict-free ds_read_b32 -- no transposes anywhere;
+//   * XCD-aware tile order: each XCD walks a contiguous run of 8x8 super-tiles so the A and
+//     B panels it touches stay in its private 4 MiB L2;
+//   * split-K (workspace + deterministic reduce) when the output has too few tiles to
+//     fill 256 CUs (weight gradients: M,N ~ 288..768, K = tokens).
+// f32 MFMA is an exact k-ordered fmaf chain, so results match a scalar fp32 dot product
+// in a different summation order only (tolerance documented in tests/).
+#include "common.h"
+#include <vector>
+#include <mutex>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define GEMM_BK 32
+#define GEMM_PAD 4
+
+struct GemmParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  float* ws;
+  int M, N, K;
+  int64_t a_rs, a_cs, b_rs, b_cs, ldc;
+  int nb2;
+  int64_t a_bs1, a_bs2, b_bs1, b_bs2, c_bs1, c_bs2;
+  float alpha, beta;
+  int splits, k_per_split;
+  int tiles_m, tiles_n;
+};
+
+// ---- global -> register staging -------------------------------------------------------
+// Tile of an operand: MN rows (m or n index) x BK contraction columns.
+// KIN  : LDS image [MN][BK+PAD]   (contraction contiguous), unit = float4 along k
+// !KIN : LDS image [BK][MN+PAD]   (m/n contiguous),         unit = float4 along m/n
+template <int MN, bool KIN, bool VEC, int NT>
+struct TileLoader {
+  static constexpr int UNITS = MN * GEMM_BK / 4;
+  static constexpr int NP = (UNITS + NT - 1) / NT;
+  static constexpr int LD = KIN ? (GEMM_BK + GEMM_PAD) : (MN + GEMM_PAD);
+  static constexpr int SIZE = KIN ? MN * LD : GEMM_BK * LD;
+
+  __device__ __forceinline__ static void load(float4 (&r)[NP], const float* __restrict__ base,
+                                              int64_t s_mn, int64_t s_k, int mn0, int k0,
+                                              int mn_end, int k_end, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int u = tid + p * NT;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (UNITS % NT == 0 || u < UNITS) {
+        if (KIN) {
+          const int row = u / (GEMM_BK / 4), c4 = u % (GEMM_BK / 4);
+          const int mn = mn0 + row, k = k0 + 4 * c4;
+          if (VEC) {
+            if (mn < mn_end && k < k_end)
+              v = *reinterpret_cast<const float4*>(base + (int64_t)mn * s_mn + k);
+          } else if (mn < mn_end) {
+            const float* q = base + (int64_t)mn * s_mn + (int64_t)k * s_k;
+            if (k + 0 < k_end) v.x = q[0];
+            if (k + 1 < k_end) v.y = q[s_k];
+            if (k + 2 < k_end) v.z = q[2 * s_k];
+            if (k + 3 < k_end) v.w = q[3 * s_k];
+          }
+        } else {
+          const int kr = u / (MN / 4), c4 = u % (MN / 4);
+          const int k = k0 + kr, mn = mn0 + 4 * c4;
+          if (VEC) {
+            if (k < k_end && mn < mn_end)
+              v = *reinterpret_cast<const float4*>(base + (int64_t)k * s_k + mn);
+          } else if (k < k_end) {
+            const float* q = base + (int64_t)k * s_k + (int64_t)mn * s_mn;
+            if (mn + 0 < mn_end) v.x = q[0];
+            if (mn + 1 < mn_end) v.y = q[s_mn];
+            if (mn + 2 < mn_end) v.z = q[2 * s_mn];
+            if (mn + 3 < mn_end) v.w = q[3 * s_mn];
+          }
+        }
+      }
+      r[p] = v;
+    }
+  }
+
+  __device__ __forceinline__ static void store(const float4 (&r)[NP], float* lds, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int u = tid + p * NT;
+      if (UNITS % NT == 0 || u < UNITS) {
+        int off;
+        if (KIN) {
+          const int row = u / (GEMM_BK / 4), c4 = u % (GEMM_BK / 4);
+          off = row * LD + 4 * c4;
+        } else {
+          const int kr = u / (MN / 4), c4 = u % (MN / 4);
+          off = kr * LD + 4 * c4;
+        }
+        *reinterpret_cast<float4*>(lds + off) = r[p];
+      }
+    }
+  }
+
+  // Fragment for MFMA steps j=0..3 of k-group t: lane (i = lane&31, h = lane>>5) needs
+  // operand(row0 + i, k = 8t + 4h + j).
+  __device__ __forceinline__ static void frag(float (&f)[4], const float* lds, int row0, int t,
+                                              int li, int lh) {
+    if (KIN) {
+      const float4 v =
+          *reinterpret_cast<const float4*>(lds + (row0 + li) * LD + 8 * t + 4 * lh);
+      f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+    } else {
+      const float* q = lds + (8 * t + 4 * lh) * LD + row0 + li;
+      f[0] = q[0]; f[1] = q[LD]; f[2] = q[2 * LD]; f[3] = q[3 * LD];
+    }
+  }
+};
+
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KIN, bool B_KIN, bool VEC>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(GemmParams p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+  using LA = TileLoader<BM, A_KIN, VEC, NT>;
+  using LB = TileLoader<BN, B_KIN, VEC, NT>;
+  constexpr int STAGE = LA::SIZE + LB::SIZE;
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+
+  // ---- which tile / batch / k-split ---------------------------------------------------
+  const int nwg = p.tiles_m * p.tiles_n;
+  int L;
+  {
+    const int bid = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int tile_m, tile_n;
+  {
+    constexpr int GROUP = 8;
+    const int width = GROUP * p.tiles_n;
+    const int g = L / width, first = g * GROUP;
+    const int gsz = min(p.tiles_m - first, GROUP);
+    const int w = L - g * width;
+    tile_m = first + w % gsz;
+    tile_n = w / gsz;
+  }
+  const int z = blockIdx.y;
+  const int split = z % p.splits, batch = z / p.splits;
+  const int b1 = batch / p.nb2, b2 = batch % p.nb2;
+  const float* __restrict__ A = p.A + b1 * p.a_bs1 + b2 * p.a_bs2;
+  const float* __restrict__ B = p.B + b1 * p.b_bs1 + b2 * p.b_bs2;
+
+  const int k_begin = split * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  float4 ra[LA::NP], rb[LB::NP];
+  const int ntile = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+
+  if (ntile > 0) {
+    LA::load(ra, A, p.a_rs, p.a_cs, m0, k_begin, p.M, k_end, tid);
+    LB::load(rb, B, p.b_cs, p.b_rs, n0, k_begin, p.N, k_end, tid);
+    LA::store(ra, smem, tid);
+    LB::store(rb, smem + LA::SIZE, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const float* As = smem + (t & 1) * STAGE;
+    const float* Bs = As + LA::SIZE;
+    const bool more = (t + 1 < ntile);
+    if (more) {
+      const int k0 = k_begin + (t + 1) * GEMM_BK;
+      LA::load(ra, A, p.a_rs, p.a_cs, m0, k0, p.M, k_end, tid);
+      LB::load(rb, B, p.b_cs, p.b_rs, n0, k0, p.N, k_end, tid);
+    }
+#pragma unroll
+    for (int g = 0; g < GEMM_BK / 8; ++g) {
+      float a[WM][4], b[WN][4];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) LA::frag(a[i], As, (wave_m * WM + i) * 32, g, li, lh);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) LB::frag(b[j], Bs, (wave_n * WN + j) * 32, g, li, lh);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      float* An = smem + ((t + 1) & 1) * STAGE;
+      LA::store(ra, An, tid);
+      LB::store(rb, An + LA::SIZE, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------
+  // 32x32 accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const bool partial = p.splits > 1;
+  float* __restrict__ C =
+      partial ? p.ws + ((int64_t)batch * p.splits + split) * (int64_t)p.M * p.N
+              : p.C + b1 * p.c_bs1 + b2 * p.c_bs2;
+  const int64_t ldc = partial ? p.N : p.ldc;
+#pragma unroll
+  for (int i = 0; i < WM; ++i) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int col = n0 + (wave_n * WN + j) * 32 + li;
+      const int rbase = m0 + (wave_m * WM + i) * 32 + 4 * lh;
+      if (col < p.N) {
+        const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < p.M) {
+            float v = p.alpha * acc[i][j][r];
+            float* dst = C + (int64_t)row * ldc + col;
+            if (!partial) {
+              v += bv;
+              if (p.beta != 0.f) v += p.beta * (*dst);
+            }
+            *dst = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// C = beta*C + sum_s ws[s] + bias, deterministic order.
+__global__ void gemm_splitk_reduce_kernel(GemmParams p, int nbatch) {
+  const int64_t mn = (int64_t)p.M * p.N;
+  const int64_t total = mn * nbatch;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int batch = (int)(i / mn);
+    const int64_t e = i - batch * mn;
+    const int row = (int)(e / p.N), col = (int)(e - (int64_t)row * p.N);
+    const float* w = p.ws + (int64_t)batch * p.splits * mn + e;
+    float s = 0.f;
+    for (int k = 0; k < p.splits; ++k) s += w[k * mn];
+    const int b1 = batch / p.nb2, b2 = batch % p.nb2;
+    float* dst = p.C + b1 * p.c_bs1 + b2 * p.c_bs2 + (int64_t)row * p.ldc + col;
+    if (p.bias) s += p.bias[col];
+    if (p.beta != 0.f) s += p.beta * (*dst);
+    *dst = s;
+  }
+}
+
+// ---- host side ----------------------------------------------------------------------
+struct TileCfg {
+  int waves_m, waves_n, wm, wn;
+  float eff;  // relative MFMA efficiency of the tile shape (operand reuse)
+};
+static const TileCfg kCfgs[] = {
+    {2, 2, 2, 2, 1.00f},  // 128 x 128
+    {4, 1, 1, 3, 0.94f},  // 128 x  96   (N = 288 = 3*96)
+    {1, 4, 3, 1, 0.94f},  //  96 x 128   (M = 288, weight gradients)
+    {4, 1, 1, 2, 0.90f},  // 128 x  64
+    {1, 4, 2, 1, 0.90f},  //  64 x 128
+    {2, 2, 1, 1, 0.80f},  //  64 x  64
+};
+static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int WMV, int WNV, int WM, int WN, bool VEC>
+static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid, hipStream_t st) {
+  constexpr int NT = WMV * WNV * 64;
+  if (a_kin && b_kin)
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, true, true, VEC>), grid, dim3(NT), 0, st, p);
+  else if (a_kin && !b_kin)
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, true, false, VEC>), grid, dim3(NT), 0, st, p);
+  else if (!a_kin && b_kin)
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, false, true, VEC>), grid, dim3(NT), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, false, false, VEC>), grid, dim3(NT), 0, st, p);
+}
+
+// ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+struct ProfRec { hipEvent_t e0, e1; double flops; };
+static std::vector<ProfRec> g_prof;
+
+extern "C" int pdn_gemm_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+  return PDN_OK;
+}
+
+extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0, fl = 0;
+  for (auto& r : g_prof) {
+    PDN_HIP(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    PDN_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+    ms += t;
+    fl += r.flops;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = (int64_t)g_prof.size();
+  g_prof.clear();
+  return PDN_OK;
+}
+
+extern "C" int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch) {
+  // Enough for up to 64 splits of one output; pdn_gemm_f32 never uses more than it is given.
+  (void)K;
+  return (int64_t)64 * M * N * (int64_t)nbatch * 4;
+}
+
+extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
+                            int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta,
+                            float* C, int64_t ldc, const float* bias, int nb1, int nb2,
+                            int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
+                            int64_t c_bs1, int64_t c_bs2, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  PDN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && nb1 >= 0 && nb2 >= 0, "pdn_gemm_f32: negative extent");
+  if (M == 0 || N == 0 || nb1 == 0 || nb2 == 0) return PDN_OK;
+  PDN_CHECK_ARG(A && B && C, "pdn_gemm_f32: null operand");
+  PDN_CHECK_ARG(ldc >= N, "pdn_gemm_f32: ldc (%lld) < N (%d)", (long long)ldc, N);
+  hipStream_t st = (hipStream_t)stream;
+  const int nbatch = nb1 * nb2;
+
+  GemmParams p;
+  p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = (float*)workspace;
+  p.M = M; p.N = N; p.K = K;
+  p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
+  p.nb2 = nb2;
+  p.a_bs1 = a_bs1; p.a_bs2 = a_bs2; p.b_bs1 = b_bs1; p.b_bs2 = b_bs2; p.c_bs1 = c_bs1; p.c_bs2 = c_bs2;
+  p.alpha = alpha; p.beta = beta;
+
+  // LDS layout per operand: contraction-contiguous (KIN) unless the m/n index is the unit stride.
+  const bool a_kin = !(a_rs == 1 && a_cs != 1) || M == 1;
+  const bool b_kin = (b_rs == 1 && b_cs != 1) || (b_rs == 1 && N == 1);
+  auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+  auto m4 = [](int64_t v) { return (v & 3) == 0; };
+  // float4 path: unit stride on the staged-contiguous index, every row start 16B aligned,
+  // extents along the contiguous index multiples of 4.
+  bool vec = al16(A) && al16(B) && m4(a_bs1) && m4(a_bs2) && m4(b_bs1) && m4(b_bs2);
+  if (a_kin) vec = vec && a_cs == 1 && m4(a_rs) && m4(K);
+  else vec = vec && a_rs == 1 && m4(a_cs) && m4(M);
+  if (b_kin) vec = vec && b_rs == 1 && m4(b_cs) && m4(K);
+  else vec = vec && b_cs == 1 && m4(b_rs) && m4(N);
+
+  // ---- pick tile shape and k-split with a small cost model -----------------------------
+  const int64_t slots = 256 * 2;
+  const int64_t ws_cap = (workspace && workspace_bytes > 0) ? workspace_bytes / 4 : 0;
+  int best = -1, best_splits = 1;
+  double best_cost = 1e300;
+  for (int c = 0; c < kNumCfgs; ++c) {
+    if (!vec && c != kNumCfgs - 1) continue;  // scalar staging: 64x64 only
+    const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
+    const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN) * nbatch;
+    const int ktiles = (int)cdiv64(K > 0 ? K : 1, GEMM_BK);
+    for (int s = 1; s <= 64; s *= 2) {
+      if (s > 1) {
+        if (ktiles / s < 4) break;
+        if ((int64_t)s * M * N * nbatch > ws_cap) break;
+      }
+      const int kps = (int)cdiv64(ktiles, s);
+      const int64_t blocks = tiles * s;
+      const double waves = (double)cdiv64(blocks, slots);
+      // per-block time ~ tile flops / eff + fixed prologue/epilogue; split adds a reduce pass
+      double cost = waves * ((double)BM * BN * (kps * GEMM_BK + 48) / kCfgs[c].eff);
+      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 0.75 / 256.0 * 8.0;
+      if (cost < best_cost) { best_cost = cost; best = c; best_splits = s; }
+    }
+  }
+  PDN_CHECK_ARG(best >= 0, "pdn_gemm_f32: no tile configuration");
+  const TileCfg& cfg = kCfgs[best];
+  const int BM = cfg.waves_m * cfg.wm * 32, BN = cfg.waves_n * cfg.wn * 32;
+  p.tiles_m = (int)cdiv64(M, BM);
+  p.tiles_n = (int)cdiv64(N, BN);
+  const int ktiles = (int)cdiv64(K > 0 ? K : 1, GEMM_BK);
+  p.k_per_split = (int)cdiv64(ktiles, best_splits) * GEMM_BK;
+  p.splits = (int)cdiv64(K > 0 ? K : 1, p.k_per_split);
+  if (p.splits < 1) p.splits = 1;
+  PDN_CHECK_ARG((int64_t)nbatch * p.splits <= 65535, "pdn_gemm_f32: batch*splits too large (%d)",
+                nbatch * p.splits);
+  dim3 grid(p.tiles_m * p.tiles_n, nbatch * p.splits);
+
+  bool prof;
+  ProfRec rec;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof = g_prof_on;
+  }
+  if (prof) {
+    PDN_HIP(hipEventCreate(&rec.e0));
+    PDN_HIP(hipEventCreate(&rec.e1));
+    rec.flops = 2.0 * M * N * (double)K * nbatch;
+    PDN_HIP(hipEventRecord(rec.e0, st));
+  }
+
+  if (vec) {
+    switch (best) {
+      case 0: launch_layout<2, 2, 2, 2, true>(p, a_kin, b_kin, grid, st); break;
+      case 1: launch_layout<4, 1, 1, 3, true>(p, a_kin, b_kin, grid, st); break;
+      case 2: launch_layout<1, 4, 3, 1, true>(p, a_kin, b_kin, grid, st); break;
+      case 3: launch_layout<4, 1, 1, 2, true>(p, a_kin, b_kin, grid, st); break;
+      case 4: launch_layout<1, 4, 2, 1, true>(p, a_kin, b_kin, grid, st); break;
+      default: launch_layout<2, 2, 1, 1, true>(p, a_kin, b_kin, grid, st); break;
+    }
+  } else {
+    launch_layout<2, 2, 1, 1, false>(p, a_kin, b_kin, grid, st);
+  }
+  PDN_LAUNCH_CHECK();
+  if (p.splits > 1) {
+    const int64_t total = (int64_t)M * N * nbatch;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, nbatch);
+    PDN_LAUNCH_CHECK();
+  }
+  if (prof) {
+    PDN_HIP(hipEventRecord(rec.e1, st));
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(rec);
+  }
+  return PDN_OK;
+}

@@ -1,0 +1,364 @@
+"""GPU parity of each C-ABI kernel against a NumPy statement of the same reference op.
+
+Tolerances: bit-exact for index/copy work (gather, scatter-assign, strided copy, compare);
+fp32 math within rtol 2e-5 / atol 2e-6 of NumPy's fp32 result for streams, and within
+1e-4 relative (north_star tolerance) for GEMM-shaped reductions whose summation order
+differs from OpenBLAS.
+"""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RT, AT = 2e-5, 2e-6
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(256, 288, 288), (256, 768, 288), (256, 288, 768),
+                                   (128, 32000, 288), (100, 70, 50), (1, 5, 7), (33, 1, 9),
+                                   (64, 64, 27), (512, 96, 64)])
+def test_gemm_nn(hip, M, N, K):
+    rng = np.random.default_rng(M * 7 + N)
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    b = rng.standard_normal((K, N), dtype=np.float32)
+    c = hip.matmul(hip.from_numpy(a), hip.from_numpy(b)).get()
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    assert c.shape == (M, N) and c.dtype == np.float32
+    assert rel_err(c, ref) < 1e-5
+
+
+def test_gemm_transposed_views_and_identity_check(hip):
+    # asymmetric B with A = I catches swapped row/col in the MFMA C layout
+    n = 96
+    a = np.eye(n, dtype=np.float32)
+    b = (np.arange(n * 80, dtype=np.float32).reshape(n, 80) % 17) - 3.0
+    c = hip.matmul(hip.from_numpy(a), hip.from_numpy(b)).get()
+    assert np.array_equal(c, b)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((300, 288), dtype=np.float32)
+    w = rng.standard_normal((288, 768), dtype=np.float32)
+    g = rng.standard_normal((300, 768), dtype=np.float32)
+    X, W, G = map(hip.from_numpy, (x, w, g))
+    dx = hip.matmul(G, W.T).get()          # NT
+    dw = hip.matmul(X.T, G).get()          # TN
+    assert rel_err(dx, g.astype(np.float64) @ w.T.astype(np.float64)) < 1e-5
+    assert rel_err(dw, x.T.astype(np.float64) @ g.astype(np.float64)) < 1e-5
+
+
+def test_gemm_split_k_weight_gradient(hip):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((8192, 288), dtype=np.float32)
+    g = rng.standard_normal((8192, 288), dtype=np.float32)
+    dw = hip.matmul(hip.from_numpy(x).T, hip.from_numpy(g)).get()
+    ref = x.T.astype(np.float64) @ g.astype(np.float64)
+    assert rel_err(dw, ref) < 2e-5
+
+
+def test_gemm_batched_head_views(hip):
+    # attention layout: (B, L, H, hd) viewed as (B, H, L, hd) without a copy
+    B, L, H, hd = 2, 64, 6, 48
+    rng = np.random.default_rng(2)
+    q = rng.standard_normal((B, L, H, hd), dtype=np.float32)
+    k = rng.standard_normal((B, L, H, hd), dtype=np.float32)
+    Q, Kt = hip.from_numpy(q).transpose(0, 2, 1, 3), hip.from_numpy(k).transpose(0, 2, 3, 1)
+    s = hip.matmul(Q, Kt).get()
+    ref = np.matmul(q.transpose(0, 2, 1, 3).astype(np.float64), k.transpose(0, 2, 3, 1).astype(np.float64))
+    assert s.shape == (B, H, L, L)
+    assert rel_err(s, ref) < 1e-5
+    p = rng.standard_normal((B, H, L, L), dtype=np.float32)
+    o = hip.matmul(hip.from_numpy(p), hip.from_numpy(k).transpose(0, 2, 1, 3)).get()
+    assert rel_err(o, np.matmul(p.astype(np.float64), k.transpose(0, 2, 1, 3).astype(np.float64))) < 1e-5
+
+
+def test_gemm_bias_beta_and_1d_rules(hip):
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal((40, 36), dtype=np.float32)
+    b = rng.standard_normal((36, 52), dtype=np.float32)
+    bias = rng.standard_normal(52, dtype=np.float32)
+    c0 = rng.standard_normal((40, 52), dtype=np.float32)
+    C = hip.from_numpy(c0.copy())
+    hip.gemm(hip.from_numpy(a), hip.from_numpy(b), C, alpha=0.5, beta=2.0, bias=hip.from_numpy(bias))
+    assert np.allclose(C.get(), 0.5 * (a @ b) + bias + 2.0 * c0, rtol=1e-5, atol=1e-5)
+    v = rng.standard_normal(36, dtype=np.float32)
+    assert np.allclose(hip.matmul(hip.from_numpy(v), hip.from_numpy(b)).get(), v @ b, rtol=1e-5, atol=1e-5)
+    assert np.allclose(hip.matmul(hip.from_numpy(a), hip.from_numpy(v)).get(), a @ v, rtol=1e-5, atol=1e-5)
+    d = hip.matmul(hip.from_numpy(v), hip.from_numpy(v)).get()
+    assert d.shape == () and np.allclose(d, v @ v, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------
+def test_elementwise_broadcast_and_scalars(hip):
+    rng = np.random.default_rng(4)
+    a = rng.standard_normal((3, 1, 5, 4), dtype=np.float32)
+    b = rng.standard_normal((2, 1, 4), dtype=np.float32)
+    A, B = hip.from_numpy(a), hip.from_numpy(b)
+    for f in ("__add__", "__sub__", "__mul__", "__truediv__"):
+        got = getattr(A, f)(B).get()
+        ref = getattr(a, f)(b)
+        assert got.shape == ref.shape and got.dtype == ref.dtype
+        assert np.allclose(got, ref, rtol=RT, atol=AT)
+    assert np.array_equal((A > B).get(), a > b)
+    assert np.array_equal((A == A).get(), a == a)
+    assert np.allclose((A * 2.5).get(), a * 2.5, rtol=RT)
+    assert np.allclose((1 - A).get(), 1 - a, rtol=RT, atol=AT)
+    assert np.allclose((2.0 / (A * A + 1)).get(), 2.0 / (a * a + 1), rtol=RT)
+    pos = np.abs(a) + 0.5
+    assert np.allclose((hip.from_numpy(pos) ** 0.5).get(), pos ** 0.5, rtol=RT)
+    assert np.allclose((hip.from_numpy(pos) ** hip.from_numpy(b)).get(), pos ** b, rtol=1e-4)
+    assert np.allclose(hip.maximum(0.0, A).get(), np.maximum(0.0, a))
+    assert np.allclose(hip.minimum(A, B).get(), np.minimum(a, b))
+    for name in ("exp", "abs", "sign"):
+        assert np.allclose(getattr(hip, name)(A).get(), getattr(np, name)(a), rtol=RT, atol=AT)
+    assert np.allclose(hip.log(hip.from_numpy(pos)).get(), np.log(pos), rtol=RT, atol=AT)
+    assert np.allclose((-A).get(), -a)
+
+
+def test_elementwise_views_inplace_and_cast(hip):
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((6, 8), dtype=np.float32)
+    A = hip.from_numpy(a)
+    at = A.T
+    assert np.array_equal(at.get(), a.T)
+    assert np.array_equal((at + 1).get(), a.T + 1)
+    A2 = hip.from_numpy(a.copy())
+    A2[1:3, ::2] = 7.0
+    ref = a.copy(); ref[1:3, ::2] = 7.0
+    assert np.array_equal(A2.get(), ref)
+    A2[:, 0] = hip.from_numpy(np.arange(6, dtype=np.float32))
+    ref[:, 0] = np.arange(6)
+    assert np.array_equal(A2.get(), ref)
+    A2 += hip.from_numpy(a)
+    ref += a
+    assert np.allclose(A2.get(), ref)
+    A2 *= 0.5; ref *= 0.5
+    assert np.allclose(A2.get(), ref)
+    assert np.array_equal(A.astype(np.float64).get(), a.astype(np.float64))
+    assert np.array_equal(A.astype(np.int64).get(), a.astype(np.int64))
+    m = a > 0
+    A3 = hip.from_numpy(a.copy()); A3[hip.from_numpy(m)] = -1.0
+    ref3 = a.copy(); ref3[m] = -1.0
+    assert np.array_equal(A3.get(), ref3)
+    r = A.reshape(2, 3, 8).transpose(1, 0, 2).reshape(6, 8)  # forces a copy
+    assert np.array_equal(r.get(), a.reshape(2, 3, 8).transpose(1, 0, 2).reshape(6, 8))
+    assert np.array_equal(hip.concatenate([A, A2], axis=1).get(), np.concatenate([a, ref], axis=1))
+    assert np.array_equal(hip.pad(A, [(0, 0), (1, 2)]).get(), np.pad(a, [(0, 0), (1, 2)]))
+
+
+@pytest.mark.parametrize("shape,axis,keep", [((7, 288), -1, True), ((4, 6, 256), (0, 1), False),
+                                             ((300, 1000), None, False), ((5000, 33), 0, False),
+                                             ((3, 4, 5), 1, True), ((2, 3, 4, 5), (1, 3), False),
+                                             ((70000,), 0, False)])
+def test_reductions(hip, shape, axis, keep):
+    rng = np.random.default_rng(6)
+    a = rng.standard_normal(shape, dtype=np.float32)
+    A = hip.from_numpy(a)
+    for name in ("sum", "mean", "max", "min"):
+        got = getattr(A, name)(axis, keep).get()
+        ref = getattr(a, name)(axis=axis, keepdims=keep)
+        assert got.shape == ref.shape, name
+        assert np.allclose(got, ref, rtol=1e-4, atol=1e-4), name
+    if axis is None or isinstance(axis, int):
+        assert np.array_equal(A.argmax(axis).get(), a.argmax(axis))
+        assert np.array_equal(A.argmin(axis).get(), a.argmin(axis))
+
+
+def test_reduce_transposed_view_and_ties(hip):
+    a = np.array([[1, 5, 5, 2], [9, 9, 0, 9]], dtype=np.float32)
+    A = hip.from_numpy(a)
+    assert np.array_equal(A.argmax(1).get(), a.argmax(1))
+    assert np.array_equal(A.T.sum(0).get(), a.T.sum(0))
+    assert np.array_equal((A == A).sum().get(), (a == a).sum())
+
+
+# ---------------------------------------------------------------------------------------
+def np_softmax(x, axis=-1):
+    m = x.max(axis, keepdims=True)
+    e = np.exp(x - m)
+    return e / e.sum(axis, keepdims=True)
+
+
+def test_softmax_fwd_bwd_and_causal(hip):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(7)
+    for rows, cols in [(24, 256), (5, 288), (3, 32000), (4, 10)]:
+        x = rng.standard_normal((rows, cols), dtype=np.float32) * 3
+        dy = rng.standard_normal((rows, cols), dtype=np.float32)
+        X, DY = hip.from_numpy(x), hip.from_numpy(dy)
+        Y, DX = hip.empty((rows, cols)), hip.empty((rows, cols))
+        L.call("pdn_softmax_fwd_f32", X._ptr, Y._ptr, rows, cols, 1.0, 0, 0, hip.stream())
+        y = np_softmax(x)
+        assert np.allclose(Y.get(), y, rtol=2e-5, atol=1e-7)
+        L.call("pdn_softmax_bwd_f32", Y._ptr, DY._ptr, DX._ptr, rows, cols, 1.0, hip.stream())
+        dx = (dy - (dy * y).sum(-1, keepdims=True)) * y
+        assert np.allclose(DX.get(), dx, rtol=1e-4, atol=1e-6)
+    # attention prologue: / sqrt(hd) + causal mask, rows = (b*h, L)
+    Lq, hd = 64, 48
+    s = rng.standard_normal((3, Lq, Lq), dtype=np.float32)
+    mask = np.triu(np.full((Lq, Lq), -np.inf, dtype=np.float32), 1)
+    ref = np_softmax(s / np.float32(math.sqrt(hd)) + mask)
+    S, P = hip.from_numpy(s), hip.empty(s.shape)
+    L.call("pdn_softmax_fwd_f32", S._ptr, P._ptr, 3 * Lq, Lq, math.sqrt(hd), Lq, 0, hip.stream())
+    got = P.get()
+    assert np.allclose(got, ref, rtol=2e-5, atol=1e-7)
+    assert np.all(got[:, np.triu_indices(Lq, 1)[0], np.triu_indices(Lq, 1)[1]] == 0.0)
+
+
+def test_rmsnorm_fwd_bwd(hip):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(8)
+    rows, cols, eps = 700, 288, 1e-6
+    x = rng.standard_normal((rows, cols), dtype=np.float32)
+    w = rng.standard_normal(cols, dtype=np.float32)
+    dy = rng.standard_normal((rows, cols), dtype=np.float32)
+    X, W, DY = map(hip.from_numpy, (x, w, dy))
+    Y, R, DX = hip.empty((rows, cols)), hip.empty((rows,)), hip.empty((rows, cols))
+    DW = hip.zeros((cols,), np.float32)
+    L.call("pdn_rmsnorm_fwd_f32", X._ptr, W._ptr, Y._ptr, R._ptr, rows, cols, eps, hip.stream())
+    r = np.sqrt((x.astype(np.float64) ** 2).mean(-1, keepdims=True) + eps)
+    z = x / r
+    assert np.allclose(Y.get(), z * w, rtol=2e-5, atol=2e-6)
+    ws, wsb = hip.workspace(L.query("pdn_rmsnorm_bwd_workspace_bytes", rows, cols))
+    L.call("pdn_rmsnorm_bwd_f32", X._ptr, W._ptr, R._ptr, DY._ptr, DX._ptr, DW._ptr, 1, rows, cols,
+           ws, wsb, hip.stream())
+    dz = dy * w
+    dx = (dz - z * (z * dz).mean(-1, keepdims=True)) / r
+    assert np.allclose(DX.get(), dx, rtol=1e-4, atol=1e-5)
+    assert np.allclose(DW.get(), (dy * z).sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_swiglu_rope_relu(hip):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(9)
+    n = 1000 * 768 + 3
+    g = rng.standard_normal(n, dtype=np.float32) * 2
+    u = rng.standard_normal(n, dtype=np.float32)
+    dy = rng.standard_normal(n, dtype=np.float32)
+    G, U, DY = map(hip.from_numpy, (g, u, dy))
+    Y, DG, DU = hip.empty((n,)), hip.empty((n,)), hip.empty((n,))
+    L.call("pdn_swiglu_fwd_f32", G._ptr, U._ptr, Y._ptr, n, hip.stream())
+    g64 = g.astype(np.float64)
+    s = 1 / (1 + np.exp(-g64))
+    assert np.allclose(Y.get(), g64 * s * u, rtol=2e-5, atol=2e-6)
+    L.call("pdn_swiglu_bwd_f32", G._ptr, U._ptr, DY._ptr, DG._ptr, DU._ptr, n, hip.stream())
+    assert np.allclose(DU.get(), dy * g64 * s, rtol=2e-5, atol=2e-6)
+    assert np.allclose(DG.get(), dy * u * s * (1 + g64 * (1 - s)), rtol=1e-4, atol=1e-5)
+    L.call("pdn_swiglu_fwd_f32", G._ptr, None, Y._ptr, n, hip.stream())
+    assert np.allclose(Y.get(), g64 * s, rtol=2e-5, atol=2e-6)
+    # relu backward: gradient 1 at x == 0 (reference quirk)
+    x = np.array([-1.0, 0.0, 2.0, -0.0], dtype=np.float32)
+    X, D = hip.from_numpy(x), hip.empty((4,))
+    L.call("pdn_relu_bwd_f32", X._ptr, hip.from_numpy(np.ones(4, np.float32))._ptr, D._ptr, 4, hip.stream())
+    assert np.array_equal(D.get(), np.array([0, 1, 1, 1], np.float32))
+    # RoPE
+    B, Lq, H, hd = 2, 16, 6, 48
+    xq = rng.standard_normal((B, Lq, H, hd), dtype=np.float32)
+    inv = 1.0 / (10000 ** (np.arange(0, hd, 2) / hd))
+    fr = np.outer(np.arange(Lq), inv).astype(np.float32)
+    cos, sin = np.cos(fr), np.sin(fr)
+    xr, xi = xq[..., 0::2], xq[..., 1::2]
+    c, s_ = cos[None, :, None, :], sin[None, :, None, :]
+    ref = np.stack([xr * c - xi * s_, xr * s_ + xi * c], -1).reshape(xq.shape)
+    XQ, OUT = hip.from_numpy(xq), hip.empty(xq.shape)
+    L.call("pdn_rope_f32", XQ._ptr, hip.from_numpy(cos)._ptr, hip.from_numpy(sin)._ptr, OUT._ptr,
+           B * Lq, Lq, H, hd, 0, hip.stream())
+    assert np.allclose(OUT.get(), ref, rtol=2e-5, atol=2e-6)
+    BACK = hip.empty(xq.shape)
+    L.call("pdn_rope_f32", OUT._ptr, hip.from_numpy(cos)._ptr, hip.from_numpy(sin)._ptr, BACK._ptr,
+           B * Lq, Lq, H, hd, 1, hip.stream())
+    assert np.allclose(BACK.get(), xq, rtol=1e-4, atol=1e-5)   # rotation by -theta inverts it
+
+
+def test_embedding_gather_scatter_assign_bit_exact(hip):
+    rng = np.random.default_rng(10)
+    V, D = 500, 288
+    w = rng.standard_normal((V, D), dtype=np.float32)
+    ids = rng.integers(0, V, size=(4, 64))
+    ids[0, :5] = 7          # duplicates: last write must win
+    W = hip.from_numpy(w)
+    out = W[hip.from_numpy(ids)]
+    assert np.array_equal(out.get(), w[ids])
+    assert np.array_equal(W[ids.tolist()].get(), w[ids])
+    g = rng.standard_normal((4, 64, D), dtype=np.float32)
+    full = hip.zeros((V, D), np.float32)
+    full[hip.from_numpy(ids)] = hip.from_numpy(g)
+    ref = np.zeros((V, D), np.float32); ref[ids] = g
+    assert np.array_equal(full.get(), ref)
+    # pick one column per row and its scatter
+    x = rng.standard_normal((50, 33), dtype=np.float32)
+    t = rng.integers(0, 33, size=50)
+    assert np.array_equal(hip.from_numpy(x)[range(50), hip.from_numpy(t)].get(), x[range(50), t])
+    z = hip.zeros((50, 33), np.float32)
+    gv = rng.standard_normal(50, dtype=np.float32)
+    z[range(50), hip.from_numpy(t)] = hip.from_numpy(gv)
+    zr = np.zeros((50, 33), np.float32); zr[range(50), t] = gv
+    assert np.array_equal(z.get(), zr)
+    hip.check_index_errors()
+
+
+def test_cross_entropy_fused(hip):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for rows, V in [(64, 32000), (37, 10)]:
+        x = rng.standard_normal((rows, V), dtype=np.float32) * 2
+        t = rng.integers(0, V, size=rows)
+        X, T = hip.from_numpy(x), hip.from_numpy(t)
+        lr, lse, out = hip.empty((rows,)), hip.empty((rows,)), hip.empty((1,))
+        import torch
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        L.call("pdn_cross_entropy_fwd_f32", X._ptr, T._ptr, rows, V, 1, lr._ptr, lse._ptr, out._ptr,
+               err.data_ptr(), hip.stream())
+        x64 = x.astype(np.float64)
+        m = x64.max()
+        l = np.log(np.exp(x64 - m).sum(1)) + m
+        ref = (l - x64[np.arange(rows), t]).mean()
+        assert abs(out.get()[0] - ref) < 1e-5 * abs(ref)
+        DX = hip.empty((rows, V))
+        L.call("pdn_cross_entropy_bwd_f32", X._ptr, T._ptr, lse._ptr, None, 1.0 / rows, DX._ptr, rows, V, hip.stream())
+        sm = np.exp(x64 - l[:, None]); sm[np.arange(rows), t] -= 1
+        assert np.allclose(DX.get(), sm / rows, rtol=1e-4, atol=1e-8)
+        assert int(err.item()) == 0
+
+
+def test_adam_multi_matches_reference_update(hip):
+    from pydynet_amd import _lib
+    import torch
+    L = _lib.lib()
+    rng = np.random.default_rng(12)
+    sizes = [288 * 288, 288, 1000, 7]
+    P = [rng.standard_normal(n, dtype=np.float32) for n in sizes]
+    G = [rng.standard_normal(n, dtype=np.float32) for n in sizes]
+    M = [np.zeros(n, np.float32) for n in sizes]
+    Vv = [np.zeros(n, np.float32) for n in sizes]
+    dP, dG, dM, dV = [[hip.from_numpy(a) for a in lst] for lst in (P, G, M, Vv)]
+    CH = 16384
+    rows = []
+    for p, g, m, v in zip(dP, dG, dM, dV):
+        for off in range(0, p.size, CH):
+            n = min(CH, p.size - off)
+            rows.append([p._ptr + 4 * off, g._ptr + 4 * off, m._ptr + 4 * off, v._ptr + 4 * off, n])
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    for t in (1, 2, 3):
+        a_t = math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        L.call("pdn_adam_multi_f32", table.data_ptr(), len(rows), lr * a_t, b1, b2, 1 - b1, 1 - b2,
+               eps, 0.0, 1.0, hip.stream())
+        for i in range(len(sizes)):      # optimizer.py:187-195, verbatim order of operations
+            grad = G[i]
+            M[i] *= b1; M[i] += (1 - b1) * grad
+            Vv[i] *= b2; Vv[i] += (1 - b2) * grad ** 2
+            P[i] -= lr * a_t * M[i] / (Vv[i] ** 0.5 + eps)
+    for i in range(len(sizes)):
+        assert np.allclose(dP[i].get(), P[i], rtol=1e-5, atol=1e-7)
+        assert np.allclose(dM[i].get(), M[i], rtol=1e-5, atol=1e-8)
+        assert np.allclose(dV[i].get(), Vv[i], rtol=1e-5, atol=1e-10)

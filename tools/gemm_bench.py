@@ -1,0 +1,52 @@
+"""Micro-benchmark of pdn_gemm_f32 on the Llama hot-path shapes (run on the GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from pydynet_amd import hipnp as hp
+
+hp.set_device(0)
+PEAK = 157.3e12
+
+
+def bench(name, A, B, C, iters=20):
+    hp.gemm(A, B, C)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        hp.gemm(A, B, C)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    M, K = A.shape[-2:]; N = B.shape[-1]
+    nb = int(np.prod(C.shape[:-2])) if C.ndim > 2 else 1
+    fl = 2.0 * M * N * K * nb
+    print(f"{name:34s} M={M:6d} N={N:6d} K={K:6d} nb={nb:4d}  {ms*1e3:9.1f} us  {fl/ms/1e9:8.1f} TF/s  {100*fl/ms/1e-3/PEAK:5.1f}% of fp32-MFMA peak", flush=True)
+
+
+def rnd(*shape):
+    return hp.from_numpy(np.random.default_rng(0).standard_normal(shape, dtype=np.float32))
+
+
+for Bsz in (16, 64):
+    T = Bsz * 256
+    x, w288, w768, wv = rnd(T, 288), rnd(288, 288), rnd(288, 768), rnd(288, 32000)
+    h768, wd = rnd(T, 768), rnd(768, 288)
+    g288, g768 = rnd(T, 288), rnd(T, 768)
+    print(f"--- tokens = {T}")
+    bench("linear 288->288 fwd (NN)", x, w288, hp.empty((T, 288)))
+    bench("linear 288->768 fwd (NN)", x, w768, hp.empty((T, 768)))
+    bench("linear 768->288 fwd (NN)", h768, wd, hp.empty((T, 288)))
+    bench("dX 288<-768 (NT)", g768, w768.T, hp.empty((T, 288)))
+    bench("dW 288x768 (TN, split-K)", x.T, g768, hp.empty((288, 768)))
+    bench("dW 288x288 (TN, split-K)", x.T, g288, hp.empty((288, 288)))
+    logits = hp.empty((T, 32000))
+    bench("lm_head fwd (NN)", x, wv, logits)
+    bench("lm_head dX (NT)", logits, wv.T, hp.empty((T, 288)))
+    bench("lm_head dW (TN)", x.T, logits, hp.empty((288, 32000)))
+    del logits
+    q = rnd(Bsz, 256, 6, 48); k = rnd(Bsz, 256, 6, 48)
+    s = hp.empty((Bsz, 6, 256, 256))
+    bench("attn QK^T (batched NT views)", q.transpose(0, 2, 1, 3), k.transpose(0, 2, 3, 1), s)
+    bench("attn PV (batched NN views)", s, k.transpose(0, 2, 1, 3), hp.empty((Bsz, 6, 256, 48)))
