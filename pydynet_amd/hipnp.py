@@ -11,6 +11,7 @@ Supported dtypes on the device: float32 (the hot path), float64, int64, bool.
 """
 from __future__ import annotations
 
+import builtins as _bi
 import ctypes
 import math
 import numbers
@@ -35,6 +36,10 @@ _ROP = dict(sum=0, mean=1, max=2, min=3, argmax=4, argmin=5)
 
 _torch = None
 _state = {"device": 0, "stream": 0}
+
+
+def _dev():
+    return f"cuda:{_state['device']}"
 
 
 def _t():
@@ -107,8 +112,8 @@ def workspace(nbytes: int):
         return 0, 0
     if _ws["bytes"] < nbytes:
         t = _t()
-        cap = max(nbytes, 1 << 20)
-        _ws["buf"] = t.empty(cap, dtype=t.uint8, device=f"cuda:{_state['device']}")
+        cap = _bi.max(nbytes, 1 << 20)
+        _ws["buf"] = t.empty(cap, dtype=t.uint8, device=_dev())
         _ws["bytes"] = cap
     return _ws["buf"].data_ptr(), _ws["bytes"]
 
@@ -119,7 +124,7 @@ _err = {"buf": None}
 def _err_flag():
     if _err["buf"] is None:
         t = _t()
-        _err["buf"] = t.zeros(1, dtype=t.int32, device=f"cuda:{_state['device']}")
+        _err["buf"] = t.zeros(1, dtype=t.int32, device=_dev())
     return _err["buf"]
 
 
@@ -370,7 +375,7 @@ def empty(shape, dtype=np.float32):
     _dtcode(dtype)
     t = _t()
     n = int(math.prod(shape))
-    buf = t.empty(max(n, 1), dtype=_torch_dtype(dtype), device=f"cuda:{_state['device']}")
+    buf = t.empty(_bi.max(n, 1), dtype=_torch_dtype(dtype), device=_dev())
     return ndarray(buf, buf.data_ptr(), shape, _contig_strides(shape), dtype)
 
 
@@ -401,7 +406,7 @@ def from_numpy(a: np.ndarray) -> ndarray:
     a = np.ascontiguousarray(a)
     _dtcode(a.dtype)
     t = _t()
-    buf = t.from_numpy(a.reshape(-1) if a.size else np.zeros(1, a.dtype)).to(f"cuda:{_state['device']}")
+    buf = t.from_numpy(a.reshape(-1) if a.size else np.zeros(1, a.dtype)).to(_dev())
     return ndarray(buf, buf.data_ptr(), a.shape, _contig_strides(a.shape), a.dtype)
 
 
@@ -584,11 +589,11 @@ def _reduce(op, a, axis=None, keepdims=False):
         src = a.astype(np.int64)
     if src.dtype == np.int64 and op == "mean":
         src = src.astype(np.float64)
-    flags = (ctypes.c_uint8 * max(a.ndim, 1))(*[1 if i in axes else 0 for i in range(a.ndim)])
+    flags = (ctypes.c_uint8 * _bi.max(a.ndim, 1))(*[1 if i in axes else 0 for i in range(a.ndim)])
     kept = tuple(s for i, s in enumerate(a.shape) if i not in axes)
     odt = np.int64 if op in ("argmax", "argmin") else src.dtype
     out = empty(kept, odt)
-    outn = max(int(math.prod(kept)), 1)
+    outn = _bi.max(int(math.prod(kept)), 1)
     ws_ptr, ws_bytes = workspace(outn * 1024 * 16 + 4096 if outn <= 4096 else outn * 16 * 64)
     _lib.lib().call("pdn_reduce", _dtcode(src.dtype), _ROP[op], src.ndim, _i64(src.shape),
                     _i64(src._strides), flags, src._ptr, out._ptr, ws_ptr, ws_bytes, _state["stream"])
@@ -608,10 +613,10 @@ def _basic_index(a: ndarray, key):
         key = (key,)
     if not all(_is_basic(k) for k in key):
         return None
-    n_spec = sum(1 for k in key if k is not None and k is not Ellipsis)
+    n_spec = _bi.sum(1 for k in key if k is not None and k is not Ellipsis)
     if n_spec > a.ndim:
         raise IndexError("too many indices for array")
-    if sum(1 for k in key if k is Ellipsis) > 1:
+    if _bi.sum(1 for k in key if k is Ellipsis) > 1:
         raise IndexError("an index can only have a single ellipsis")
     if Ellipsis in key:
         i = key.index(Ellipsis)
@@ -683,7 +688,7 @@ def _advanced_get(a: ndarray, key):
             src = a.copy()
         else:
             src = a
-        row_stride = src._strides[0] if src.shape[0] > 1 else max(D, 1)
+        row_stride = src._strides[0] if src.shape[0] > 1 else _bi.max(D, 1)
         out = empty(idx.shape + a.shape[1:], a.dtype)
         L.call("pdn_embedding_gather_f32", src._ptr, a.shape[0], D, row_stride, idx._ptr, idx.size,
                out._ptr, _err_flag().data_ptr(), _state["stream"])
@@ -785,7 +790,7 @@ def concatenate(arrs, axis=0):
     axis = axis % nd
     dt = np.result_type(*[a.dtype for a in arrs])
     shape = list(arrs[0].shape)
-    shape[axis] = builtins_sum(a.shape[axis] for a in arrs)
+    shape[axis] = _bi.sum(a.shape[axis] for a in arrs)
     out = empty(shape, dt)
     pos = 0
     for a in arrs:
@@ -881,7 +886,7 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None):
     (n1, (a1, b1, c1)), (n2, (a2, b2, c2)) = merged
     ws_ptr, ws_bytes = workspace(L.query("pdn_gemm_f32_workspace_bytes", M, N, K, n1 * n2)
                                  if (M * N <= (1 << 21) and K >= 1024) else 0)
-    ldc = C._strides[-2] if M > 1 else builtins_max(C._strides[-2], N)
+    ldc = C._strides[-2] if M > 1 else _bi.max(C._strides[-2], N)
     L.call("pdn_gemm_f32", M, N, K, float(alpha), A._ptr, A._strides[-2], A._strides[-1], B._ptr,
            B._strides[-2], B._strides[-1], float(beta), C._ptr, ldc,
            bias._ptr if bias is not None else None, n1, n2, a1, a2, b1, b2, c1, c2, ws_ptr, ws_bytes,
@@ -889,8 +894,6 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None):
     return C
 
 
-import builtins as _bi  # noqa: E402
-builtins_sum, builtins_max = _bi.sum, _bi.max
 
 
 class _Random:

@@ -315,7 +315,7 @@ def test_cross_entropy_fused(hip):
         X, T = hip.from_numpy(x), hip.from_numpy(t)
         lr, lse, out = hip.empty((rows,)), hip.empty((rows,)), hip.empty((1,))
         import torch
-        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        err = torch.zeros(1, dtype=torch.int32, device=hip._dev())
         L.call("pdn_cross_entropy_fwd_f32", X._ptr, T._ptr, rows, V, 1, lr._ptr, lse._ptr, out._ptr,
                err.data_ptr(), hip.stream())
         x64 = x.astype(np.float64)
@@ -347,7 +347,7 @@ def test_adam_multi_matches_reference_update(hip):
         for off in range(0, p.size, CH):
             n = min(CH, p.size - off)
             rows.append([p._ptr + 4 * off, g._ptr + 4 * off, m._ptr + 4 * off, v._ptr + 4 * off, n])
-    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    table = torch.tensor(rows, dtype=torch.int64).to(hip._dev())
     lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
     for t in (1, 2, 3):
         a_t = math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
