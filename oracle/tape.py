@@ -62,11 +62,9 @@ class Var:
         if self.requires_grad:
             if not np.issubdtype(self.value.dtype, np.floating):
                 raise TypeError("Only Tensors of floating point dtype can require gradients!")  # :85-88
-            # :90 -- eager zero grad with dtype=`dtype` argument: a leaf made without an explicit
-            # dtype gets a float64 grad even for float32 data; op nodes pass data.dtype.
-            gdt = dtype if (dtype is not None or not _parents) else self.value.dtype
-            self.grad = np.zeros(self.value.shape, dtype=gdt if _parents is None or dtype is not None
-                                 else self.value.dtype)
+            # :90 -- eager zero grad allocated with the constructor's `dtype` ARGUMENT: a leaf made
+            # without an explicit dtype gets a float64 grad even when its data is float32.
+            self.grad = np.zeros(self.value.shape, dtype=dtype)
             _State.counter += 1
             self.idx = _State.counter
             _State.nodes.append(self)

@@ -256,8 +256,8 @@ def test_swiglu_rope_relu(hip):
     assert np.allclose(Y.get(), g64 * s, rtol=2e-5, atol=2e-6)
     # relu backward: gradient 1 at x == 0 (reference quirk)
     x = np.array([-1.0, 0.0, 2.0, -0.0], dtype=np.float32)
-    X, D = hip.from_numpy(x), hip.empty((4,))
-    L.call("pdn_relu_bwd_f32", X._ptr, hip.from_numpy(np.ones(4, np.float32))._ptr, D._ptr, 4, hip.stream())
+    X, D, ONES = hip.from_numpy(x), hip.empty((4,)), hip.from_numpy(np.ones(4, np.float32))
+    L.call("pdn_relu_bwd_f32", X._ptr, ONES._ptr, D._ptr, 4, hip.stream())
     assert np.array_equal(D.get(), np.array([0, 1, 1, 1], np.float32))
     # RoPE
     B, Lq, H, hd = 2, 16, 6, 48
@@ -268,12 +268,12 @@ def test_swiglu_rope_relu(hip):
     xr, xi = xq[..., 0::2], xq[..., 1::2]
     c, s_ = cos[None, :, None, :], sin[None, :, None, :]
     ref = np.stack([xr * c - xi * s_, xr * s_ + xi * c], -1).reshape(xq.shape)
-    XQ, OUT = hip.from_numpy(xq), hip.empty(xq.shape)
-    L.call("pdn_rope_f32", XQ._ptr, hip.from_numpy(cos)._ptr, hip.from_numpy(sin)._ptr, OUT._ptr,
+    XQ, OUT, COS, SIN = hip.from_numpy(xq), hip.empty(xq.shape), hip.from_numpy(cos), hip.from_numpy(sin)
+    L.call("pdn_rope_f32", XQ._ptr, COS._ptr, SIN._ptr, OUT._ptr,
            B * Lq, Lq, H, hd, 0, hip.stream())
     assert np.allclose(OUT.get(), ref, rtol=2e-5, atol=2e-6)
     BACK = hip.empty(xq.shape)
-    L.call("pdn_rope_f32", OUT._ptr, hip.from_numpy(cos)._ptr, hip.from_numpy(sin)._ptr, BACK._ptr,
+    L.call("pdn_rope_f32", OUT._ptr, COS._ptr, SIN._ptr, BACK._ptr,
            B * Lq, Lq, H, hd, 1, hip.stream())
     assert np.allclose(BACK.get(), xq, rtol=1e-4, atol=1e-5)   # rotation by -theta inverts it
 
