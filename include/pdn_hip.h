@@ -144,6 +144,21 @@ int pdn_cross_entropy_bwd_f32(const float* logits, const int64_t* targets, const
                               const float* upstream, float gscale, float* dlogits, int64_t rows,
                               int V, void* stream);
 
+/* ---- Conv2d building blocks (nn/functional.py:194-339).  im2col folds the zero padding of
+ * __pad2d (:241-245) into the gather and writes the reference's exact layout
+ * (N, C, kh, kw, oh, ow) -- bit-exact with `as_strided(...).copy()` (:211-222).  col2im is the
+ * adjoint of `xp.add.at` on the overlapping view (:224-232) as a deterministic gather.
+ * Pooling (mode 0 = max, 1 = avg) works on the zero-padded input like the reference; max
+ * backward sends the gradient to every tied position (core/tensor.py:744-750). */
+int pdn_im2col2d_f32(const float* x, int N, int C, int H, int W, int k, int stride, int pad,
+                     float* col, void* stream);
+int pdn_col2im2d_f32(const float* dcol, int N, int C, int H, int W, int k, int stride, int pad,
+                     float* dx, void* stream);
+int pdn_pool2d_fwd_f32(const float* x, int N, int C, int H, int W, int k, int stride, int pad,
+                       int mode, float* y, void* stream);
+int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, int C, int H, int W,
+                       int k, int stride, int pad, int mode, float* dx, void* stream);
+
 /* ---- Adam.step for all parameters in one launch (optim/optimizer.py:185-196).
  * chunk_table_dev: device int64[nchunks][5] = {p, g, m, v addresses, n elements}.
  * step = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host as the reference does. */

@@ -1,0 +1,551 @@
+"""Fused differentiable nodes of the training hot path.
+
+Each class is an ordinary tape node (same protocol as the reference's operators) that stands
+for a chain of generic nodes in the reference and runs as ONE forward and ONE backward HIP
+kernel (or GEMM) on a GPU device; on "cpu" the same node evaluates the equivalent NumPy
+expression.  Reference chains replaced:
+
+    linear          nn/functional.py:7-11           (matmul + broadcast add; dW summed by the engine)
+    rms_norm        nn/modules/norm.py:245-248      (6 nodes)
+    silu / swiglu   nn/functional.py:39-40, llm/llama/model.py:56-58
+    relu            nn/functional.py:31-32          (maximum(0., x); gradient 1 at x == 0)
+    softmax         nn/functional.py:43-49          (last axis)
+    rope            llm/llama/model.py:23-44        (26 nodes)
+    attention       llm/llama/model.py:112-121      (transpose, matmul, /sqrt(hd), +mask, softmax, matmul)
+    embedding       nn/functional.py:14-20 + tensor.py:937-940 (scatter-ASSIGN gradient)
+    cross_entropy   nn/functional.py:364-381        (7 nodes, integer targets)
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .tensor import Tensor, _Operator, _as_operand
+
+
+def _hip():
+    from .. import hipnp
+    return hipnp
+
+
+def _L():
+    from .. import _lib
+    return _lib.lib()
+
+
+def _contig(a):
+    return a if a.is_contiguous() else a.copy()
+
+
+def _is_leaf_f32(t):
+    return (t.requires_grad and not t.last and t.grad is not None and t.grad.dtype == np.float32
+            and (isinstance(t.grad, np.ndarray) or t.grad.is_contiguous()))
+
+
+# ---------------------------------------------------------------------------------------
+class linear(_Operator):
+    """y = x @ W (+ b) over the last axis of x; W is (in, out)."""
+
+    def __init__(self, x, weight, bias=None):
+        self.has_bias = bias is not None
+        super().__init__(*((x, weight, bias) if self.has_bias else (x, weight)))
+
+    def forward_(self, x, w, b=None):
+        if self.xp is np:
+            y = x.data @ w.data
+            return y + b.data if b is not None else y
+        hp = _hip()
+        fin, fout = w.shape
+        x2 = x.data.reshape(-1, fin)
+        out = hp.empty(x.shape[:-1] + (fout,), np.float32)
+        hp.gemm(x2, w.data, out.reshape(-1, fout), bias=b.data.reshape(-1) if b is not None else None)
+        return out
+
+    def backward_all(self, g):
+        x, w = self.last[0], self.last[1]
+        b = self.last[2] if self.has_bias else None
+        fin, fout = w.shape
+        grads = [None, None, None][:len(self.last)]
+        if self.xp is np:
+            g2, x2 = g.reshape(-1, fout), x.data.reshape(-1, fin)
+            if x.requires_grad:
+                grads[0] = (g2 @ w.data.T).reshape(x.shape)
+            if w.requires_grad:
+                grads[1] = x2.T @ g2
+            if b is not None and b.requires_grad:
+                grads[2] = g2.sum(0).reshape(b.shape)
+            return grads
+        hp = _hip()
+        g2 = _contig(g).reshape(-1, fout)
+        x2 = x.data.reshape(-1, fin)
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            hp.gemm(g2, w.data.T, dx.reshape(-1, fin))                     # NT
+            grads[0] = dx
+        if w.requires_grad:
+            if _is_leaf_f32(w):
+                hp.gemm(x2.T, g2, w.grad, beta=1.0)                        # TN, += into the leaf
+            else:
+                dw = hp.empty((fin, fout), np.float32)
+                hp.gemm(x2.T, g2, dw)
+                grads[1] = dw
+        if b is not None and b.requires_grad:
+            grads[2] = g2.sum(0).reshape(b.shape)
+        return grads
+
+
+class rms_norm(_Operator):
+    """y = x / sqrt(mean(x^2, -1) + eps) * w   (w 1-D over the last axis)."""
+
+    def __init__(self, x, weight, eps=1e-6):
+        self.eps = float(eps)
+        super().__init__(x, weight)
+
+    def forward_(self, x, w):
+        if self.xp is np:
+            self._rms = np.sqrt((x.data * x.data).mean(-1, keepdims=True) + np.asarray(self.eps, x.dtype))
+            return x.data / self._rms * w.data
+        hp, L = _hip(), _L()
+        cols = x.shape[-1]
+        self._x = _contig(x.data)
+        rows = self._x.size // cols
+        out = hp.empty(x.shape, np.float32)
+        self._rms = hp.empty((rows,), np.float32)
+        L.call("pdn_rmsnorm_fwd_f32", self._x._ptr, w.data._ptr, out._ptr, self._rms._ptr, rows, cols,
+               self.eps, hp.stream())
+        return out
+
+    def backward_all(self, g):
+        x, w = self.last
+        if self.xp is np:
+            z = x.data / self._rms
+            dz = g * w.data
+            dx = (dz - z * (z * dz).mean(-1, keepdims=True)) / self._rms
+            return [dx if x.requires_grad else None,
+                    (g * z).reshape(-1, w.shape[-1]).sum(0) if w.requires_grad else None]
+        hp, L = _hip(), _L()
+        cols = x.shape[-1]
+        rows = self._x.size // cols
+        g = _contig(g)
+        dx = hp.empty(x.shape, np.float32)
+        direct = w.requires_grad and _is_leaf_f32(w)
+        dw = w.grad if direct else (hp.empty((cols,), np.float32) if w.requires_grad else None)
+        ws, wsb = hp.workspace(L.query("pdn_rmsnorm_bwd_workspace_bytes", rows, cols))
+        L.call("pdn_rmsnorm_bwd_f32", self._x._ptr, w.data._ptr, self._rms._ptr, g._ptr, dx._ptr,
+               dw._ptr if dw is not None else None, 1 if direct else 0, rows, cols, ws, wsb, hp.stream())
+        return [dx if x.requires_grad else None, None if direct else dw]
+
+
+class swiglu(_Operator):
+    """y = silu(gate) * up,  silu(g) = g / (1 + exp(-g))."""
+
+    def forward_(self, gate, up):
+        if self.xp is np:
+            return gate.data / (1 + np.exp(-gate.data)) * up.data
+        hp, L = _hip(), _L()
+        self._g, self._u = _contig(gate.data), _contig(up.data)
+        out = hp.empty(gate.shape, np.float32)
+        L.call("pdn_swiglu_fwd_f32", self._g._ptr, self._u._ptr, out._ptr, out.size, hp.stream())
+        return out
+
+    def backward_all(self, dy):
+        gate, up = self.last
+        if self.xp is np:
+            s = 1 / (1 + np.exp(-gate.data))
+            return [dy * up.data * s * (1 + gate.data * (1 - s)), dy * gate.data * s]
+        hp, L = _hip(), _L()
+        dy = _contig(dy)
+        dg, du = hp.empty(gate.shape, np.float32), hp.empty(gate.shape, np.float32)
+        L.call("pdn_swiglu_bwd_f32", self._g._ptr, self._u._ptr, dy._ptr, dg._ptr, du._ptr, dy.size, hp.stream())
+        return [dg, du]
+
+
+class silu(_Operator):
+    def forward_(self, x):
+        if self.xp is np:
+            return x.data / (1 + np.exp(-x.data))
+        hp, L = _hip(), _L()
+        self._x = _contig(x.data)
+        out = hp.empty(x.shape, np.float32)
+        L.call("pdn_swiglu_fwd_f32", self._x._ptr, None, out._ptr, out.size, hp.stream())
+        return out
+
+    def backward_all(self, dy):
+        x = self.last[0]
+        if self.xp is np:
+            s = 1 / (1 + np.exp(-x.data))
+            return [dy * s * (1 + x.data * (1 - s))]
+        hp, L = _hip(), _L()
+        dy = _contig(dy)
+        dx = hp.empty(x.shape, np.float32)
+        L.call("pdn_swiglu_bwd_f32", self._x._ptr, None, dy._ptr, dx._ptr, None, dy.size, hp.stream())
+        return [dx]
+
+
+class relu(_Operator):
+    """maximum(0., x); the gradient passes where out == x, i.e. also at x == 0 (reference quirk)."""
+
+    def forward_(self, x):
+        return self.xp.maximum(np.array(0., dtype=x.dtype) if self.xp is np else 0.0, x.data)
+
+    def backward_all(self, dy):
+        x = self.last[0]
+        if self.xp is np or x.dtype != np.float32:
+            return [(self.data == x.data) * dy]
+        hp, L = _hip(), _L()
+        xd, dy = _contig(x.data), _contig(dy)
+        dx = hp.empty(x.shape, np.float32)
+        L.call("pdn_relu_bwd_f32", xd._ptr, dy._ptr, dx._ptr, dy.size, hp.stream())
+        return [dx]
+
+
+class softmax(_Operator):
+    """softmax over the LAST axis (x - rowmax; the max is not differentiated, as in the reference)."""
+
+    def forward_(self, x):
+        if self.xp is np:
+            e = np.exp(x.data - x.data.max(-1, keepdims=True))
+            return e / e.sum(-1, keepdims=True)
+        hp, L = _hip(), _L()
+        xd = _contig(x.data)
+        cols = x.shape[-1]
+        out = hp.empty(x.shape, np.float32)
+        L.call("pdn_softmax_fwd_f32", xd._ptr, out._ptr, xd.size // cols, cols, 1.0, 0, 0, hp.stream())
+        return out
+
+    def backward_all(self, dy):
+        y = self.data
+        if self.xp is np:
+            return [(dy - (dy * y).sum(-1, keepdims=True)) * y]
+        hp, L = _hip(), _L()
+        dy = _contig(dy)
+        cols = y.shape[-1]
+        dx = hp.empty(y.shape, np.float32)
+        L.call("pdn_softmax_bwd_f32", y._ptr, dy._ptr, dx._ptr, y.size // cols, cols, 1.0, hp.stream())
+        return [dx]
+
+
+class rope(_Operator):
+    """Rotary embedding on interleaved pairs; x: (B, L, H, hd), cos/sin: (L, hd/2) (no grad)."""
+
+    def __init__(self, x, cos, sin):
+        self._cos, self._sin = cos, sin
+        super().__init__(x)
+
+    def _apply(self, a, sign):
+        B, Lq, H, hd = a.shape
+        cos, sin = self._cos.data, self._sin.data
+        if self.xp is np:
+            r, i = a[..., 0::2], a[..., 1::2]
+            c, s = cos[None, :, None, :], sign * sin[None, :, None, :]
+            out = np.empty(a.shape, dtype=a.dtype)
+            out[..., 0::2] = r * c - i * s
+            out[..., 1::2] = r * s + i * c
+            return out
+        hp, L = _hip(), _L()
+        a, cos, sin = _contig(a), _contig(cos), _contig(sin)   # locals keep any copies alive
+        out = hp.empty(a.shape, np.float32)
+        L.call("pdn_rope_f32", a._ptr, cos._ptr, sin._ptr, out._ptr, B * Lq, Lq, H, hd,
+               1 if sign < 0 else 0, hp.stream())
+        return out
+
+    def forward_(self, x):
+        return self._apply(x.data, 1.0)
+
+    def backward_all(self, dy):
+        return [self._apply(dy, -1.0)]
+
+
+class attention(_Operator):
+    """softmax(q k^T / sqrt(hd) + causal_mask) v  per (batch, head).
+
+    q: (B, L, H, hd); k, v: (B, Lk, H, hd) -- the layout the Q/K/V projections produce, consumed
+    through strides (no transposes, no copies).  Output (B, L, H, hd).  `causal` applies the
+    additive -inf upper-triangular mask of llm/llama/model.py:199-203 with `start_pos`."""
+
+    def __init__(self, q, k, v, causal=True, start_pos=0):
+        self.causal, self.start_pos = bool(causal), int(start_pos)
+        super().__init__(q, k, v)
+
+    def forward_(self, q, k, v):
+        B, Lq, H, hd = q.shape
+        Lk = k.shape[1]
+        if self.xp is np:
+            s = np.matmul(q.data.transpose(0, 2, 1, 3), k.data.transpose(0, 2, 3, 1)) / np.asarray(math.sqrt(hd), q.dtype)
+            if self.causal and Lq > 1:
+                m = np.triu(np.full((Lq, Lq), float("-inf")), k=1)
+                s = s + np.concatenate([np.zeros((Lq, self.start_pos)), m], axis=1).astype(q.dtype)
+            e = np.exp(s - s.max(-1, keepdims=True))
+            self._p = e / e.sum(-1, keepdims=True)
+            return np.ascontiguousarray(np.matmul(self._p, v.data.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3))
+        hp, L = _hip(), _L()
+        p = hp.empty((B, H, Lq, Lk), np.float32)
+        hp.gemm(q.data.transpose(0, 2, 1, 3), k.data.transpose(0, 2, 3, 1), p)
+        L.call("pdn_softmax_fwd_f32", p._ptr, p._ptr, B * H * Lq, Lk, math.sqrt(hd),
+               Lq if (self.causal and Lq > 1) else 0, self.start_pos, hp.stream())
+        self._p = p
+        out = hp.empty((B, Lq, H, hd), np.float32)
+        hp.gemm(p, v.data.transpose(0, 2, 1, 3), out.transpose(0, 2, 1, 3))
+        return out
+
+    def backward_all(self, do):
+        q, k, v = self.last
+        B, Lq, H, hd = q.shape
+        Lk = k.shape[1]
+        p = self._p
+        if self.xp is np:
+            doT = do.transpose(0, 2, 1, 3)
+            dv = np.matmul(p.swapaxes(-1, -2), doT).transpose(0, 2, 1, 3)
+            dp = np.matmul(doT, v.data.transpose(0, 2, 3, 1))
+            ds = (dp - (dp * p).sum(-1, keepdims=True)) * p / np.asarray(math.sqrt(hd), q.dtype)
+            dq = np.matmul(ds, k.data.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
+            dk = np.matmul(ds.swapaxes(-1, -2), q.data.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
+            return [dq, dk, dv]
+        hp, L = _hip(), _L()
+        doT = do.transpose(0, 2, 1, 3)
+        dv = hp.empty(v.shape, np.float32)
+        hp.gemm(p.swapaxes(-1, -2), doT, dv.transpose(0, 2, 1, 3))                  # P^T dO
+        dp = hp.empty(p.shape, np.float32)
+        hp.gemm(doT, v.data.transpose(0, 2, 3, 1), dp)                              # dO V^T
+        L.call("pdn_softmax_bwd_f32", p._ptr, dp._ptr, dp._ptr, B * H * Lq, Lk, math.sqrt(hd), hp.stream())
+        dq, dk = hp.empty(q.shape, np.float32), hp.empty(k.shape, np.float32)
+        hp.gemm(dp, k.data.transpose(0, 2, 1, 3), dq.transpose(0, 2, 1, 3))         # dS K
+        hp.gemm(dp.swapaxes(-1, -2), q.data.transpose(0, 2, 1, 3), dk.transpose(0, 2, 1, 3))  # dS^T Q
+        return [dq, dk, dv]
+
+
+class embedding(_Operator):
+    """out = W[ids]; gradient = scatter-ASSIGN of the last occurrence of each id (reference
+    semantics, tensor.py:937-940); `accumulate=True` opts into torch-style scatter-add."""
+
+    accumulate = False
+
+    def __init__(self, ids, weight):
+        if isinstance(ids, Tensor):
+            ids = ids.data
+        self._ids = ids
+        super().__init__(weight)
+
+    def forward_(self, w):
+        if self.xp is np:
+            return w.data[self._ids]
+        hp = _hip()
+        if isinstance(self._ids, np.ndarray) or not hasattr(self._ids, "_ptr"):
+            self._ids = hp.from_numpy(np.asarray(self._ids).astype(np.int64))
+        return w.data[self._ids]
+
+    def backward_all(self, g):
+        w = self.last[0]
+        if self.xp is np:
+            full = np.zeros(w.shape, dtype=w.dtype)
+            if self.accumulate:
+                np.add.at(full, self._ids, g)
+            else:
+                full[self._ids] = g
+            return [full]
+        hp, L = _hip(), _L()
+        V, D = w.shape
+        g = _contig(g)
+        ids = _contig(self._ids)
+        ws, wsb = hp.workspace(V * 4)
+        if _is_leaf_f32(w):
+            L.call("pdn_embedding_scatter_f32", g._ptr, ids._ptr, ids.size, w.grad._ptr, V, D,
+                   2 if self.accumulate else 1, ws, wsb, hp.stream())
+            return [None]
+        full = hp.zeros(w.shape, np.float32)
+        L.call("pdn_embedding_scatter_f32", g._ptr, ids._ptr, ids.size, full._ptr, V, D,
+               2 if self.accumulate else 0, ws, wsb, hp.stream())
+        return [full]
+
+
+class cross_entropy(_Operator):
+    """mean / sum over rows of  logsumexp(x_n) - x_n[t_n]   (integer targets)."""
+
+    def __init__(self, logits, targets, reduction="mean"):
+        if reduction not in ("mean", "sum"):
+            raise ValueError("reduction must be mean or sum.")
+        self.reduction = reduction
+        self._t = targets.data if isinstance(targets, Tensor) else targets
+        super().__init__(logits)
+
+    def forward_(self, x):
+        n, V = x.shape
+        if self.xp is np:
+            t = np.asarray(self._t)
+            m = x.data.max(-1, keepdims=True)
+            self._lse = np.log(np.exp(x.data - m).sum(-1, keepdims=True)) + m
+            rows = self._lse[:, 0] - x.data[np.arange(n), t]
+            return rows.mean() if self.reduction == "mean" else rows.sum()
+        hp, L = _hip(), _L()
+        if not hasattr(self._t, "_ptr"):
+            self._t = hp.from_numpy(np.asarray(self._t).astype(np.int64))
+        self._x = _contig(x.data)
+        self._t = _contig(self._t)
+        loss_row = hp.empty((n,), np.float32)
+        self._lse = hp.empty((n,), np.float32)
+        out = hp.empty((1,), np.float32)
+        L.call("pdn_cross_entropy_fwd_f32", self._x._ptr, self._t._ptr, n, V,
+               1 if self.reduction == "mean" else 0, loss_row._ptr, self._lse._ptr, out._ptr,
+               hp._err_flag().data_ptr(), hp.stream())
+        return out.reshape(())
+
+    def backward_all(self, g):
+        x = self.last[0]
+        n, V = x.shape
+        scale = 1.0 / n if self.reduction == "mean" else 1.0
+        if self.xp is np:
+            sm = np.exp(x.data - self._lse)
+            sm[np.arange(n), np.asarray(self._t)] -= 1
+            return [sm * (g * np.asarray(scale, x.dtype))]
+        hp, L = _hip(), _L()
+        dx = hp.empty((n, V), np.float32)
+        g = _contig(g)
+        L.call("pdn_cross_entropy_bwd_f32", self._x._ptr, self._t._ptr, self._lse._ptr, g._ptr,
+               scale, dx._ptr, n, V, hp.stream())
+        return [dx]
+
+
+class conv2d(_Operator):
+    """Square-kernel 2-D convolution = im2col + ONE batched GEMM (nn/functional.py:254-281).
+
+    The im2col buffer keeps the reference layout (N, C, kh, kw, oh, ow); per image it is read by
+    the GEMM as an M-contiguous A operand, the kernel tensor (O, C*k*k) as a K-contiguous B
+    operand, and the product lands in an NHWC buffer that is returned as an NCHW view -- the
+    same (non-contiguous) memory layout the reference produces.  Optional bias (1, O, 1, 1) is
+    fused into the GEMM epilogue."""
+
+    def __init__(self, x, kernel, bias=None, padding=0, stride=1):
+        self.padding, self.stride = int(padding), int(stride)
+        self.has_bias = bias is not None
+        super().__init__(*((x, kernel, bias) if self.has_bias else (x, kernel)))
+
+    def _dims(self, x, kernel):
+        N, C, H, W = x.shape
+        O, _, k, _ = kernel.shape
+        oh = (H + 2 * self.padding - k) // self.stride + 1
+        ow = (W + 2 * self.padding - k) // self.stride + 1
+        return N, C, H, W, O, k, oh, ow
+
+    def _im2col_np(self, xd, k):
+        p, s = self.padding, self.stride
+        xp_ = np.pad(xd, [(0, 0), (0, 0), (p, p), (p, p)], "constant")
+        N, C, H, W = xp_.shape
+        oh, ow = (H - k) // s + 1, (W - k) // s + 1
+        s0, s1, s2, s3 = xp_.strides
+        return np.lib.stride_tricks.as_strided(xp_, (N, C, k, k, oh, ow), (s0, s1, s2, s3, s2 * s, s3 * s)).copy()
+
+    def forward_(self, x, kernel, bias=None):
+        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        if self.xp is np:
+            self._col = self._im2col_np(x.data, k)
+            a = self._col.transpose(0, 4, 5, 1, 2, 3).reshape(N * oh * ow, -1)
+            out = a @ kernel.data.reshape(O, -1).T
+            if bias is not None:
+                out = out + bias.data.reshape(1, O)
+            return out.reshape(N, oh, ow, O).transpose(0, 3, 1, 2)
+        hp, L = _hip(), _L()
+        xd = _contig(x.data)
+        col = hp.empty((N, C, k, k, oh, ow), np.float32)
+        L.call("pdn_im2col2d_f32", xd._ptr, N, C, H, W, k, self.stride, self.padding, col._ptr, hp.stream())
+        self._col = col
+        K = C * k * k
+        out = hp.empty((N, oh, ow, O), np.float32)
+        w2 = _contig(kernel.data).reshape(O, K)
+        hp.gemm(col.reshape(N, K, oh * ow).transpose(0, 2, 1), w2.T, out.reshape(N, oh * ow, O),
+                bias=_contig(bias.data).reshape(-1) if bias is not None else None)
+        return out.transpose(0, 3, 1, 2)
+
+    def backward_all(self, g):
+        x, kernel = self.last[0], self.last[1]
+        bias = self.last[2] if self.has_bias else None
+        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        K, M = C * k * k, oh * ow
+        grads = [None] * len(self.last)
+        if self.xp is np:
+            g2 = g.transpose(0, 2, 3, 1).reshape(N * M, O)
+            a = self._col.transpose(0, 4, 5, 1, 2, 3).reshape(N * M, K)
+            if kernel.requires_grad:
+                grads[1] = (g2.T @ a).reshape(kernel.shape)
+            if bias is not None and bias.requires_grad:
+                grads[2] = g2.sum(0).reshape(bias.shape)
+            if x.requires_grad:
+                dcol = (g2 @ kernel.data.reshape(O, K)).reshape(N, oh, ow, C, k, k).transpose(0, 3, 4, 5, 1, 2)
+                p, s = self.padding, self.stride
+                dxp = np.zeros((N, C, H + 2 * p, W + 2 * p), dtype=g.dtype)
+                s0, s1, s2, s3 = dxp.strides
+                view = np.lib.stride_tricks.as_strided(dxp, (N, C, k, k, oh, ow), (s0, s1, s2, s3, s2 * s, s3 * s))
+                np.add.at(view, (...,), dcol)
+                grads[0] = dxp[:, :, p:p + H, p:p + W] if p else dxp
+            return grads
+        hp, L = _hip(), _L()
+        g2 = _contig(g.transpose(0, 2, 3, 1)).reshape(N, M, O)          # NHWC rows
+        w2 = _contig(kernel.data).reshape(O, K)
+        colT = self._col.reshape(N, K, M)
+        if kernel.requires_grad:
+            part = hp.empty((N, O, K), np.float32)
+            hp.gemm(g2.transpose(0, 2, 1), colT.transpose(0, 2, 1), part)     # per image g^T col
+            grads[1] = part.sum(0).reshape(kernel.shape)
+        if bias is not None and bias.requires_grad:
+            grads[2] = g2.reshape(N * M, O).sum(0).reshape(bias.shape)
+        if x.requires_grad:
+            dcol = hp.empty((N, K, M), np.float32)
+            hp.gemm(w2.T, g2.transpose(0, 2, 1), dcol)                        # (K,O) (O,M) per image
+            dx = hp.empty((N, C, H, W), np.float32)
+            L.call("pdn_col2im2d_f32", dcol._ptr, N, C, H, W, k, self.stride, self.padding, dx._ptr, hp.stream())
+            grads[0] = dx
+        return grads
+
+
+class pool2d(_Operator):
+    """max / avg pooling over k x k windows of the zero-padded input (nn/functional.py:284-339)."""
+
+    def __init__(self, x, kernel_size, stride, padding=0, mode="max"):
+        self.k, self.stride, self.padding = int(kernel_size), int(stride), int(padding)
+        self.mode = mode
+        super().__init__(x)
+
+    def _windows(self, xd):
+        p, s, k = self.padding, self.stride, self.k
+        xp_ = np.pad(xd, [(0, 0), (0, 0), (p, p), (p, p)], "constant")
+        N, C, H, W = xp_.shape
+        oh, ow = (H - k) // s + 1, (W - k) // s + 1
+        s0, s1, s2, s3 = xp_.strides
+        return xp_, np.lib.stride_tricks.as_strided(xp_, (N, C, oh, ow, k, k), (s0, s1, s2 * s, s3 * s, s2, s3))
+
+    def forward_(self, x):
+        N, C, H, W = x.shape
+        if self.xp is np:
+            _, win = self._windows(x.data)
+            return win.max((-1, -2)) if self.mode == "max" else win.mean((-1, -2))
+        hp, L = _hip(), _L()
+        self._x = _contig(x.data)
+        oh = (H + 2 * self.padding - self.k) // self.stride + 1
+        ow = (W + 2 * self.padding - self.k) // self.stride + 1
+        out = hp.empty((N, C, oh, ow), np.float32)
+        L.call("pdn_pool2d_fwd_f32", self._x._ptr, N, C, H, W, self.k, self.stride, self.padding,
+               0 if self.mode == "max" else 1, out._ptr, hp.stream())
+        return out
+
+    def backward_all(self, g):
+        x = self.last[0]
+        N, C, H, W = x.shape
+        if self.xp is np:
+            p = self.padding
+            xpad, win = self._windows(x.data)
+            dxp = np.zeros(xpad.shape, dtype=g.dtype)
+            s0, s1, s2, s3 = dxp.strides
+            s = self.stride
+            view = np.lib.stride_tricks.as_strided(dxp, win.shape, (s0, s1, s2 * s, s3 * s, s2, s3))
+            if self.mode == "max":
+                contrib = (win == self.data[..., None, None]) * g[..., None, None]
+            else:
+                contrib = np.broadcast_to(g[..., None, None] / (self.k * self.k), win.shape)
+            np.add.at(view, (...,), contrib)
+            return [dxp[:, :, p:p + H, p:p + W] if p else dxp]
+        hp, L = _hip(), _L()
+        dx = hp.empty(x.shape, np.float32)
+        y, g = _contig(self.data), _contig(g)
+        L.call("pdn_pool2d_bwd_f32", self._x._ptr, y._ptr, g._ptr, N, C, H, W,
+               self.k, self.stride, self.padding, 0 if self.mode == "max" else 1, dx._ptr, hp.stream())
+        return [dx]

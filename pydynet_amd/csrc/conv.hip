@@ -1,0 +1,170 @@
+// im2col / col2im / pooling kernels for the Conv2d path (gfx950), fp32.
+//
+// Reference: pydynet/nn/functional.py:194-339.  The reference pads (xp.pad, :241-245), builds a
+// strided window view and copies it (`as_strided(...).copy()`, :211-222) into the layout
+// (N, C, kh, kw, oh, ow); the backward is `xp.add.at` on the overlapping view (:224-232).
+// Here padding is folded into the gather (values are identical: bit-exact `col`), and the
+// backward is a GATHER per input pixel over the <= k*k windows that cover it, so it needs no
+// atomics and is deterministic.  These are pure HBM streams: every lane walks the fastest
+// (ow / W) index so loads and stores coalesce.
+#include "common.h"
+
+// col[n][c][i][j][oy][ox] = x[n][c][oy*s + i - p][ox*s + j - p]   (0 outside)
+__global__ void im2col2d_kernel(const float* __restrict__ x, float* __restrict__ col, int N, int C,
+                                int H, int W, int k, int s, int p, int oh, int ow) {
+  const int64_t total = (int64_t)N * C * k * k * oh * ow;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int ox = (int)(t % ow); t /= ow;
+    const int oy = (int)(t % oh); t /= oh;
+    const int j = (int)(t % k); t /= k;
+    const int i = (int)(t % k); t /= k;      // t = n*C + c
+    const int y = oy * s + i - p, xx = ox * s + j - p;
+    float v = 0.f;
+    if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(t * H + y) * W + xx];
+    col[idx] = v;
+  }
+}
+
+// dx[n][c][y][x] = sum over (i,j) with (y+p-i) % s == 0, (x+p-j) % s == 0 of dcol[n][c][i][j][oy][ox]
+__global__ void col2im2d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int N, int C,
+                                int H, int W, int k, int s, int p, int oh, int ow) {
+  const int64_t total = (int64_t)N * C * H * W;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int xx = (int)(t % W); t /= W;
+    const int y = (int)(t % H); t /= H;      // t = n*C + c
+    const float* base = dcol + t * (int64_t)k * k * oh * ow;
+    float acc = 0.f;
+    for (int i = 0; i < k; ++i) {
+      const int ny = y + p - i;
+      if (ny < 0 || ny % s) continue;
+      const int oy = ny / s;
+      if (oy >= oh) continue;
+      for (int j = 0; j < k; ++j) {
+        const int nx = xx + p - j;
+        if (nx < 0 || nx % s) continue;
+        const int ox = nx / s;
+        if (ox >= ow) continue;
+        acc += base[((int64_t)(i * k + j) * oh + oy) * ow + ox];
+      }
+    }
+    dx[idx] = acc;
+  }
+}
+
+// Pooling over k x k windows of the zero-padded input (the pad value 0 takes part in max,
+// exactly as in the reference where pooling runs on the padded array).  mode 0 = max, 1 = avg.
+// Output is NCHW contiguous.
+__global__ void pool2d_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int NC, int H,
+                                  int W, int k, int s, int p, int oh, int ow, int mode) {
+  const int64_t total = (int64_t)NC * oh * ow;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int ox = (int)(t % ow); t /= ow;
+    const int oy = (int)(t % oh); t /= oh;
+    const float* xp = x + t * (int64_t)H * W;
+    float acc = mode == 0 ? -INFINITY : 0.f;
+    for (int i = 0; i < k; ++i)
+      for (int j = 0; j < k; ++j) {
+        const int yy = oy * s + i - p, xx = ox * s + j - p;
+        const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xp[yy * W + xx] : 0.f;
+        acc = mode == 0 ? fmaxf(acc, v) : acc + v;
+      }
+    y[idx] = mode == 0 ? acc : acc / (float)(k * k);
+  }
+}
+
+// max: every position equal to its window's max receives that window's gradient (ties all get
+// it: tensor.py:744-750); avg: g / k^2.  Gather formulation over the windows covering a pixel.
+__global__ void pool2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                  const float* __restrict__ dy, float* __restrict__ dx, int NC, int H,
+                                  int W, int k, int s, int p, int oh, int ow, int mode) {
+  const int64_t total = (int64_t)NC * H * W;
+  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = idx;
+    const int xx = (int)(t % W); t /= W;
+    const int yy = (int)(t % H); t /= H;
+    const float v = x[idx];
+    const float* yp = y + t * (int64_t)oh * ow;
+    const float* gp = dy + t * (int64_t)oh * ow;
+    float acc = 0.f;
+    for (int i = 0; i < k; ++i) {
+      const int ny = yy + p - i;
+      if (ny < 0 || ny % s) continue;
+      const int oy = ny / s;
+      if (oy >= oh) continue;
+      for (int j = 0; j < k; ++j) {
+        const int nx = xx + p - j;
+        if (nx < 0 || nx % s) continue;
+        const int ox = nx / s;
+        if (ox >= ow) continue;
+        const float g = gp[oy * ow + ox];
+        if (mode == 0) acc += (yp[oy * ow + ox] == v) ? g : 0.f;
+        else acc += g / (float)(k * k);
+      }
+    }
+    dx[idx] = acc;
+  }
+}
+
+static inline int grid1d(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+#define CONV_ARGS_OK(name)                                                                   \
+  PDN_CHECK_ARG(N >= 0 && C > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0, name ": bad dims"); \
+  const int oh = (H + 2 * pad - k) / stride + 1, ow = (W + 2 * pad - k) / stride + 1;         \
+  PDN_CHECK_ARG(oh > 0 && ow > 0, name ": kernel larger than padded input");
+
+extern "C" int pdn_im2col2d_f32(const float* x, int N, int C, int H, int W, int k, int stride,
+                                int pad, float* col, void* stream) {
+  CONV_ARGS_OK("pdn_im2col2d_f32")
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && col, "pdn_im2col2d_f32: null operand");
+  hipLaunchKernelGGL(im2col2d_kernel, dim3(grid1d((int64_t)N * C * k * k * oh * ow)), dim3(256), 0,
+                     (hipStream_t)stream, x, col, N, C, H, W, k, stride, pad, oh, ow);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_col2im2d_f32(const float* dcol, int N, int C, int H, int W, int k, int stride,
+                                int pad, float* dx, void* stream) {
+  CONV_ARGS_OK("pdn_col2im2d_f32")
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(dcol && dx, "pdn_col2im2d_f32: null operand");
+  hipLaunchKernelGGL(col2im2d_kernel, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0,
+                     (hipStream_t)stream, dcol, dx, N, C, H, W, k, stride, pad, oh, ow);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_pool2d_fwd_f32(const float* x, int N, int C, int H, int W, int k, int stride,
+                                  int pad, int mode, float* y, void* stream) {
+  CONV_ARGS_OK("pdn_pool2d_fwd_f32")
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && y && (mode == 0 || mode == 1), "pdn_pool2d_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(pool2d_fwd_kernel, dim3(grid1d((int64_t)N * C * oh * ow)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, N * C, H, W, k, stride, pad, oh, ow, mode);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, int C,
+                                  int H, int W, int k, int stride, int pad, int mode, float* dx,
+                                  void* stream) {
+  CONV_ARGS_OK("pdn_pool2d_bwd_f32")
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && y && dy && dx && (mode == 0 || mode == 1), "pdn_pool2d_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0,
+                     (hipStream_t)stream, x, y, dy, dx, N * C, H, W, k, stride, pad, oh, ow, mode);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

@@ -141,6 +141,7 @@ class ndarray:
 
     __slots__ = ("_buf", "_ptr", "shape", "_strides", "dtype", "__weakref__")
     __array_priority__ = 1000.0
+    __array_ufunc__ = None     # numpy scalars/arrays defer to our reflected operators
 
     def __init__(self, buf, ptr, shape, strides, dtype):
         self._buf = buf
@@ -403,10 +404,12 @@ def empty_like(a, dtype=None): return empty(a.shape, dtype or a.dtype)
 
 
 def from_numpy(a: np.ndarray) -> ndarray:
-    a = np.ascontiguousarray(a)
+    a = np.asarray(a, order="C")          # (np.ascontiguousarray would turn 0-d into 1-d)
     _dtcode(a.dtype)
     t = _t()
-    buf = t.from_numpy(a.reshape(-1) if a.size else np.zeros(1, a.dtype)).to(_dev())
+    buf = t.from_numpy(a.reshape(-1) if a.size else np.zeros(1, a.dtype))
+    dev = _dev()
+    buf = buf.to(dev) if dev != "cpu" else buf.clone()   # "cpu" only under the test emulator
     return ndarray(buf, buf.data_ptr(), a.shape, _contig_strides(a.shape), a.dtype)
 
 
@@ -674,20 +677,17 @@ def _advanced_get(a: ndarray, key):
             raise IndexError("shape mismatch: indexing arrays could not be broadcast together")
         src = a if a._strides[1] == 1 else a.copy()
         out = empty((a.shape[0],), a.dtype)
+        idx = ascontiguousarray(idx)
         L.call("pdn_take_cols_f32", src._ptr, a.shape[0], a.shape[1], src._strides[0],
-               ascontiguousarray(idx)._ptr, out._ptr, _err_flag().data_ptr(), _state["stream"])
+               idx._ptr, out._ptr, _err_flag().data_ptr(), _state["stream"])
         return out
     # integer array on axis 0 (embedding lookup), trailing basic keys applied afterwards
-    if not _is_basic(key[0]) and all(_is_basic(k) for k in key[1:]) and a.dtype == np.float32:
+    if (a.ndim >= 1 and not _is_basic(key[0]) and all(_is_basic(k) for k in key[1:])
+            and a.dtype == np.float32):
         idx = ascontiguousarray(_index_array(key[0]))
-        src = a if a.ndim >= 1 and a[0:1].reshape(-1).is_contiguous() else a.copy()
-        if a.ndim == 0:
-            raise IndexError("too many indices for array")
+        inner = ndarray(a._buf, a._ptr, a.shape[1:], a._strides[1:], a.dtype)
+        src = a if inner.is_contiguous() else a.copy()
         D = int(math.prod(a.shape[1:]))
-        if a.ndim > 1 and not ndarray(a._buf, a._ptr, a.shape[1:], a._strides[1:], a.dtype).is_contiguous():
-            src = a.copy()
-        else:
-            src = a
         row_stride = src._strides[0] if src.shape[0] > 1 else _bi.max(D, 1)
         out = empty(idx.shape + a.shape[1:], a.dtype)
         L.call("pdn_embedding_gather_f32", src._ptr, a.shape[0], D, row_stride, idx._ptr, idx.size,

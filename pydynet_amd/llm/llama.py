@@ -1,0 +1,153 @@
+"""6-layer Llama3 -- the north-star workload (llm/llama/model.py of the reference), restated
+on this package's fused nodes.
+
+Same constructor signature, same registered parameter names (`layers.{i}.attention.Q.weight`,
+`layers.{i}.ffn.gate.weight`, `lm_head.bias`, ...), same construction order (so a seeded NumPy
+RNG yields the reference's initial weights), same `forward_logits / finetune_step / forward /
+generate` entry points.  What differs is the number of tape nodes per block: 62 in the
+reference, 12 here (rms_norm, 3x linear, 2x rope, attention, linear, add, rms_norm, 2x linear,
+swiglu, linear, add), each one HIP kernel or GEMM per direction.
+"""
+import math
+
+import numpy as np
+
+from .. import nn
+from ..core import Tensor, fused
+from ..special import zeros
+
+
+def compute_cos_sin_cache(head_dim: int, max_seq_len: int, base: int = 10000, dtype=None):
+    """cos/sin(outer(arange(max_seq_len), base^(-2i/head_dim))) -> two (max_seq_len, head_dim/2) tensors."""
+    inv_freq = 1.0 / (base ** (np.arange(0, head_dim, 2)[: head_dim // 2] / head_dim))
+    freqs = np.outer(np.arange(max_seq_len), inv_freq).astype(dtype)
+    return Tensor(np.cos(freqs)), Tensor(np.sin(freqs))
+
+
+def apply_rotary_emb(xq, xk, freqs_cos, freqs_sin):
+    """Rotate interleaved pairs (x[2i], x[2i+1]) of q and k by the position angle: one fused node each."""
+    return fused.rope(xq, freqs_cos, freqs_sin), fused.rope(xk, freqs_cos, freqs_sin)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, up_dim, dtype=None):
+        super().__init__()
+        self.dim, self.up_dim = dim, up_dim
+        self.up = nn.Linear(dim, up_dim, bias=False, dtype=dtype)
+        self.gate = nn.Linear(dim, up_dim, bias=False, dtype=dtype)
+        self.down = nn.Linear(up_dim, dim, bias=False, dtype=dtype)
+
+    def forward(self, x):
+        return self.down(fused.swiglu(self.gate(x), self.up(x)))
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, n_heads, max_seq_len, max_batch_size=None, dtype=None):
+        super().__init__()
+        assert dim % n_heads == 0
+        self.dim, self.n_heads, self.head_dim = dim, n_heads, dim // n_heads
+        self.Q = nn.Linear(dim, dim, bias=False, dtype=dtype)
+        self.K = nn.Linear(dim, dim, bias=False, dtype=dtype)
+        self.V = nn.Linear(dim, dim, bias=False, dtype=dtype)
+        self.O = nn.Linear(dim, dim, bias=False, dtype=dtype)
+        self.max_seq_len = max_seq_len
+        self.max_batch_size = max_batch_size if max_batch_size is not None else 1
+        shape = (self.max_batch_size, max_seq_len, n_heads, self.head_dim)
+        self.cache_k = nn.Parameter(zeros(shape, dtype=dtype), requires_grad=False)
+        self.cache_v = nn.Parameter(zeros(shape, dtype=dtype), requires_grad=False)
+
+    def __call__(self, x, start_pos, mask, freqs_cos, freqs_sin):
+        B, L, _ = x.shape
+        H, hd = self.n_heads, self.head_dim
+        xq = self.Q(x).reshape(B, L, H, hd)
+        xk = self.K(x).reshape(B, L, H, hd)
+        xv = self.V(x).reshape(B, L, H, hd)
+        xq, xk = apply_rotary_emb(xq, xk, freqs_cos, freqs_sin)
+        if not self._train:                       # KV cache: inference only (model.py:105-110)
+            self.cache_k[:B, start_pos:start_pos + L] = xk
+            self.cache_v[:B, start_pos:start_pos + L] = xv
+            xk = self.cache_k[:B, :start_pos + L]
+            xv = self.cache_v[:B, :start_pos + L]
+        out = fused.attention(xq, xk, xv, causal=mask is not None, start_pos=start_pos)
+        return self.O(out.reshape(B, L, -1))
+
+
+class TransformerBlock(nn.Module):
+    def __init__(self, dim, n_heads, ffn_dim, max_seq_len, max_batch_size=None, dtype=None):
+        super().__init__()
+        self.attention = Attention(dim, n_heads, max_seq_len, max_batch_size, dtype)
+        self.ffn = FeedForward(dim, ffn_dim, dtype)
+        self.input_norm = nn.RMSNorm(dim, dtype=dtype)
+        self.post_attn_norm = nn.RMSNorm(dim, dtype=dtype)
+
+    def forward(self, x, start_pos, mask, freqs_cos, freqs_sin):
+        z = x + self.attention(self.input_norm(x), start_pos, mask, freqs_cos, freqs_sin)
+        return z + self.ffn(self.post_attn_norm(z))
+
+
+class Llama(nn.Module):
+    def __init__(self, vocab_size, embed_dim, n_heads, ffn_dim, max_seq_len, max_batch_size=None,
+                 n_layers=6, dtype=None):
+        super().__init__()
+        self.vocab_size, self.embed_dim, self.n_heads, self.ffn_dim = vocab_size, embed_dim, n_heads, ffn_dim
+        self.max_seq_len, self.max_batch_size, self.n_layers = max_seq_len, max_batch_size, n_layers
+        self.tok_embedding = nn.Embedding(vocab_size, embed_dim, dtype=dtype)
+        cos, sin = compute_cos_sin_cache(embed_dim // n_heads, max_seq_len, dtype=dtype)
+        self.freqs_cos = nn.Parameter(cos, False)
+        self.freqs_sin = nn.Parameter(sin, False)
+        self.layers = nn.ModuleList([
+            TransformerBlock(embed_dim, n_heads, ffn_dim, max_seq_len, max_batch_size, dtype)
+            for _ in range(n_layers)])
+        self.norm = nn.RMSNorm(embed_dim, dtype=dtype)
+        self.lm_head = nn.Linear(embed_dim, vocab_size, dtype=dtype)      # bias=True, as the reference
+
+    def _forward_hidden(self, input_ids, start_pos: int):
+        L = input_ids.shape[-1]
+        h = self.tok_embedding(input_ids)
+        cos = self.freqs_cos[start_pos:start_pos + L]
+        sin = self.freqs_sin[start_pos:start_pos + L]
+        # the reference rebuilds an additive -inf mask on the host every call (model.py:199-203);
+        # here causality is a flag of the fused attention node and nothing is uploaded.
+        mask = True if L > 1 else None
+        for layer in self.layers:
+            h = layer(h, start_pos, mask, cos, sin)
+        return self.norm(h)
+
+    def forward_logits(self, input_ids, start_pos: int = 0):
+        return self.lm_head(self._forward_hidden(input_ids, start_pos))
+
+    def set_trainable_parameters(self, trainable_prefixes=("lm_head",)):
+        trainable = frozen = 0
+        for name, p in self._parameters.items():
+            p.requires_grad = any(name.startswith(pre) for pre in trainable_prefixes)
+            trainable, frozen = trainable + p.requires_grad, frozen + (not p.requires_grad)
+        return trainable, frozen
+
+    def loss(self, input_ids, target_ids, criterion=None, start_pos: int = 0):
+        logits = self.forward_logits(input_ids, start_pos)
+        B, L, V = logits.shape
+        if isinstance(target_ids, Tensor):
+            targets = target_ids.reshape(-1)
+        else:
+            targets = Tensor(np.asarray(target_ids).reshape(-1), dtype=np.int64, device=logits.device)
+        return (criterion or nn.CrossEntropyLoss())(logits.reshape(B * L, V), targets)
+
+    def finetune_step(self, input_ids, target_ids, optimizer, criterion=None, start_pos: int = 0):
+        """zero_grad -> forward -> cross entropy -> backward -> optimizer step; returns the loss."""
+        self.train(True)
+        optimizer.zero_grad()
+        loss = self.loss(input_ids, target_ids, criterion, start_pos)
+        loss.backward()
+        optimizer.step()
+        return loss.item()
+
+    def forward(self, input_ids, start_pos: int):
+        return self.lm_head(self._forward_hidden(input_ids, start_pos)[:, [-1], :])
+
+    def generate(self, input_ids, max_new_tokens: int):
+        _, L = input_ids.shape
+        next_id = None
+        for i, pos in enumerate(range(L, max_new_tokens)):
+            logits = self(input_ids, 0) if i == 0 else self(next_id, pos)
+            next_id = logits[:, -1, :].argmax(-1, True)
+            yield next_id

@@ -1,0 +1,136 @@
+"""Functional layer API (surface of pydynet/nn/functional.py).  Where the reference composes
+several generic nodes, the same mathematical function is issued as ONE fused node
+(pydynet_amd/core/fused.py) -- on a HIP device that is one hand-written kernel per direction."""
+import numpy as np
+
+from ..core import tensor, function, fused
+from ..core.tensor import Tensor
+from ..core.function import unsqueeze
+from ..autograd import no_grad
+
+
+def linear(x, weight, bias):
+    if x.ndim >= 1 and weight.ndim == 2 and x.dtype == weight.dtype and x.ndim >= 2:
+        return fused.linear(x, weight, bias)
+    affine = x @ weight
+    return affine + bias if bias is not None else affine
+
+
+def embedding(x, weight, padding_idx):
+    if weight.ndim == 2 and weight.dtype == np.float32:
+        query = fused.embedding(x, weight)
+    else:
+        query = weight[x]
+    if padding_idx is not None:
+        with no_grad():
+            mask = unsqueeze(x.ne(padding_idx), -1)
+        query = query * mask
+    return query
+
+
+def sigmoid(x): return tensor.sigmoid(x)
+def tanh(x): return tensor.tanh(x)
+def relu(x): return fused.relu(x)
+def leaky_relu(x, alpha: float): return tensor.maximum(x, alpha * x)
+
+
+def silu(x):
+    if x.dtype == np.float32:
+        return fused.silu(x)
+    return x / (1 + tensor.exp(-x))
+
+
+def softmax(x, axis=None):
+    if axis is not None and x.ndim >= 1 and axis in (-1, x.ndim - 1) and x.dtype == np.float32:
+        return fused.softmax(x)
+    with no_grad():
+        max_ = x.max(axis, keepdims=True)
+    exp_ = tensor.exp(x - max_)
+    return exp_ / tensor.sum(exp_, axis=axis, keepdims=True)
+
+
+def log_softmax(x, axis=None, keepdims=False):
+    with no_grad():
+        max_ = x.max(axis, keepdims=True)
+    shifted = x - max_
+    return shifted - tensor.log(tensor.sum(tensor.exp(shifted), axis=axis, keepdims=keepdims))
+
+
+def conv2d(x, kernel, padding: int = 0, stride: int = 1, bias=None):
+    """x (N, C, H, W), kernel (O, C, k, k); square kernel / stride / padding only."""
+    return fused.conv2d(x, kernel, bias, padding, stride)
+
+
+def max_pool2d(x, kernel_size: int, stride: int, padding=0):
+    return fused.pool2d(x, kernel_size, stride, padding, "max")
+
+
+def avg_pool2d(x, kernel_size: int, stride: int, padding=0):
+    return fused.pool2d(x, kernel_size, stride, padding, "avg")
+
+
+def _as4d(x):
+    return x.reshape(x.shape[0], x.shape[1], 1, x.shape[2])
+
+
+def conv1d(x, kernel, padding: int = 0, stride: int = 1):
+    """1-D convolution expressed on the 2-D kernels: (N, C, F) -> (N, C, 1, F) is not square, so
+    this path uses the generic operators (window gather by slicing + matmul)."""
+    N, C, F = x.shape
+    O, _, k = kernel.shape
+    if padding:
+        zeros = Tensor(np.zeros((N, C, padding)), dtype=x.dtype, device=x.device)
+        x = tensor.concat([zeros, x, zeros], axis=2)
+        F = F + 2 * padding
+    n_out = (F - k) // stride + 1
+    cols = [function.unsqueeze(x[:, :, i:i + stride * (n_out - 1) + 1:stride], 2) for i in range(k)]
+    col = tensor.concat(cols, axis=2)                       # (N, C, k, n_out)
+    return (col.transpose(0, 1, 3, 2) @ kernel.transpose(1, 2, 0)).sum(1).swapaxes(1, 2)
+
+
+def _pool1d(x, kernel_size, stride, padding, reducer):
+    N, C, F = x.shape
+    if padding:
+        zeros = Tensor(np.zeros((N, C, padding)), dtype=x.dtype, device=x.device)
+        x = tensor.concat([zeros, x, zeros], axis=2)
+        F = F + 2 * padding
+    n_out = (F - kernel_size) // stride + 1
+    cols = [function.unsqueeze(x[:, :, i:i + stride * (n_out - 1) + 1:stride], 3) for i in range(kernel_size)]
+    return reducer(tensor.concat(cols, axis=3))
+
+
+def max_pool1d(x, kernel_size, stride, padding=0):
+    return _pool1d(x, kernel_size, stride, padding, lambda c: c.max(-1))
+
+
+def avg_pool1d(x, kernel_size, stride, padding=0):
+    return _pool1d(x, kernel_size, stride, padding, lambda c: c.mean(-1))
+
+
+def _reduce(value, reduction):
+    if reduction == 'mean':
+        return tensor.mean(value)
+    if reduction == 'sum':
+        return tensor.sum(value)
+    raise ValueError("reduction must be mean or sum.")
+
+
+def mse_loss(y_pred, y_true, reduction='mean'):
+    return _reduce(function.square(y_pred - y_true), reduction)
+
+
+def nll_loss(y_pred, y_true, reduction='mean'):
+    return _reduce(-y_pred * y_true, reduction)
+
+
+def cross_entropy_loss(y_pred, y_true, reduction='mean'):
+    if reduction not in ('mean', 'sum'):
+        raise ValueError("reduction must be mean or sum.")
+    if y_true.ndim == 1 and y_pred.ndim == 2 and y_pred.dtype == np.float32:
+        return fused.cross_entropy(y_pred, y_true, reduction)
+    # one-hot / soft targets: the reference's generic chain, including its mean over N*C
+    shifted = y_pred - y_pred.max().item()
+    log_sum_exp = tensor.log(tensor.sum(tensor.exp(shifted), 1, keepdims=True))
+    neg_log_sm = log_sum_exp - shifted
+    nll = neg_log_sm[range(len(neg_log_sm)), y_true] if y_true.ndim == 1 else neg_log_sm * y_true
+    return _reduce(nll, reduction)

@@ -1,0 +1,344 @@
+"""TEST-ONLY host emulation of the pdnhip C ABI.
+
+Lets the whole Python front end (hipnp striding / broadcasting / views / indexing, the tape
+engine, nn, optim, data-parallel wrapper) run in the GPU-less container: `hipnp` is pointed
+at host memory and every `pdn_*` entry point is answered by a NumPy statement of the same
+contract (include/pdn_hip.h).  It is NOT a product path: `pydynet_amd` never imports it, and
+on the GPU box the `-m gpu` tests exercise the real library.  Numerics here follow NumPy, so
+CPU tests compare against the oracle at fp32 round-off.
+"""
+import ctypes
+import math
+
+import numpy as np
+
+from pydynet_amd import _lib
+
+_NP = {0: np.float32, 1: np.float64, 2: np.int64, 3: np.uint8, 4: np.int32}
+
+
+def _ints(arr, n):
+    return [int(arr[i]) for i in range(n)] if n else []
+
+
+def view(ptr, shape, strides, dtype):
+    """NumPy view of host memory at `ptr` with element strides (may be 0 or negative)."""
+    dtype = np.dtype(dtype)
+    shape, strides = [int(s) for s in shape], [int(s) for s in strides]
+    if any(s == 0 for s in shape) or not ptr:
+        return np.zeros(shape, dtype)
+    lo = sum((s - 1) * st for s, st in zip(shape, strides) if st < 0)
+    hi = sum((s - 1) * st for s, st in zip(shape, strides) if st > 0)
+    n = hi - lo + 1
+    buf = (ctypes.c_char * (n * dtype.itemsize)).from_address(int(ptr) + lo * dtype.itemsize)
+    base = np.frombuffer(buf, dtype=dtype)
+    return np.lib.stride_tricks.as_strided(base[-lo:], shape=shape, strides=[st * dtype.itemsize for st in strides])
+
+
+def flat(ptr, n, dtype=np.float32):
+    return view(ptr, (n,), (1,), dtype)
+
+
+class EmulatedLib:
+    def __init__(self):
+        self.protos = _lib.parse_header()
+        self.calls = []
+
+    # -- dispatch -------------------------------------------------------------------------
+    def call(self, name, *args):
+        assert name in self.protos, f"{name} is not declared in include/pdn_hip.h"
+        assert len(args) == len(self.protos[name][1]), (name, len(args), len(self.protos[name][1]))
+        self.calls.append(name)
+        rc = getattr(self, name)(*args)
+        if rc:
+            raise _lib.HipLibraryError(f"{name} failed (emulated, code {rc})")
+
+    def query(self, name, *args):
+        assert name in self.protos and len(args) == len(self.protos[name][1]), name
+        return getattr(self, name)(*args)
+
+    # -- library ----------------------------------------------------------------------------
+    def pdn_device_count(self): return 1
+    def pdn_abi_version(self): return 1
+    def pdn_stream_synchronize(self, stream): return 0
+    def pdn_gemm_f32_workspace_bytes(self, M, N, K, nb): return 64 * M * N * nb * 4
+    def pdn_rmsnorm_bwd_workspace_bytes(self, rows, cols): return 512 * cols * 4
+    def pdn_embedding_scatter_workspace_bytes(self, V): return V * 4
+    def pdn_gemm_prof_enable(self, on): return 0
+
+    # -- gemm -------------------------------------------------------------------------------
+    def pdn_gemm_f32(self, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, nb1, nb2,
+                     a1, a2, b1, b2, c1, c2, ws, wsb, stream):
+        if M == 0 or N == 0 or nb1 == 0 or nb2 == 0:
+            return 0
+        a = view(A, (nb1, nb2, M, K), (a1, a2, a_rs, a_cs), np.float32)
+        b = view(B, (nb1, nb2, K, N), (b1, b2, b_rs, b_cs), np.float32)
+        c = view(C, (nb1, nb2, M, N), (c1, c2, ldc, 1), np.float32)
+        r = np.float32(alpha) * np.matmul(a, b)
+        if bias:
+            r = r + flat(bias, N)
+        if beta != 0.0:
+            r = r + np.float32(beta) * c
+        c[...] = r
+        return 0
+
+    # -- elementwise --------------------------------------------------------------------------
+    def pdn_ew_binary(self, dt, op, mode, ndim, shape, a, sa, b, sb, scalar, out, so, stream):
+        shp = _ints(shape, ndim)
+        T = _NP[dt]
+        x = view(a, shp, _ints(sa, ndim), T)
+        y = view(b, shp, _ints(sb, ndim), T) if mode == 0 else np.asarray(scalar).astype(T)
+        if mode == 2:
+            x, y = y, x
+        if T == np.uint8:
+            x, y = x.astype(bool), (y.astype(bool) if isinstance(y, np.ndarray) else y)
+        f = {0: np.add, 1: np.subtract, 2: np.multiply, 3: np.divide, 4: np.power, 5: np.maximum,
+             6: np.minimum, 16: np.equal, 17: np.not_equal, 18: np.less, 19: np.less_equal,
+             20: np.greater, 21: np.greater_equal}[op]
+        with np.errstate(all="ignore"):
+            r = f(x, y)
+        o = view(out, shp, _ints(so, ndim), np.uint8 if op >= 16 else T)
+        o[...] = r
+        return 0
+
+    def pdn_ew_unary(self, dt, op, ndim, shape, a, sa, out, so, stream):
+        shp = _ints(shape, ndim)
+        T = _NP[dt]
+        x = view(a, shp, _ints(sa, ndim), T)
+        one = T(1)
+
+        def sig(v):
+            r = np.zeros(v.shape, v.dtype); m = v > 0
+            r[m] = 1 / (1 + np.exp(-v[m])); r[~m] = 1 - 1 / (1 + np.exp(v[~m])); return r
+
+        def tnh(v):
+            r = np.zeros(v.shape, v.dtype); m = v > 0
+            r[m] = 2 / (1 + np.exp(-2 * v[m])) - 1; r[~m] = 1 - 2 / (1 + np.exp(2 * v[~m])); return r
+
+        f = {0: lambda v: v, 1: np.negative, 2: np.exp, 3: np.log, 4: np.abs, 5: np.sign, 6: np.sqrt,
+             7: np.square, 8: lambda v: one / v, 9: sig, 10: tnh}[op]
+        with np.errstate(all="ignore"):
+            r = f(np.array(x))
+        view(out, shp, _ints(so, ndim), T)[...] = r
+        return 0
+
+    def pdn_cast(self, sdt, ddt, ndim, shape, a, sa, out, so, stream):
+        shp = _ints(shape, ndim)
+        src = np.array(view(a, shp, _ints(sa, ndim), _NP[sdt]))
+        dst = view(out, shp, _ints(so, ndim), _NP[ddt])
+        if ddt == 3:
+            dst[...] = (src != 0).astype(np.uint8)
+        else:
+            with np.errstate(all="ignore"):
+                dst[...] = src.astype(_NP[ddt])
+        return 0
+
+    def pdn_fill(self, dt, value, ndim, shape, out, so, stream):
+        view(out, _ints(shape, ndim), _ints(so, ndim), _NP[dt])[...] = np.asarray(value).astype(_NP[dt])
+        return 0
+
+    def pdn_masked_fill(self, dt, value, ndim, shape, mask, sm, out, so, stream):
+        shp = _ints(shape, ndim)
+        m = view(mask, shp, _ints(sm, ndim), np.uint8)
+        o = view(out, shp, _ints(so, ndim), _NP[dt])
+        o[m != 0] = np.asarray(value).astype(_NP[dt])
+        return 0
+
+    def pdn_reduce(self, dt, op, ndim, shape, strides, flags, x, out, ws, wsb, stream):
+        shp = _ints(shape, ndim)
+        a = np.array(view(x, shp, _ints(strides, ndim), _NP[dt]))
+        axes = tuple(i for i in range(ndim) if flags[i])
+        kept = [s for i, s in enumerate(shp) if i not in axes]
+        if op in (4, 5):
+            moved = np.moveaxis(a, axes, list(range(ndim - len(axes), ndim))).reshape(kept + [-1]) if axes else a.reshape(kept + [1])
+            r = (np.argmax if op == 4 else np.argmin)(moved, axis=-1)
+            flat(out, max(int(np.prod(kept)), 1), np.int64)[...] = np.asarray(r).reshape(-1)
+            return 0
+        f = {0: np.sum, 1: np.mean, 2: np.max, 3: np.min}[op]
+        r = f(a, axis=axes) if axes else a
+        flat(out, max(int(np.prod(kept)), 1), _NP[dt])[...] = np.asarray(r, dtype=_NP[dt]).reshape(-1)
+        return 0
+
+    # -- fused ----------------------------------------------------------------------------------
+    def pdn_softmax_fwd_f32(self, x, y, rows, cols, divisor, causal_L, start_pos, stream):
+        a = np.array(flat(x, rows * cols).reshape(rows, cols)) / np.float32(divisor)
+        if causal_L > 0:
+            r = (np.arange(rows) % causal_L)[:, None] + start_pos
+            a = np.where(np.arange(cols)[None, :] > r, -np.inf, a).astype(np.float32)
+        e = np.exp(a - a.max(-1, keepdims=True))
+        flat(y, rows * cols).reshape(rows, cols)[...] = e / e.sum(-1, keepdims=True)
+        return 0
+
+    def pdn_softmax_bwd_f32(self, y, dy, dx, rows, cols, divisor, stream):
+        p = np.array(flat(y, rows * cols).reshape(rows, cols))
+        g = np.array(flat(dy, rows * cols).reshape(rows, cols))
+        flat(dx, rows * cols).reshape(rows, cols)[...] = (g - (g * p).sum(-1, keepdims=True)) * p / np.float32(divisor)
+        return 0
+
+    def pdn_rmsnorm_fwd_f32(self, x, w, y, rms, rows, cols, eps, stream):
+        a = flat(x, rows * cols).reshape(rows, cols)
+        r = np.sqrt((a * a).mean(-1, keepdims=True) + np.float32(eps))
+        flat(y, rows * cols).reshape(rows, cols)[...] = a / r * flat(w, cols)
+        if rms:
+            flat(rms, rows)[...] = r[:, 0]
+        return 0
+
+    def pdn_rmsnorm_bwd_f32(self, x, w, rms, dy, dx, dw, acc, rows, cols, ws, wsb, stream):
+        a = flat(x, rows * cols).reshape(rows, cols)
+        g = np.array(flat(dy, rows * cols).reshape(rows, cols))
+        r = flat(rms, rows)[:, None]
+        z = a / r
+        dz = g * flat(w, cols)
+        flat(dx, rows * cols).reshape(rows, cols)[...] = (dz - z * (z * dz).mean(-1, keepdims=True)) / r
+        if dw:
+            s = (g * z).sum(0)
+            flat(dw, cols)[...] = flat(dw, cols) + s if acc else s
+        return 0
+
+    def pdn_swiglu_fwd_f32(self, g, u, y, n, stream):
+        a = flat(g, n)
+        r = a / (1 + np.exp(-a))
+        flat(y, n)[...] = r * flat(u, n) if u else r
+        return 0
+
+    def pdn_swiglu_bwd_f32(self, g, u, dy, dg, du, n, stream):
+        a, d = np.array(flat(g, n)), np.array(flat(dy, n))
+        s = 1 / (1 + np.exp(-a))
+        r = d * s * (1 + a * (1 - s))
+        if u:
+            uu = np.array(flat(u, n))
+            flat(du, n)[...] = d * a * s
+            r = r * uu
+        flat(dg, n)[...] = r
+        return 0
+
+    def pdn_relu_bwd_f32(self, x, dy, dx, n, stream):
+        a = flat(x, n)
+        flat(dx, n)[...] = np.where(np.maximum(0, a) == a, flat(dy, n), 0)
+        return 0
+
+    def pdn_rope_f32(self, x, cos, sin, y, rows, L, heads, hd, backward, stream):
+        half = hd // 2
+        a = np.array(flat(x, rows * heads * hd).reshape(rows, heads, half, 2))
+        pos = np.arange(rows) % L
+        c = flat(cos, L * half).reshape(L, half)[pos][:, None, :]
+        s = flat(sin, L * half).reshape(L, half)[pos][:, None, :] * (-1 if backward else 1)
+        o = flat(y, rows * heads * hd).reshape(rows, heads, half, 2)
+        r, i = a[..., 0], a[..., 1]
+        o[..., 0] = r * c - i * s
+        o[..., 1] = r * s + i * c
+        return 0
+
+    def pdn_embedding_gather_f32(self, W, V, D, rs, ids, n, out, err, stream):
+        w = view(W, (V, D), (rs, 1), np.float32)
+        flat(out, n * D).reshape(n, D)[...] = w[flat(ids, n, np.int64)]
+        return 0
+
+    def pdn_embedding_scatter_f32(self, g, ids, n, dW, V, D, mode, ws, wsb, stream):
+        w = flat(dW, V * D).reshape(V, D)
+        gg = np.array(flat(g, n * D).reshape(n, D))
+        idx = np.array(flat(ids, n, np.int64))
+        if mode == 0:
+            w[idx] = gg
+        elif mode == 1:
+            tmp = np.zeros((V, D), np.float32); tmp[idx] = gg
+            w += tmp
+        else:
+            np.add.at(w, idx, gg)
+        return 0
+
+    def pdn_take_cols_f32(self, x, n, C, rs, idx, out, err, stream):
+        a = view(x, (n, C), (rs, 1), np.float32)
+        flat(out, n)[...] = a[np.arange(n), flat(idx, n, np.int64)]
+        return 0
+
+    def pdn_put_cols_f32(self, g, idx, dx, n, C, stream):
+        flat(dx, n * C).reshape(n, C)[np.arange(n), flat(idx, n, np.int64)] = flat(g, n)
+        return 0
+
+    def pdn_cross_entropy_fwd_f32(self, logits, targets, rows, V, mean, loss_row, lse_row, loss_out, err, stream):
+        a = flat(logits, rows * V).reshape(rows, V)
+        t = flat(targets, rows, np.int64)
+        m = a.max(-1, keepdims=True)
+        lse = (np.log(np.exp(a - m).sum(-1, keepdims=True)) + m)[:, 0]
+        lr = lse - a[np.arange(rows), t]
+        flat(lse_row, rows)[...] = lse
+        flat(loss_row, rows)[...] = lr
+        flat(loss_out, 1)[0] = lr.mean() if mean else lr.sum()
+        return 0
+
+    def pdn_cross_entropy_bwd_f32(self, logits, targets, lse_row, upstream, gscale, dlogits, rows, V, stream):
+        a = np.array(flat(logits, rows * V).reshape(rows, V))
+        t = flat(targets, rows, np.int64)
+        sm = np.exp(a - flat(lse_row, rows)[:, None])
+        sm[np.arange(rows), t] -= 1
+        gs = np.float32(gscale) * (flat(upstream, 1)[0] if upstream else np.float32(1))
+        flat(dlogits, rows * V).reshape(rows, V)[...] = sm * gs
+        return 0
+
+    def pdn_adam_multi_f32(self, table, nchunks, step, b1, b2, omb1, omb2, eps, wd, gscale, stream):
+        tab = flat(table, nchunks * 5, np.int64).reshape(nchunks, 5)
+        f = np.float32
+        for p_, g_, m_, v_, n in tab:
+            p, g, m, v = flat(p_, n), flat(g_, n), flat(m_, n), flat(v_, n)
+            gg = g * f(gscale) + f(wd) * p
+            m[...] = m * f(b1) + f(omb1) * gg
+            v[...] = v * f(b2) + f(omb2) * (gg * gg)
+            p -= f(step) * m / (np.sqrt(v) + f(eps))
+        return 0
+
+    # -- conv ------------------------------------------------------------------------------------
+    @staticmethod
+    def _windows(xp, k, s):
+        N, C, H, W = xp.shape
+        oh, ow = (H - k) // s + 1, (W - k) // s + 1
+        s0, s1, s2, s3 = xp.strides
+        return oh, ow, (N, C, k, k, oh, ow), (s0, s1, s2, s3, s2 * s, s3 * s)
+
+    def pdn_im2col2d_f32(self, x, N, C, H, W, k, s, p, col, stream):
+        xp = np.pad(flat(x, N * C * H * W).reshape(N, C, H, W), [(0, 0), (0, 0), (p, p), (p, p)])
+        oh, ow, shape, strides = self._windows(xp, k, s)
+        flat(col, int(np.prod(shape))).reshape(shape)[...] = np.lib.stride_tricks.as_strided(xp, shape, strides)
+        return 0
+
+    def pdn_col2im2d_f32(self, dcol, N, C, H, W, k, s, p, dx, stream):
+        dxp = np.zeros((N, C, H + 2 * p, W + 2 * p), np.float32)
+        oh, ow, shape, strides = self._windows(dxp, k, s)
+        np.add.at(np.lib.stride_tricks.as_strided(dxp, shape, strides), (...,),
+                  flat(dcol, int(np.prod(shape))).reshape(shape))
+        flat(dx, N * C * H * W).reshape(N, C, H, W)[...] = dxp[:, :, p:p + H, p:p + W]
+        return 0
+
+    def pdn_pool2d_fwd_f32(self, x, N, C, H, W, k, s, p, mode, y, stream):
+        xp = np.pad(flat(x, N * C * H * W).reshape(N, C, H, W), [(0, 0), (0, 0), (p, p), (p, p)])
+        oh, ow, shape, strides = self._windows(xp, k, s)
+        win = np.lib.stride_tricks.as_strided(xp, shape, strides)
+        flat(y, N * C * oh * ow).reshape(N, C, oh, ow)[...] = win.max((2, 3)) if mode == 0 else win.mean((2, 3))
+        return 0
+
+    def pdn_pool2d_bwd_f32(self, x, y, dy, N, C, H, W, k, s, p, mode, dx, stream):
+        xp = np.pad(flat(x, N * C * H * W).reshape(N, C, H, W), [(0, 0), (0, 0), (p, p), (p, p)])
+        oh, ow, shape, strides = self._windows(xp, k, s)
+        win = np.lib.stride_tricks.as_strided(xp, shape, strides)
+        yy = flat(y, N * C * oh * ow).reshape(N, C, 1, 1, oh, ow)
+        g = flat(dy, N * C * oh * ow).reshape(N, C, 1, 1, oh, ow)
+        contrib = (win == yy) * g if mode == 0 else np.broadcast_to(g / np.float32(k * k), shape)
+        dxp = np.zeros(xp.shape, np.float32)
+        np.add.at(np.lib.stride_tricks.as_strided(dxp, shape, [st for st in dxp.strides[:2]] +
+                                                  [dxp.strides[2], dxp.strides[3], dxp.strides[2] * s, dxp.strides[3] * s]),
+                  (...,), contrib)
+        flat(dx, N * C * H * W).reshape(N, C, H, W)[...] = dxp[:, :, p:p + H, p:p + W]
+        return 0
+
+
+def install(monkeypatch):
+    """Point hipnp at host memory and the emulated library; returns the emulator."""
+    from pydynet_amd import hipnp
+    emu = EmulatedLib()
+    monkeypatch.setattr(_lib, "_LIB", emu)
+    monkeypatch.setattr(_lib, "is_built", lambda: True)
+    monkeypatch.setattr(hipnp, "_dev", lambda: "cpu")
+    monkeypatch.setattr(hipnp, "_ws", {"buf": None, "bytes": 0})
+    monkeypatch.setattr(hipnp, "_err", {"buf": None})
+    monkeypatch.setattr(hipnp, "set_device", lambda i: hipnp._state.__setitem__("device", int(i)))
+    return emu

@@ -36,3 +36,32 @@ def hip():
     _lib.lib()
     hipnp.set_device(0)
     return hipnp
+
+
+@pytest.fixture()
+def emulated_hip(monkeypatch):
+    """hipnp running on host memory against the NumPy emulation of the C ABI (tests/abi_emulator.py)."""
+    from tests import abi_emulator
+    from pydynet_amd import hipnp
+    from pydynet_amd.core.tensor import Graph
+    abi_emulator.install(monkeypatch)
+    Graph.clear()
+    yield hipnp
+    Graph.clear()
+
+
+def device_variants(namespace, fn):
+    """Register `fn(device)` twice: on the real MI355X (-m gpu) and on the emulated ABI (CPU)."""
+    name = fn.__name__.replace("check_", "")
+
+    @pytest.mark.gpu
+    def on_gpu(hip):
+        from pydynet_amd.core.tensor import Graph
+        Graph.clear()
+        fn("hip:0")
+
+    def on_emulator(emulated_hip):
+        fn("hip:0")
+
+    namespace[f"test_{name}_gpu"] = on_gpu
+    namespace[f"test_{name}_emulated"] = on_emulator

@@ -1,0 +1,367 @@
+"""Parity of the product front end (pydynet_amd: Tensor / autograd / nn / optim / llama) with the
+reference, through the golden vectors (tests/golden, generated from the real reference) and the
+oracle.  Every check runs three ways:
+  * device "cpu"  (NumPy device of the product)                         -- always
+  * device "hip:0" on the NumPy emulation of the C ABI (host logic)     -- always (no GPU needed)
+  * device "hip:0" on a real MI355X through libpdnhip.so                -- `-m gpu`
+Tolerances: index / gather / concat / im2col paths bit-exact; fp32 math rtol 1e-4 (north_star).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import pydynet_amd as pdn
+import pydynet_amd.nn as nn
+import pydynet_amd.nn.functional as F
+from pydynet_amd.optim import Adam
+from pydynet_amd.core.tensor import Graph
+from pydynet_amd.llm.llama import Llama
+from tests.conftest import device_variants
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+RT = 1e-4
+
+
+def load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def T(a, dev, rg=False):
+    a = np.asarray(a)
+    return pdn.Tensor(a, dtype=a.dtype, device=dev, requires_grad=rg)
+
+
+def host(x):
+    if isinstance(x, pdn.Tensor):
+        return x.numpy()
+    return x if isinstance(x, np.ndarray) else x.get()
+
+
+def close(a, b, rtol=RT, atol=1e-6):
+    a, b = np.asarray(host(a)), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(float(np.abs(b).max()) if b.size else 0.0, 1e-30)
+    err = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if b.size else 0.0
+    assert err <= atol + rtol * scale, (err, scale)
+
+
+def same(a, b):
+    a, b = np.asarray(host(a)), np.asarray(b)
+    assert a.shape == b.shape and np.array_equal(a, b)
+
+
+def all_devices(fn):
+    """cpu variant + hip (gpu / emulated) variants."""
+    def on_cpu():
+        Graph.clear()
+        fn("cpu")
+    on_cpu.__name__ = fn.__name__.replace("check_", "test_") + "_cpu"
+    globals()[on_cpu.__name__] = on_cpu
+    device_variants(globals(), fn)
+    return fn
+
+
+# ---------------------------------------------------------------------------------------
+@all_devices
+def check_reference_generators_binary_matmul(dev):
+    d = load("ops.npz")
+    hip = dev != "cpu"
+    with np.errstate(all="ignore"):
+        for i in range(8):
+            a, b = d[f"bin{i}_a"], d[f"bin{i}_b"]
+            if hip and (a.dtype == np.float16 or b.dtype == np.float16):
+                continue          # the HIP backend carries float32/float64 only
+            for n in ["add", "sub", "mul", "div", "pow", "maximum", "minimum"]:
+                out = getattr(pdn, n)(T(a, dev), T(b, dev))
+                ref = d[f"bin{i}_{n}"]
+                assert out.shape == ref.shape and out.dtype == ref.dtype, (n, i)
+                got = host(out)
+                assert np.allclose(got, ref, rtol=1e-5, atol=1e-6, equal_nan=True), (n, i)
+        for i in range(8):
+            a, b = d[f"mm{i}_a"], d[f"mm{i}_b"]
+            if hip and not (a.dtype == np.float32 and b.dtype == np.float32):
+                continue          # MFMA GEMM is float32
+            out = pdn.matmul(T(a, dev), T(b, dev))
+            ref = d[f"mm{i}_out"]
+            assert out.shape == ref.shape and out.dtype == ref.dtype
+            close(out, ref, 1e-5, 1e-5)
+
+
+@all_devices
+def check_op_gradients(dev):
+    d = load("ops.npz")
+    x, y = d["g_x"], d["g_y"]
+    for n in ["add", "sub", "mul", "div", "pow", "maximum"]:
+        a, b = T(x, dev, True), T(y, dev, True)
+        out = getattr(pdn, n)(a, b)
+        (out * out).sum().backward()
+        close(out, d[f"g_{n}_out"]); close(a.grad, d[f"g_{n}_da"]); close(b.grad, d[f"g_{n}_db"])
+    for n in ["exp", "log", "sigmoid", "tanh", "sqrt", "square"]:
+        a = T(x, dev, True)
+        out = getattr(pdn, n)(a)
+        (out * out).sum().backward()
+        close(out, d[f"g_{n}_out"]); close(a.grad, d[f"g_{n}_da"])
+    for n, ax, kd in [("sum", 1, False), ("mean", (0, 1), True), ("max", 0, False), ("min", None, False), ("mean", -1, True)]:
+        a = T(x, dev, True)
+        out = getattr(pdn, n)(a, ax, kd)
+        (out * out).sum().backward()
+        key = f"g_{n}_{str(ax).replace(' ', '')}_{int(kd)}"
+        close(out, d[key + "_out"]); close(a.grad, d[key + "_da"])
+    a, b = T(x, dev, True), T(y[:, :2].copy(), dev, True)
+    out = pdn.concat([a, b], axis=1).reshape(3, 2, 3).transpose(1, 0, 2).swapaxes(0, 2)
+    (out * out).sum().backward()
+    same(out, d["g_views_out"]); close(a.grad, d["g_views_da"]); close(b.grad, d["g_views_db"])
+    a, w = T(x, dev, True), T(d["g_mm_w"], dev, True)
+    (a @ w).sum().backward()
+    close(a.grad, d["g_mm_da"]); close(w.grad, d["g_mm_dw"])
+
+
+@all_devices
+def check_engine_contract(dev):
+    """The five behaviours pinned by the reference's tests/test_backward.py, + error contract."""
+    f32 = np.float32
+    x = pdn.Tensor(2.0, dtype=f32, device=dev, requires_grad=True)
+    (x ** 2 + 3 * x - 1).backward()
+    close(x.grad, np.array(7.0, f32))
+    xn, bn = np.random.RandomState(0).randn(2, 3).astype(f32), np.random.RandomState(1).randn(1, 3).astype(f32)
+    a, b = T(xn, dev, True), T(bn, dev, True)
+    (a + b).sum().backward()
+    close(a.grad, np.ones_like(xn)); close(b.grad, np.full_like(bn, 2.0))
+    x = pdn.Tensor(2.0, dtype=f32, device=dev, requires_grad=True)
+    y = x * x
+    y.backward(retain_graph=True)
+    close(x.grad, np.array(4.0, f32))
+    y.backward()
+    close(x.grad, np.array(8.0, f32))
+    with pytest.raises(ValueError):
+        y.backward()                                  # graph was freed
+    with pytest.raises(ValueError, match="scalar"):
+        T(np.array([1.0, 2.0], f32), dev, True).backward()
+    with pytest.raises(TypeError):
+        pdn.Tensor(np.array([1, 2]), device=dev, requires_grad=True)
+    with pytest.raises(ValueError):
+        pdn.Tensor(pdn.Tensor(1.0))
+    t = T(np.ones(3, f32), dev, True)
+    with pytest.raises(ValueError):
+        t += 1.0
+    with pdn.no_grad():
+        assert not (T(np.ones(3, f32), dev, True) * 2).requires_grad
+    # broadcasting the smaller operand anywhere (the reference only handles pure suffixes)
+    p, q = T(np.ones((3, 2, 4), f32), dev, True), T(np.ones((2, 1), f32), dev, True)
+    (p * q).sum().backward()
+    close(q.grad, np.full((2, 1), 12.0, f32))
+    # minimum has zero gradient (reference quirk); relu passes the gradient at 0
+    m, n = T(np.array([1.0, 5.0], f32), dev, True), T(np.array([2.0, 3.0], f32), dev, True)
+    pdn.minimum(m, n).sum().backward()
+    assert not host(m.grad).any() and not host(n.grad).any()
+
+
+@all_devices
+def check_functional_goldens(dev):
+    d = load("functional.npz")
+    x = d["sm_x"]
+    for ax in (-1, None, 1):
+        a = T(x, dev, True)
+        out = F.softmax(a, ax)
+        (out * T(np.arange(out.size, dtype=np.float32).reshape(out.shape) / out.size, dev)).sum().backward()
+        close(out, d[f"sm_{ax}_out"]); close(a.grad, d[f"sm_{ax}_dx"], RT, 1e-7)
+    a = T(x, dev, True)
+    out = F.log_softmax(a, -1, True)
+    (out * out).sum().backward()
+    close(out, d["lsm_out"]); close(a.grad, d["lsm_dx"])
+    lg, tg = d["ce_logits"], d["ce_t"]
+    for red in ("mean", "sum"):
+        a = T(lg, dev, True)
+        loss = F.cross_entropy_loss(a, pdn.Tensor(tg, dtype=np.int64, device=dev), red)
+        loss.backward()
+        close(loss, d[f"ce_{red}_loss"]); close(a.grad, d[f"ce_{red}_dx"])
+    a = T(lg, dev, True)
+    loss = F.cross_entropy_loss(a, T(np.eye(7, dtype=np.float32)[tg], dev))      # one-hot: mean over N*C
+    loss.backward()
+    close(loss, d["ce_onehot_loss"]); close(a.grad, d["ce_onehot_dx"])
+    W = T(d["emb_w"], dev, True)
+    e = F.embedding(d["emb_ids"], W, None)
+    (e * T(np.arange(e.size, dtype=np.float32).reshape(e.shape), dev)).sum().backward()
+    same(e, d["emb_out"]); same(W.grad, d["emb_dw"])      # gather bit-exact; duplicate ids: last write wins
+    for n, f in [("relu", F.relu), ("lrelu", lambda t: F.leaky_relu(t, 0.1)), ("silu", F.silu),
+                 ("sigmoid", F.sigmoid), ("tanh", F.tanh)]:
+        a = T(d[f"{n}_x"], dev, True)
+        out = f(a)
+        (out * 2.0).sum().backward()
+        close(out, d[f"{n}_out"]); close(a.grad, d[f"{n}_dx"])
+
+
+@all_devices
+def check_conv_pool_goldens(dev):
+    d = load("functional.npz")
+    cx, ck = d["conv_x"], d["conv_k"]
+    for s, p in [(1, 0), (1, 1), (2, 1), (2, 0)]:
+        a, k = T(cx, dev, True), T(ck, dev, True)
+        out = F.conv2d(a, k, p, s)
+        same(out._col, d[f"col_s{s}p{p}"])               # im2col buffer: reference layout, bit-exact
+        (out * out).sum().backward()
+        close(out, d[f"conv_s{s}p{p}_out"]); close(a.grad, d[f"conv_s{s}p{p}_dx"]); close(k.grad, d[f"conv_s{s}p{p}_dk"])
+    for n, f in [("maxpool", F.max_pool2d), ("avgpool", F.avg_pool2d)]:
+        a = T(cx, dev, True)
+        out = f(a, 2, 2)
+        (out * out).sum().backward()
+        close(out, d[f"{n}_out"]); close(a.grad, d[f"{n}_dx"])
+    a = T(d["maxpool_tie_x"], dev, True)
+    F.max_pool2d(a, 2, 2).sum().backward()
+    same(a.grad, d["maxpool_tie_dx"])                     # every tied position gets the gradient
+
+
+@all_devices
+def check_norms_and_cells(dev):
+    d = load("functional.npz")
+    nx = d["norm_x"]
+    rn = nn.RMSNorm(16, dtype=np.float32)
+    rn.weight.data[...] = d["rms_w"]
+    rn.to(dev)
+    a = T(nx, dev, True)
+    out = rn(a)
+    (out * out).sum().backward()
+    close(out, d["rms_out"]); close(a.grad, d["rms_dx"]); close(rn.weight.grad, d["rms_dw"])
+    ln = nn.LayerNorm(16, dtype=np.float32).to(dev)
+    a = T(nx, dev, True)
+    o1 = ln(a)
+    (o1 * o1).sum().backward()
+    ln(T(nx * 2, dev))
+    close(o1, d["ln_out1"]); close(a.grad, d["ln_dx"], RT, 1e-5)
+    close(ln.scale.grad, d["ln_dscale"]); close(ln.shift.grad, d["ln_dshift"])
+    close(ln.running_mean, d["ln_running_mean"]); close(ln.running_var, d["ln_running_var"])
+    ln.set_module_state(False)
+    close(ln(T(nx, dev)), d["ln_eval_out"])
+    ln.set_module_state(True)
+    cell = nn.GRUCell(6, 8, dtype=np.float32)
+    for n in ["Wx1", "Wx2", "Wh1", "Wh2", "bias1", "bias2"]:
+        getattr(cell, n).data[...] = d[f"gru_{n}"]
+    cell.to(dev)
+    a, h = T(d["gru_x"], dev, True), T(d["gru_h"], dev, True)
+    out = cell(a, h)
+    (out * out).sum().backward()
+    close(out, d["gru_out"]); close(a.grad, d["gru_dx"]); close(h.grad, d["gru_dh"])
+    for n in ["Wx1", "Wx2", "Wh1", "Wh2", "bias1", "bias2"]:
+        close(getattr(cell, n).grad, d[f"gru_d{n}"])
+    gru = nn.GRU(3, 8, dtype=np.float32)
+    for n in ["Wx1", "Wx2", "Wh1", "Wh2", "bias1", "bias2"]:
+        getattr(gru.GRUCells[0], n).data[...] = d[f"gruseq_{n}"]
+    gru.to(dev)
+    a = T(d["gruseq_x"], dev, True)
+    out, hn = gru(a)
+    (out * out).sum().backward()
+    close(out, d["gruseq_out"]); close(hn, d["gruseq_hn"]); close(a.grad, d["gruseq_dx"])
+    for n in ["Wx1", "Wx2", "Wh1", "Wh2", "bias1", "bias2"]:
+        close(getattr(gru.GRUCells[0], n).grad, d[f"gruseq_d{n}"])
+    rc = nn.RNNCell(6, 8, dtype=np.float32)
+    for n in ["Wx", "Wh", "bias"]:
+        getattr(rc, n).data[...] = d[f"rnn_{n}"]
+    rc.to(dev)
+    a, h = T(d["gru_x"], dev, True), T(d["gru_h"], dev, True)
+    out = rc(a, h)
+    (out * out).sum().backward()
+    close(out, d["rnn_out"]); close(a.grad, d["rnn_dx"]); close(h.grad, d["rnn_dh"])
+
+
+@all_devices
+def check_adam_three_steps(dev):
+    d = load("adam.npz")
+    a = nn.Parameter(pdn.Tensor(d["p1"].copy(), dtype=np.float32, device=dev))
+    b = nn.Parameter(pdn.Tensor(d["p2"].copy(), dtype=np.float32, device=dev))
+    opt = Adam([a, b], lr=1e-2, weight_decay=0.01)
+    for t in range(3):
+        a.grad[...] = d[f"g1_{t}"]; b.grad[...] = d[f"g2_{t}"]
+        opt.step()
+        close(a, d[f"p1_{t}"], 1e-6, 1e-7); close(b, d[f"p2_{t}"], 1e-6, 1e-7)
+
+
+@all_devices
+def check_tiny_llama_five_steps(dev):
+    d = load("tiny_llama.npz")
+    np.random.seed(1234)
+    m = Llama(64, 48, 2, 96, 64, 2, 2, np.float32)
+    names = [k[5:] for k in d.files if k.startswith("init/")]
+    assert sorted(names) == sorted(n for n, _ in m.named_parameters())
+    for n in names:
+        if n != "tok_embedding.weight":                   # constructor consumed the RNG in reference order
+            assert np.array_equal(m._parameters[n].data, d["init/" + n]), n
+        m._parameters[n].data[...] = d["init/" + n]
+    m.to(dev)
+    opt = Adam(m.parameters(), lr=1e-3)
+    losses = []
+    for s in range(5):
+        losses.append(m.finetune_step(d["ids"], d["tgt"], opt))
+        if s == 0:
+            for n in names:
+                close(m._parameters[n].grad, d["grad1/" + n], RT, 1e-7)
+    close(np.array(losses), d["losses"], RT, 0)
+    for n in names:
+        close(m._parameters[n], d["final/" + n], RT, 1e-6)
+
+
+class _MLP(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.layer1 = nn.Linear(784, 1024, dtype=np.float32)
+        self.layer2 = nn.Linear(1024, 1024, dtype=np.float32)
+        self.layer3 = nn.Linear(1024, 10, dtype=np.float32)
+
+    def forward(self, x):
+        x = x.reshape(x.shape[0], -1)
+        return self.layer3(F.relu(self.layer2(F.relu(self.layer1(x)))))
+
+
+class _LeNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 20, 3, 1, 1, dtype=np.float32)
+        self.conv2 = nn.Conv2d(20, 50, 3, 1, 1, dtype=np.float32)
+        self.fc1 = nn.Linear(8 * 8 * 50, 500, dtype=np.float32)
+        self.fc2 = nn.Linear(500, 10, dtype=np.float32)
+
+    def forward(self, x):
+        x = F.max_pool2d(F.relu(self.conv1(x)), 2, 2)
+        x = F.max_pool2d(F.relu(self.conv2(x)), 2, 2)
+        return self.fc2(F.relu(self.fc1(x.reshape(-1, 8 * 8 * 50))))
+
+
+@all_devices
+def check_mlp_lenet_three_steps(dev):
+    d = load("mlp_lenet.npz")
+    for name, cls in [("mlp", _MLP), ("lenet", _LeNet)]:
+        Graph.clear()
+        np.random.seed(42)
+        net = cls().to(dev)
+        X, y = T(d[f"{name}_X"], dev), pdn.Tensor(d[f"{name}_y"], dtype=np.int64, device=dev)
+        opt = Adam(net.parameters(), lr=1e-4)
+        losses = []
+        for s in range(3):
+            loss = F.cross_entropy_loss(net(X), y)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+            if s == 0:
+                for n, p in net.named_parameters():
+                    g = float(np.linalg.norm(host(p.grad).astype(np.float64)))
+                    ref = float(d[f"{name}_gnorm/{n}"])
+                    assert abs(g - ref) <= RT * ref + 1e-9, (name, n, g, ref)
+                    if f"{name}_grad1/{n}" in d.files:
+                        close(p.grad, d[f"{name}_grad1/{n}"], RT, 1e-7)
+        close(np.array(losses), d[f"{name}_losses"], RT, 0)
+
+
+def test_autograd2d_cpu_config():
+    """BASELINE.json configs[0]: examples/pydynet/autograd2d.py on the NumPy device."""
+    ref = json.load(open(os.path.join(G, "autograd2d.json")))["trajectory"]
+    Graph.clear()
+    A, b = pdn.Tensor([[3, 1.], [1, 2.]]), pdn.Tensor([-1., 1])
+    np.random.seed(42)
+    x = pdn.randn(2, requires_grad=True)
+    for step in ref:
+        obj = x @ A @ x / 2 + b @ x
+        assert np.allclose([*x.data.tolist(), obj.item()], step, rtol=1e-12, atol=1e-14)
+        obj.backward()
+        assert np.allclose(x.grad, A.data @ x.data + b.data, rtol=1e-12)   # closed form, autograd2d.py:36-49
+        x.data -= 0.1 * x.grad
+        x.zero_grad()
