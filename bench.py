@@ -1,0 +1,148 @@
+"""Headline benchmark: training-step samples/s of the 6-layer Llama3 (seq 256) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = zero_grad -> forward -> cross entropy -> backward -> (bucketed RCCL all-reduce,
+overlapped) -> Adam, on synthetic token ids resident in HBM, random-init weights, fp32.
+Per-GPU batch is fixed (weak scaling).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V, D, H, F_, L, LAYERS = 32000, 288, 6, 768, 256, 6
+FLOP_PER_SAMPLE = 3 * L * (LAYERS * (4 * 2 * D * D + 3 * 2 * D * F_ + 2 * 2 * L * D) + 2 * D * V)   # 24.688e9
+PEAK_FP32_MFMA = 157.3e12
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (NumPy port of the reference's op sequence) timed on this host's cores."""
+    from oracle import llama as ollama, nn as onn, tape as otape
+    otape.reset_tape()
+    np.random.seed(0)
+    m = ollama.Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)
+    m.params["tok_embedding.weight"].value[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
+    ids, tgt = np.random.randint(0, V, (1, L)), np.random.randint(0, V, (1, L))
+    opt = onn.Adam(m.parameters(), lr=1e-4)
+    m.finetune_step(ids, tgt, opt)                      # warm-up (page faults)
+    t0, n = time.perf_counter(), 0
+    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
+        m.finetune_step(ids, tgt, opt)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n} steps of the same model at batch 1 (seq 256), NumPy/BLAS default threads, after 1 warm-up step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "32")), help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gemm-prof", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from pydynet_amd import hipnp, _lib
+    import pydynet_amd as pdn
+    from pydynet_amd.llm.llama import Llama
+    from pydynet_amd.optim import Adam
+    from pydynet_amd.distributed import DataParallel, init_process_group
+
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    lib = _lib.lib()                                        # no CPU fallback: fail loudly
+    hipnp.set_device(local)
+    rank, world = init_process_group("nccl", local) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = f"hip:{local}"
+    B = args.batch
+
+    np.random.seed(0)                                       # identical weights on every rank
+    model = Llama(V, D, H, F_, 1024, B, LAYERS, np.float32)
+    model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
+    model.to(dev)
+    opt = Adam(model.parameters(), lr=1e-4)
+    dp = DataParallel(model, opt) if world > 1 else None
+    rng = np.random.default_rng(1000 + rank)                # each rank owns its shard of the global batch
+    ids = pdn.Tensor(rng.integers(0, V, (B, L)), dtype=np.int64, device=dev)
+    tgt = pdn.Tensor(rng.integers(0, V, (B * L,)), dtype=np.int64, device=dev)
+    model.train(True)
+
+    def step():
+        opt.zero_grad()
+        loss = model.loss(ids, tgt)
+        loss.backward()
+        if dp is not None:
+            dp.finish()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    prev = None
+    for _ in range(args.warmup):
+        prev = step()
+    fence()
+    if not args.no_gemm_prof:
+        lib.call("pdn_gemm_prof_enable", 1)
+    losses = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cur = step()
+        if prev is not None:
+            losses.append(prev.item())                      # loss read-back pipelined one step behind
+        prev = cur
+    fence()
+    dt = time.perf_counter() - t0
+    losses.append(prev.item())
+
+    roof = None
+    if not args.no_gemm_prof:
+        import ctypes
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.call("pdn_gemm_prof_enable", 0)
+        lib.call("pdn_gemm_prof_collect", ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
+        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel (all launches of the timed region)",
+                "achieved": ach, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
+                "frac": ach / (PEAK_FP32_MFMA / 1e12), "traffic": None,
+                "launches": cnt.value, "avg_launch_us": 1e3 * ms.value / max(cnt.value, 1),
+                "gemm_time_share_of_step": ms.value * 1e-3 / dt}
+    if world > 1:
+        t = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    value = world * B * args.steps / dt
+    out = {
+        "metric": "training-step samples/sec (6L Llama3, seq=256)", "value": value, "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "llm/llama 6-layer Llama3 (dim 288, 6 heads, ffn 768, vocab 32000) fwd+bwd+Adam, random init",
+                   "seq_len": L, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+        "model_flops_frac_of_fp32_mfma_peak": FLOP_PER_SAMPLE * value / world / PEAK_FP32_MFMA,
+        "final_loss": losses[-1],
+        "roofline": roof,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
