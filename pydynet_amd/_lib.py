@@ -56,6 +56,10 @@ class _Lib:
             raise HipLibraryError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C pydynet_amd/csrc`). The HIP backend has no CPU fallback.")
+        # PyTorch owns the device memory these kernels touch, so both must share ONE HIP runtime:
+        # importing torch first makes libpdnhip.so bind to the libamdhip64 torch already loaded
+        # (loading ours first can pick a different copy that sees no device).
+        import torch  # noqa: F401
         self.cdll = ctypes.CDLL(LIB_PATH)
         self.protos = parse_header()
         self.fn = {}

@@ -298,17 +298,27 @@ __global__ void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __r
 }
 
 // out[c] (+)= sum_b part[b][c]   -- fixed order
+// block = 32 columns x 8 row lanes; each lane sums every 8th partial row, LDS combine in order.
 __global__ void colsum_partials_kernel(const float* __restrict__ part, int nb, int cols,
                                        float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= cols) return;
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * cols + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < cols)
+    for (int b = ty; b < nb; b += 8) s += part[(int64_t)b * cols + c];
+  red[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float t = red[0][tx];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][tx];
+    out[c] = accumulate ? out[c] + t : t;
+  }
 }
 
 extern "C" int64_t pdn_rmsnorm_bwd_workspace_bytes(int64_t rows, int cols) {
-  int64_t nb = (rows + 63) / 64; if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+  int64_t nb = (rows + 63) / 64; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
   return nb * (int64_t)cols * 4;
 }
 
@@ -339,7 +349,7 @@ extern "C" int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* 
   PDN_CHECK_ARG(cols > 0 && cols % 4 == 0 && cols <= 2048,
                 "pdn_rmsnorm_bwd_f32: cols=%d must be a multiple of 4 and <= 2048", cols);
   hipStream_t st = (hipStream_t)stream;
-  int64_t nb = (rows + 63) / 64; if (nb > 512) nb = 512; if (nb < 1) nb = 1;
+  int64_t nb = (rows + 63) / 64; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
   float* part = nullptr;
   if (dw) {
     if (workspace_bytes < nb * (int64_t)cols * 4 || !workspace) {
@@ -355,7 +365,7 @@ extern "C" int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* 
                  case 5: RB(5); break; case 6: RB(6); break; case 7: RB(7); break; default: RB(8); }
   PDN_LAUNCH_CHECK();
   if (dw) {
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, part,
                        (int)nb, cols, dw, accumulate_dw);
     PDN_LAUNCH_CHECK();
   }

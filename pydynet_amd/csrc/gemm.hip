@@ -25,6 +25,7 @@
 #include "common.h"
 #include <vector>
 #include <mutex>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -130,6 +131,67 @@ struct TileLoader {
   }
 };
 
+// One k-loop over [k_begin, k_end) for the tile at (m0, n0).  INTERIOR tiles (fully inside M x N
+// with whole k-tiles) take loads with no bounds tests so the staging code is branch-free.
+template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KIN, bool B_KIN, bool VEC, bool INTERIOR>
+__device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* __restrict__ A,
+                                              const float* __restrict__ B, float* smem, int m0, int n0,
+                                              int k_begin, int k_end, f32x16 (&acc)[WM][WN]) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;
+  constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+  using LA = TileLoader<BM, A_KIN, VEC, NT>;
+  using LB = TileLoader<BN, B_KIN, VEC, NT>;
+  constexpr int STAGE = LA::SIZE + LB::SIZE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+  // interior tiles: lift the bounds so every `<` test folds to true
+  const int m_end = INTERIOR ? 0x7fffffff : p.M, n_end = INTERIOR ? 0x7fffffff : p.N;
+  const int kk_end = INTERIOR ? 0x7fffffff : k_end;
+
+  float4 ra[LA::NP], rb[LB::NP];
+  const int ntile = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+  if (ntile > 0) {
+    LA::load(ra, A, p.a_rs, p.a_cs, m0, k_begin, m_end, kk_end, tid);
+    LB::load(rb, B, p.b_cs, p.b_rs, n0, k_begin, n_end, kk_end, tid);
+    LA::store(ra, smem, tid);
+    LB::store(rb, smem + LA::SIZE, tid);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const float* As = smem + (t & 1) * STAGE;
+    const float* Bs = As + LA::SIZE;
+    const bool more = (t + 1 < ntile);
+    if (more) {
+      const int k0 = k_begin + (t + 1) * GEMM_BK;
+      LA::load(ra, A, p.a_rs, p.a_cs, m0, k0, m_end, kk_end, tid);
+      LB::load(rb, B, p.b_cs, p.b_rs, n0, k0, n_end, kk_end, tid);
+    }
+#pragma unroll
+    for (int g = 0; g < GEMM_BK / 8; ++g) {
+      float a[WM][4], b[WN][4];
+#pragma unroll
+      for (int i = 0; i < WM; ++i) LA::frag(a[i], As, (wave_m * WM + i) * 32, g, li, lh);
+#pragma unroll
+      for (int j = 0; j < WN; ++j) LB::frag(b[j], Bs, (wave_n * WN + j) * 32, g, li, lh);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      float* An = smem + ((t + 1) & 1) * STAGE;
+      LA::store(ra, An, tid);
+      LB::store(rb, An + LA::SIZE, tid);
+    }
+    __syncthreads();
+  }
+}
+
 template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KIN, bool B_KIN, bool VEC>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
@@ -137,7 +199,11 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
   using LA = TileLoader<BM, A_KIN, VEC, NT>;
   using LB = TileLoader<BN, B_KIN, VEC, NT>;
   constexpr int STAGE = LA::SIZE + LB::SIZE;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  // epilogue staging: each wave parks its (WM*32) x (WN*32) accumulator block in LDS, row-major
+  constexpr int EW = WN * 32 + 4;                       // padded row length (floats)
+  constexpr int EPI = WAVES_M * WAVES_N * WM * 32 * EW;
+  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
   // ---- which tile / batch / k-split ---------------------------------------------------
   const int nwg = p.tiles_m * p.tiles_n;
@@ -165,10 +231,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
-  const int li = lane & 31, lh = lane >> 5;
+  const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((k_end - k_begin) % GEMM_BK == 0);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -178,56 +241,63 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  float4 ra[LA::NP], rb[LB::NP];
-  const int ntile = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
-
-  if (ntile > 0) {
-    LA::load(ra, A, p.a_rs, p.a_cs, m0, k_begin, p.M, k_end, tid);
-    LB::load(rb, B, p.b_cs, p.b_rs, n0, k_begin, p.N, k_end, tid);
-    LA::store(ra, smem, tid);
-    LB::store(rb, smem + LA::SIZE, tid);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < ntile; ++t) {
-    const float* As = smem + (t & 1) * STAGE;
-    const float* Bs = As + LA::SIZE;
-    const bool more = (t + 1 < ntile);
-    if (more) {
-      const int k0 = k_begin + (t + 1) * GEMM_BK;
-      LA::load(ra, A, p.a_rs, p.a_cs, m0, k0, p.M, k_end, tid);
-      LB::load(rb, B, p.b_cs, p.b_rs, n0, k0, p.N, k_end, tid);
-    }
-#pragma unroll
-    for (int g = 0; g < GEMM_BK / 8; ++g) {
-      float a[WM][4], b[WN][4];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) LA::frag(a[i], As, (wave_m * WM + i) * 32, g, li, lh);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) LB::frag(b[j], Bs, (wave_n * WN + j) * 32, g, li, lh);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      float* An = smem + ((t + 1) & 1) * STAGE;
-      LA::store(ra, An, tid);
-      LB::store(rb, An + LA::SIZE, tid);
-    }
-    __syncthreads();
-  }
+  if (interior)
+    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, A_KIN, B_KIN, VEC, true>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
+  else
+    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, A_KIN, B_KIN, VEC, false>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
 
   // ---- epilogue -----------------------------------------------------------------------
   // 32x32 accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
   const bool partial = p.splits > 1;
   float* __restrict__ C =
       partial ? p.ws + ((int64_t)batch * p.splits + split) * (int64_t)p.M * p.N
               : p.C + b1 * p.c_bs1 + b2 * p.c_bs2;
   const int64_t ldc = partial ? p.N : p.ldc;
+  const float* bias = partial ? nullptr : p.bias;
+  const float beta = partial ? 0.f : p.beta;
+
+  const bool wide = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((ldc & 3) == 0) &&
+                    (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+  if (wide) {
+    // Park the wave's block in LDS (the main loop's last barrier has retired every read of the
+    // staging buffers), then write it out as whole 16-byte pieces: 16 lanes cover 256 B of a row.
+    float* ws = smem + wave * (WM * 32 * EW);
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int j = 0; j < WN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EW + j * 32 + li] = p.alpha * acc[i][j][r];
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): own LDS writes visible to the wave
+    __builtin_amdgcn_wave_barrier();
+    constexpr int C4 = WN * 8;                   // float4 per row of the wave block
+    constexpr int UNITS = WM * 32 * C4;
+    const int row0 = m0 + wave_m * WM * 32, col0 = n0 + wave_n * WN * 32;
+#pragma unroll
+    for (int u0 = 0; u0 < UNITS; u0 += 64) {
+      const int u = u0 + lane;
+      if (UNITS % 64 == 0 || u < UNITS) {
+        const int r = u / C4, c4 = u % C4;
+        float4 v = *reinterpret_cast<const float4*>(ws + r * EW + 4 * c4);
+        float* dst = C + (int64_t)(row0 + r) * ldc + col0 + 4 * c4;
+        if (bias) {
+          const float4 bv = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
+          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+        }
+        if (beta != 0.f) {
+          const float4 o = *reinterpret_cast<const float4*>(dst);
+          v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+    }
+    return;
+  }
+  // edge tiles / unaligned outputs: guarded scalar path
 #pragma unroll
   for (int i = 0; i < WM; ++i) {
 #pragma unroll
@@ -235,19 +305,17 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
       const int col = n0 + (wave_n * WN + j) * 32 + li;
       const int rbase = m0 + (wave_m * WM + i) * 32 + 4 * lh;
       if (col < p.N) {
-        const float bv = (!partial && p.bias) ? p.bias[col] : 0.f;
+        const float bv = bias ? bias[col] : 0.f;
+        float old[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < p.M) {
-            float v = p.alpha * acc[i][j][r];
-            float* dst = C + (int64_t)row * ldc + col;
-            if (!partial) {
-              v += bv;
-              if (p.beta != 0.f) v += p.beta * (*dst);
-            }
-            *dst = v;
-          }
+          old[r] = (beta != 0.f && row < p.M) ? C[(int64_t)row * ldc + col] : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = rbase + (r & 3) + 8 * (r >> 2);
+          if (row < p.M) C[(int64_t)row * ldc + col] = p.alpha * acc[i][j][r] + bv + beta * old[r];
         }
       }
     }
@@ -281,11 +349,11 @@ struct TileCfg {
 };
 static const TileCfg kCfgs[] = {
     {2, 2, 2, 2, 1.00f},  // 128 x 128
-    {4, 1, 1, 3, 0.94f},  // 128 x  96   (N = 288 = 3*96)
-    {1, 4, 3, 1, 0.94f},  //  96 x 128   (M = 288, weight gradients)
-    {4, 1, 1, 2, 0.90f},  // 128 x  64
-    {1, 4, 2, 1, 0.90f},  //  64 x 128
-    {2, 2, 1, 1, 0.80f},  //  64 x  64
+    {4, 1, 1, 3, 0.95f},  // 128 x  96   (N = 288 = 3*96)
+    {1, 4, 3, 1, 0.95f},  //  96 x 128   (M = 288, weight gradients)
+    {4, 1, 1, 2, 0.85f},  // 128 x  64
+    {1, 4, 2, 1, 0.85f},  //  64 x 128
+    {2, 2, 1, 1, 0.60f},  //  64 x  64
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -374,7 +442,9 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   else vec = vec && b_cs == 1 && m4(b_rs) && m4(N);
 
   // ---- pick tile shape and k-split with a small cost model -----------------------------
-  const int64_t slots = 256 * 2;
+  // The matrix pipes of a CU are shared by its resident workgroups, so MFMA throughput is
+  // counted per CU (256), not per residency slot: n blocks take ceil(n/256) block-times until
+  // the grid is large enough (>= 4 rounds) for the dispatcher to even the load out.
   const int64_t ws_cap = (workspace && workspace_bytes > 0) ? workspace_bytes / 4 : 0;
   int best = -1, best_splits = 1;
   double best_cost = 1e300;
@@ -390,14 +460,23 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       }
       const int kps = (int)cdiv64(ktiles, s);
       const int64_t blocks = tiles * s;
-      const double waves = (double)cdiv64(blocks, slots);
-      // per-block time ~ tile flops / eff + fixed prologue/epilogue; split adds a reduce pass
-      double cost = waves * ((double)BM * BN * (kps * GEMM_BK + 48) / kCfgs[c].eff);
-      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 0.75 / 256.0 * 8.0;
+      const double waves = blocks >= 1024 ? (double)blocks / 256.0 : (double)cdiv64(blocks, 256);
+      // per-block time ~ tile flops / eff + fixed prologue/epilogue (~2 k-tiles); a split adds
+      // one pass over s partial slabs (HBM-bound, ~16 B/clk/CU) plus a launch
+      double cost = waves * ((double)BM * BN * (kps * GEMM_BK + 64) / kCfgs[c].eff);
+      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 4.0 / 16.0 * 4.0 + 2.0e6;
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = s; }
     }
   }
   PDN_CHECK_ARG(best >= 0, "pdn_gemm_f32: no tile configuration");
+  if (const char* e = getenv("PDN_GEMM_CFG")) {            // tuning override: "<cfg>[,<splits>]"
+    int c = -1, sp = 0;
+    if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec) {
+      best = c;
+      if (sp >= 1 && (int64_t)sp * M * N * nbatch <= (ws_cap > 0 ? ws_cap : (sp == 1 ? 1 : 0))) best_splits = sp;
+      else if (sp == 1) best_splits = 1;
+    }
+  }
   const TileCfg& cfg = kCfgs[best];
   const int BM = cfg.waves_m * cfg.wm * 32, BN = cfg.waves_n * cfg.wn * 32;
   p.tiles_m = (int)cdiv64(M, BM);

@@ -230,7 +230,9 @@ def check_norms_and_cells(dev):
     (o1 * o1).sum().backward()
     ln(T(nx * 2, dev))
     close(o1, d["ln_out1"]); close(a.grad, d["ln_dx"], RT, 1e-5)
-    close(ln.scale.grad, d["ln_dscale"]); close(ln.shift.grad, d["ln_dshift"])
+    # d(shift) = sum of 2*o1 over tokens is ~0 by construction (o1 is mean-free): compare at the
+    # scale of the summed terms, not of the cancelled result
+    close(ln.scale.grad, d["ln_dscale"], RT, 1e-4); close(ln.shift.grad, d["ln_dshift"], RT, 1e-4)
     close(ln.running_mean, d["ln_running_mean"]); close(ln.running_var, d["ln_running_var"])
     ln.set_module_state(False)
     close(ln(T(nx, dev)), d["ln_eval_out"])
