@@ -9,13 +9,20 @@
 // (q.transpose(0,2,1,3), W.T, x.T ...) are consumed in place, never copied:
 //   A(m,k) = A[m*a_rs + k*a_cs]      B(k,n) = B[k*b_rs + n*b_cs]      C(m,n) = C[m*ldc + n]
 //
-// Kernel structure (one workgroup = 4 wave64, one wave per SIMD, 2 workgroups per CU):
-//   * block tile BM x BN x 32, wave tile (WM*32) x (WN*32) of 32x32 MFMA accumulators;
-//   * global -> registers -> LDS staging, double-buffered in LDS, the loads for tile t+1
-//     are in flight while tile t is multiplied (one barrier per k-tile);
+// Kernel structure (one workgroup = 2 or 4 wave64, one wave per SIMD, 2+ workgroups per CU):
+//   * block tile BM x BN x BK, wave tile (WM*32) x (WN*32) of 32x32 MFMA accumulators; BK is
+//     32 for tiles up to 128x128 and 16 for the 256-wide ones so that every shape keeps
+//     <= 74 KB of LDS (two workgroups per CU) and one barrier per >= 2048 MFMA cycles;
+//   * global -> registers -> LDS staging, double-buffered in LDS: the loads for tile t+1 are
+//     issued before the MFMAs of tile t, and their LDS writes are slotted into the MIDDLE of
+//     that MFMA stream (the matrix pipe keeps executing queued MFMAs while the wave issues
+//     ds_write), so staging costs no matrix-pipe time; one barrier per k-tile;
 //   * the contraction index inside an MFMA is permuted (half-wave h, step j -> k = 8t+4h+j)
 //     so a K-contiguous operand is fetched from LDS with ONE ds_read_b128 per four MFMAs
 //     and an M/N-contiguous operand with conflict-free ds_read_b32 -- no transposes anywhere;
+//   * interior tiles run a bounds-test-free copy of the main loop;
+//   * epilogue: accumulators are parked in LDS one 32-row band at a time and written as
+//     16-byte pieces (16 lanes cover 256 B of a row) with alpha / bias / beta*C applied;
 //   * XCD-aware tile order: each XCD walks a contiguous run of 8x8 super-tiles so the A and
 //     B panels it touches stay in its private 4 MiB L2;
 //   * split-K (workspace + deterministic reduce) when the output has too few tiles to
@@ -29,7 +36,6 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define GEMM_BK 32
 #define GEMM_PAD 4
 
 struct GemmParams {
@@ -47,16 +53,16 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
-// ---- global -> register staging -------------------------------------------------------
+// ---- global -> register -> LDS staging -------------------------------------------------------
 // Tile of an operand: MN rows (m or n index) x BK contraction columns.
 // KIN  : LDS image [MN][BK+PAD]   (contraction contiguous), unit = float4 along k
 // !KIN : LDS image [BK][MN+PAD]   (m/n contiguous),         unit = float4 along m/n
-template <int MN, bool KIN, bool VEC, int NT>
+template <int MN, int BK, bool KIN, bool VEC, int NT>
 struct TileLoader {
-  static constexpr int UNITS = MN * GEMM_BK / 4;
+  static constexpr int UNITS = MN * BK / 4;
   static constexpr int NP = (UNITS + NT - 1) / NT;
-  static constexpr int LD = KIN ? (GEMM_BK + GEMM_PAD) : (MN + GEMM_PAD);
-  static constexpr int SIZE = KIN ? MN * LD : GEMM_BK * LD;
+  static constexpr int LD = KIN ? (BK + GEMM_PAD) : (MN + GEMM_PAD);
+  static constexpr int SIZE = KIN ? MN * LD : BK * LD;
 
   __device__ __forceinline__ static void load(float4 (&r)[NP], const float* __restrict__ base,
                                               int64_t s_mn, int64_t s_k, int mn0, int k0,
@@ -67,7 +73,7 @@ struct TileLoader {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (UNITS % NT == 0 || u < UNITS) {
         if (KIN) {
-          const int row = u / (GEMM_BK / 4), c4 = u % (GEMM_BK / 4);
+          const int row = u / (BK / 4), c4 = u % (BK / 4);
           const int mn = mn0 + row, k = k0 + 4 * c4;
           if (VEC) {
             if (mn < mn_end && k < k_end)
@@ -105,7 +111,7 @@ struct TileLoader {
       if (UNITS % NT == 0 || u < UNITS) {
         int off;
         if (KIN) {
-          const int row = u / (GEMM_BK / 4), c4 = u % (GEMM_BK / 4);
+          const int row = u / (BK / 4), c4 = u % (BK / 4);
           off = row * LD + 4 * c4;
         } else {
           const int kr = u / (MN / 4), c4 = u % (MN / 4);
@@ -133,15 +139,16 @@ struct TileLoader {
 
 // One k-loop over [k_begin, k_end) for the tile at (m0, n0).  INTERIOR tiles (fully inside M x N
 // with whole k-tiles) take loads with no bounds tests so the staging code is branch-free.
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KIN, bool B_KIN, bool VEC, bool INTERIOR>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool INTERIOR>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* __restrict__ A,
                                               const float* __restrict__ B, float* smem, int m0, int n0,
                                               int k_begin, int k_end, f32x16 (&acc)[WM][WN]) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-  using LA = TileLoader<BM, A_KIN, VEC, NT>;
-  using LB = TileLoader<BN, B_KIN, VEC, NT>;
+  using LA = TileLoader<BM, BK, A_KIN, VEC, NT>;
+  using LB = TileLoader<BN, BK, B_KIN, VEC, NT>;
   constexpr int STAGE = LA::SIZE + LB::SIZE;
+  constexpr int NG = BK / 8;                      // k-groups (4 MFMA steps each) per k-tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
@@ -150,7 +157,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   const int kk_end = INTERIOR ? 0x7fffffff : k_end;
 
   float4 ra[LA::NP], rb[LB::NP];
-  const int ntile = (k_end - k_begin + GEMM_BK - 1) / GEMM_BK;
+  const int ntile = (k_end - k_begin + BK - 1) / BK;
   if (ntile > 0) {
     LA::load(ra, A, p.a_rs, p.a_cs, m0, k_begin, m_end, kk_end, tid);
     LB::load(rb, B, p.b_cs, p.b_rs, n0, k_begin, n_end, kk_end, tid);
@@ -162,14 +169,15 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   for (int t = 0; t < ntile; ++t) {
     const float* As = smem + (t & 1) * STAGE;
     const float* Bs = As + LA::SIZE;
+    float* An = smem + ((t + 1) & 1) * STAGE;
     const bool more = (t + 1 < ntile);
     if (more) {
-      const int k0 = k_begin + (t + 1) * GEMM_BK;
+      const int k0 = k_begin + (t + 1) * BK;
       LA::load(ra, A, p.a_rs, p.a_cs, m0, k0, m_end, kk_end, tid);
       LB::load(rb, B, p.b_cs, p.b_rs, n0, k0, n_end, kk_end, tid);
     }
 #pragma unroll
-    for (int g = 0; g < GEMM_BK / 8; ++g) {
+    for (int g = 0; g < NG; ++g) {
       float a[WM][4], b[WN][4];
 #pragma unroll
       for (int i = 0; i < WM; ++i) LA::frag(a[i], As, (wave_m * WM + i) * 32, g, li, lh);
@@ -182,26 +190,27 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (more) {
-      float* An = smem + ((t + 1) & 1) * STAGE;
-      LA::store(ra, An, tid);
-      LB::store(rb, An + LA::SIZE, tid);
+      // Park tile t+1 in the other LDS buffer in the shadow of this tile's MFMAs: the buffer was
+      // last read during tile t-1 and every wave has passed that tile's closing barrier.
+      if (g == (NG - 1) / 2 && more) {
+        LA::store(ra, An, tid);
+        LB::store(rb, An + LA::SIZE, tid);
+      }
     }
     __syncthreads();
   }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, bool A_KIN, bool B_KIN, bool VEC>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(GemmParams p) {
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC>
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel(GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
-  using LA = TileLoader<BM, A_KIN, VEC, NT>;
-  using LB = TileLoader<BN, B_KIN, VEC, NT>;
+  using LA = TileLoader<BM, BK, A_KIN, VEC, NT>;
+  using LB = TileLoader<BN, BK, B_KIN, VEC, NT>;
   constexpr int STAGE = LA::SIZE + LB::SIZE;
-  // epilogue staging: each wave parks its (WM*32) x (WN*32) accumulator block in LDS, row-major
+  // epilogue staging: each wave parks ONE 32-row band of its accumulator block at a time
   constexpr int EW = WN * 32 + 4;                       // padded row length (floats)
-  constexpr int EPI = WAVES_M * WAVES_N * WM * 32 * EW;
+  constexpr int EPI = WAVES_M * WAVES_N * 32 * EW;
   constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
 
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((k_end - k_begin) % GEMM_BK == 0);
+  const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((k_end - k_begin) % BK == 0);
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -242,9 +251,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   if (interior)
-    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, A_KIN, B_KIN, VEC, true>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
+    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, BK, A_KIN, B_KIN, VEC, true>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
   else
-    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, A_KIN, B_KIN, VEC, false>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
+    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, BK, A_KIN, B_KIN, VEC, false>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
 
   // ---- epilogue -----------------------------------------------------------------------
   // 32x32 accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -262,38 +271,42 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64) void gemm_f32_mfma_kernel(Ge
   const bool wide = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((ldc & 3) == 0) &&
                     (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
   if (wide) {
-    // Park the wave's block in LDS (the main loop's last barrier has retired every read of the
-    // staging buffers), then write it out as whole 16-byte pieces: 16 lanes cover 256 B of a row.
-    float* ws = smem + wave * (WM * 32 * EW);
+    // The main loop's last barrier has retired every read of the staging buffers, and each wave
+    // only touches its own band region, so wave-level ordering is all that is needed from here.
+    float* ws = smem + wave * (32 * EW);
+    constexpr int C4 = WN * 8;                   // float4 per row of the wave block
+    constexpr int UNITS = 32 * C4;
+    const int col0 = n0 + wave_n * WN * 32;
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int i = 0; i < WM; ++i) {
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          ws[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * EW + j * 32 + li] = p.alpha * acc[i][j][r];
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): own LDS writes visible to the wave
-    __builtin_amdgcn_wave_barrier();
-    constexpr int C4 = WN * 8;                   // float4 per row of the wave block
-    constexpr int UNITS = WM * 32 * C4;
-    const int row0 = m0 + wave_m * WM * 32, col0 = n0 + wave_n * WN * 32;
+          ws[((r & 3) + 8 * (r >> 2) + 4 * lh) * EW + j * 32 + li] = p.alpha * acc[i][j][r];
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): own LDS writes landed
+      __builtin_amdgcn_wave_barrier();
+      const int row0 = m0 + (wave_m * WM + i) * 32;
 #pragma unroll
-    for (int u0 = 0; u0 < UNITS; u0 += 64) {
-      const int u = u0 + lane;
-      if (UNITS % 64 == 0 || u < UNITS) {
-        const int r = u / C4, c4 = u % C4;
-        float4 v = *reinterpret_cast<const float4*>(ws + r * EW + 4 * c4);
-        float* dst = C + (int64_t)(row0 + r) * ldc + col0 + 4 * c4;
-        if (bias) {
-          const float4 bv = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
-          v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      for (int u0 = 0; u0 < UNITS; u0 += 64) {
+        const int u = u0 + lane;
+        if (UNITS % 64 == 0 || u < UNITS) {
+          const int r = u / C4, c4 = u % C4;
+          float4 v = *reinterpret_cast<const float4*>(ws + r * EW + 4 * c4);
+          float* dst = C + (int64_t)(row0 + r) * ldc + col0 + 4 * c4;
+          if (bias) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+          }
+          if (beta != 0.f) {
+            const float4 o = *reinterpret_cast<const float4*>(dst);
+            v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+          }
+          *reinterpret_cast<float4*>(dst) = v;
         }
-        if (beta != 0.f) {
-          const float4 o = *reinterpret_cast<const float4*>(dst);
-          v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
-        }
-        *reinterpret_cast<float4*>(dst) = v;
       }
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // band reads done before the next band overwrites
+      __builtin_amdgcn_wave_barrier();
     }
     return;
   }
@@ -344,30 +357,37 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int nbatch) {
 
 // ---- host side ----------------------------------------------------------------------
 struct TileCfg {
-  int waves_m, waves_n, wm, wn;
-  float eff;  // relative MFMA efficiency of the tile shape (operand reuse)
+  int waves_m, waves_n, wm, wn, bk;
+  float eff;  // relative efficiency of the tile shape (operand bytes per MFMA, barrier rate)
 };
 static const TileCfg kCfgs[] = {
-    {2, 2, 2, 2, 1.00f},  // 128 x 128
-    {4, 1, 1, 3, 0.95f},  // 128 x  96   (N = 288 = 3*96)
-    {1, 4, 3, 1, 0.95f},  //  96 x 128   (M = 288, weight gradients)
-    {4, 1, 1, 2, 0.85f},  // 128 x  64
-    {1, 4, 2, 1, 0.85f},  //  64 x 128
-    {2, 2, 1, 1, 0.60f},  //  64 x  64
+    {2, 2, 2, 2, 32, 1.00f},  // 0: 128 x 128
+    {4, 1, 1, 3, 32, 0.95f},  // 1: 128 x  96   (N = 288 = 3*96)
+    {1, 4, 3, 1, 32, 0.95f},  // 2:  96 x 128   (M = 288, weight gradients)
+    {4, 1, 1, 2, 32, 0.85f},  // 3: 128 x  64
+    {1, 4, 2, 1, 32, 0.85f},  // 4:  64 x 128
+    {2, 2, 1, 1, 32, 0.60f},  // 5:  64 x  64
+    {2, 2, 4, 2, 16, 1.10f},  // 6: 256 x 128
+    {2, 2, 2, 4, 16, 1.10f},  // 7: 128 x 256
+    {4, 1, 2, 3, 16, 1.05f},  // 8: 256 x  96
+    {1, 4, 3, 2, 16, 1.05f},  // 9:  96 x 256
+    {2, 1, 1, 3, 32, 0.80f},  // 10: 64 x  96   (2 waves: finer quantisation for N = 288)
+    {1, 2, 3, 1, 32, 0.80f},  // 11: 96 x  64
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+static const int kScalarCfg = 5;
 
-template <int WMV, int WNV, int WM, int WN, bool VEC>
+template <int WMV, int WNV, int WM, int WN, int BK, bool VEC>
 static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid, hipStream_t st) {
   constexpr int NT = WMV * WNV * 64;
   if (a_kin && b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, true, true, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, true, VEC>), grid, dim3(NT), 0, st, p);
   else if (a_kin && !b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, true, false, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, false, VEC>), grid, dim3(NT), 0, st, p);
   else if (!a_kin && b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, false, true, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, true, VEC>), grid, dim3(NT), 0, st, p);
   else
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, false, false, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC>), grid, dim3(NT), 0, st, p);
 }
 
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
@@ -449,22 +469,24 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   int best = -1, best_splits = 1;
   double best_cost = 1e300;
   for (int c = 0; c < kNumCfgs; ++c) {
-    if (!vec && c != kNumCfgs - 1) continue;  // scalar staging: 64x64 only
+    if (!vec && c != kScalarCfg) continue;  // scalar staging: 64x64 only
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
+    const int bk = kCfgs[c].bk;
+    const double pipes = kCfgs[c].waves_m * kCfgs[c].waves_n / 4.0;   // 2-wave blocks use half a CU
     const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN) * nbatch;
-    const int ktiles = (int)cdiv64(K > 0 ? K : 1, GEMM_BK);
+    const int ktiles = (int)cdiv64(K > 0 ? K : 1, bk);
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1) {
-        if (ktiles / s < 4) break;
+        if (ktiles * bk / s < 128) break;
         if ((int64_t)s * M * N * nbatch > ws_cap) break;
       }
       const int kps = (int)cdiv64(ktiles, s);
-      const int64_t blocks = tiles * s;
-      const double waves = blocks >= 1024 ? (double)blocks / 256.0 : (double)cdiv64(blocks, 256);
-      // per-block time ~ tile flops / eff + fixed prologue/epilogue (~2 k-tiles); a split adds
-      // one pass over s partial slabs (HBM-bound, ~16 B/clk/CU) plus a launch
-      double cost = waves * ((double)BM * BN * (kps * GEMM_BK + 64) / kCfgs[c].eff);
-      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 4.0 / 16.0 * 4.0 + 2.0e6;
+      const double blocks = (double)tiles * s * pipes;
+      const double waves = blocks >= 1024 ? blocks / 256.0 : (double)cdiv64((int64_t)(blocks + 0.999), 256);
+      // per-block time ~ tile flops / eff + fixed prologue/epilogue (~64 k); a split adds
+      // one pass over s partial slabs plus a launch
+      double cost = waves * ((double)BM * BN / pipes * (kps * bk + 64) / kCfgs[c].eff);
+      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 1.0 + 2.0e6;
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = s; }
     }
   }
@@ -473,16 +495,15 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     int c = -1, sp = 0;
     if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec) {
       best = c;
-      if (sp >= 1 && (int64_t)sp * M * N * nbatch <= (ws_cap > 0 ? ws_cap : (sp == 1 ? 1 : 0))) best_splits = sp;
-      else if (sp == 1) best_splits = 1;
+      if (sp >= 1 && (sp == 1 || (int64_t)sp * M * N * nbatch <= ws_cap)) best_splits = sp;
     }
   }
   const TileCfg& cfg = kCfgs[best];
   const int BM = cfg.waves_m * cfg.wm * 32, BN = cfg.waves_n * cfg.wn * 32;
   p.tiles_m = (int)cdiv64(M, BM);
   p.tiles_n = (int)cdiv64(N, BN);
-  const int ktiles = (int)cdiv64(K > 0 ? K : 1, GEMM_BK);
-  p.k_per_split = (int)cdiv64(ktiles, best_splits) * GEMM_BK;
+  const int ktiles = (int)cdiv64(K > 0 ? K : 1, cfg.bk);
+  p.k_per_split = (int)cdiv64(ktiles, best_splits) * cfg.bk;
   p.splits = (int)cdiv64(K > 0 ? K : 1, p.k_per_split);
   if (p.splits < 1) p.splits = 1;
   PDN_CHECK_ARG((int64_t)nbatch * p.splits <= 65535, "pdn_gemm_f32: batch*splits too large (%d)",
@@ -504,15 +525,21 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
 
   if (vec) {
     switch (best) {
-      case 0: launch_layout<2, 2, 2, 2, true>(p, a_kin, b_kin, grid, st); break;
-      case 1: launch_layout<4, 1, 1, 3, true>(p, a_kin, b_kin, grid, st); break;
-      case 2: launch_layout<1, 4, 3, 1, true>(p, a_kin, b_kin, grid, st); break;
-      case 3: launch_layout<4, 1, 1, 2, true>(p, a_kin, b_kin, grid, st); break;
-      case 4: launch_layout<1, 4, 2, 1, true>(p, a_kin, b_kin, grid, st); break;
-      default: launch_layout<2, 2, 1, 1, true>(p, a_kin, b_kin, grid, st); break;
+      case 0: launch_layout<2, 2, 2, 2, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 1: launch_layout<4, 1, 1, 3, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 2: launch_layout<1, 4, 3, 1, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 3: launch_layout<4, 1, 1, 2, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 4: launch_layout<1, 4, 2, 1, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 6: launch_layout<2, 2, 4, 2, 16, true>(p, a_kin, b_kin, grid, st); break;
+      case 7: launch_layout<2, 2, 2, 4, 16, true>(p, a_kin, b_kin, grid, st); break;
+      case 8: launch_layout<4, 1, 2, 3, 16, true>(p, a_kin, b_kin, grid, st); break;
+      case 9: launch_layout<1, 4, 3, 2, 16, true>(p, a_kin, b_kin, grid, st); break;
+      case 10: launch_layout<2, 1, 1, 3, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 11: launch_layout<1, 2, 3, 1, 32, true>(p, a_kin, b_kin, grid, st); break;
+      default: launch_layout<2, 2, 1, 1, 32, true>(p, a_kin, b_kin, grid, st); break;
     }
   } else {
-    launch_layout<2, 2, 1, 1, false>(p, a_kin, b_kin, grid, st);
+    launch_layout<2, 2, 1, 1, 32, false>(p, a_kin, b_kin, grid, st);
   }
   PDN_LAUNCH_CHECK();
   if (p.splits > 1) {

@@ -50,3 +50,27 @@ for Bsz in (16, 64):
     s = hp.empty((Bsz, 6, 256, 256))
     bench("attn QK^T (batched NT views)", q.transpose(0, 2, 1, 3), k.transpose(0, 2, 3, 1), s)
     bench("attn PV (batched NN views)", s, k.transpose(0, 2, 1, 3), hp.empty((Bsz, 6, 256, 48)))
+
+# ---- tile-shape sweep on the key shapes (PDN_GEMM_CFG override) -------------------------------
+import os
+print("--- sweep: cfg 0=128x128 1=128x96 2=96x128 3=128x64 4=64x128 5=64x64 6=256x128 7=128x256 8=256x96 9=96x256 10=64x96 11=96x64")
+T = 64 * 256
+x, w288, w768, wv = rnd(T, 288), rnd(288, 288), rnd(288, 768), rnd(288, 32000)
+g768, g288, h768, wd = rnd(T, 768), rnd(T, 288), rnd(T, 768), rnd(768, 288)
+logits = rnd(T // 4, 32000)
+shapes = [("fwd 288->288", x, w288, (T, 288), "1 3 8 10"), ("fwd 288->768", x, w768, (T, 768), "0 1 6 7 8"),
+          ("fwd 768->288", h768, wd, (T, 288), "1 8 10"), ("dX 768->288 NT", g768, w768.T, (T, 288), "1 8 10"),
+          ("dX 288->768 NT", g288, wd.T, (T, 768), "0 1 6 7 8"),
+          ("dW 288x768 TN", x.T, g768, (288, 768), "2,4 2,8 4,4 4,8 9,4 9,8 9,16 11,8 11,16 0,8"),
+          ("dW 288x288 TN", x.T, g288, (288, 288), "2,8 2,16 4,8 4,16 9,8 9,16 11,8 11,16 11,32"),
+          ("dW 768x288 TN", h768.T, g288, (768, 288), "2,4 2,8 3,8 9,8 11,8 11,16 0,8"),
+          ("lm_head fwd", x[:T // 4], wv, (T // 4, 32000), "0 6 7"),
+          ("lm_head dX NT", logits, wv.T, (T // 4, 288), "1 8 10"),
+          ("lm_head dW TN", x[:T // 4].T, logits, (288, 32000), "2 9 0")]
+for name, A, B, cs, cfgs in shapes:
+    C = hp.empty(cs)
+    for cfg in cfgs.split():
+        os.environ["PDN_GEMM_CFG"] = cfg
+        bench(f"{name} cfg={cfg}", A, B, C, iters=10)
+    os.environ.pop("PDN_GEMM_CFG")
+    bench(f"{name} auto", A, B, C, iters=10)
