@@ -361,18 +361,19 @@ struct TileCfg {
   float eff;  // relative efficiency of the tile shape (operand bytes per MFMA, barrier rate)
 };
 static const TileCfg kCfgs[] = {
+    // eff values are fitted to the round-1 tile sweep on MI355X (tools/gemm_bench.py, profiles/)
     {2, 2, 2, 2, 32, 1.00f},  // 0: 128 x 128
-    {4, 1, 1, 3, 32, 0.95f},  // 1: 128 x  96   (N = 288 = 3*96)
+    {4, 1, 1, 3, 32, 0.97f},  // 1: 128 x  96   (N = 288 = 3*96)
     {1, 4, 3, 1, 32, 0.95f},  // 2:  96 x 128   (M = 288, weight gradients)
     {4, 1, 1, 2, 32, 0.85f},  // 3: 128 x  64
-    {1, 4, 2, 1, 32, 0.85f},  // 4:  64 x 128
+    {1, 4, 2, 1, 32, 0.90f},  // 4:  64 x 128
     {2, 2, 1, 1, 32, 0.60f},  // 5:  64 x  64
-    {2, 2, 4, 2, 16, 1.10f},  // 6: 256 x 128
-    {2, 2, 2, 4, 16, 1.10f},  // 7: 128 x 256
-    {4, 1, 2, 3, 16, 1.05f},  // 8: 256 x  96
-    {1, 4, 3, 2, 16, 1.05f},  // 9:  96 x 256
-    {2, 1, 1, 3, 32, 0.80f},  // 10: 64 x  96   (2 waves: finer quantisation for N = 288)
-    {1, 2, 3, 1, 32, 0.80f},  // 11: 96 x  64
+    {2, 2, 4, 2, 16, 0.85f},  // 6: 256 x 128
+    {2, 2, 2, 4, 16, 1.10f},  // 7: 128 x 256   (only offered to very wide outputs, see below)
+    {4, 1, 2, 3, 16, 0.99f},  // 8: 256 x  96
+    {1, 4, 3, 2, 16, 0.70f},  // 9:  96 x 256
+    {2, 1, 1, 3, 32, 0.78f},  // 10: 64 x  96   (2 waves: finer quantisation for N = 288)
+    {1, 2, 3, 1, 32, 0.70f},  // 11: 96 x  64
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kScalarCfg = 5;
@@ -470,6 +471,8 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   double best_cost = 1e300;
   for (int c = 0; c < kNumCfgs; ++c) {
     if (!vec && c != kScalarCfg) continue;  // scalar staging: 64x64 only
+    if (c == 7 && N < 2048) continue;
+    if (c == 8 && N < 768) continue;        // 256-row tiles lose on narrow outputs (one block per CU)
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
     const int bk = kCfgs[c].bk;
     const double pipes = kCfgs[c].waves_m * kCfgs[c].waves_n / 4.0;   // 2-wave blocks use half a CU

@@ -79,29 +79,19 @@ class DataParallel:
         if optimizer is not None:
             optimizer.grad_scale = 1.0 / self.world
             optimizer._table_key = None               # grads moved: rebuild the chunk table
+            if [id(p) for p in optimizer.params][::-1] == [id(p) for p in self.params]:
+                optimizer._flat_grad, optimizer._flat_offsets = self.flat, self.offsets[::-1]
+                optimizer._flat_views = [p.grad for p in optimizer.params]
         if broadcast_parameters and self.world > 1:
             self.broadcast_parameters()
         self._reset()
 
     # -- flat gradient storage ----------------------------------------------------------------
     def _flatten(self, bucket_mb):
+        from .optim.flat import flatten_gradients
         sizes = [p.size for p in self.params]
-        for p in self.params:
-            if p.dtype != np.float32:
-                raise TypeError("DataParallel supports float32 parameters")
-        # keep every view 16-byte aligned for the float4 kernels
-        offs, total = [], 0
-        for n in sizes:
-            offs.append(total)
-            total += (n + 3) // 4 * 4
-        xp = self.device.xp
-        with self.device:
-            self.flat = xp.zeros((total,), dtype=np.float32)
+        self.flat, offs = flatten_gradients(self.params)
         self.offsets = offs
-        for p, off, n in zip(self.params, offs, sizes):
-            view = self.flat[off:off + n].reshape(p.shape)
-            view[...] = p.grad                       # keep whatever was accumulated so far
-            p.grad = view
         cap = max(int(bucket_mb * (1 << 20) / 4), 1)
         self.buckets, start, first = [], 0, 0        # (elem_lo, elem_hi, param_lo, param_hi)
         for i, (off, n) in enumerate(zip(offs, sizes)):

@@ -12,13 +12,32 @@ from ..core import Tensor
 class Optimizer:
     def __init__(self, params) -> None:
         self.params = list(params)
+        self._flat_grad = None
 
     def step(self):
         raise NotImplementedError
 
     def zero_grad(self):
+        if self._flat_grad is not None and self._flat_ok():
+            with self.params[0].device:
+                self._flat_grad[...] = 0.          # one fill instead of one per parameter
+            return
         for p in self.params:
             p.zero_grad()
+
+    def flatten_grads(self):
+        """Move all gradients into one flat buffer (see optim/flat.py); optional, HIP or CPU."""
+        from .flat import flatten_gradients
+        self._flat_grad, self._flat_offsets = flatten_gradients(self.params)
+        self._flat_views = [p.grad for p in self.params]
+        return self._flat_grad
+
+    def _flat_ok(self):
+        # user code may have re-assigned p.grad; fall back to per-parameter zeroing then
+        for p, v in zip(self.params, self._flat_views):
+            if p.grad is not v:
+                return False
+        return True
 
     def _state(self):
         out = []
