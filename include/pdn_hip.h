@@ -49,12 +49,17 @@ int pdn_stream_synchronize(void* stream);
 /* ---- matmul: `x.data @ y.data`, and `grad @ B^T`, `A^T @ grad` (tensor.py:659,670-675) ----
  * C[b1,b2] = alpha * A[b1,b2](MxK) * B[b1,b2](KxN) + bias[N] + beta * C[b1,b2]
  * A(m,k)=A[m*a_rs+k*a_cs], B(k,n)=B[k*b_rs+n*b_cs], C(m,n)=C[m*ldc+n]; two batch dims with
- * independent (possibly 0) strides.  fp32 MFMA, split-K through `workspace` when given. */
+ * independent (possibly 0) strides.  fp32 MFMA, split-K through `workspace` when given.
+ * Optional epilogue fusions: `residual` (indexed like C) is added to the result -- the
+ * `x + sublayer(x)` of llm/llama/model.py:146,150; `b_colsum[N]` receives the column sums of B
+ * for the A^T-form product x^T @ g -- the bias gradient the engine obtains by summing the
+ * broadcast axes (tensor.py:360-370) -- in the same pass that forms dW. */
 int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs, int64_t a_cs,
                  const float* B, int64_t b_rs, int64_t b_cs, float beta, float* C, int64_t ldc,
                  const float* bias, int nb1, int nb2, int64_t a_bs1, int64_t a_bs2,
-                 int64_t b_bs1, int64_t b_bs2, int64_t c_bs1, int64_t c_bs2, void* workspace,
-                 int64_t workspace_bytes, void* stream);
+                 int64_t b_bs1, int64_t b_bs2, int64_t c_bs1, int64_t c_bs2, const float* residual,
+                 float* b_colsum, int colsum_accumulate, void* workspace, int64_t workspace_bytes,
+                 void* stream);
 int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
 /* per-launch HIP-event timing of the GEMM kernel for bench.py's roofline block */
 int pdn_gemm_prof_enable(int on);
@@ -158,6 +163,15 @@ int pdn_pool2d_fwd_f32(const float* x, int N, int C, int H, int W, int k, int st
                        int mode, float* y, void* stream);
 int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, int C, int H, int W,
                        int k, int stride, int pad, int mode, float* dx, void* stream);
+
+/* Forward and backward of the same loss in one pass over HBM: dlogits = (softmax - onehot) *
+ * gscale is written while the row is L2-resident.  Backward then only applies the upstream
+ * scalar with pdn_scale_by_device_scalar_f32, which reads it on the device and leaves the
+ * buffer untouched when it is exactly 1 (the `loss.backward()` case) -- no host sync. */
+int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, int64_t rows, int V,
+                                  int mean, float gscale, float* loss_row, float* lse_row,
+                                  float* loss_out, float* dlogits, int* err_flag, void* stream);
+int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* scalar_dev, void* stream);
 
 /* ---- Adam.step for all parameters in one launch (optim/optimizer.py:185-196).
  * chunk_table_dev: device int64[nchunks][5] = {p, g, m, v addresses, n elements}.

@@ -45,28 +45,43 @@ def _is_leaf_f32(t):
 
 # ---------------------------------------------------------------------------------------
 class linear(_Operator):
-    """y = x @ W (+ b) over the last axis of x; W is (in, out)."""
+    """y = x @ W (+ b) (+ residual) over the last axis of x; W is (in, out).
 
-    def __init__(self, x, weight, bias=None):
-        self.has_bias = bias is not None
-        super().__init__(*((x, weight, bias) if self.has_bias else (x, weight)))
+    `residual` (shape of y) folds the `z = x + sublayer(x)` add of a transformer block into the
+    GEMM epilogue; its gradient is the upstream gradient itself."""
 
-    def forward_(self, x, w, b=None):
+    def __init__(self, x, weight, bias=None, residual=None):
+        self.has_bias, self.has_res = bias is not None, residual is not None
+        ins = [x, weight] + ([bias] if self.has_bias else []) + ([residual] if self.has_res else [])
+        super().__init__(*ins)
+
+    def _split(self, ins):
+        b = ins[2] if self.has_bias else None
+        r = ins[2 + self.has_bias] if self.has_res else None
+        return ins[0], ins[1], b, r
+
+    def forward_(self, *ins):
+        x, w, b, r = self._split(ins)
         if self.xp is np:
             y = x.data @ w.data
-            return y + b.data if b is not None else y
+            if b is not None:
+                y = y + b.data
+            return y + r.data if r is not None else y
         hp = _hip()
         fin, fout = w.shape
         x2 = x.data.reshape(-1, fin)
         out = hp.empty(x.shape[:-1] + (fout,), np.float32)
-        hp.gemm(x2, w.data, out.reshape(-1, fout), bias=b.data.reshape(-1) if b is not None else None)
+        res = _contig(r.data).reshape(-1, fout) if r is not None else None
+        hp.gemm(x2, w.data, out.reshape(-1, fout), bias=b.data.reshape(-1) if b is not None else None,
+                residual=res)
         return out
 
     def backward_all(self, g):
-        x, w = self.last[0], self.last[1]
-        b = self.last[2] if self.has_bias else None
+        x, w, b, r = self._split(self.last)
         fin, fout = w.shape
-        grads = [None, None, None][:len(self.last)]
+        grads = [None] * len(self.last)
+        if self.has_res and r.requires_grad:
+            grads[2 + self.has_bias] = g
         if self.xp is np:
             g2, x2 = g.reshape(-1, fout), x.data.reshape(-1, fin)
             if x.requires_grad:
@@ -83,14 +98,20 @@ class linear(_Operator):
             dx = hp.empty(x.shape, np.float32)
             hp.gemm(g2, w.data.T, dx.reshape(-1, fin))                     # NT
             grads[0] = dx
+        need_db = b is not None and b.requires_grad
+        # bias gradient = column sums of g: formed inside the dW GEMM (both read g once) when the
+        # operands have the aligned x^T @ g layout and the leaf buffers can be accumulated into
+        fuse_db = (need_db and w.requires_grad and _is_leaf_f32(b) and x2.is_contiguous()
+                   and fin % 4 == 0 and fout % 4 == 0 and x2.shape[0] % 4 == 0)
         if w.requires_grad:
+            cs = b.grad.reshape(-1) if fuse_db else None
             if _is_leaf_f32(w):
-                hp.gemm(x2.T, g2, w.grad, beta=1.0)                        # TN, += into the leaf
+                hp.gemm(x2.T, g2, w.grad, beta=1.0, b_colsum=cs, colsum_accumulate=True)   # TN, += into the leaf
             else:
                 dw = hp.empty((fin, fout), np.float32)
-                hp.gemm(x2.T, g2, dw)
+                hp.gemm(x2.T, g2, dw, b_colsum=cs, colsum_accumulate=True)
                 grads[1] = dw
-        if b is not None and b.requires_grad:
+        if need_db and not fuse_db:
             grads[2] = g2.sum(0).reshape(b.shape)
         return grads
 
@@ -385,9 +406,19 @@ class cross_entropy(_Operator):
         loss_row = hp.empty((n,), np.float32)
         self._lse = hp.empty((n,), np.float32)
         out = hp.empty((1,), np.float32)
-        L.call("pdn_cross_entropy_fwd_f32", self._x._ptr, self._t._ptr, n, V,
-               1 if self.reduction == "mean" else 0, loss_row._ptr, self._lse._ptr, out._ptr,
-               hp._err_flag().data_ptr(), hp.stream())
+        mean = 1 if self.reduction == "mean" else 0
+        self._dx = None
+        from ..autograd import is_grad_enable
+        if x.requires_grad and is_grad_enable():
+            # the gradient w.r.t. the logits needs nothing computed later: write it now, while each
+            # row is still in L2 (one pass over HBM for forward + backward)
+            self._dx = hp.empty((n, V), np.float32)
+            L.call("pdn_cross_entropy_fwd_bwd_f32", self._x._ptr, self._t._ptr, n, V, mean,
+                   1.0 / n if mean else 1.0, loss_row._ptr, self._lse._ptr, out._ptr, self._dx._ptr,
+                   hp._err_flag().data_ptr(), hp.stream())
+        else:
+            L.call("pdn_cross_entropy_fwd_f32", self._x._ptr, self._t._ptr, n, V, mean, loss_row._ptr,
+                   self._lse._ptr, out._ptr, hp._err_flag().data_ptr(), hp.stream())
         return out.reshape(())
 
     def backward_all(self, g):
@@ -399,8 +430,12 @@ class cross_entropy(_Operator):
             sm[np.arange(n), np.asarray(self._t)] -= 1
             return [sm * (g * np.asarray(scale, x.dtype))]
         hp, L = _hip(), _L()
-        dx = hp.empty((n, V), np.float32)
         g = _contig(g)
+        if self._dx is not None:
+            dx, self._dx = self._dx, None       # written in forward; apply the upstream scalar (1 -> no-op)
+            L.call("pdn_scale_by_device_scalar_f32", dx._ptr, dx.size, g._ptr, hp.stream())
+            return [dx]
+        dx = hp.empty((n, V), np.float32)
         L.call("pdn_cross_entropy_bwd_f32", self._x._ptr, self._t._ptr, self._lse._ptr, g._ptr,
                scale, dx._ptr, n, V, hp.stream())
         return [dx]

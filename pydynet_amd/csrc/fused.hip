@@ -793,3 +793,96 @@ extern "C" int pdn_adam_multi_f32(const int64_t* chunk_table_dev, int nchunks, f
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
+
+// ======================================================================================
+// Cross entropy, forward and backward in ONE pass over HBM.  The gradient of the loss with
+// respect to the logits does not depend on anything produced later, so it is written while the
+// row is still in L2: pass 1 max, pass 2 sum-exp, pass 3 dlogits = (softmax - onehot) * gscale.
+// Backward then only has to apply the upstream scalar, which is 1 for `loss.backward()`:
+// pdn_scale_by_device_scalar_f32 reads it ON THE DEVICE and returns without touching the
+// buffer when it is exactly 1 (no host sync, no extra pass).
+// ======================================================================================
+__global__ void ce_fwd_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                  float* __restrict__ loss_row, float* __restrict__ lse_row,
+                                  float* __restrict__ dx, float gscale, int64_t rows, int V,
+                                  int* __restrict__ err) {
+  __shared__ float red[16];
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float* xr = x + row * (int64_t)V;
+    float* dr = dx + row * (int64_t)V;
+    const int n4 = ((((uintptr_t)xr | (uintptr_t)dr) & 15) == 0) ? V >> 2 : 0;
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(xr)[i];
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    for (int c = n4 * 4 + threadIdx.x; c < V; c += blockDim.x) m = fmaxf(m, xr[c]);
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(xr)[i];
+      s += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+    }
+    for (int c = n4 * 4 + threadIdx.x; c < V; c += blockDim.x) s += expf(xr[c] - m);
+    s = block_sum(s, red);
+    const float lse = logf(s) + m;
+    int64_t t = tgt[row];
+    if (t < 0) t += V;
+    if (t < 0 || t >= V) { if (threadIdx.x == 0) *err = 1; t = 0; }
+    if (threadIdx.x == 0) {
+      lse_row[row] = lse;
+      loss_row[row] = lse - xr[t];
+    }
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(xr)[i];
+      float4 r;
+      r.x = expf(v.x - lse); r.y = expf(v.y - lse); r.z = expf(v.z - lse); r.w = expf(v.w - lse);
+      const int c = 4 * i;
+      if (t >= c && t < c + 4) {
+        if (t == c) r.x -= 1.f; else if (t == c + 1) r.y -= 1.f;
+        else if (t == c + 2) r.z -= 1.f; else r.w -= 1.f;
+      }
+      r.x *= gscale; r.y *= gscale; r.z *= gscale; r.w *= gscale;
+      reinterpret_cast<float4*>(dr)[i] = r;
+    }
+    for (int c = n4 * 4 + threadIdx.x; c < V; c += blockDim.x)
+      dr[c] = (expf(xr[c] - lse) - (c == t ? 1.f : 0.f)) * gscale;
+    __syncthreads();
+  }
+}
+
+extern "C" int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, int64_t rows,
+                                             int V, int mean, float gscale, float* loss_row,
+                                             float* lse_row, float* loss_out, float* dlogits,
+                                             int* err_flag, void* stream) {
+  PDN_CHECK_ARG(rows > 0 && V > 0, "pdn_cross_entropy_fwd_bwd_f32: empty input");
+  PDN_CHECK_ARG(logits && targets && loss_row && lse_row && loss_out && dlogits && err_flag,
+                "pdn_cross_entropy_fwd_bwd_f32: null operand");
+  hipStream_t st = (hipStream_t)stream;
+  const int g = (int)(rows < 65535 ? rows : 65535);
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(g), dim3(256), 0, st, logits, targets, loss_row, lse_row,
+                     dlogits, gscale, rows, V, err_flag);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows,
+                     mean ? 1.f / (float)rows : 1.f, loss_out);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+__global__ void scale_by_device_scalar_kernel(float* __restrict__ x, int64_t n,
+                                              const float* __restrict__ scalar) {
+  const float s = scalar[0];
+  if (s == 1.0f) return;                                   // the common case: nothing to do
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) x[i] *= s;
+}
+
+// x[i] *= scalar_dev[0]; a no-op pass (blocks exit after one load) when the scalar is exactly 1.
+extern "C" int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* scalar_dev, void* stream) {
+  if (n == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && scalar_dev && n > 0, "pdn_scale_by_device_scalar_f32: bad arguments");
+  hipLaunchKernelGGL(scale_by_device_scalar_kernel, dim3(stream_grid(n / 4 + 1)), dim3(256), 0,
+                     (hipStream_t)stream, x, n, scalar_dev);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

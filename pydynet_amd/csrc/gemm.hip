@@ -43,6 +43,9 @@ struct GemmParams {
   const float* B;
   float* C;
   const float* bias;
+  const float* residual;   // optional, same indexing as C: C += residual
+  float* colsum;           // optional, length N: column sums of B (bias gradient of x^T @ g)
+  int colsum_acc;
   float* ws;
   int M, N, K;
   int64_t a_rs, a_cs, b_rs, b_cs, ldc;
@@ -139,10 +142,11 @@ struct TileLoader {
 
 // One k-loop over [k_begin, k_end) for the tile at (m0, n0).  INTERIOR tiles (fully inside M x N
 // with whole k-tiles) take loads with no bounds tests so the staging code is branch-free.
-template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool INTERIOR>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool INTERIOR, bool COLSUM>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* __restrict__ A,
                                               const float* __restrict__ B, float* smem, int m0, int n0,
-                                              int k_begin, int k_end, f32x16 (&acc)[WM][WN]) {
+                                              int k_begin, int k_end, f32x16 (&acc)[WM][WN],
+                                              bool do_colsum, float& csum) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   using LA = TileLoader<BM, BK, A_KIN, VEC, NT>;
@@ -176,6 +180,16 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
       LA::load(ra, A, p.a_rs, p.a_cs, m0, k0, m_end, kk_end, tid);
       LB::load(rb, B, p.b_cs, p.b_rs, n0, k0, n_end, kk_end, tid);
     }
+    if (COLSUM && do_colsum) {
+      // column sums of the staged B tile ([BK][BN+pad], zero-filled outside K x N): thread ->
+      // (column, row group); only the tile_m == 0 blocks do this so each column is counted once
+      constexpr int CG = NT / BN > 0 ? NT / BN : 1;
+      if (tid < CG * BN) {
+        const int col = tid % BN, grp = tid / BN;
+#pragma unroll
+        for (int k = grp; k < BK; k += CG) csum += Bs[k * LB::LD + col];
+      }
+    }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       float a[WM][4], b[WN][4];
@@ -201,7 +215,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   }
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC>
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel(GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -250,10 +264,25 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  const bool do_colsum = COLSUM && p.colsum != nullptr && tile_m == 0;
+  float csum = 0.f;
   if (interior)
-    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, BK, A_KIN, B_KIN, VEC, true>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
+    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, BK, A_KIN, B_KIN, VEC, true, COLSUM>(p, A, B, smem, m0, n0, k_begin, k_end, acc, do_colsum, csum);
   else
-    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, BK, A_KIN, B_KIN, VEC, false>(p, A, B, smem, m0, n0, k_begin, k_end, acc);
+    gemm_mainloop<WAVES_M, WAVES_N, WM, WN, BK, A_KIN, B_KIN, VEC, false, COLSUM>(p, A, B, smem, m0, n0, k_begin, k_end, acc, do_colsum, csum);
+  if (COLSUM && do_colsum) {
+    constexpr int CG = NT / BN > 0 ? NT / BN : 1;
+    if (threadIdx.x < CG * BN) smem[threadIdx.x] = csum;
+    __syncthreads();
+    if (threadIdx.x < BN && n0 + (int)threadIdx.x < p.N) {
+      float s = smem[threadIdx.x];
+#pragma unroll
+      for (int g = 1; g < CG; ++g) s += smem[g * BN + threadIdx.x];
+      float* dst = p.colsum + n0 + threadIdx.x;
+      *dst = p.colsum_acc ? *dst + s : s;
+    }
+    __syncthreads();
+  }
 
   // ---- epilogue -----------------------------------------------------------------------
   // 32x32 accumulator map: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -266,10 +295,12 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel
               : p.C + b1 * p.c_bs1 + b2 * p.c_bs2;
   const int64_t ldc = partial ? p.N : p.ldc;
   const float* bias = partial ? nullptr : p.bias;
+  const float* __restrict__ R = (partial || !p.residual) ? nullptr : p.residual + b1 * p.c_bs1 + b2 * p.c_bs2;
   const float beta = partial ? 0.f : p.beta;
 
   const bool wide = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((ldc & 3) == 0) &&
-                    (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0);
+                    (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                    (!R || ((uintptr_t)R & 15) == 0);
   if (wide) {
     // The main loop's last barrier has retired every read of the staging buffers, and each wave
     // only touches its own band region, so wave-level ordering is all that is needed from here.
@@ -298,6 +329,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel
             const float4 bv = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
             v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
           }
+          if (R) {
+            const float4 rv = *reinterpret_cast<const float4*>(R + (int64_t)(row0 + r) * ldc + col0 + 4 * c4);
+            v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+          }
           if (beta != 0.f) {
             const float4 o = *reinterpret_cast<const float4*>(dst);
             v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
@@ -323,21 +358,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
-          old[r] = (beta != 0.f && row < p.M) ? C[(int64_t)row * ldc + col] : 0.f;
+          old[r] = (beta != 0.f && row < p.M) ? beta * C[(int64_t)row * ldc + col] : 0.f;
+          if (R && row < p.M) old[r] += R[(int64_t)row * ldc + col];
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < p.M) C[(int64_t)row * ldc + col] = p.alpha * acc[i][j][r] + bv + beta * old[r];
+          if (row < p.M) C[(int64_t)row * ldc + col] = p.alpha * acc[i][j][r] + bv + old[r];
         }
       }
     }
   }
 }
 
-// C = beta*C + sum_s ws[s] + bias, deterministic order.
-__global__ void gemm_splitk_reduce_kernel(GemmParams p, int nbatch) {
+// C = beta*C + sum_s ws[s] + bias (+ residual), deterministic order.  Rows of the slabs are N
+// floats; when N and ldc are multiples of 4 every thread combines one 16-byte piece.
+__global__ void gemm_splitk_reduce_kernel(GemmParams p, int nbatch, int vec) {
   const int64_t mn = (int64_t)p.M * p.N;
+  if (vec) {
+    const int n4 = p.N >> 2;
+    const int64_t total4 = (mn >> 2) * nbatch;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+      const int batch = (int)(i / (mn >> 2));
+      const int64_t e4 = i - batch * (mn >> 2);
+      const int row = (int)(e4 / n4), c4 = (int)(e4 - (int64_t)row * n4);
+      const float4* w = reinterpret_cast<const float4*>(p.ws + (int64_t)batch * p.splits * mn) + e4;
+      float4 s = w[0];
+      for (int k = 1; k < p.splits; ++k) {
+        const float4 t = w[(int64_t)k * (mn >> 2)];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+      }
+      const int b1 = batch / p.nb2, b2 = batch % p.nb2;
+      const int64_t off = b1 * p.c_bs1 + b2 * p.c_bs2 + (int64_t)row * p.ldc + 4 * c4;
+      if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + 4 * c4); s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w; }
+      if (p.residual) { const float4 r = *reinterpret_cast<const float4*>(p.residual + off); s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w; }
+      float4* dst = reinterpret_cast<float4*>(p.C + off);
+      if (p.beta != 0.f) { const float4 o = *dst; s.x += p.beta * o.x; s.y += p.beta * o.y; s.z += p.beta * o.z; s.w += p.beta * o.w; }
+      *dst = s;
+    }
+    return;
+  }
   const int64_t total = mn * nbatch;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -348,10 +409,11 @@ __global__ void gemm_splitk_reduce_kernel(GemmParams p, int nbatch) {
     float s = 0.f;
     for (int k = 0; k < p.splits; ++k) s += w[k * mn];
     const int b1 = batch / p.nb2, b2 = batch % p.nb2;
-    float* dst = p.C + b1 * p.c_bs1 + b2 * p.c_bs2 + (int64_t)row * p.ldc + col;
+    const int64_t off = b1 * p.c_bs1 + b2 * p.c_bs2 + (int64_t)row * p.ldc + col;
     if (p.bias) s += p.bias[col];
-    if (p.beta != 0.f) s += p.beta * (*dst);
-    *dst = s;
+    if (p.residual) s += p.residual[off];
+    if (p.beta != 0.f) s += p.beta * p.C[off];
+    p.C[off] = s;
   }
 }
 
@@ -382,13 +444,15 @@ template <int WMV, int WNV, int WM, int WN, int BK, bool VEC>
 static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid, hipStream_t st) {
   constexpr int NT = WMV * WNV * 64;
   if (a_kin && b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, true, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, true, VEC, false>), grid, dim3(NT), 0, st, p);
   else if (a_kin && !b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, false, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, false, VEC, false>), grid, dim3(NT), 0, st, p);
   else if (!a_kin && b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, true, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, true, VEC, false>), grid, dim3(NT), 0, st, p);
+  else if (p.colsum && VEC)   // x^T @ g with the bias gradient (column sums of g) fused in
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC, VEC>), grid, dim3(NT), 0, st, p);
   else
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC, false>), grid, dim3(NT), 0, st, p);
 }
 
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
@@ -432,7 +496,8 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
                             int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta,
                             float* C, int64_t ldc, const float* bias, int nb1, int nb2,
                             int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
-                            int64_t c_bs1, int64_t c_bs2, void* workspace,
+                            int64_t c_bs1, int64_t c_bs2, const float* residual,
+                            float* b_colsum, int colsum_accumulate, void* workspace,
                             int64_t workspace_bytes, void* stream) {
   PDN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && nb1 >= 0 && nb2 >= 0, "pdn_gemm_f32: negative extent");
   if (M == 0 || N == 0 || nb1 == 0 || nb2 == 0) return PDN_OK;
@@ -443,6 +508,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
 
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = (float*)workspace;
+  p.residual = residual; p.colsum = b_colsum; p.colsum_acc = colsum_accumulate;
   p.M = M; p.N = N; p.K = K;
   p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
   p.nb2 = nb2;
@@ -462,6 +528,14 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   if (b_kin) vec = vec && b_rs == 1 && m4(b_cs) && m4(K);
   else vec = vec && b_cs == 1 && m4(b_rs) && m4(N);
 
+  if (b_colsum) {
+    // fused column sums need B staged n-contiguous, A m-contiguous (the dW = x^T @ g form), the
+    // float4 path, a single batch and no k-split (each column is summed by exactly one block)
+    if (a_kin || b_kin || !vec || nbatch != 1) {
+      pdn_set_error("pdn_gemm_f32: b_colsum needs the x^T @ g layout (A m-contiguous, B n-contiguous, aligned, unbatched)");
+      return PDN_EUNSUPPORTED;
+    }
+  }
   // ---- pick tile shape and k-split with a small cost model -----------------------------
   // The matrix pipes of a CU are shared by its resident workgroups, so MFMA throughput is
   // counted per CU (256), not per residency slot: n blocks take ceil(n/256) block-times until
@@ -479,6 +553,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN) * nbatch;
     const int ktiles = (int)cdiv64(K > 0 ? K : 1, bk);
     for (int s = 1; s <= 64; s *= 2) {
+      if (s > 1 && b_colsum) break;
       if (s > 1) {
         if (ktiles * bk / s < 128) break;
         if ((int64_t)s * M * N * nbatch > ws_cap) break;
@@ -498,7 +573,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     int c = -1, sp = 0;
     if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec) {
       best = c;
-      if (sp >= 1 && (sp == 1 || (int64_t)sp * M * N * nbatch <= ws_cap)) best_splits = sp;
+      if (sp >= 1 && (sp == 1 || ((int64_t)sp * M * N * nbatch <= ws_cap && !b_colsum))) best_splits = sp;
     }
   }
   const TileCfg& cfg = kCfgs[best];
@@ -548,7 +623,9 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   if (p.splits > 1) {
     const int64_t total = (int64_t)M * N * nbatch;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, nbatch);
+    const int rvec = (N % 4 == 0) && (ldc % 4 == 0) && al16(C) && m4(c_bs1) && m4(c_bs2) && (!bias || al16(bias)) &&
+                     (!residual || al16(residual)) && al16(workspace);
+    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, nbatch, rvec);
     PDN_LAUNCH_CHECK();
   }
   if (prof) {

@@ -854,8 +854,10 @@ def _collapse_batch(shape, *stride_lists):
     return merged
 
 
-def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None):
-    """C[...] = alpha * A[...] @ B[...] + bias + beta * C (batch dims broadcast, views consumed in place)."""
+def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None, residual=None, b_colsum=None, colsum_accumulate=False):
+    """C[...] = alpha * A[...] @ B[...] + bias + residual + beta * C (batch dims broadcast, views
+    consumed in place).  `residual` must have C's strides; `b_colsum` (N,) receives the column
+    sums of B in the same pass (only for the unbatched x^T @ g form)."""
     L = _lib.lib()
     M, K = A.shape[-2:]
     N = B.shape[-1]
@@ -871,6 +873,8 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None):
 
     if C._strides[-1] != 1 and N > 1:
         raise ValueError("gemm: output must have unit column stride")
+    if residual is not None and (residual.shape != C.shape or residual._strides != C._strides):
+        raise ValueError("gemm: residual must have the shape and strides of the output")
     merged = _collapse_batch(bshape, bstr(A), bstr(B), bstr(C))
     if len(merged) > 2:
         # rare: materialise operands so the batch collapses to one dim
@@ -889,8 +893,10 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None):
     ldc = C._strides[-2] if M > 1 else _bi.max(C._strides[-2], N)
     L.call("pdn_gemm_f32", M, N, K, float(alpha), A._ptr, A._strides[-2], A._strides[-1], B._ptr,
            B._strides[-2], B._strides[-1], float(beta), C._ptr, ldc,
-           bias._ptr if bias is not None else None, n1, n2, a1, a2, b1, b2, c1, c2, ws_ptr, ws_bytes,
-           _state["stream"])
+           bias._ptr if bias is not None else None, n1, n2, a1, a2, b1, b2, c1, c2,
+           residual._ptr if residual is not None else None,
+           b_colsum._ptr if b_colsum is not None else None, 1 if colsum_accumulate else 0,
+           ws_ptr, ws_bytes, _state["stream"])
     return C
 
 

@@ -37,8 +37,11 @@ class FeedForward(nn.Module):
         self.gate = nn.Linear(dim, up_dim, bias=False, dtype=dtype)
         self.down = nn.Linear(up_dim, dim, bias=False, dtype=dtype)
 
-    def forward(self, x):
-        return self.down(fused.swiglu(self.gate(x), self.up(x)))
+    def forward(self, x, residual=None):
+        h = fused.swiglu(self.gate(x), self.up(x))
+        if residual is None:
+            return self.down(h)
+        return fused.linear(h, self.down.weight, None, residual)      # residual add in the GEMM epilogue
 
 
 class Attention(nn.Module):
@@ -56,7 +59,7 @@ class Attention(nn.Module):
         self.cache_k = nn.Parameter(zeros(shape, dtype=dtype), requires_grad=False)
         self.cache_v = nn.Parameter(zeros(shape, dtype=dtype), requires_grad=False)
 
-    def __call__(self, x, start_pos, mask, freqs_cos, freqs_sin):
+    def __call__(self, x, start_pos, mask, freqs_cos, freqs_sin, residual=None):
         B, L, _ = x.shape
         H, hd = self.n_heads, self.head_dim
         xq = self.Q(x).reshape(B, L, H, hd)
@@ -69,7 +72,10 @@ class Attention(nn.Module):
             xk = self.cache_k[:B, :start_pos + L]
             xv = self.cache_v[:B, :start_pos + L]
         out = fused.attention(xq, xk, xv, causal=mask is not None, start_pos=start_pos)
-        return self.O(out.reshape(B, L, -1))
+        out = out.reshape(B, L, -1)
+        if residual is None:
+            return self.O(out)
+        return fused.linear(out, self.O.weight, None, residual)
 
 
 class TransformerBlock(nn.Module):
@@ -81,8 +87,9 @@ class TransformerBlock(nn.Module):
         self.post_attn_norm = nn.RMSNorm(dim, dtype=dtype)
 
     def forward(self, x, start_pos, mask, freqs_cos, freqs_sin):
-        z = x + self.attention(self.input_norm(x), start_pos, mask, freqs_cos, freqs_sin)
-        return z + self.ffn(self.post_attn_norm(z))
+        # z = x + attn(norm(x)); out = z + ffn(norm(z)) -- both adds ride in the GEMM epilogues
+        z = self.attention(self.input_norm(x), start_pos, mask, freqs_cos, freqs_sin, residual=x)
+        return self.ffn(self.post_attn_norm(z), residual=z)
 
 
 class Llama(nn.Module):

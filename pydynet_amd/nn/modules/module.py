@@ -15,8 +15,8 @@ class Module:
         self.device = Device("cpu")
         self._parameters = OrderedDict()
 
-    def __call__(self, *x):
-        return self.forward(*x)
+    def __call__(self, *x, **kw):
+        return self.forward(*x, **kw)
 
     def __setattr__(self, name, value) -> None:
         self.__dict__[name] = value

@@ -68,7 +68,7 @@ class EmulatedLib:
 
     # -- gemm -------------------------------------------------------------------------------
     def pdn_gemm_f32(self, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, nb1, nb2,
-                     a1, a2, b1, b2, c1, c2, ws, wsb, stream):
+                     a1, a2, b1, b2, c1, c2, residual, colsum, colsum_acc, ws, wsb, stream):
         if M == 0 or N == 0 or nb1 == 0 or nb2 == 0:
             return 0
         a = view(A, (nb1, nb2, M, K), (a1, a2, a_rs, a_cs), np.float32)
@@ -77,6 +77,12 @@ class EmulatedLib:
         r = np.float32(alpha) * np.matmul(a, b)
         if bias:
             r = r + flat(bias, N)
+        if residual:
+            r = r + view(residual, (nb1, nb2, M, N), (c1, c2, ldc, 1), np.float32)
+        if colsum:
+            assert nb1 * nb2 == 1 and a_rs == 1 and b_cs == 1, "b_colsum: x^T @ g layout only"
+            cs = b[0, 0].sum(0)
+            flat(colsum, N)[...] = flat(colsum, N) + cs if colsum_acc else cs
         if beta != 0.0:
             r = r + np.float32(beta) * c
         c[...] = r
@@ -274,6 +280,17 @@ class EmulatedLib:
         sm[np.arange(rows), t] -= 1
         gs = np.float32(gscale) * (flat(upstream, 1)[0] if upstream else np.float32(1))
         flat(dlogits, rows * V).reshape(rows, V)[...] = sm * gs
+        return 0
+
+    def pdn_cross_entropy_fwd_bwd_f32(self, logits, targets, rows, V, mean, gscale, loss_row, lse_row,
+                                      loss_out, dlogits, err, stream):
+        self.pdn_cross_entropy_fwd_f32(logits, targets, rows, V, mean, loss_row, lse_row, loss_out, err, stream)
+        return self.pdn_cross_entropy_bwd_f32(logits, targets, lse_row, None, gscale, dlogits, rows, V, stream)
+
+    def pdn_scale_by_device_scalar_f32(self, x, n, scalar, stream):
+        s = flat(scalar, 1)[0]
+        if s != 1.0:
+            flat(x, n)[...] *= s
         return 0
 
     def pdn_adam_multi_f32(self, table, nchunks, step, b1, b2, omb1, omb2, eps, wd, gscale, stream):

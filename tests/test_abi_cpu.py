@@ -41,11 +41,11 @@ def test_error_convention_without_launching():
     L = _lib.lib()
     assert L.query("pdn_abi_version") == 1
     rc = L.fn["pdn_gemm_f32"](-1, 4, 4, 1.0, None, 1, 1, None, 1, 1, 0.0, None, 4, None, 1, 1,
-                              0, 0, 0, 0, 0, 0, None, 0, None)
+                              0, 0, 0, 0, 0, 0, None, None, 0, None, 0, None)
     assert rc == -1 and b"negative" in L.fn["pdn_last_error"]()
     with pytest.raises(_lib.HipLibraryError, match="pdn_gemm_f32"):
         L.call("pdn_gemm_f32", 4, 4, 4, 1.0, None, 1, 1, None, 1, 1, 0.0, None, 4, None, 1, 1,
-               0, 0, 0, 0, 0, 0, None, 0, None)       # null operands
+               0, 0, 0, 0, 0, 0, None, None, 0, None, 0, None)       # null operands
     shape = (ctypes.c_int64 * 1)(4)
     rc = L.fn["pdn_ew_binary"](0, 99, 0, 1, shape, 8, shape, 8, shape, 0.0, 8, shape, None)
     assert rc == -1                                    # bad op code rejected before any launch

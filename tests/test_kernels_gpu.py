@@ -362,3 +362,50 @@ def test_adam_multi_matches_reference_update(hip):
         assert np.allclose(dP[i].get(), P[i], rtol=1e-5, atol=1e-7)
         assert np.allclose(dM[i].get(), M[i], rtol=1e-5, atol=1e-8)
         assert np.allclose(dV[i].get(), Vv[i], rtol=1e-5, atol=1e-10)
+
+
+def test_gemm_residual_and_fused_bias_gradient(hip):
+    rng = np.random.default_rng(13)
+    # residual add in the epilogue (interior tiles and ragged edges)
+    for M, N, K in [(256, 288, 768), (100, 52, 36)]:
+        a = rng.standard_normal((M, K), dtype=np.float32)
+        b = rng.standard_normal((K, N), dtype=np.float32)
+        r = rng.standard_normal((M, N), dtype=np.float32)
+        C = hip.empty((M, N))
+        hip.gemm(hip.from_numpy(a), hip.from_numpy(b), C, residual=hip.from_numpy(r))
+        assert rel_err(C.get(), a.astype(np.float64) @ b + r) < 1e-5
+    # dW = x^T @ g with the column sums of g (bias gradient) produced by the same kernel
+    for T, fin, fout in [(2048, 288, 32000), (512, 96, 200), (8192, 288, 288)]:
+        x = rng.standard_normal((T, fin), dtype=np.float32)
+        g = rng.standard_normal((T, fout), dtype=np.float32)
+        dw0 = rng.standard_normal((fin, fout), dtype=np.float32)
+        db0 = rng.standard_normal(fout, dtype=np.float32)
+        DW, DB = hip.from_numpy(dw0.copy()), hip.from_numpy(db0.copy())
+        hip.gemm(hip.from_numpy(x).T, hip.from_numpy(g), DW, beta=1.0, b_colsum=DB, colsum_accumulate=True)
+        assert rel_err(DW.get(), dw0 + x.T.astype(np.float64) @ g) < 2e-5
+        assert rel_err(DB.get(), db0 + g.astype(np.float64).sum(0)) < 2e-5
+
+
+def test_cross_entropy_one_pass_forward_backward(hip):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(14)
+    for rows, V in [(48, 32000), (19, 10)]:
+        x = rng.standard_normal((rows, V), dtype=np.float32) * 2
+        t = rng.integers(0, V, size=rows)
+        X, T = hip.from_numpy(x), hip.from_numpy(t)
+        lr, lse, out, DX = hip.empty((rows,)), hip.empty((rows,)), hip.empty((1,)), hip.empty((rows, V))
+        L.call("pdn_cross_entropy_fwd_bwd_f32", X._ptr, T._ptr, rows, V, 1, 1.0 / rows, lr._ptr, lse._ptr,
+               out._ptr, DX._ptr, hip._err_flag().data_ptr(), hip.stream())
+        x64 = x.astype(np.float64)
+        l = np.log(np.exp(x64 - x64.max()).sum(1)) + x64.max()
+        assert abs(out.get()[0] - (l - x64[np.arange(rows), t]).mean()) < 1e-5 * abs(l.mean())
+        sm = np.exp(x64 - l[:, None]); sm[np.arange(rows), t] -= 1
+        assert np.allclose(DX.get(), sm / rows, rtol=1e-4, atol=1e-8)
+        one, half = hip.from_numpy(np.ones(1, np.float32)), hip.from_numpy(np.full(1, 0.5, np.float32))
+        before = DX.get()
+        L.call("pdn_scale_by_device_scalar_f32", DX._ptr, DX.size, one._ptr, hip.stream())
+        assert np.array_equal(DX.get(), before)                       # scalar 1: buffer untouched
+        L.call("pdn_scale_by_device_scalar_f32", DX._ptr, DX.size, half._ptr, hip.stream())
+        assert np.array_equal(DX.get(), before * np.float32(0.5))
+    hip.check_index_errors()
