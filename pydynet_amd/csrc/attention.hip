@@ -1,0 +1,200 @@
+// Fused causal self-attention for the training path, fp32 MFMA (gfx950).
+//
+// Replaces the chain of llm/llama/model.py:112-121 --
+//     xq.T(0,2,1,3) @ xk.T(0,2,3,1) / sqrt(hd) + mask -> softmax(-1) -> @ xv.T(0,2,1,3) -> T(0,2,1,3)
+// -- i.e. 2 batched matmuls, a divide, an add and the 4-node softmax, which materialise a
+// (B, H, L, L) score tensor three times in HBM.  Here the scores never leave registers.
+//
+// Layout: q, k, v, o are (B, L, H, hd) exactly as the projections produce them (row stride
+// H*hd, head offset h*hd); nothing is transposed or copied.
+//
+// One workgroup (4 wave64, one per SIMD) per (batch, head).  K and V of that head are staged in
+// LDS once ([L][hd+4] each).  A wave owns 32-query tiles; tiles are dealt zig-zag (0,7 | 1,6 |
+// 2,5 | 3,4 for L = 256) so the causal work is balanced across the four waves.
+//
+// Per query tile (32 rows), with the 32x32x2 f32 MFMA:
+//   S^T[key][q]  = K Q^T      (A = K rows from LDS, B = Q rows held in registers, k = head dim)
+//     -> accumulator layout: lane = query, registers = keys, so the softmax row reductions are
+//        in-lane plus ONE cross-half shuffle;
+//   P^T = exp(S^T / sqrt(hd) - rowmax), l = rowsum
+//   O^T[d][q]    = V^T P^T    (A = V columns from LDS, B = the P^T accumulator registers as they are:
+//        inside one MFMA the two half-waves may contract over any two keys as long as A and B
+//        agree, so register r of the accumulator pairs key krow(r) / krow(r)+4 with no data movement)
+// Fully masked key tiles (key tile > query tile) are skipped; the diagonal tile is masked per
+// element with -inf exactly like the reference's additive mask (masked probabilities are 0).
+// The head dim (48) is padded to 64 in the O^T product only (two 32-row MFMA tiles).
+// Saved for backward: lse[b,h,q] = rowmax + log(rowsum).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define ATT_MAX_TILES 8      // L <= 256
+#define ATT_LD(hd) ((hd) + 4)
+
+__device__ __forceinline__ int att_krow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// zig-zag owner of query tile i among 4 waves
+__device__ __forceinline__ int att_owner(int i) { return ((i >> 2) & 1) ? 3 - (i & 3) : (i & 3); }
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attention_fwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
+    int64_t batch_stride, float sqrt_hd, int causal) {
+  constexpr int LD = ATT_LD(HD);
+  constexpr int NT8 = HD / 8;                    // k-groups of 8 along the head dim
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ks = lds;                               // [L][LD]
+  float* Vs = lds + (size_t)L * LD;              // [L][LD]
+  float* Os = Vs + (size_t)L * LD;               // 4 waves x [32][LD] output staging
+
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
+  const float* Qb = Q + base;
+  const float* Kb = K + base;
+  const float* Vb = V + base;
+  float* Ob = O + base;
+
+  // ---- stage K and V: each row is HD contiguous floats ------------------------------------
+  constexpr int F4 = HD / 4;
+  for (int u = tid; u < L * F4; u += 256) {
+    const int row = u / F4, c4 = u % F4;
+    const float4 kv = *reinterpret_cast<const float4*>(Kb + (int64_t)row * row_stride + 4 * c4);
+    const float4 vv = *reinterpret_cast<const float4*>(Vb + (int64_t)row * row_stride + 4 * c4);
+    *reinterpret_cast<float4*>(Ks + row * LD + 4 * c4) = kv;
+    *reinterpret_cast<float4*>(Vs + row * LD + 4 * c4) = vv;
+  }
+  __syncthreads();
+
+  const int ntile = L / 32;
+  float* Ow = Os + wave * (32 * LD);
+  for (int qt = 0; qt < ntile; ++qt) {
+    if (att_owner(qt) != wave) continue;
+    const int nk = causal ? qt + 1 : ntile;       // key tiles that can be unmasked
+    // Q fragments: lane (li, lh) holds Q[q = qt*32+li][8t + 4lh .. +3]
+    float4 qf[NT8];
+    {
+      const float* qrow = Qb + (int64_t)(qt * 32 + li) * row_stride + 4 * lh;
+#pragma unroll
+      for (int t = 0; t < NT8; ++t) qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+    }
+    // ---- S^T tiles ---------------------------------------------------------------------
+    f32x16 s[ATT_MAX_TILES];
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      if (kt < nk) {
+        const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
+#pragma unroll
+        for (int t = 0; t < NT8; ++t) {
+          const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s[kt], 0, 0, 0);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s[kt], 0, 0, 0);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s[kt], 0, 0, 0);
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s[kt], 0, 0, 0);
+        }
+      }
+    }
+    // ---- scale, mask, softmax over keys (per lane = per query) ------------------------------
+    const int qpos = qt * 32 + li;
+    float m = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+      if (kt < nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = s[kt][r] / sqrt_hd;
+          if (causal && kt * 32 + att_krow(r, lh) > qpos) v = -INFINITY;
+          s[kt][r] = v;
+          m = fmaxf(m, v);
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+      if (kt < nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = expf(s[kt][r] - m);
+          s[kt][r] = p;
+          l += p;
+        }
+      }
+    }
+    l += __shfl_xor(l, 32, 64);
+    // ---- O^T = V^T P^T  (two 32-row tiles over the head dim, the second half empty for hd=48)
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    const bool hi_ok = (32 + li) < HD;
+#pragma unroll
+    for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
+      if (kt < nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* vrow = Vs + (kt * 32 + att_krow(r, lh)) * LD;
+          const float a0 = vrow[li];
+          const float a1 = hi_ok ? vrow[32 + li] : 0.f;
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[kt][r], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[kt][r], o1, 0, 0, 0);
+        }
+      }
+    }
+    // ---- normalise, stage [q][d] in LDS, store rows coalesced -------------------------------
+    const float inv_l = 1.f / l;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = att_krow(r, lh);
+      Ow[li * LD + d] = o0[r] * inv_l;
+      if (32 + d < HD) Ow[li * LD + 32 + d] = o1[r] * inv_l;
+    }
+    if (lh == 0) LSE[(int64_t)bh * L + qpos] = m + logf(l);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int u = lane; u < 32 * F4; u += 64) {
+      const int row = u / F4, c4 = u % F4;
+      *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * row_stride + 4 * c4) =
+          *reinterpret_cast<const float4*>(Ow + row * LD + 4 * c4);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
+  return ((int64_t)2 * L + 4 * 32) * ATT_LD(head_dim) * 4;
+}
+
+// q, k, v, o: (B, L, H, head_dim) contiguous in head_dim, `row_stride` between consecutive
+// positions, `batch_stride` between batches.  lse: (B, H, L).  causal: keys > query masked.
+extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o,
+                                     float* lse, int B, int H, int L, int head_dim,
+                                     int64_t row_stride, int64_t batch_stride, int causal,
+                                     void* stream) {
+  if (B == 0 || H == 0 || L == 0) return PDN_OK;
+  PDN_CHECK_ARG(q && k && v && o && lse, "pdn_attention_fwd_f32: null operand");
+  if (head_dim != 48 || L % 32 != 0 || L > 32 * ATT_MAX_TILES) {
+    pdn_set_error("pdn_attention_fwd_f32: fused path supports head_dim 48, L multiple of 32 and <= %d",
+                  32 * ATT_MAX_TILES);
+    return PDN_EUNSUPPORTED;
+  }
+  PDN_CHECK_ARG((row_stride % 4) == 0 && (batch_stride % 4) == 0 &&
+                    ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0),
+                "pdn_attention_fwd_f32: 16-byte alignment required");
+  const size_t shm = (size_t)pdn_attention_lds_bytes(L, head_dim);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PDN_HIP(hipFuncSetAttribute((const void*)attention_fwd_kernel<48>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(256), shm, (hipStream_t)stream, q, k,
+                     v, o, lse, H, L, row_stride, batch_stride, sqrtf((float)head_dim), causal);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

@@ -160,59 +160,71 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   const int m_end = INTERIOR ? 0x7fffffff : p.M, n_end = INTERIOR ? 0x7fffffff : p.N;
   const int kk_end = INTERIOR ? 0x7fffffff : k_end;
 
-  float4 ra[LA::NP], rb[LB::NP];
+  // Two register sets: while tile t is multiplied, tile t+1 waits in one set (it is written to
+  // LDS in the middle of tile t's MFMA stream) and tile t+2 is in flight into the other.  The
+  // global-load window is therefore ~1.5 tiles of MFMA time (3-6k cycles), enough to cover HBM
+  // latency when an operand is streamed with no reuse (weight gradients, K = tokens).  The sets
+  // are named, not indexed, so they stay in registers (the loop is unrolled by two).
+  float4 ra0[LA::NP], rb0[LB::NP], ra1[LA::NP], rb1[LB::NP];
   const int ntile = (k_end - k_begin + BK - 1) / BK;
   if (ntile > 0) {
-    LA::load(ra, A, p.a_rs, p.a_cs, m0, k_begin, m_end, kk_end, tid);
-    LB::load(rb, B, p.b_cs, p.b_rs, n0, k_begin, n_end, kk_end, tid);
-    LA::store(ra, smem, tid);
-    LB::store(rb, smem + LA::SIZE, tid);
+    LA::load(ra0, A, p.a_rs, p.a_cs, m0, k_begin, m_end, kk_end, tid);
+    LB::load(rb0, B, p.b_cs, p.b_rs, n0, k_begin, n_end, kk_end, tid);
+    if (ntile > 1) {
+      LA::load(ra1, A, p.a_rs, p.a_cs, m0, k_begin + BK, m_end, kk_end, tid);
+      LB::load(rb1, B, p.b_cs, p.b_rs, n0, k_begin + BK, n_end, kk_end, tid);
+    }
+    LA::store(ra0, smem, tid);
+    LB::store(rb0, smem + LA::SIZE, tid);
   }
   __syncthreads();
 
-  for (int t = 0; t < ntile; ++t) {
-    const float* As = smem + (t & 1) * STAGE;
-    const float* Bs = As + LA::SIZE;
-    float* An = smem + ((t + 1) & 1) * STAGE;
-    const bool more = (t + 1 < ntile);
-    if (more) {
-      const int k0 = k_begin + (t + 1) * BK;
-      LA::load(ra, A, p.a_rs, p.a_cs, m0, k0, m_end, kk_end, tid);
-      LB::load(rb, B, p.b_cs, p.b_rs, n0, k0, n_end, kk_end, tid);
-    }
-    if (COLSUM && do_colsum) {
-      // column sums of the staged B tile ([BK][BN+pad], zero-filled outside K x N): thread ->
-      // (column, row group); only the tile_m == 0 blocks do this so each column is counted once
-      constexpr int CG = NT / BN > 0 ? NT / BN : 1;
-      if (tid < CG * BN) {
-        const int col = tid % BN, grp = tid / BN;
-#pragma unroll
-        for (int k = grp; k < BK; k += CG) csum += Bs[k * LB::LD + col];
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      float a[WM][4], b[WN][4];
-#pragma unroll
-      for (int i = 0; i < WM; ++i) LA::frag(a[i], As, (wave_m * WM + i) * 32, g, li, lh);
-#pragma unroll
-      for (int j = 0; j < WN; ++j) LB::frag(b[j], Bs, (wave_n * WN + j) * 32, g, li, lh);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < WM; ++i)
-#pragma unroll
-          for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-      // Park tile t+1 in the other LDS buffer in the shadow of this tile's MFMAs: the buffer was
-      // last read during tile t-1 and every wave has passed that tile's closing barrier.
-      if (g == (NG - 1) / 2 && more) {
-        LA::store(ra, An, tid);
-        LB::store(rb, An + LA::SIZE, tid);
-      }
-    }
-    __syncthreads();
+  // body(t, free set, waiting set): `waiting` holds tile t+1, `free` receives tile t+2
+#define GEMM_TILE_BODY(T, FA, FB, WA, WB)                                                          \
+  {                                                                                                \
+    const int t_ = (T);                                                                            \
+    const float* As = smem + (t_ & 1) * STAGE;                                                     \
+    const float* Bs = As + LA::SIZE;                                                               \
+    float* An = smem + ((t_ + 1) & 1) * STAGE;                                                     \
+    if (t_ + 2 < ntile) {                                                                          \
+      const int k0 = k_begin + (t_ + 2) * BK;                                                      \
+      LA::load(FA, A, p.a_rs, p.a_cs, m0, k0, m_end, kk_end, tid);                                 \
+      LB::load(FB, B, p.b_cs, p.b_rs, n0, k0, n_end, kk_end, tid);                                 \
+    }                                                                                              \
+    if (COLSUM && do_colsum) {                                                                     \
+      constexpr int CG = NT / BN > 0 ? NT / BN : 1;                                                \
+      if (tid < CG * BN) {                                                                         \
+        const int col = tid % BN, grp = tid / BN;                                                  \
+        _Pragma("unroll") for (int k = grp; k < BK; k += CG) csum += Bs[k * LB::LD + col];         \
+      }                                                                                            \
+    }                                                                                              \
+    _Pragma("unroll") for (int g = 0; g < NG; ++g) {                                               \
+      float a[WM][4], b[WN][4];                                                                    \
+      _Pragma("unroll") for (int i = 0; i < WM; ++i)                                               \
+          LA::frag(a[i], As, (wave_m * WM + i) * 32, g, li, lh);                                   \
+      _Pragma("unroll") for (int j = 0; j < WN; ++j)                                               \
+          LB::frag(b[j], Bs, (wave_n * WN + j) * 32, g, li, lh);                                   \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                \
+        _Pragma("unroll") for (int i = 0; i < WM; ++i)                                             \
+          _Pragma("unroll") for (int j = 0; j < WN; ++j)                                           \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0); \
+      if (g == (NG - 1) / 2 && t_ + 1 < ntile) {                                                   \
+        LA::store(WA, An, tid);                                                                    \
+        LB::store(WB, An + LA::SIZE, tid);                                                         \
+      }                                                                                            \
+    }                                                                                              \
+    __syncthreads();                                                                               \
   }
+
+  // column sums of the staged B tile ([BK][BN+pad], zero-filled outside K x N) are taken by the
+  // tile_m == 0 blocks only, so each column is counted once (COLSUM instantiation)
+  int t = 0;
+  for (; t + 1 < ntile; t += 2) {
+    GEMM_TILE_BODY(t, ra0, rb0, ra1, rb1)       // tile t+1 waits in set 1, t+2 loads into set 0
+    GEMM_TILE_BODY(t + 1, ra1, rb1, ra0, rb0)   // tile t+2 waits in set 0, t+3 loads into set 1
+  }
+  if (t < ntile) GEMM_TILE_BODY(t, ra0, rb0, ra1, rb1)
+#undef GEMM_TILE_BODY
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM>
