@@ -123,6 +123,22 @@ int pdn_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void
 int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* y, int64_t rows,
                  int L, int heads, int head_dim, int backward, void* stream);
 
+/* ---- fused causal self-attention of the training path (llm/llama/model.py:112-121):
+ * softmax(q k^T / sqrt(hd) + causal_mask) v per (batch, head), scores kept in registers.
+ * q, k, v, o (and their gradients) are (B, L, H, head_dim) as the projections produce them;
+ * lse (B, H, L) = row log-sum-exp saved for the backward, which recomputes the probabilities.
+ * Supported: head_dim 48, L a multiple of 32 up to 256 (else PDN_EUNSUPPORTED: the caller uses
+ * the GEMM + softmax path). */
+int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
+                          int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                          int causal, void* stream);
+int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
+                          const float* d_o, const float* lse, float* dq, float* dk, float* dv, int B,
+                          int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                          int causal, void* stream);
+int64_t pdn_attention_lds_bytes(int L, int head_dim);
+int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
+
 /* ---- embedding: `weight[ids]` (nn/functional.py:14-20) and its gradient
  * `full = zeros; full[key] = grad` (tensor.py:937-940: scatter-ASSIGN, last write wins).
  * scatter mode 0: assign, 1: assign-last accumulated into dW, 2: atomic scatter-add. */

@@ -285,8 +285,11 @@ class attention(_Operator):
     through strides (no transposes, no copies).  Output (B, L, H, hd).  `causal` applies the
     additive -inf upper-triangular mask of llm/llama/model.py:199-203 with `start_pos`."""
 
+    use_flash = True      # class switch: False forces the GEMM + softmax path (A/B and tests)
+
     def __init__(self, q, k, v, causal=True, start_pos=0):
         self.causal, self.start_pos = bool(causal), int(start_pos)
+        self._flash = False
         super().__init__(q, k, v)
 
     def forward_(self, q, k, v):
@@ -301,6 +304,16 @@ class attention(_Operator):
             self._p = e / e.sum(-1, keepdims=True)
             return np.ascontiguousarray(np.matmul(self._p, v.data.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3))
         hp, L = _hip(), _L()
+        self._flash = (attention.use_flash and Lq == Lk and self.start_pos == 0 and hd == 48 and Lq % 32 == 0
+                       and Lq <= 256 and q.data.is_contiguous() and k.data.is_contiguous()
+                       and v.data.is_contiguous())
+        if self._flash:
+            # scores stay in registers: one kernel, nothing of size L x L in HBM; lse kept for backward
+            out = hp.empty((B, Lq, H, hd), np.float32)
+            self._lse = hp.empty((B, H, Lq), np.float32)
+            L.call("pdn_attention_fwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, out._ptr, self._lse._ptr,
+                   B, H, Lq, hd, H * hd, Lq * H * hd, 1 if (self.causal and Lq > 1) else 0, hp.stream())
+            return out
         p = hp.empty((B, H, Lq, Lk), np.float32)
         hp.gemm(q.data.transpose(0, 2, 1, 3), k.data.transpose(0, 2, 3, 1), p)
         L.call("pdn_softmax_fwd_f32", p._ptr, p._ptr, B * H * Lq, Lk, math.sqrt(hd),
@@ -314,6 +327,14 @@ class attention(_Operator):
         q, k, v = self.last
         B, Lq, H, hd = q.shape
         Lk = k.shape[1]
+        if self.xp is not np and self._flash:
+            hp, L = _hip(), _L()
+            do = _contig(do)
+            dq, dk, dv = (hp.empty(q.shape, np.float32) for _ in range(3))
+            L.call("pdn_attention_bwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, self.data._ptr, do._ptr,
+                   self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd,
+                   1 if (self.causal and Lq > 1) else 0, hp.stream())
+            return [dq, dk, dv]
         p = self._p
         if self.xp is np:
             doT = do.transpose(0, 2, 1, 3)

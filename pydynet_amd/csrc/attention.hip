@@ -198,3 +198,261 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
+
+// ======================================================================================
+// Backward.  Same decomposition (one workgroup per (batch, head), K and V resident in LDS),
+// probabilities recomputed from the saved log-sum-exp:   P = exp(S/sqrt(hd) - lse).
+//   delta[q] = sum_d dO[q,d] * O[q,d]
+//   dV = P^T dO        dP = dO V^T        dS = P o (dP - delta) / sqrt(hd)
+//   dQ = dS K          dK = dS^T Q
+// An MFMA accumulator holds its column index in the lane and its row index in registers, and
+// can feed the next MFMA only as the operand that contracts over the ROW index.  dQ contracts
+// over keys, dK / dV over queries, so the score tile is needed in both orientations:
+//   phase 1 (a wave owns query tiles):  S^T[key][q] = K Q^T, dP^T = V dO^T  ->  dQ^T += K^T dS^T
+//   phase 2 (a wave owns key tiles):    S[q][key]   = Q K^T, dP   = dO V^T  ->  dV^T += dO^T P,
+//                                                                               dK^T += Q^T dS
+// 80 + 112 MFMAs per (query tile, key tile) pair, fully masked pairs skipped.  Q / dO tiles used
+// column-wise in phase 2 are parked in a per-wave LDS slot.  Nothing of size L x L touches HBM.
+// ======================================================================================
+template <int HD>
+__device__ __forceinline__ void att_store_tile_T(float* slot, const f32x16& t0, const f32x16& t1,
+                                                 float* dst_rows, int64_t row_stride, int li, int lh,
+                                                 int lane, float scale) {
+  // t0/t1 hold X^T[d][row]: lane = row, registers = d.  Stage as [row][d] and write rows.
+  constexpr int LD = ATT_LD(HD);
+  constexpr int F4 = HD / 4;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = att_krow(r, lh);
+    slot[li * LD + d] = t0[r] * scale;
+    if (32 + d < HD) slot[li * LD + 32 + d] = t1[r] * scale;
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+  for (int u = lane; u < 32 * F4; u += 64) {
+    const int row = u / F4, c4 = u % F4;
+    *reinterpret_cast<float4*>(dst_rows + (int64_t)row * row_stride + 4 * c4) =
+        *reinterpret_cast<const float4*>(slot + row * LD + 4 * c4);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int HD>
+__global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
+    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int H, int L,
+    int64_t row_stride, int64_t batch_stride, float sqrt_hd, int causal) {
+  constexpr int LD = ATT_LD(HD);
+  constexpr int NT8 = HD / 8;
+  constexpr int F4 = HD / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ks = lds;                                 // [L][LD]
+  float* Vs = Ks + (size_t)L * LD;                 // [L][LD]
+  float* slots = Vs + (size_t)L * LD;              // 4 waves x 2 x [32][LD]
+  float* lse_s = slots + 4 * 2 * 32 * LD;          // [L]
+  float* delta_s = lse_s + L;                      // [L]
+
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
+  const float* Qb = Q + base; const float* Kb = K + base; const float* Vb = V + base;
+  const float* Ob = O + base; const float* dOb = dO + base;
+  float* dQb = dQ + base; float* dKb = dK + base; float* dVb = dV + base;
+  float* slotA = slots + wave * (2 * 32 * LD);
+  float* slotB = slotA + 32 * LD;
+
+  // ---- phase 0: stage K, V; delta and lse per query -------------------------------------------
+  for (int u = tid; u < L * F4; u += 256) {
+    const int row = u / F4, c4 = u % F4;
+    *reinterpret_cast<float4*>(Ks + row * LD + 4 * c4) =
+        *reinterpret_cast<const float4*>(Kb + (int64_t)row * row_stride + 4 * c4);
+    *reinterpret_cast<float4*>(Vs + row * LD + 4 * c4) =
+        *reinterpret_cast<const float4*>(Vb + (int64_t)row * row_stride + 4 * c4);
+  }
+  for (int q = tid; q < L; q += 256) {
+    const float4* o4 = reinterpret_cast<const float4*>(Ob + (int64_t)q * row_stride);
+    const float4* g4 = reinterpret_cast<const float4*>(dOb + (int64_t)q * row_stride);
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < F4; ++c) {
+      const float4 a = o4[c], g = g4[c];
+      acc += (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
+    }
+    delta_s[q] = acc;
+    lse_s[q] = LSE[(int64_t)bh * L + q];
+  }
+  __syncthreads();
+
+  const int ntile = L / 32;
+  const float inv_sqrt = 1.f / sqrt_hd;
+  const bool hi_ok = (32 + li) < HD;
+
+  // ---- phase 1: dQ (wave owns query tiles) -------------------------------------------------
+  for (int qt = 0; qt < ntile; ++qt) {
+    if (att_owner(qt) != wave) continue;
+    const int nk = causal ? qt + 1 : ntile;
+    const int qpos = qt * 32 + li;
+    float4 qf[NT8], gf[NT8];
+    {
+      const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
+      const float* grow = dOb + (int64_t)qpos * row_stride + 4 * lh;
+#pragma unroll
+      for (int t = 0; t < NT8; ++t) {
+        qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+        gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
+      }
+    }
+    const float lse_q = lse_s[qpos], delta_q = delta_s[qpos];
+    f32x16 dq0, dq1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+    for (int kt = 0; kt < nk; ++kt) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
+      const float* vrow = Vs + (kt * 32 + li) * LD + 4 * lh;
+#pragma unroll
+      for (int t = 0; t < NT8; ++t) {
+        const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t);
+        const float4 vf = *reinterpret_cast<const float4*>(vrow + 8 * t);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t].y, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, gf[t].z, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
+      }
+      // dS^T[key][q] = P^T o (dP^T - delta_q) / sqrt(hd)   (lane = q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool masked = causal && (kt * 32 + att_krow(r, lh) > qpos);
+        const float p = masked ? 0.f : expf(s[r] / sqrt_hd - lse_q);
+        s[r] = p * (dp[r] - delta_q) * inv_sqrt;
+      }
+      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* kr = Ks + (kt * 32 + att_krow(r, lh)) * LD;
+        const float a0 = kr[li];
+        const float a1 = hi_ok ? kr[32 + li] : 0.f;
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], dq1, 0, 0, 0);
+      }
+    }
+    att_store_tile_T<HD>(slotA, dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+  }
+
+  // ---- phase 2: dK, dV (wave owns key tiles) -----------------------------------------------
+  for (int kt = 0; kt < ntile; ++kt) {
+    if (att_owner(kt) != wave) continue;
+    const int kpos = kt * 32 + li;
+    float4 kf[NT8], vf[NT8];
+    {
+      const float* krow = Ks + kpos * LD + 4 * lh;
+      const float* vrow = Vs + kpos * LD + 4 * lh;
+#pragma unroll
+      for (int t = 0; t < NT8; ++t) {
+        kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
+        vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
+      }
+    }
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+    const int q_first = causal ? kt : 0;
+    for (int qt = q_first; qt < ntile; ++qt) {
+      // park the Q and dO tiles of this query tile in the wave's LDS slots ([q][d])
+      for (int u = lane; u < 32 * F4; u += 64) {
+        const int row = u / F4, c4 = u % F4;
+        *reinterpret_cast<float4*>(slotA + row * LD + 4 * c4) =
+            *reinterpret_cast<const float4*>(Qb + (int64_t)(qt * 32 + row) * row_stride + 4 * c4);
+        *reinterpret_cast<float4*>(slotB + row * LD + 4 * c4) =
+            *reinterpret_cast<const float4*>(dOb + (int64_t)(qt * 32 + row) * row_stride + 4 * c4);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+      const float* qrow = slotA + li * LD + 4 * lh;
+      const float* grow = slotB + li * LD + 4 * lh;
+#pragma unroll
+      for (int t = 0; t < NT8; ++t) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * t);
+        const float4 g4 = *reinterpret_cast<const float4*>(grow + 8 * t);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t].x, s, 0, 0, 0);    // S[q][key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t].x, dp, 0, 0, 0);  // dP[q][key]
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[t].y, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.y, vf[t].y, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[t].z, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.z, vf[t].z, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[t].w, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.w, vf[t].w, dp, 0, 0, 0);
+      }
+      // lane = key, registers = queries
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qt * 32 + att_krow(r, lh);
+        const bool masked = causal && (kpos > q);
+        const float p = masked ? 0.f : expf(s[r] / sqrt_hd - lse_s[q]);
+        s[r] = p;                                          // P[q][key]
+        dp[r] = p * (dp[r] - delta_s[q]) * inv_sqrt;       // dS[q][key]
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = att_krow(r, lh);
+        const float g0 = slotB[qr * LD + li], q0 = slotA[qr * LD + li];
+        const float g1 = hi_ok ? slotB[qr * LD + 32 + li] : 0.f;
+        const float q1 = hi_ok ? slotA[qr * LD + 32 + li] : 0.f;
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, s[r], dv0, 0, 0, 0);     // dV^T += dO^T P
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, dp[r], dk0, 0, 0, 0);    // dK^T += Q^T dS
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, s[r], dv1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, dp[r], dk1, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_wave_barrier();
+    }
+    att_store_tile_T<HD>(slotA, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+    att_store_tile_T<HD>(slotB, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+  }
+}
+
+extern "C" int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim) {
+  return ((int64_t)2 * L + 4 * 2 * 32) * ATT_LD(head_dim) * 4 + (int64_t)2 * L * 4;
+}
+
+extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
+                                     const float* d_o, const float* lse, float* dq, float* dk,
+                                     float* dv, int B, int H, int L, int head_dim,
+                                     int64_t row_stride, int64_t batch_stride, int causal,
+                                     void* stream) {
+  if (B == 0 || H == 0 || L == 0) return PDN_OK;
+  PDN_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv, "pdn_attention_bwd_f32: null operand");
+  if (head_dim != 48 || L % 32 != 0 || L > 32 * ATT_MAX_TILES) {
+    pdn_set_error("pdn_attention_bwd_f32: fused path supports head_dim 48, L multiple of 32 and <= %d",
+                  32 * ATT_MAX_TILES);
+    return PDN_EUNSUPPORTED;
+  }
+  PDN_CHECK_ARG((row_stride % 4) == 0 && (batch_stride % 4) == 0 &&
+                    ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o |
+                       (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0),
+                "pdn_attention_bwd_f32: 16-byte alignment required");
+  const size_t shm = (size_t)pdn_attention_bwd_lds_bytes(L, head_dim);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PDN_HIP(hipFuncSetAttribute((const void*)attention_bwd_kernel<48>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((attention_bwd_kernel<48>), dim3(B * H), dim3(256), shm, (hipStream_t)stream, q, k,
+                     v, o, d_o, lse, dq, dk, dv, H, L, row_stride, batch_stride,
+                     sqrtf((float)head_dim), causal);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

@@ -719,8 +719,10 @@ extern "C" int pdn_cross_entropy_fwd_f32(const float* logits, const int64_t* tar
   PDN_CHECK_ARG(rows > 0 && V > 0, "pdn_cross_entropy_fwd_f32: empty input");
   PDN_CHECK_ARG(logits && targets && loss_row && lse_row && loss_out && err_flag, "pdn_cross_entropy_fwd_f32: null operand");
   hipStream_t st = (hipStream_t)stream;
-  const int g = (int)(rows < 65535 ? rows : 65535);
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(g), dim3(256), 0, st, logits, targets, loss_row, lse_row, rows, V, err_flag);
+  // long rows: few, fat workgroups so the rows in flight (grid x V x 4 B) stay within L2 for the re-read pass
+  const int ce_threads = V >= 4096 ? 1024 : 256;
+  const int g = (int)(V >= 4096 ? (rows < 512 ? rows : 512) : (rows < 65535 ? rows : 65535));
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row, lse_row, rows, V, err_flag);
   PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows,
                      mean ? 1.f / (float)rows : 1.f, loss_out);
@@ -859,8 +861,9 @@ extern "C" int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t*
   PDN_CHECK_ARG(logits && targets && loss_row && lse_row && loss_out && dlogits && err_flag,
                 "pdn_cross_entropy_fwd_bwd_f32: null operand");
   hipStream_t st = (hipStream_t)stream;
-  const int g = (int)(rows < 65535 ? rows : 65535);
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(g), dim3(256), 0, st, logits, targets, loss_row, lse_row,
+  const int ce_threads = V >= 4096 ? 1024 : 256;   // see pdn_cross_entropy_fwd_f32
+  const int g = (int)(V >= 4096 ? (rows < 512 ? rows : 512) : (rows < 65535 ? rows : 65535));
+  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row, lse_row,
                      dlogits, gscale, rows, V, err_flag);
   PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows,

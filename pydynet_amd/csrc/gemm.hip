@@ -107,6 +107,34 @@ struct TileLoader {
     }
   }
 
+  // Interior tiles (VEC layout): per-thread element offsets are computed ONCE, relative to the
+  // first contraction index; a k-tile then costs one 64-bit add and one 16-byte load per piece,
+  // with no bounds tests and no zero-fill moves in the loop.
+  __device__ __forceinline__ static void init_offsets(int64_t (&off)[NP], int64_t s_mn, int64_t s_k,
+                                                      int mn0, int tid) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int u = (UNITS % NT == 0) ? tid + p * NT : min(tid + p * NT, UNITS - 1);
+      if (KIN) {
+        const int row = u / (BK / 4), c4 = u % (BK / 4);
+        off[p] = (int64_t)(mn0 + row) * s_mn + 4 * c4;
+      } else {
+        const int kr = u / (MN / 4), c4 = u % (MN / 4);
+        off[p] = (int64_t)kr * s_k + mn0 + 4 * c4;
+      }
+    }
+  }
+  __device__ __forceinline__ static void load_fast(float4 (&r)[NP], const float* __restrict__ base_k,
+                                                   const int64_t (&off)[NP]) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      // component-wise copy: a whole-float4 store into the by-reference array defeats SROA on
+      // hipcc 7.2 and sends the staging registers to scratch
+      const float4 v = *reinterpret_cast<const float4*>(base_k + off[p]);
+      r[p].x = v.x; r[p].y = v.y; r[p].z = v.z; r[p].w = v.w;
+    }
+  }
+
   __device__ __forceinline__ static void store(const float4 (&r)[NP], float* lds, int tid) {
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
@@ -166,13 +194,26 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   // latency when an operand is streamed with no reuse (weight gradients, K = tokens).  The sets
   // are named, not indexed, so they stay in registers (the loop is unrolled by two).
   float4 ra0[LA::NP], rb0[LB::NP], ra1[LA::NP], rb1[LB::NP];
+  int64_t offa[LA::NP], offb[LB::NP];
+  if (INTERIOR) {
+    LA::init_offsets(offa, p.a_rs, p.a_cs, m0, tid);
+    LB::init_offsets(offb, p.b_cs, p.b_rs, n0, tid);
+  }
+  // contraction stride of each operand in the staged layout (1 for K-contiguous operands)
+  const int64_t ka = p.a_cs, kb = p.b_rs;
+#define GEMM_LOAD(RA, RB, K0)                                                        \
+  if (INTERIOR) {                                                                    \
+    LA::load_fast(RA, A + (int64_t)(K0) * ka, offa);                                 \
+    LB::load_fast(RB, B + (int64_t)(K0) * kb, offb);                                 \
+  } else {                                                                           \
+    LA::load(RA, A, p.a_rs, p.a_cs, m0, (K0), m_end, kk_end, tid);                   \
+    LB::load(RB, B, p.b_cs, p.b_rs, n0, (K0), n_end, kk_end, tid);                   \
+  }
   const int ntile = (k_end - k_begin + BK - 1) / BK;
   if (ntile > 0) {
-    LA::load(ra0, A, p.a_rs, p.a_cs, m0, k_begin, m_end, kk_end, tid);
-    LB::load(rb0, B, p.b_cs, p.b_rs, n0, k_begin, n_end, kk_end, tid);
+    GEMM_LOAD(ra0, rb0, k_begin)
     if (ntile > 1) {
-      LA::load(ra1, A, p.a_rs, p.a_cs, m0, k_begin + BK, m_end, kk_end, tid);
-      LB::load(rb1, B, p.b_cs, p.b_rs, n0, k_begin + BK, n_end, kk_end, tid);
+      GEMM_LOAD(ra1, rb1, k_begin + BK)
     }
     LA::store(ra0, smem, tid);
     LB::store(rb0, smem + LA::SIZE, tid);
@@ -188,8 +229,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
     float* An = smem + ((t_ + 1) & 1) * STAGE;                                                     \
     if (t_ + 2 < ntile) {                                                                          \
       const int k0 = k_begin + (t_ + 2) * BK;                                                      \
-      LA::load(FA, A, p.a_rs, p.a_cs, m0, k0, m_end, kk_end, tid);                                 \
-      LB::load(FB, B, p.b_cs, p.b_rs, n0, k0, n_end, kk_end, tid);                                 \
+      GEMM_LOAD(FA, FB, k0)                                                                        \
     }                                                                                              \
     if (COLSUM && do_colsum) {                                                                     \
       constexpr int CG = NT / BN > 0 ? NT / BN : 1;                                                \
@@ -225,6 +265,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   }
   if (t < ntile) GEMM_TILE_BODY(t, ra0, rb0, ra1, rb1)
 #undef GEMM_TILE_BODY
+#undef GEMM_LOAD
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM>

@@ -205,7 +205,9 @@ class ndarray:
         a = self if self.is_contiguous() else self.copy()
         t = _t()
         flat = t.as_strided(a._typed_buf(), (a.size,), (1,), a._elem_offset())
-        return flat.cpu().numpy().reshape(a.shape).astype(self.dtype, copy=False)
+        host = flat.cpu().numpy().reshape(a.shape).astype(self.dtype, copy=False)
+        # .cpu() of a host tensor aliases it (only under the test emulator): always hand out a copy
+        return host.copy() if self._buf.device.type == "cpu" else host
 
     def _typed_buf(self):
         return self._buf

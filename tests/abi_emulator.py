@@ -282,6 +282,49 @@ class EmulatedLib:
         flat(dlogits, rows * V).reshape(rows, V)[...] = sm * gs
         return 0
 
+    # -- fused attention (NumPy statement of the same contract) -------------------------------------
+    @staticmethod
+    def _att_views(ptrs, B, H, L, hd, rs, bs):
+        return [view(p, (B, H, L, hd), (bs, hd, rs, 1), np.float32) for p in ptrs]
+
+    def _att_probs(self, q, k, L, hd, causal):
+        s = np.matmul(q, k.swapaxes(-1, -2)) / np.float32(math.sqrt(hd))
+        if causal:
+            s = s + np.triu(np.full((L, L), -np.inf, np.float32), 1)
+        m = s.max(-1, keepdims=True)
+        e = np.exp(s - m)
+        l = e.sum(-1, keepdims=True)
+        return e / l, (m + np.log(l))[..., 0]
+
+    def pdn_attention_lds_bytes(self, L, hd): return (2 * L + 128) * (hd + 4) * 4
+    def pdn_attention_bwd_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4 + 8 * L
+
+    def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, causal, stream):
+        if hd != 48 or L % 32 or L > 256:
+            return -2
+        Q, K, V, O = self._att_views([q, k, v, o], B, H, L, hd, rs, bs)
+        p, ls = self._att_probs(np.array(Q), np.array(K), L, hd, causal)
+        O[...] = np.matmul(p, np.array(V))
+        flat(lse, B * H * L).reshape(B, H, L)[...] = ls
+        return 0
+
+    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, causal, stream):
+        if hd != 48 or L % 32 or L > 256:
+            return -2
+        Q, K, V, O, DO, DQ, DK, DV = [np.array(a) if i < 5 else a for i, a in
+                                      enumerate(self._att_views([q, k, v, o, do, dq, dk, dv], B, H, L, hd, rs, bs))]
+        s = np.matmul(Q, K.swapaxes(-1, -2)) / np.float32(math.sqrt(hd))
+        p = np.exp(s - flat(lse, B * H * L).reshape(B, H, L, 1))
+        if causal:
+            p = p * np.tril(np.ones((L, L), np.float32))
+        delta = (DO * O).sum(-1, keepdims=True)
+        dp = np.matmul(DO, V.swapaxes(-1, -2))
+        ds = p * (dp - delta) / np.float32(math.sqrt(hd))
+        DV[...] = np.matmul(p.swapaxes(-1, -2), DO)
+        DQ[...] = np.matmul(ds, K)
+        DK[...] = np.matmul(ds.swapaxes(-1, -2), Q)
+        return 0
+
     def pdn_cross_entropy_fwd_bwd_f32(self, logits, targets, rows, V, mean, gscale, loss_row, lse_row,
                                       loss_out, dlogits, err, stream):
         self.pdn_cross_entropy_fwd_f32(logits, targets, rows, V, mean, loss_row, lse_row, loss_out, err, stream)

@@ -409,3 +409,38 @@ def test_cross_entropy_one_pass_forward_backward(hip):
         L.call("pdn_scale_by_device_scalar_f32", DX._ptr, DX.size, half._ptr, hip.stream())
         assert np.array_equal(DX.get(), before * np.float32(0.5))
     hip.check_index_errors()
+
+
+@pytest.mark.parametrize("B,H,L,causal", [(2, 6, 256, 1), (3, 2, 64, 1), (1, 6, 128, 0), (2, 3, 32, 1)])
+def test_fused_attention_forward_backward(hip, B, H, L, causal):
+    """Fused attention vs a float64 statement of llm/llama/model.py:112-121 and its gradients."""
+    from pydynet_amd import _lib
+    Lb = _lib.lib()
+    hd = 48
+    rng = np.random.default_rng(100 + L)
+    q, k, v, do = (rng.standard_normal((B, L, H, hd), dtype=np.float32) for _ in range(4))
+    k[0, L // 2, 0] *= 6.0                       # a spiky key: large scores exercise the max shift
+    dq, dk, dv, o = (hip.empty((B, L, H, hd)) for _ in range(4))
+    Q, K, V, DO = map(hip.from_numpy, (q, k, v, do))
+    lse = hip.empty((B, H, L))
+    Lb.call("pdn_attention_fwd_f32", Q._ptr, K._ptr, V._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd,
+            causal, hip.stream())
+    q64, k64, v64, g64 = (a.astype(np.float64).transpose(0, 2, 1, 3) for a in (q, k, v, do))
+    s = q64 @ k64.swapaxes(-1, -2) / math.sqrt(hd)
+    if causal:
+        s = s + np.triu(np.full((L, L), -np.inf), 1)
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m)
+    p = e / e.sum(-1, keepdims=True)
+    ref_o = (p @ v64).transpose(0, 2, 1, 3)
+    assert rel_err(o.get(), ref_o) < 2e-5
+    assert np.allclose(lse.get(), (m + np.log(e.sum(-1, keepdims=True)))[..., 0], rtol=1e-5, atol=1e-5)
+    Lb.call("pdn_attention_bwd_f32", Q._ptr, K._ptr, V._ptr, o._ptr, DO._ptr, lse._ptr, dq._ptr, dk._ptr, dv._ptr,
+            B, H, L, hd, H * hd, L * H * hd, causal, hip.stream())
+    dp = g64 @ v64.swapaxes(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / math.sqrt(hd)
+    assert rel_err(dv.get(), (p.swapaxes(-1, -2) @ g64).transpose(0, 2, 1, 3)) < 5e-5
+    assert rel_err(dq.get(), (ds @ k64).transpose(0, 2, 1, 3)) < 5e-5
+    assert rel_err(dk.get(), (ds.swapaxes(-1, -2) @ q64).transpose(0, 2, 1, 3)) < 5e-5
+    if causal:                                    # masked probabilities are exactly zero: the first
+        assert np.allclose(o.get()[:, 0], v[:, 0], rtol=1e-6)   # query attends only to key 0
