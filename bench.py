@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "32")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "128")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-prof", action="store_true")
     args = ap.parse_args()
@@ -73,6 +73,8 @@ def main():
     model.to(dev)
     opt = Adam(model.parameters(), lr=1e-4)
     dp = DataParallel(model, opt) if world > 1 else None
+    if dp is None:
+        opt.flatten_grads()                                 # one flat gradient buffer: zero_grad is a single fill
     rng = np.random.default_rng(1000 + rank)                # each rank owns its shard of the global batch
     ids = pdn.Tensor(rng.integers(0, V, (B, L)), dtype=np.int64, device=dev)
     tgt = pdn.Tensor(rng.integers(0, V, (B * L,)), dtype=np.int64, device=dev)

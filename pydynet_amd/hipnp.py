@@ -890,8 +890,10 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None, residual=None, b_colsum=None, 
     while len(merged) < 2:
         merged.insert(0, (1, (0, 0, 0)))
     (n1, (a1, b1, c1)), (n2, (a2, b2, c2)) = merged
-    ws_ptr, ws_bytes = workspace(L.query("pdn_gemm_f32_workspace_bytes", M, N, K, n1 * n2)
-                                 if (M * N <= (1 << 21) and K >= 1024) else 0)
+    # split-K scratch: offered whenever the contraction is long; capped at 256 MiB (the library
+    # never splits further than the slabs it is given room for)
+    ws_ptr, ws_bytes = workspace(_bi.min(L.query("pdn_gemm_f32_workspace_bytes", M, N, K, n1 * n2), 1 << 28)
+                                 if (K >= 1024 and M * N * n1 * n2 <= (1 << 25)) else 0)
     ldc = C._strides[-2] if M > 1 else _bi.max(C._strides[-2], N)
     L.call("pdn_gemm_f32", M, N, K, float(alpha), A._ptr, A._strides[-2], A._strides[-1], B._ptr,
            B._strides[-2], B._strides[-1], float(beta), C._ptr, ldc,
