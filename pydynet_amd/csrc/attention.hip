@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(
   __syncthreads();
 
   const int ntile = L / 32;
+  const float inv_sqrt = 1.f / sqrt_hd;
   float* Ow = Os + wave * (32 * LD);
   for (int qt = 0; qt < ntile; ++qt) {
     if (att_owner(qt) != wave) continue;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(
       if (kt < nk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          float v = s[kt][r] / sqrt_hd;
+          float v = s[kt][r] * inv_sqrt;   // (x * (1/sqrt(hd)): within 1 ulp of the reference division)
           if (causal && kt * 32 + att_krow(r, lh) > qpos) v = -INFINITY;
           s[kt][r] = v;
           m = fmaxf(m, v);
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(
       if (kt < nk) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = expf(s[kt][r] - m);
+          const float p = __expf(s[kt][r] - m);
           s[kt][r] = p;
           l += p;
         }
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const bool masked = causal && (kt * 32 + att_krow(r, lh) > qpos);
-        const float p = masked ? 0.f : expf(s[r] / sqrt_hd - lse_q);
+        const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_q);
         s[r] = p * (dp[r] - delta_q) * inv_sqrt;
       }
       // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + att_krow(r, lh);
         const bool masked = causal && (kpos > q);
-        const float p = masked ? 0.f : expf(s[r] / sqrt_hd - lse_s[q]);
+        const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_s[q]);
         s[r] = p;                                          // P[q][key]
         dp[r] = p * (dp[r] - delta_s[q]) * inv_sqrt;       // dS[q][key]
       }

@@ -853,6 +853,11 @@ __global__ void ce_fwd_bwd_kernel(const float* __restrict__ x, const int64_t* __
   }
 }
 
+__global__ void ce_fwd_bwd_lds_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                      float* __restrict__ loss_row, float* __restrict__ lse_row,
+                                      float* __restrict__ dx, float gscale, int64_t rows, int V,
+                                      int* __restrict__ err);
+
 extern "C" int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, int64_t rows,
                                              int V, int mean, float gscale, float* loss_row,
                                              float* lse_row, float* loss_out, float* dlogits,
@@ -863,8 +868,22 @@ extern "C" int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t*
   hipStream_t st = (hipStream_t)stream;
   const int ce_threads = V >= 4096 ? 1024 : 256;   // see pdn_cross_entropy_fwd_f32
   const int g = (int)(V >= 4096 ? (rows < 512 ? rows : 512) : (rows < 65535 ? rows : 65535));
-  hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row, lse_row,
-                     dlogits, gscale, rows, V, err_flag);
+  const bool lds_row = V >= 4096 && V % 4 == 0 && (size_t)V * 4 <= 160 * 1024 - 1024 &&
+                       ((((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0);
+  if (lds_row) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      PDN_HIP(hipFuncSetAttribute((const void*)ce_fwd_bwd_lds_kernel,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      attr_set = true;
+    }
+    const int gl = (int)(rows < 256 ? rows : 256);
+    hipLaunchKernelGGL(ce_fwd_bwd_lds_kernel, dim3(gl), dim3(1024), (size_t)V * 4, st, logits, targets,
+                       loss_row, lse_row, dlogits, gscale, rows, V, err_flag);
+  } else {
+    hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row,
+                       lse_row, dlogits, gscale, rows, V, err_flag);
+  }
   PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows,
                      mean ? 1.f / (float)rows : 1.f, loss_out);
@@ -888,4 +907,56 @@ extern "C" int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* 
                      (hipStream_t)stream, x, n, scalar_dev);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
+}
+
+// ---- cross entropy fwd+bwd with the row held in LDS ---------------------------------------------
+// A vocabulary row of up to 40000 floats (160 KB LDS) is loaded from HBM exactly once: pass 1
+// copies it to LDS and takes the max, pass 2 (LDS) the sum of exponentials, pass 3 (LDS) writes
+// dlogits.  One 1024-thread workgroup per CU; algorithmic traffic = 4 B read + 4 B written per logit.
+__global__ __launch_bounds__(1024) void ce_fwd_bwd_lds_kernel(
+    const float* __restrict__ x, const int64_t* __restrict__ tgt, float* __restrict__ loss_row,
+    float* __restrict__ lse_row, float* __restrict__ dx, float gscale, int64_t rows, int V,
+    int* __restrict__ err) {
+  extern __shared__ __attribute__((aligned(16))) float row_lds[];
+  __shared__ float red[16];
+  const int n4 = V >> 2;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+    const float4* xr = reinterpret_cast<const float4*>(x + row * (int64_t)V);
+    float4* dr = reinterpret_cast<float4*>(dx + row * (int64_t)V);
+    float4* l4 = reinterpret_cast<float4*>(row_lds);
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = xr[i];
+      l4[i] = v;
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    m = block_max(m, red);            // (its barriers also publish the LDS row)
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = l4[i];
+      s += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
+    }
+    s = block_sum(s, red);
+    const float lse = logf(s) + m;
+    int64_t t = tgt[row];
+    if (t < 0) t += V;
+    if (t < 0 || t >= V) { if (threadIdx.x == 0) *err = 1; t = 0; }
+    if (threadIdx.x == 0) {
+      lse_row[row] = lse;
+      loss_row[row] = lse - row_lds[t];
+    }
+    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+      const float4 v = l4[i];
+      float4 r;
+      r.x = expf(v.x - lse); r.y = expf(v.y - lse); r.z = expf(v.z - lse); r.w = expf(v.w - lse);
+      const int c = 4 * i;
+      if (t >= c && t < c + 4) {
+        if (t == c) r.x -= 1.f; else if (t == c + 1) r.y -= 1.f;
+        else if (t == c + 2) r.z -= 1.f; else r.w -= 1.f;
+      }
+      r.x *= gscale; r.y *= gscale; r.z *= gscale; r.w *= gscale;
+      dr[i] = r;
+    }
+    __syncthreads();                  // row_lds is overwritten by the next row
+  }
 }

@@ -602,7 +602,6 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     if (c == 8 && N < 768) continue;        // 256-row tiles lose on narrow outputs (one block per CU)
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
     const int bk = kCfgs[c].bk;
-    const double pipes = kCfgs[c].waves_m * kCfgs[c].waves_n / 4.0;   // 2-wave blocks use half a CU
     const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN) * nbatch;
     const int ktiles = (int)cdiv64(K > 0 ? K : 1, bk);
     for (int s = 1; s <= 64; s *= 2) {
@@ -612,12 +611,18 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
         if ((int64_t)s * M * N * nbatch > ws_cap) break;
       }
       const int kps = (int)cdiv64(ktiles, s);
-      const double blocks = (double)tiles * s * pipes;
-      const double waves = blocks >= 1024 ? blocks / 256.0 : (double)cdiv64((int64_t)(blocks + 0.999), 256);
-      // per-block time ~ tile flops / eff + fixed prologue/epilogue (~64 k); a split adds
-      // one pass over s partial slabs plus a launch
-      double cost = waves * ((double)BM * BN / pipes * (kps * bk + 64) / kCfgs[c].eff);
-      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 1.0 + 2.0e6;
+      // Model (fitted to tools/gemm_sweep_dw.py and the tile sweep): a block keeps `waves_pb`
+      // SIMDs busy for BM*BN*K/waves_pb MFMA-cycles; blocks are dealt round-robin over the 256
+      // CUs, so a grid needs ceil(blocks/slots) rounds until it is large enough to even out; a CU
+      // with at least two resident blocks hides their barriers/prologues behind each other
+      // (~0.7 -> 1.0 matrix-pipe duty), which is why ~480 blocks beat 240 longer ones.
+      const double waves_pb = kCfgs[c].waves_m * kCfgs[c].waves_n;
+      const double blocks = (double)tiles * s;
+      const double slots = 256.0 * (4.0 / waves_pb);
+      const double rounds = blocks >= 4 * slots ? blocks / slots : (double)cdiv64((int64_t)blocks, (int64_t)slots);
+      const double util = blocks >= 480 ? 1.0 : (blocks > 256 ? 0.7 + 0.3 * (blocks - 256) / 224.0 : 0.7);
+      double cost = rounds * ((double)BM * BN * (kps * bk + 64) / waves_pb * 4.0 / (kCfgs[c].eff * util));
+      if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 0.5 + 1.0e6;   // slab pass + extra launch
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = s; }
     }
   }

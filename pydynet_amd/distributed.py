@@ -63,12 +63,15 @@ class DataParallel:
     """
 
     def __init__(self, module, optimizer=None, bucket_mb: float = 25.0, process_group=None,
-                 broadcast_parameters=True):
+                 broadcast_parameters=True, always_reduce=False):
         dist = _dist()
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # `always_reduce` runs the collectives even on a single rank (used to exercise the RCCL path
+        # on a one-GPU box); normally a lone rank skips them
+        self._comm = dist.is_initialized() and (self.world > 1 or always_reduce)
         self.params = [p for p in module.parameters()][::-1]        # reverse registration order
         if not self.params:
             raise ValueError("DataParallel: module has no trainable parameters")
@@ -82,7 +85,7 @@ class DataParallel:
             if [id(p) for p in optimizer.params][::-1] == [id(p) for p in self.params]:
                 optimizer._flat_grad, optimizer._flat_offsets = self.flat, self.offsets[::-1]
                 optimizer._flat_views = [p.grad for p in optimizer.params]
-        if broadcast_parameters and self.world > 1:
+        if broadcast_parameters and self._comm:
             self.broadcast_parameters()
         self._reset()
 
@@ -125,7 +128,7 @@ class DataParallel:
         return hook
 
     def _launch_ready(self):
-        if self.world == 1:
+        if not self._comm:
             return
         dist = _dist()
         while self._next < len(self.buckets):
@@ -140,7 +143,7 @@ class DataParallel:
         """Call after backward(): issues any bucket not yet launched (parameters that received no
         gradient this step) and waits for all reductions.  Gradients then hold the SUM over ranks;
         the optimizer divides by the world size through `grad_scale`."""
-        if self.world > 1:
+        if self._comm:
             dist = _dist()
             while self._next < len(self.buckets):
                 lo, hi, _, _ = self.buckets[self._next]
