@@ -620,7 +620,8 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       const double blocks = (double)tiles * s;
       const double slots = 256.0 * (4.0 / waves_pb);
       const double rounds = blocks >= 4 * slots ? blocks / slots : (double)cdiv64((int64_t)blocks, (int64_t)slots);
-      const double util = blocks >= 480 ? 1.0 : (blocks > 256 ? 0.7 + 0.3 * (blocks - 256) / 224.0 : 0.7);
+      const double wps = blocks * waves_pb / 1024.0;   // resident waves per SIMD in a round
+      const double util = wps >= 1.875 ? 1.0 : (wps > 1.0 ? 0.7 + 0.3 * (wps - 1.0) / 0.875 : 0.7);
       double cost = rounds * ((double)BM * BN * (kps * bk + 64) / waves_pb * 4.0 / (kCfgs[c].eff * util));
       if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 0.5 + 1.0e6;   // slab pass + extra launch
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = s; }
