@@ -105,7 +105,8 @@ int pdn_softmax_bwd_f32(const float* y, const float* dy, float* dx, int64_t rows
 int pdn_rmsnorm_fwd_f32(const float* x, const float* w, float* y, float* rms, int64_t rows,
                         int cols, float eps, void* stream);
 int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* rms, const float* dy,
-                        float* dx, float* dw, int accumulate_dw, int64_t rows, int cols,
+                        const float* dx_residual, float* dx, float* dw, int accumulate_dw,
+                        int64_t rows, int cols,
                         void* workspace, int64_t workspace_bytes, void* stream);
 int64_t pdn_rmsnorm_bwd_workspace_bytes(int64_t rows, int cols);
 

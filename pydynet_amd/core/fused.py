@@ -38,6 +38,18 @@ def _contig(a):
     return a if a.is_contiguous() else a.copy()
 
 
+def _foldable(node, idx, t):
+    """The gradient input `idx` already holds (handed over by the engine as `node._existing`) if
+    this node can add it inside its own kernel; marks the input as folded."""
+    ex = getattr(node, "_existing", None)
+    ex = ex[idx] if ex is not None else None
+    if ex is None or isinstance(ex, np.ndarray) or ex.dtype != np.float32 \
+            or ex.shape != tuple(t.shape) or not ex.is_contiguous():
+        return None
+    node._folded.add(idx)
+    return ex
+
+
 def _is_leaf_f32(t):
     return (t.requires_grad and not t.last and t.grad is not None and t.grad.dtype == np.float32
             and (isinstance(t.grad, np.ndarray) or t.grad.is_contiguous()))
@@ -49,6 +61,8 @@ class linear(_Operator):
 
     `residual` (shape of y) folds the `z = x + sublayer(x)` add of a transformer block into the
     GEMM epilogue; its gradient is the upstream gradient itself."""
+
+    folds_existing = True      # backward adds the gradient x already holds inside the dX GEMM
 
     def __init__(self, x, weight, bias=None, residual=None):
         self.has_bias, self.has_res = bias is not None, residual is not None
@@ -96,7 +110,9 @@ class linear(_Operator):
         x2 = x.data.reshape(-1, fin)
         if x.requires_grad:
             dx = hp.empty(x.shape, np.float32)
-            hp.gemm(g2, w.data.T, dx.reshape(-1, fin))                     # NT
+            ex = _foldable(self, 0, x)
+            hp.gemm(g2, w.data.T, dx.reshape(-1, fin),                     # NT
+                    residual=ex.reshape(-1, fin) if ex is not None else None)
             grads[0] = dx
         need_db = b is not None and b.requires_grad
         # bias gradient = column sums of g: formed inside the dW GEMM (both read g once) when the
@@ -118,6 +134,8 @@ class linear(_Operator):
 
 class rms_norm(_Operator):
     """y = x / sqrt(mean(x^2, -1) + eps) * w   (w 1-D over the last axis)."""
+
+    folds_existing = True
 
     def __init__(self, x, weight, eps=1e-6):
         self.eps = float(eps)
@@ -153,7 +171,9 @@ class rms_norm(_Operator):
         direct = w.requires_grad and _is_leaf_f32(w)
         dw = w.grad if direct else (hp.empty((cols,), np.float32) if w.requires_grad else None)
         ws, wsb = hp.workspace(L.query("pdn_rmsnorm_bwd_workspace_bytes", rows, cols))
-        L.call("pdn_rmsnorm_bwd_f32", self._x._ptr, w.data._ptr, self._rms._ptr, g._ptr, dx._ptr,
+        ex = _foldable(self, 0, x) if x.requires_grad else None
+        L.call("pdn_rmsnorm_bwd_f32", self._x._ptr, w.data._ptr, self._rms._ptr, g._ptr,
+               ex._ptr if ex is not None else None, dx._ptr,
                dw._ptr if dw is not None else None, 1 if direct else 0, rows, cols, ws, wsb, hp.stream())
         return [dx if x.requires_grad else None, None if direct else dw]
 

@@ -238,13 +238,26 @@ class Tensor:
                 if not inputs:
                     continue
                 if g is not None:
+                    folded = ()
                     if hasattr(node, "backward_all"):
+                        if node.folds_existing:
+                            # hand the node the gradients its non-leaf inputs already hold: it may
+                            # add them inside its own kernel (GEMM / norm epilogue) instead of the
+                            # engine running a separate accumulation pass afterwards
+                            node._existing = [inp.grad if (inp.requires_grad and inp.last) else None
+                                              for inp in inputs]
+                            folded = node._folded = set()
                         grads = node.backward_all(g)
+                        if node.folds_existing:
+                            node._existing = None
                     else:
                         grads = [node.grad_fn(inp, g) if inp.requires_grad else None for inp in inputs]
-                    for inp, add_grad in zip(inputs, grads):
+                    for i, (inp, add_grad) in enumerate(zip(inputs, grads)):
                         if inp.requires_grad and add_grad is not None:
-                            _accumulate(inp, add_grad, xp)
+                            if i in folded:
+                                inp.grad, inp._grad_owned = add_grad, True
+                            else:
+                                _accumulate(inp, add_grad, xp)
                 for inp in inputs:
                     if inp.requires_grad and not inp.last:       # a leaf: count down its edges
                         left = pending.get(inp._gid, 0) - 1
@@ -321,7 +334,11 @@ def _as_operand(v, like: Tensor):
 
 class _Operator(Tensor):
     """n-ary differentiable node.  Subclasses implement `forward_(*inputs) -> array` and either
-    `grad_fn(input, grad) -> array` (per edge) or `backward_all(grad) -> [array|None]`."""
+    `grad_fn(input, grad) -> array` (per edge) or `backward_all(grad) -> [array|None]`.  A node with
+    `folds_existing = True` receives `self._existing` (gradients its inputs already hold) during
+    backward_all and lists in `self._folded` the inputs whose returned gradient includes them."""
+
+    folds_existing = False
 
     def _init_node(self, data, device, inputs):
         self.data = data

@@ -241,8 +241,8 @@ __global__ void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __r
 template <int VPL>
 __global__ void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                    const float* __restrict__ rms, const float* __restrict__ dy,
-                                   float* __restrict__ dx, float* __restrict__ dw_part,
-                                   int64_t rows, int cols) {
+                                   const float* __restrict__ res, float* __restrict__ dx,
+                                   float* __restrict__ dw_part, int64_t rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [4][cols]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t wave = blockIdx.x * 4ll + wid;
@@ -258,7 +258,7 @@ __global__ void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __r
   for (int64_t row = wave; row < rows; row += nwaves) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * cols);
     const float4* gr = reinterpret_cast<const float4*>(dy + row * cols);
-    const float r = rms[row];
+    const float rinv = 1.0f / rms[row];
     float4 z[VPL], dz[VPL];
     float dot = 0.f;
 #pragma unroll
@@ -266,20 +266,22 @@ __global__ void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __r
       const int idx = lane + 64 * i;
       float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), gv = xv;
       if (idx < n4) { xv = xr[idx]; gv = gr[idx]; }
-      z[i].x = xv.x / r; z[i].y = xv.y / r; z[i].z = xv.z / r; z[i].w = xv.w / r;
+      z[i].x = xv.x * rinv; z[i].y = xv.y * rinv; z[i].z = xv.z * rinv; z[i].w = xv.w * rinv;
       dz[i].x = gv.x * wv[i].x; dz[i].y = gv.y * wv[i].y; dz[i].z = gv.z * wv[i].z; dz[i].w = gv.w * wv[i].w;
       acc[i].x += gv.x * z[i].x; acc[i].y += gv.y * z[i].y; acc[i].z += gv.z * z[i].z; acc[i].w += gv.w * z[i].w;
       dot += (z[i].x * dz[i].x + z[i].y * dz[i].y) + (z[i].z * dz[i].z + z[i].w * dz[i].w);
     }
     dot = wave_sum(dot) / (float)cols;
     float4* dr = reinterpret_cast<float4*>(dx + row * cols);
+    const float4* rr = reinterpret_cast<const float4*>(res ? res + row * cols : nullptr);
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int idx = lane + 64 * i;
       if (idx < n4) {
         float4 t;
-        t.x = (dz[i].x - z[i].x * dot) / r; t.y = (dz[i].y - z[i].y * dot) / r;
-        t.z = (dz[i].z - z[i].z * dot) / r; t.w = (dz[i].w - z[i].w * dot) / r;
+        t.x = (dz[i].x - z[i].x * dot) * rinv; t.y = (dz[i].y - z[i].y * dot) * rinv;
+        t.z = (dz[i].z - z[i].z * dot) * rinv; t.w = (dz[i].w - z[i].w * dot) * rinv;
+        if (res) { const float4 e = rr[idx]; t.x += e.x; t.y += e.y; t.z += e.z; t.w += e.w; }
         dr[idx] = t;
       }
     }
@@ -318,7 +320,7 @@ __global__ void colsum_partials_kernel(const float* __restrict__ part, int nb, i
 }
 
 extern "C" int64_t pdn_rmsnorm_bwd_workspace_bytes(int64_t rows, int cols) {
-  int64_t nb = (rows + 63) / 64; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  int64_t nb = (rows + 15) / 16; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
   return nb * (int64_t)cols * 4;
 }
 
@@ -339,9 +341,11 @@ extern "C" int pdn_rmsnorm_fwd_f32(const float* x, const float* w, float* y, flo
 }
 
 // dw: if dw != NULL, dw (+)= column sums (accumulate_dw selects += vs =). workspace from
-// pdn_rmsnorm_bwd_workspace_bytes.
+// pdn_rmsnorm_bwd_workspace_bytes.  dx_residual (nullable, shape of dx) is added to dx: the
+// gradient x already received from another consumer, folded in instead of a separate add pass.
 extern "C" int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* rms,
-                                   const float* dy, float* dx, float* dw, int accumulate_dw,
+                                   const float* dy, const float* dx_residual, float* dx,
+                                   float* dw, int accumulate_dw,
                                    int64_t rows, int cols, void* workspace,
                                    int64_t workspace_bytes, void* stream) {
   if (rows == 0) return PDN_OK;
@@ -349,7 +353,7 @@ extern "C" int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* 
   PDN_CHECK_ARG(cols > 0 && cols % 4 == 0 && cols <= 2048,
                 "pdn_rmsnorm_bwd_f32: cols=%d must be a multiple of 4 and <= 2048", cols);
   hipStream_t st = (hipStream_t)stream;
-  int64_t nb = (rows + 63) / 64; if (nb > 256) nb = 256; if (nb < 1) nb = 1;
+  int64_t nb = (rows + 15) / 16; if (nb > 1024) nb = 1024; if (nb < 1) nb = 1;
   float* part = nullptr;
   if (dw) {
     if (workspace_bytes < nb * (int64_t)cols * 4 || !workspace) {
@@ -360,7 +364,7 @@ extern "C" int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* 
   }
   const int vpl = (cols / 4 + 63) / 64;
   const size_t shm = (size_t)4 * cols * sizeof(float);
-#define RB(V) hipLaunchKernelGGL((rmsnorm_bwd_kernel<V>), dim3((unsigned)nb), dim3(256), shm, st, x, w, rms, dy, dx, part, rows, cols)
+#define RB(V) hipLaunchKernelGGL((rmsnorm_bwd_kernel<V>), dim3((unsigned)nb), dim3(256), shm, st, x, w, rms, dy, dx_residual, dx, part, rows, cols)
   switch (vpl) { case 1: RB(1); break; case 2: RB(2); break; case 3: RB(3); break; case 4: RB(4); break;
                  case 5: RB(5); break; case 6: RB(6); break; case 7: RB(7); break; default: RB(8); }
   PDN_LAUNCH_CHECK();

@@ -62,7 +62,7 @@ class EmulatedLib:
     def pdn_abi_version(self): return 1
     def pdn_stream_synchronize(self, stream): return 0
     def pdn_gemm_f32_workspace_bytes(self, M, N, K, nb): return 64 * M * N * nb * 4
-    def pdn_rmsnorm_bwd_workspace_bytes(self, rows, cols): return 512 * cols * 4
+    def pdn_rmsnorm_bwd_workspace_bytes(self, rows, cols): return 1024 * cols * 4
     def pdn_embedding_scatter_workspace_bytes(self, V): return V * 4
     def pdn_gemm_prof_enable(self, on): return 0
 
@@ -189,13 +189,16 @@ class EmulatedLib:
             flat(rms, rows)[...] = r[:, 0]
         return 0
 
-    def pdn_rmsnorm_bwd_f32(self, x, w, rms, dy, dx, dw, acc, rows, cols, ws, wsb, stream):
+    def pdn_rmsnorm_bwd_f32(self, x, w, rms, dy, res, dx, dw, acc, rows, cols, ws, wsb, stream):
         a = flat(x, rows * cols).reshape(rows, cols)
         g = np.array(flat(dy, rows * cols).reshape(rows, cols))
         r = flat(rms, rows)[:, None]
         z = a / r
         dz = g * flat(w, cols)
-        flat(dx, rows * cols).reshape(rows, cols)[...] = (dz - z * (z * dz).mean(-1, keepdims=True)) / r
+        d = (dz - z * (z * dz).mean(-1, keepdims=True)) / r
+        if res:
+            d = d + flat(res, rows * cols).reshape(rows, cols)
+        flat(dx, rows * cols).reshape(rows, cols)[...] = d
         if dw:
             s = (g * z).sum(0)
             flat(dw, cols)[...] = flat(dw, cols) + s if acc else s

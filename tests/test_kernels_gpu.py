@@ -227,12 +227,18 @@ def test_rmsnorm_fwd_bwd(hip):
     z = x / r
     assert np.allclose(Y.get(), z * w, rtol=2e-5, atol=2e-6)
     ws, wsb = hip.workspace(L.query("pdn_rmsnorm_bwd_workspace_bytes", rows, cols))
-    L.call("pdn_rmsnorm_bwd_f32", X._ptr, W._ptr, R._ptr, DY._ptr, DX._ptr, DW._ptr, 1, rows, cols,
+    L.call("pdn_rmsnorm_bwd_f32", X._ptr, W._ptr, R._ptr, DY._ptr, None, DX._ptr, DW._ptr, 1, rows, cols,
            ws, wsb, hip.stream())
     dz = dy * w
     dx = (dz - z * (z * dz).mean(-1, keepdims=True)) / r
     assert np.allclose(DX.get(), dx, rtol=1e-4, atol=1e-5)
     assert np.allclose(DW.get(), (dy * z).sum(0), rtol=1e-4, atol=1e-4)
+    # gradient already held by x folded into the same pass; dw skipped
+    res = rng.standard_normal((rows, cols), dtype=np.float32)
+    RES, DX2 = hip.from_numpy(res), hip.empty((rows, cols))
+    L.call("pdn_rmsnorm_bwd_f32", X._ptr, W._ptr, R._ptr, DY._ptr, RES._ptr, DX2._ptr, None, 0, rows,
+           cols, None, 0, hip.stream())
+    assert np.allclose(DX2.get(), dx + res, rtol=1e-4, atol=1e-5)
 
 
 def test_swiglu_rope_relu(hip):
