@@ -61,6 +61,28 @@ def test_gemm_split_k_weight_gradient(hip):
     assert rel_err(dw, ref) < 2e-5
 
 
+@pytest.mark.parametrize("T,M,N", [(8192, 288, 768), (4099, 288, 288), (2050, 200, 100), (6000, 768, 288)])
+def test_gemm_weight_gradient_streaming_kernel(hip, T, M, N):
+    # long-K x^T @ g: wave-streaming kernel, k-split over waves and blocks, ragged K and edges,
+    # accumulation into an existing gradient (beta = 1), bit-reproducible across runs
+    rng = np.random.default_rng(T + M)
+    x = rng.standard_normal((T, M), dtype=np.float32)
+    g = rng.standard_normal((T, N), dtype=np.float32)
+    c0 = rng.standard_normal((M, N), dtype=np.float32)
+    X, G = hip.from_numpy(x), hip.from_numpy(g)
+    ref = x.T.astype(np.float64) @ g.astype(np.float64)
+    C = hip.from_numpy(c0.copy())
+    hip.gemm(X.T, G, C, beta=1.0)
+    first = C.get()
+    assert rel_err(first, ref + c0) < 2e-5
+    C2 = hip.from_numpy(c0.copy())
+    hip.gemm(X.T, G, C2, beta=1.0)
+    assert np.array_equal(first, C2.get())
+    C3 = hip.empty((M, N))
+    hip.gemm(X.T, G, C3, alpha=0.5)
+    assert rel_err(C3.get(), 0.5 * ref) < 2e-5
+
+
 def test_gemm_batched_head_views(hip):
     # attention layout: (B, L, H, hd) viewed as (B, H, L, hd) without a copy
     B, L, H, hd = 2, 64, 6, 48

@@ -7,7 +7,7 @@ P3="TCC_HIT_sum TCC_MISS_sum"
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o g -- python $R/tools/gemm_one.py 5 > $OUT/p$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $P --output-format csv -d $OUT/p$i -o g -- python $R/tools/gemm_one.py 5 $PMC_ARG > $OUT/p$i.log 2>&1
 done
 cd $R
 python - <<'PY'
