@@ -182,12 +182,19 @@ int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, i
                        int k, int stride, int pad, int mode, float* dx, void* stream);
 
 /* Forward and backward of the same loss in one pass over HBM: dlogits = (softmax - onehot) *
- * gscale is written while the row is L2-resident.  Backward then only applies the upstream
+ * gscale is written while the row is still on chip.  Backward then only applies the upstream
  * scalar with pdn_scale_by_device_scalar_f32, which reads it on the device and leaves the
- * buffer untouched when it is exactly 1 (the `loss.backward()` case) -- no host sync. */
+ * buffer untouched when it is exactly 1 (the `loss.backward()` case) -- no host sync.
+ * dlogits_colsum (nullable, (V,)): column sums of dlogits, i.e. the bias gradient of the Linear
+ * that produced the logits (nn/modules/linear.py:41, tensor.py:360-370 un-broadcast sum) formed
+ * while the rows stream through; needs pdn_cross_entropy_colsum_workspace_bytes(rows, V) bytes of
+ * workspace, which is 0 when the shape cannot take the fused path (then pass NULL). */
 int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, int64_t rows, int V,
                                   int mean, float gscale, float* loss_row, float* lse_row,
-                                  float* loss_out, float* dlogits, int* err_flag, void* stream);
+                                  float* loss_out, float* dlogits, float* dlogits_colsum,
+                                  void* workspace, int64_t workspace_bytes, int* err_flag,
+                                  void* stream);
+int64_t pdn_cross_entropy_colsum_workspace_bytes(int64_t rows, int V);
 int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* scalar_dev, void* stream);
 
 /* ---- Adam.step for all parameters in one launch (optim/optimizer.py:185-196).

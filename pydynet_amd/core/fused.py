@@ -115,6 +115,14 @@ class linear(_Operator):
                     residual=ex.reshape(-1, fin) if ex is not None else None)
             grads[0] = dx
         need_db = b is not None and b.requires_grad
+        aux = getattr(g, "_aux", None)
+        if need_db and aux is not None and aux[0] == "colsum" and aux[1].size == b.size:
+            # the producer of g (fused cross entropy) already summed its columns
+            if _is_leaf_f32(b):
+                b.grad += aux[1].reshape(b.grad.shape)
+            else:
+                grads[2] = aux[1].reshape(b.shape)
+            need_db = False
         # bias gradient = column sums of g: formed inside the dW GEMM (both read g once) when the
         # operands have the aligned x^T @ g layout and the leaf buffers can be accumulated into
         fuse_db = (need_db and w.requires_grad and _is_leaf_f32(b) and x2.is_contiguous()
@@ -454,9 +462,15 @@ class cross_entropy(_Operator):
             # the gradient w.r.t. the logits needs nothing computed later: write it now, while each
             # row is still in L2 (one pass over HBM for forward + backward)
             self._dx = hp.empty((n, V), np.float32)
+            # column sums of dlogits (= the bias gradient of the Linear that made the logits) come
+            # for free while the rows stream through; handed to that Linear via the array's `_aux`
+            wsb = L.query("pdn_cross_entropy_colsum_workspace_bytes", n, V)
+            cs = hp.empty((V,), np.float32) if wsb else None
+            ws, wsb = hp.workspace(wsb) if wsb else (None, 0)
             L.call("pdn_cross_entropy_fwd_bwd_f32", self._x._ptr, self._t._ptr, n, V, mean,
                    1.0 / n if mean else 1.0, loss_row._ptr, self._lse._ptr, out._ptr, self._dx._ptr,
-                   hp._err_flag().data_ptr(), hp.stream())
+                   cs._ptr if cs is not None else None, ws, wsb, hp._err_flag().data_ptr(), hp.stream())
+            self._dx._aux = ("colsum", cs) if cs is not None else None
         else:
             L.call("pdn_cross_entropy_fwd_f32", self._x._ptr, self._t._ptr, n, V, mean, loss_row._ptr,
                    self._lse._ptr, out._ptr, hp._err_flag().data_ptr(), hp.stream())
@@ -475,6 +489,9 @@ class cross_entropy(_Operator):
         if self._dx is not None:
             dx, self._dx = self._dx, None       # written in forward; apply the upstream scalar (1 -> no-op)
             L.call("pdn_scale_by_device_scalar_f32", dx._ptr, dx.size, g._ptr, hp.stream())
+            aux = getattr(dx, "_aux", None)
+            if aux is not None:
+                L.call("pdn_scale_by_device_scalar_f32", aux[1]._ptr, aux[1].size, g._ptr, hp.stream())
             return [dx]
         dx = hp.empty((n, V), np.float32)
         L.call("pdn_cross_entropy_bwd_f32", self._x._ptr, self._t._ptr, self._lse._ptr, g._ptr,

@@ -857,38 +857,66 @@ __global__ void ce_fwd_bwd_kernel(const float* __restrict__ x, const int64_t* __
   }
 }
 
-__global__ void ce_fwd_bwd_lds_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+template <bool COLSUM>
+__global__ void ce_fwd_bwd_reg_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
                                       float* __restrict__ loss_row, float* __restrict__ lse_row,
                                       float* __restrict__ dx, float gscale, int64_t rows, int V,
-                                      int* __restrict__ err);
+                                      int* __restrict__ err, float* __restrict__ colsum_part);
+
+#define CE_REG_MAX_V 32768      // 1024 threads x 8 float4 held in registers
+static inline bool ce_reg_row_ok(int V, const void* a, const void* b) {
+  return V >= 4096 && V % 4 == 0 && V <= CE_REG_MAX_V && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+}
+static inline int ce_reg_grid(int64_t rows) { return (int)(rows < 256 ? rows : 256); }
+
+// Bytes of workspace needed for the fused column sums of dlogits (the bias gradient of the layer
+// that produced the logits); 0 when this shape takes the generic path, which has no such fusion.
+extern "C" int64_t pdn_cross_entropy_colsum_workspace_bytes(int64_t rows, int V) {
+  if (!(V >= 4096 && V % 4 == 0 && V <= CE_REG_MAX_V) || rows <= 0) return 0;
+  return (int64_t)ce_reg_grid(rows) * V * 4;
+}
 
 extern "C" int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, int64_t rows,
                                              int V, int mean, float gscale, float* loss_row,
                                              float* lse_row, float* loss_out, float* dlogits,
-                                             int* err_flag, void* stream) {
+                                             float* dlogits_colsum, void* workspace,
+                                             int64_t workspace_bytes, int* err_flag, void* stream) {
   PDN_CHECK_ARG(rows > 0 && V > 0, "pdn_cross_entropy_fwd_bwd_f32: empty input");
   PDN_CHECK_ARG(logits && targets && loss_row && lse_row && loss_out && dlogits && err_flag,
                 "pdn_cross_entropy_fwd_bwd_f32: null operand");
   hipStream_t st = (hipStream_t)stream;
   const int ce_threads = V >= 4096 ? 1024 : 256;   // see pdn_cross_entropy_fwd_f32
   const int g = (int)(V >= 4096 ? (rows < 512 ? rows : 512) : (rows < 65535 ? rows : 65535));
-  const bool lds_row = V >= 4096 && V % 4 == 0 && (size_t)V * 4 <= 160 * 1024 - 1024 &&
-                       ((((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0);
-  if (lds_row) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      PDN_HIP(hipFuncSetAttribute((const void*)ce_fwd_bwd_lds_kernel,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-      attr_set = true;
+  const bool reg_row = ce_reg_row_ok(V, logits, dlogits);
+  if (dlogits_colsum) {
+    if (!reg_row) {
+      pdn_set_error("pdn_cross_entropy_fwd_bwd_f32: fused column sums need 4096 <= V <= %d, V %% 4 == 0, aligned rows", CE_REG_MAX_V);
+      return PDN_EUNSUPPORTED;
     }
-    const int gl = (int)(rows < 256 ? rows : 256);
-    hipLaunchKernelGGL(ce_fwd_bwd_lds_kernel, dim3(gl), dim3(1024), (size_t)V * 4, st, logits, targets,
-                       loss_row, lse_row, dlogits, gscale, rows, V, err_flag);
+    if (!workspace || workspace_bytes < pdn_cross_entropy_colsum_workspace_bytes(rows, V)) {
+      pdn_set_error("pdn_cross_entropy_fwd_bwd_f32: workspace too small");
+      return PDN_EWORKSPACE;
+    }
+  }
+  if (reg_row) {
+    const int gl = ce_reg_grid(rows);
+    if (dlogits_colsum)
+      hipLaunchKernelGGL((ce_fwd_bwd_reg_kernel<true>), dim3(gl), dim3(1024), 0, st, logits, targets, loss_row,
+                         lse_row, dlogits, gscale, rows, V, err_flag, (float*)workspace);
+    else
+      hipLaunchKernelGGL((ce_fwd_bwd_reg_kernel<false>), dim3(gl), dim3(1024), 0, st, logits, targets, loss_row,
+                         lse_row, dlogits, gscale, rows, V, err_flag, (float*)nullptr);
+    PDN_LAUNCH_CHECK();
+    if (dlogits_colsum) {
+      hipLaunchKernelGGL(colsum_partials_kernel, dim3((V + 31) / 32), dim3(256), 0, st,
+                         (const float*)workspace, gl, V, dlogits_colsum, 0);
+      PDN_LAUNCH_CHECK();
+    }
   } else {
     hipLaunchKernelGGL(ce_fwd_bwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row,
                        lse_row, dlogits, gscale, rows, V, err_flag);
+    PDN_LAUNCH_CHECK();
   }
-  PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows,
                      mean ? 1.f / (float)rows : 1.f, loss_out);
   PDN_LAUNCH_CHECK();
@@ -913,54 +941,106 @@ extern "C" int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* 
   return PDN_OK;
 }
 
-// ---- cross entropy fwd+bwd with the row held in LDS ---------------------------------------------
-// A vocabulary row of up to 40000 floats (160 KB LDS) is loaded from HBM exactly once: pass 1
-// copies it to LDS and takes the max, pass 2 (LDS) the sum of exponentials, pass 3 (LDS) writes
-// dlogits.  One 1024-thread workgroup per CU; algorithmic traffic = 4 B read + 4 B written per logit.
-__global__ __launch_bounds__(1024) void ce_fwd_bwd_lds_kernel(
+// ---- cross entropy fwd+bwd with the row held in registers ---------------------------------------
+// One 1024-thread workgroup per CU walks rows; a vocabulary row of up to 32768 floats lives in the
+// registers of the workgroup (8 float4 per thread), so it is read from HBM exactly once and never
+// touches LDS: max -> exp (kept in place) -> sum -> dlogits = e / sum - onehot.  The NEXT row is
+// fetched into a second register set while the current one is reduced and written, so the HBM
+// read stream overlaps the exp / store work.  Algorithmic traffic = 4 B read + 4 B written per logit.
+// COLSUM: per-thread column sums of dlogits over the workgroup's rows -> one partial row per
+// workgroup (the bias gradient of the vocabulary projection, summed by colsum_partials_kernel).
+template <bool COLSUM>
+__global__ __launch_bounds__(1024) void ce_fwd_bwd_reg_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ tgt, float* __restrict__ loss_row,
     float* __restrict__ lse_row, float* __restrict__ dx, float gscale, int64_t rows, int V,
-    int* __restrict__ err) {
-  extern __shared__ __attribute__((aligned(16))) float row_lds[];
+    int* __restrict__ err, float* __restrict__ colsum_part) {
+  constexpr int NV = CE_REG_MAX_V / 4 / 1024;     // float4 per thread
   __shared__ float red[16];
-  const int n4 = V >> 2;
-  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
+  __shared__ float xt_s;
+  const int n4 = V >> 2, tid = threadIdx.x;
+  float4 cur[NV], nxt[NV], cs[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    cs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    nxt[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  int64_t row = blockIdx.x;
+  if (row < rows) {
     const float4* xr = reinterpret_cast<const float4*>(x + row * (int64_t)V);
-    float4* dr = reinterpret_cast<float4*>(dx + row * (int64_t)V);
-    float4* l4 = reinterpret_cast<float4*>(row_lds);
-    float m = -INFINITY;
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-      const float4 v = xr[i];
-      l4[i] = v;
-      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 1024 * j;
+      if (i < n4) nxt[j] = xr[i];
     }
-    m = block_max(m, red);            // (its barriers also publish the LDS row)
-    float s = 0.f;
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-      const float4 v = l4[i];
-      s += (expf(v.x - m) + expf(v.y - m)) + (expf(v.z - m) + expf(v.w - m));
-    }
-    s = block_sum(s, red);
-    const float lse = logf(s) + m;
+  }
+  for (; row < rows; row += gridDim.x) {
     int64_t t = tgt[row];
     if (t < 0) t += V;
-    if (t < 0 || t >= V) { if (threadIdx.x == 0) *err = 1; t = 0; }
-    if (threadIdx.x == 0) {
-      lse_row[row] = lse;
-      loss_row[row] = lse - row_lds[t];
-    }
-    for (int i = threadIdx.x; i < n4; i += blockDim.x) {
-      const float4 v = l4[i];
-      float4 r;
-      r.x = expf(v.x - lse); r.y = expf(v.y - lse); r.z = expf(v.z - lse); r.w = expf(v.w - lse);
-      const int c = 4 * i;
-      if (t >= c && t < c + 4) {
-        if (t == c) r.x -= 1.f; else if (t == c + 1) r.y -= 1.f;
-        else if (t == c + 2) r.z -= 1.f; else r.w -= 1.f;
+    if (t < 0 || t >= V) { if (tid == 0) *err = 1; t = 0; }
+    const int t4 = (int)(t >> 2), tc = (int)(t & 3);
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 1024 * j;
+      cur[j] = nxt[j];
+      if (i < n4) {
+        const float4 v = cur[j];
+        m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        if (i == t4) xt_s = tc == 0 ? v.x : (tc == 1 ? v.y : (tc == 2 ? v.z : v.w));
       }
-      r.x *= gscale; r.y *= gscale; r.z *= gscale; r.w *= gscale;
-      dr[i] = r;
     }
-    __syncthreads();                  // row_lds is overwritten by the next row
+    const int64_t nrow = row + gridDim.x;
+    if (nrow < rows) {
+      const float4* xn = reinterpret_cast<const float4*>(x + nrow * (int64_t)V);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int i = tid + 1024 * j;
+        if (i < n4) nxt[j] = xn[i];
+      }
+    }
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 1024 * j;
+      if (i < n4) {
+        float4 e;
+        e.x = expf(cur[j].x - m); e.y = expf(cur[j].y - m); e.z = expf(cur[j].z - m); e.w = expf(cur[j].w - m);
+        cur[j] = e;
+        s += (e.x + e.y) + (e.z + e.w);
+      }
+    }
+    s = block_sum(s, red);            // (its barriers also publish xt_s)
+    const float lse = logf(s) + m;
+    const float inv = 1.f / s;
+    if (tid == 0) {
+      lse_row[row] = lse;
+      loss_row[row] = lse - xt_s;
+    }
+    float4* dr = reinterpret_cast<float4*>(dx + row * (int64_t)V);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 1024 * j;
+      if (i < n4) {
+        float4 r;
+        r.x = cur[j].x * inv; r.y = cur[j].y * inv; r.z = cur[j].z * inv; r.w = cur[j].w * inv;
+        if (i == t4) {
+          if (tc == 0) r.x -= 1.f; else if (tc == 1) r.y -= 1.f;
+          else if (tc == 2) r.z -= 1.f; else r.w -= 1.f;
+        }
+        r.x *= gscale; r.y *= gscale; r.z *= gscale; r.w *= gscale;
+        dr[i] = r;
+        if (COLSUM) { cs[j].x += r.x; cs[j].y += r.y; cs[j].z += r.z; cs[j].w += r.w; }
+      }
+    }
+    __syncthreads();                  // xt_s / red are rewritten by the next row
+  }
+  if (COLSUM) {
+    float4* part = reinterpret_cast<float4*>(colsum_part + (int64_t)blockIdx.x * V);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = tid + 1024 * j;
+      if (i < n4) part[i] = cs[j];
+    }
   }
 }

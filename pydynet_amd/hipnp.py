@@ -139,7 +139,7 @@ def check_index_errors():
 class ndarray:
     """Strided N-d array in HBM.  `_buf` (a 1-D torch tensor) owns the storage."""
 
-    __slots__ = ("_buf", "_ptr", "shape", "_strides", "dtype", "__weakref__")
+    __slots__ = ("_buf", "_ptr", "shape", "_strides", "dtype", "_aux", "__weakref__")
     __array_priority__ = 1000.0
     __array_ufunc__ = None     # numpy scalars/arrays defer to our reflected operators
 

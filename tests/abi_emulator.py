@@ -328,10 +328,16 @@ class EmulatedLib:
         DK[...] = np.matmul(ds.swapaxes(-1, -2), Q)
         return 0
 
+    def pdn_cross_entropy_colsum_workspace_bytes(self, rows, V):
+        return 256 * V * 4 if (V >= 4096 and V % 4 == 0 and V <= 32768 and rows > 0) else 0
+
     def pdn_cross_entropy_fwd_bwd_f32(self, logits, targets, rows, V, mean, gscale, loss_row, lse_row,
-                                      loss_out, dlogits, err, stream):
+                                      loss_out, dlogits, colsum, ws, wsb, err, stream):
         self.pdn_cross_entropy_fwd_f32(logits, targets, rows, V, mean, loss_row, lse_row, loss_out, err, stream)
-        return self.pdn_cross_entropy_bwd_f32(logits, targets, lse_row, None, gscale, dlogits, rows, V, stream)
+        rc = self.pdn_cross_entropy_bwd_f32(logits, targets, lse_row, None, gscale, dlogits, rows, V, stream)
+        if colsum:
+            flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
+        return rc
 
     def pdn_scale_by_device_scalar_f32(self, x, n, scalar, stream):
         s = flat(scalar, 1)[0]

@@ -418,18 +418,25 @@ def test_cross_entropy_one_pass_forward_backward(hip):
     from pydynet_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(14)
-    for rows, V in [(48, 32000), (19, 10)]:
+    for rows, V in [(48, 32000), (19, 10), (700, 32000)]:
         x = rng.standard_normal((rows, V), dtype=np.float32) * 2
         t = rng.integers(0, V, size=rows)
         X, T = hip.from_numpy(x), hip.from_numpy(t)
         lr, lse, out, DX = hip.empty((rows,)), hip.empty((rows,)), hip.empty((1,)), hip.empty((rows, V))
+        wsb = L.query("pdn_cross_entropy_colsum_workspace_bytes", rows, V)
+        assert (wsb > 0) == (V == 32000)
+        CS = hip.empty((V,)) if wsb else None
+        ws, wsb = hip.workspace(wsb) if wsb else (None, 0)
         L.call("pdn_cross_entropy_fwd_bwd_f32", X._ptr, T._ptr, rows, V, 1, 1.0 / rows, lr._ptr, lse._ptr,
-               out._ptr, DX._ptr, hip._err_flag().data_ptr(), hip.stream())
+               out._ptr, DX._ptr, CS._ptr if CS is not None else None, ws, wsb,
+               hip._err_flag().data_ptr(), hip.stream())
         x64 = x.astype(np.float64)
         l = np.log(np.exp(x64 - x64.max()).sum(1)) + x64.max()
         assert abs(out.get()[0] - (l - x64[np.arange(rows), t]).mean()) < 1e-5 * abs(l.mean())
         sm = np.exp(x64 - l[:, None]); sm[np.arange(rows), t] -= 1
         assert np.allclose(DX.get(), sm / rows, rtol=1e-4, atol=1e-8)
+        if CS is not None:
+            assert np.allclose(CS.get(), (sm / rows).sum(0), rtol=1e-4, atol=1e-7)
         one, half = hip.from_numpy(np.ones(1, np.float32)), hip.from_numpy(np.full(1, 0.5, np.float32))
         before = DX.get()
         L.call("pdn_scale_by_device_scalar_f32", DX._ptr, DX.size, one._ptr, hip.stream())

@@ -39,6 +39,8 @@ rows = [
     ("lm_head fwd", 1, x, wv, logits, {}),
     ("lm_head dX NT", 1, logits, wv.T, hp.empty((T, 288)), {}),
     ("lm_head dW TN", 1, x.T, logits, hp.empty((288, 32000)), {"beta": 1.0}),
+    ("lm_head dW TN +colsum", 0, x.T, logits, hp.empty((288, 32000)),
+     {"beta": 1.0, "b_colsum": hp.zeros((32000,), np.float32), "colsum_accumulate": True}),
 ]
 tot = ideal = 0.0
 print(f"tokens = {T}")
