@@ -359,9 +359,10 @@ class attention(_Operator):
             hp, L = _hip(), _L()
             do = _contig(do)
             dq, dk, dv = (hp.empty(q.shape, np.float32) for _ in range(3))
+            ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
             L.call("pdn_attention_bwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, self.data._ptr, do._ptr,
                    self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd,
-                   1 if (self.causal and Lq > 1) else 0, hp.stream())
+                   1 if (self.causal and Lq > 1) else 0, ws, wsb, hp.stream())
             return [dq, dk, dv]
         p = self._p
         if self.xp is np:

@@ -8,9 +8,11 @@
 // Layout: q, k, v, o are (B, L, H, hd) exactly as the projections produce them (row stride
 // H*hd, head offset h*hd); nothing is transposed or copied.
 //
-// One workgroup (4 wave64, one per SIMD) per (batch, head).  K and V of that head are staged in
-// LDS once ([L][hd+4] each).  A wave owns 32-query tiles; tiles are dealt zig-zag (0,7 | 1,6 |
-// 2,5 | 3,4 for L = 256) so the causal work is balanced across the four waves.
+// One workgroup (8 wave64, two per SIMD) per (batch, head).  K and V of that head are staged in
+// LDS once ([L][hd+4] each, all global loads of a thread issued before the first LDS write).  A
+// wave owns one 32-query tile; SIMD s hosts waves s and s+4, which take tiles s and 7-s, so the
+// causal work (s+1 and 8-s key tiles) is balanced over the four SIMDs and each SIMD always has a
+// second wave to issue MFMAs while the other one does its softmax.
 //
 // Per query tile (32 rows), with the 32x32x2 f32 MFMA:
 //   S^T[key][q]  = K Q^T      (A = K rows from LDS, B = Q rows held in registers, k = head dim)
@@ -36,43 +38,71 @@ __device__ __forceinline__ int att_krow(int r, int lh) { return (r & 3) + 8 * (r
 // zig-zag owner of query tile i among 4 waves
 __device__ __forceinline__ int att_owner(int i) { return ((i >> 2) & 1) ? 3 - (i & 3) : (i & 3); }
 
+// zig-zag owner: wave w (8 per workgroup) takes tile w (w < 4) or 11 - w; SIMD s = w % 4 hosts tiles s and 7 - s
+__device__ __forceinline__ int att_tile_of_wave(int w) { return w < 4 ? w : 11 - w; }
+
+// Stage two [L][HD] row-major matrices (row stride `row_stride` floats) into padded LDS images
+// [L][HD+4]; every thread issues all of its global loads before the first LDS write.
+template <int HD, int NT>
+__device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __restrict__ s1,
+                                              const float* __restrict__ g0, const float* __restrict__ g1,
+                                              int L, int64_t row_stride, int tid) {
+  constexpr int LD = ATT_LD(HD), F4 = HD / 4;
+  constexpr int NP = (ATT_MAX_TILES * 32 * F4 + NT - 1) / NT;
+  float4 r0[NP], r1[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < L * F4) {
+      const int row = u / F4, c4 = u % F4;
+      // component-wise: a whole-float4 store into the array defeats SROA (scratch) on hipcc 7.2
+      const float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)row * row_stride + 4 * c4);
+      const float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride + 4 * c4);
+      r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
+      r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < L * F4) {
+      const int row = u / F4, c4 = u % F4;
+      *reinterpret_cast<float4*>(s0 + row * LD + 4 * c4) = r0[j];
+      *reinterpret_cast<float4*>(s1 + row * LD + 4 * c4) = r1[j];
+    }
+  }
+}
+
 template <int HD>
-__global__ __launch_bounds__(256, 1) void attention_fwd_kernel(
+__global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
     int64_t batch_stride, float sqrt_hd, int causal) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;                    // k-groups of 8 along the head dim
+  constexpr int F4 = HD / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ks = lds;                               // [L][LD]
   float* Vs = lds + (size_t)L * LD;              // [L][LD]
-  float* Os = Vs + (size_t)L * LD;               // 4 waves x [32][LD] output staging
+  float* Os = Vs + (size_t)L * LD;               // 8 waves x [32][LD] output staging
 
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
   const float* Qb = Q + base;
-  const float* Kb = K + base;
-  const float* Vb = V + base;
   float* Ob = O + base;
 
-  // ---- stage K and V: each row is HD contiguous floats ------------------------------------
-  constexpr int F4 = HD / 4;
-  for (int u = tid; u < L * F4; u += 256) {
-    const int row = u / F4, c4 = u % F4;
-    const float4 kv = *reinterpret_cast<const float4*>(Kb + (int64_t)row * row_stride + 4 * c4);
-    const float4 vv = *reinterpret_cast<const float4*>(Vb + (int64_t)row * row_stride + 4 * c4);
-    *reinterpret_cast<float4*>(Ks + row * LD + 4 * c4) = kv;
-    *reinterpret_cast<float4*>(Vs + row * LD + 4 * c4) = vv;
-  }
+  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid);
   __syncthreads();
 
   const int ntile = L / 32;
+  const int qt = att_tile_of_wave(wave);
+  if (qt >= ntile) return;                       // no workgroup barrier below this point
   const float inv_sqrt = 1.f / sqrt_hd;
   float* Ow = Os + wave * (32 * LD);
-  for (int qt = 0; qt < ntile; ++qt) {
-    if (att_owner(qt) != wave) continue;
+  {
     const int nk = causal ? qt + 1 : ntile;       // key tiles that can be unmasked
     // Q fragments: lane (li, lh) holds Q[q = qt*32+li][8t + 4lh .. +3]
     float4 qf[NT8];
@@ -162,13 +192,11 @@ __global__ __launch_bounds__(256, 1) void attention_fwd_kernel(
       *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * row_stride + 4 * c4) =
           *reinterpret_cast<const float4*>(Ow + row * LD + 4 * c4);
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
   }
 }
 
 extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
-  return ((int64_t)2 * L + 4 * 32) * ATT_LD(head_dim) * 4;
+  return ((int64_t)2 * L + 8 * 32) * ATT_LD(head_dim) * 4;
 }
 
 // q, k, v, o: (B, L, H, head_dim) contiguous in head_dim, `row_stride` between consecutive
@@ -194,26 +222,28 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(256), shm, (hipStream_t)stream, q, k,
+  hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(512), shm, (hipStream_t)stream, q, k,
                      v, o, lse, H, L, row_stride, batch_stride, sqrtf((float)head_dim), causal);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
 
 // ======================================================================================
-// Backward.  Same decomposition (one workgroup per (batch, head), K and V resident in LDS),
-// probabilities recomputed from the saved log-sum-exp:   P = exp(S/sqrt(hd) - lse).
+// Backward.  Probabilities are recomputed from the saved log-sum-exp:  P = exp(S/sqrt(hd) - lse).
 //   delta[q] = sum_d dO[q,d] * O[q,d]
 //   dV = P^T dO        dP = dO V^T        dS = P o (dP - delta) / sqrt(hd)
 //   dQ = dS K          dK = dS^T Q
 // An MFMA accumulator holds its column index in the lane and its row index in registers, and
 // can feed the next MFMA only as the operand that contracts over the ROW index.  dQ contracts
-// over keys, dK / dV over queries, so the score tile is needed in both orientations:
-//   phase 1 (a wave owns query tiles):  S^T[key][q] = K Q^T, dP^T = V dO^T  ->  dQ^T += K^T dS^T
-//   phase 2 (a wave owns key tiles):    S[q][key]   = Q K^T, dP   = dO V^T  ->  dV^T += dO^T P,
-//                                                                               dK^T += Q^T dS
-// 80 + 112 MFMAs per (query tile, key tile) pair, fully masked pairs skipped.  Q / dO tiles used
-// column-wise in phase 2 are parked in a per-wave LDS slot.  Nothing of size L x L touches HBM.
+// over keys, dK / dV over queries, so the score tile is needed in both orientations -- two
+// kernels, each one workgroup of 8 waves per (batch, head) with the same zig-zag tile ownership
+// as the forward:
+//   attention_bwd_dq_kernel   K, V resident in LDS; a wave owns a query tile:
+//        S^T[key][q] = K Q^T, dP^T = V dO^T  ->  dQ^T += K^T dS^T;  also writes delta[q]
+//   attention_bwd_dkv_kernel  Q, dO resident in LDS; a wave owns a key tile:
+//        S[q][key] = Q K^T, dP = dO V^T  ->  dV^T += dO^T P,  dK^T += Q^T dS
+// 80 + 112 MFMAs per (query tile, key tile) pair, fully masked pairs skipped.  Nothing of size
+// L x L touches HBM; the only intermediate is delta (B*H*L floats of workspace).
 // ======================================================================================
 template <int HD>
 __device__ __forceinline__ void att_store_tile_T(float* slot, const f32x16& t0, const f32x16& t1,
@@ -240,199 +270,205 @@ __device__ __forceinline__ void att_store_tile_T(float* slot, const f32x16& t0, 
 }
 
 template <int HD>
-__global__ __launch_bounds__(256, 1) void attention_bwd_kernel(
+__global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
-    float* __restrict__ dQ, float* __restrict__ dK, float* __restrict__ dV, int H, int L,
-    int64_t row_stride, int64_t batch_stride, float sqrt_hd, int causal) {
+    float* __restrict__ dQ, float* __restrict__ Delta, int H, int L, int64_t row_stride,
+    int64_t batch_stride, float sqrt_hd, int causal) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
-  constexpr int F4 = HD / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ks = lds;                                 // [L][LD]
   float* Vs = Ks + (size_t)L * LD;                 // [L][LD]
-  float* slots = Vs + (size_t)L * LD;              // 4 waves x 2 x [32][LD]
-  float* lse_s = slots + 4 * 2 * 32 * LD;          // [L]
+  float* slots = Vs + (size_t)L * LD;              // 8 waves x [32][LD]
+
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
+  const float* Qb = Q + base; const float* Ob = O + base; const float* dOb = dO + base;
+  float* dQb = dQ + base;
+
+  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid);
+  __syncthreads();
+
+  const int ntile = L / 32;
+  const int qt = att_tile_of_wave(wave);
+  if (qt >= ntile) return;
+  const float inv_sqrt = 1.f / sqrt_hd;
+  const bool hi_ok = (32 + li) < HD;
+  const int nk = causal ? qt + 1 : ntile;
+  const int qpos = qt * 32 + li;
+  float4 qf[NT8], gf[NT8];
+  float dpart = 0.f;
+  {
+    const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
+    const float* grow = dOb + (int64_t)qpos * row_stride + 4 * lh;
+    const float* orow = Ob + (int64_t)qpos * row_stride + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+      gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
+      const float4 ov = *reinterpret_cast<const float4*>(orow + 8 * t);
+      dpart += (ov.x * gf[t].x + ov.y * gf[t].y) + (ov.z * gf[t].z + ov.w * gf[t].w);
+    }
+  }
+  const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
+  const float lse_q = LSE[(int64_t)bh * L + qpos];
+  if (lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
+  f32x16 dq0, dq1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  for (int kt = 0; kt < nk; ++kt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
+    const float* vrow = Vs + (kt * 32 + li) * LD + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t);
+      const float4 vf = *reinterpret_cast<const float4*>(vrow + 8 * t);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t].y, dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, gf[t].z, dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
+    }
+    // dS^T[key][q] = P^T o (dP^T - delta_q) / sqrt(hd)   (lane = q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const bool masked = causal && (kt * 32 + att_krow(r, lh) > qpos);
+      const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_q);
+      s[r] = p * (dp[r] - delta_q) * inv_sqrt;
+    }
+    // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* kr = Ks + (kt * 32 + att_krow(r, lh)) * LD;
+      const float a0 = kr[li];
+      const float a1 = hi_ok ? kr[32 + li] : 0.f;
+      dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], dq0, 0, 0, 0);
+      dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], dq1, 0, 0, 0);
+    }
+  }
+  att_store_tile_T<HD>(slots + wave * (32 * LD), dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride,
+                       row_stride, li, lh, lane, 1.f);
+}
+
+template <int HD>
+__global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Delta,
+    float* __restrict__ dK, float* __restrict__ dV, int H, int L, int64_t row_stride,
+    int64_t batch_stride, float sqrt_hd, int causal) {
+  constexpr int LD = ATT_LD(HD);
+  constexpr int NT8 = HD / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;                                 // [L][LD]
+  float* Gs = Qs + (size_t)L * LD;                 // [L][LD]   dO
+  float* slots = Gs + (size_t)L * LD;              // 8 waves x [32][LD]
+  float* lse_s = slots + 8 * 32 * LD;              // [L]
   float* delta_s = lse_s + L;                      // [L]
 
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
-  const float* Qb = Q + base; const float* Kb = K + base; const float* Vb = V + base;
-  const float* Ob = O + base; const float* dOb = dO + base;
-  float* dQb = dQ + base; float* dKb = dK + base; float* dVb = dV + base;
-  float* slotA = slots + wave * (2 * 32 * LD);
-  float* slotB = slotA + 32 * LD;
+  const float* Kb = K + base; const float* Vb = V + base;
+  float* dKb = dK + base; float* dVb = dV + base;
 
-  // ---- phase 0: stage K, V; delta and lse per query -------------------------------------------
-  for (int u = tid; u < L * F4; u += 256) {
-    const int row = u / F4, c4 = u % F4;
-    *reinterpret_cast<float4*>(Ks + row * LD + 4 * c4) =
-        *reinterpret_cast<const float4*>(Kb + (int64_t)row * row_stride + 4 * c4);
-    *reinterpret_cast<float4*>(Vs + row * LD + 4 * c4) =
-        *reinterpret_cast<const float4*>(Vb + (int64_t)row * row_stride + 4 * c4);
-  }
-  for (int q = tid; q < L; q += 256) {
-    const float4* o4 = reinterpret_cast<const float4*>(Ob + (int64_t)q * row_stride);
-    const float4* g4 = reinterpret_cast<const float4*>(dOb + (int64_t)q * row_stride);
-    float acc = 0.f;
-#pragma unroll
-    for (int c = 0; c < F4; ++c) {
-      const float4 a = o4[c], g = g4[c];
-      acc += (a.x * g.x + a.y * g.y) + (a.z * g.z + a.w * g.w);
-    }
-    delta_s[q] = acc;
+  att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + base, L, row_stride, tid);
+  for (int q = tid; q < L; q += 512) {
     lse_s[q] = LSE[(int64_t)bh * L + q];
+    delta_s[q] = Delta[(int64_t)bh * L + q];
   }
   __syncthreads();
 
   const int ntile = L / 32;
+  const int kt = att_tile_of_wave(wave);
+  if (kt >= ntile) return;
   const float inv_sqrt = 1.f / sqrt_hd;
   const bool hi_ok = (32 + li) < HD;
-
-  // ---- phase 1: dQ (wave owns query tiles) -------------------------------------------------
-  for (int qt = 0; qt < ntile; ++qt) {
-    if (att_owner(qt) != wave) continue;
-    const int nk = causal ? qt + 1 : ntile;
-    const int qpos = qt * 32 + li;
-    float4 qf[NT8], gf[NT8];
-    {
-      const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
-      const float* grow = dOb + (int64_t)qpos * row_stride + 4 * lh;
+  const int kpos = kt * 32 + li;
+  float4 kf[NT8], vf[NT8];
+  {
+    const float* krow = Kb + (int64_t)kpos * row_stride + 4 * lh;
+    const float* vrow = Vb + (int64_t)kpos * row_stride + 4 * lh;
 #pragma unroll
-      for (int t = 0; t < NT8; ++t) {
-        qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
-        gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
-      }
+    for (int t = 0; t < NT8; ++t) {
+      kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
+      vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
     }
-    const float lse_q = lse_s[qpos], delta_q = delta_s[qpos];
-    f32x16 dq0, dq1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
-    for (int kt = 0; kt < nk; ++kt) {
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
-      const float* vrow = Vs + (kt * 32 + li) * LD + 4 * lh;
-#pragma unroll
-      for (int t = 0; t < NT8; ++t) {
-        const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t);
-        const float4 vf = *reinterpret_cast<const float4*>(vrow + 8 * t);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, dp, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t].y, dp, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, gf[t].z, dp, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
-      }
-      // dS^T[key][q] = P^T o (dP^T - delta_q) / sqrt(hd)   (lane = q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const bool masked = causal && (kt * 32 + att_krow(r, lh) > qpos);
-        const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_q);
-        s[r] = p * (dp[r] - delta_q) * inv_sqrt;
-      }
-      // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float* kr = Ks + (kt * 32 + att_krow(r, lh)) * LD;
-        const float a0 = kr[li];
-        const float a1 = hi_ok ? kr[32 + li] : 0.f;
-        dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], dq0, 0, 0, 0);
-        dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], dq1, 0, 0, 0);
-      }
-    }
-    att_store_tile_T<HD>(slotA, dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
   }
-
-  // ---- phase 2: dK, dV (wave owns key tiles) -----------------------------------------------
-  for (int kt = 0; kt < ntile; ++kt) {
-    if (att_owner(kt) != wave) continue;
-    const int kpos = kt * 32 + li;
-    float4 kf[NT8], vf[NT8];
-    {
-      const float* krow = Ks + kpos * LD + 4 * lh;
-      const float* vrow = Vs + kpos * LD + 4 * lh;
+  f32x16 dk0, dk1, dv0, dv1;
 #pragma unroll
-      for (int t = 0; t < NT8; ++t) {
-        kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
-        vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
-      }
+  for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  const int q_first = causal ? kt : 0;
+  for (int qt = q_first; qt < ntile; ++qt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+    const float* qrow = Qs + (qt * 32 + li) * LD + 4 * lh;
+    const float* grow = Gs + (qt * 32 + li) * LD + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * t);
+      const float4 g4 = *reinterpret_cast<const float4*>(grow + 8 * t);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t].x, s, 0, 0, 0);    // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t].x, dp, 0, 0, 0);  // dP[q][key]
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[t].y, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.y, vf[t].y, dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[t].z, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.z, vf[t].z, dp, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[t].w, s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.w, vf[t].w, dp, 0, 0, 0);
     }
-    f32x16 dk0, dk1, dv0, dv1;
+    // lane = key, registers = queries
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
-    const int q_first = causal ? kt : 0;
-    for (int qt = q_first; qt < ntile; ++qt) {
-      // park the Q and dO tiles of this query tile in the wave's LDS slots ([q][d])
-      for (int u = lane; u < 32 * F4; u += 64) {
-        const int row = u / F4, c4 = u % F4;
-        *reinterpret_cast<float4*>(slotA + row * LD + 4 * c4) =
-            *reinterpret_cast<const float4*>(Qb + (int64_t)(qt * 32 + row) * row_stride + 4 * c4);
-        *reinterpret_cast<float4*>(slotB + row * LD + 4 * c4) =
-            *reinterpret_cast<const float4*>(dOb + (int64_t)(qt * 32 + row) * row_stride + 4 * c4);
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
-      f32x16 s, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-      const float* qrow = slotA + li * LD + 4 * lh;
-      const float* grow = slotB + li * LD + 4 * lh;
-#pragma unroll
-      for (int t = 0; t < NT8; ++t) {
-        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * t);
-        const float4 g4 = *reinterpret_cast<const float4*>(grow + 8 * t);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t].x, s, 0, 0, 0);    // S[q][key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t].x, dp, 0, 0, 0);  // dP[q][key]
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[t].y, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.y, vf[t].y, dp, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[t].z, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.z, vf[t].z, dp, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[t].w, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.w, vf[t].w, dp, 0, 0, 0);
-      }
-      // lane = key, registers = queries
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int q = qt * 32 + att_krow(r, lh);
-        const bool masked = causal && (kpos > q);
-        const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_s[q]);
-        s[r] = p;                                          // P[q][key]
-        dp[r] = p * (dp[r] - delta_s[q]) * inv_sqrt;       // dS[q][key]
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int qr = att_krow(r, lh);
-        const float g0 = slotB[qr * LD + li], q0 = slotA[qr * LD + li];
-        const float g1 = hi_ok ? slotB[qr * LD + 32 + li] : 0.f;
-        const float q1 = hi_ok ? slotA[qr * LD + 32 + li] : 0.f;
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, s[r], dv0, 0, 0, 0);     // dV^T += dO^T P
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, dp[r], dk0, 0, 0, 0);    // dK^T += Q^T dS
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, s[r], dv1, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, dp[r], dk1, 0, 0, 0);
-      }
-      __builtin_amdgcn_s_waitcnt(0xc07f);
-      __builtin_amdgcn_wave_barrier();
+    for (int r = 0; r < 16; ++r) {
+      const int q = qt * 32 + att_krow(r, lh);
+      const bool masked = causal && (kpos > q);
+      const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_s[q]);
+      s[r] = p;                                          // P[q][key]
+      dp[r] = p * (dp[r] - delta_s[q]) * inv_sqrt;       // dS[q][key]
     }
-    att_store_tile_T<HD>(slotA, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
-    att_store_tile_T<HD>(slotB, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int qr = qt * 32 + att_krow(r, lh);
+      const float g0 = Gs[qr * LD + li], q0 = Qs[qr * LD + li];
+      const float g1 = hi_ok ? Gs[qr * LD + 32 + li] : 0.f;
+      const float q1 = hi_ok ? Qs[qr * LD + 32 + li] : 0.f;
+      dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, s[r], dv0, 0, 0, 0);     // dV^T += dO^T P
+      dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, dp[r], dk0, 0, 0, 0);    // dK^T += Q^T dS
+      dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, s[r], dv1, 0, 0, 0);
+      dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, dp[r], dk1, 0, 0, 0);
+    }
   }
+  float* slot = slots + wave * (32 * LD);
+  att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+  att_store_tile_T<HD>(slot, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
 }
 
 extern "C" int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim) {
-  return ((int64_t)2 * L + 4 * 2 * 32) * ATT_LD(head_dim) * 4 + (int64_t)2 * L * 4;
+  return ((int64_t)2 * L + 8 * 32) * ATT_LD(head_dim) * 4 + (int64_t)2 * L * 4;
+}
+
+// delta[b, h, q] = sum_d dO * O is produced by the dQ kernel and consumed by the dK/dV kernel
+extern "C" int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L) {
+  return (int64_t)B * H * L * 4;
 }
 
 extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                                      const float* d_o, const float* lse, float* dq, float* dk,
                                      float* dv, int B, int H, int L, int head_dim,
                                      int64_t row_stride, int64_t batch_stride, int causal,
-                                     void* stream) {
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
   PDN_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv, "pdn_attention_bwd_f32: null operand");
   if (head_dim != 48 || L % 32 != 0 || L > 32 * ATT_MAX_TILES) {
@@ -444,16 +480,27 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o |
                        (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0),
                 "pdn_attention_bwd_f32: 16-byte alignment required");
-  const size_t shm = (size_t)pdn_attention_bwd_lds_bytes(L, head_dim);
+  if (!workspace || workspace_bytes < pdn_attention_bwd_workspace_bytes(B, H, L)) {
+    pdn_set_error("pdn_attention_bwd_f32: workspace too small");
+    return PDN_EWORKSPACE;
+  }
+  float* delta = (float*)workspace;
   static bool attr_set = false;
   if (!attr_set) {
-    PDN_HIP(hipFuncSetAttribute((const void*)attention_bwd_kernel<48>,
+    PDN_HIP(hipFuncSetAttribute((const void*)attention_bwd_dq_kernel<48>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)attention_bwd_dkv_kernel<48>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_bwd_kernel<48>), dim3(B * H), dim3(256), shm, (hipStream_t)stream, q, k,
-                     v, o, d_o, lse, dq, dk, dv, H, L, row_stride, batch_stride,
-                     sqrtf((float)head_dim), causal);
+  const float sq = sqrtf((float)head_dim);
+  hipLaunchKernelGGL((attention_bwd_dq_kernel<48>), dim3(B * H), dim3(512),
+                     (size_t)pdn_attention_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
+                     lse, dq, delta, H, L, row_stride, batch_stride, sq, causal);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL((attention_bwd_dkv_kernel<48>), dim3(B * H), dim3(512),
+                     (size_t)pdn_attention_bwd_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, d_o,
+                     lse, delta, dk, dv, H, L, row_stride, batch_stride, sq, causal);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -300,21 +300,31 @@ __global__ void rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __r
 }
 
 // out[c] (+)= sum_b part[b][c]   -- fixed order
-// block = 32 columns x 8 row lanes; each lane sums every 8th partial row, LDS combine in order.
-__global__ void colsum_partials_kernel(const float* __restrict__ part, int nb, int cols,
-                                       float* __restrict__ out, int accumulate) {
-  __shared__ float red[8][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
-  float s = 0.f;
-  if (c < cols)
-    for (int b = ty; b < nb; b += 8) s += part[(int64_t)b * cols + c];
-  red[ty][tx] = s;
+// block = 16 columns x 64 row lanes (1024 threads): each lane sums every 64th partial row (four
+// independent loads in flight), then the 64 lane sums are combined through LDS in a fixed order.
+#define COLSUM_COLS 16
+__global__ __launch_bounds__(1024) void colsum_partials_kernel(const float* __restrict__ part, int nb, int cols,
+                                                               float* __restrict__ out, int accumulate) {
+  __shared__ float red[64][COLSUM_COLS];
+  const int tx = threadIdx.x & (COLSUM_COLS - 1), ty = threadIdx.x / COLSUM_COLS;
+  const int c = blockIdx.x * COLSUM_COLS + tx;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int b = ty;
+    for (; b + 192 < nb; b += 256) {
+      s0 += part[(int64_t)b * cols + c];
+      s1 += part[(int64_t)(b + 64) * cols + c];
+      s2 += part[(int64_t)(b + 128) * cols + c];
+      s3 += part[(int64_t)(b + 192) * cols + c];
+    }
+    for (; b < nb; b += 64) s0 += part[(int64_t)b * cols + c];
+  }
+  red[ty][tx] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (ty == 0 && c < cols) {
     float t = red[0][tx];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += red[k][tx];
+    for (int k = 1; k < 64; ++k) t += red[k][tx];
     out[c] = accumulate ? out[c] + t : t;
   }
 }
@@ -369,7 +379,7 @@ extern "C" int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* 
                  case 5: RB(5); break; case 6: RB(6); break; case 7: RB(7); break; default: RB(8); }
   PDN_LAUNCH_CHECK();
   if (dw) {
-    hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + 31) / 32), dim3(256), 0, st, part,
+    hipLaunchKernelGGL(colsum_partials_kernel, dim3((cols + COLSUM_COLS - 1) / COLSUM_COLS), dim3(1024), 0, st, part,
                        (int)nb, cols, dw, accumulate_dw);
     PDN_LAUNCH_CHECK();
   }
@@ -908,7 +918,7 @@ extern "C" int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t*
                          lse_row, dlogits, gscale, rows, V, err_flag, (float*)nullptr);
     PDN_LAUNCH_CHECK();
     if (dlogits_colsum) {
-      hipLaunchKernelGGL(colsum_partials_kernel, dim3((V + 31) / 32), dim3(256), 0, st,
+      hipLaunchKernelGGL(colsum_partials_kernel, dim3((V + COLSUM_COLS - 1) / COLSUM_COLS), dim3(1024), 0, st,
                          (const float*)workspace, gl, V, dlogits_colsum, 0);
       PDN_LAUNCH_CHECK();
     }

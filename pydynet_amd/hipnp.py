@@ -271,7 +271,11 @@ class ndarray:
         if st is None:
             c = self.copy()
             return c._view(shape, _contig_strides(shape))
-        return self._view(shape, st)
+        out = self._view(shape, st)
+        aux = getattr(self, "_aux", None)
+        if aux is not None and shape and self.shape and shape[-1] == self.shape[-1]:
+            out._aux = aux          # per-column side data (e.g. column sums) survives a row regrouping
+        return out
 
     def transpose(self, *axes):
         if len(axes) == 1 and (axes[0] is None or isinstance(axes[0], (tuple, list))):

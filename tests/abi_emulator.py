@@ -299,7 +299,7 @@ class EmulatedLib:
         l = e.sum(-1, keepdims=True)
         return e / l, (m + np.log(l))[..., 0]
 
-    def pdn_attention_lds_bytes(self, L, hd): return (2 * L + 128) * (hd + 4) * 4
+    def pdn_attention_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4
     def pdn_attention_bwd_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4 + 8 * L
 
     def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, causal, stream):
@@ -311,7 +311,9 @@ class EmulatedLib:
         flat(lse, B * H * L).reshape(B, H, L)[...] = ls
         return 0
 
-    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, causal, stream):
+    def pdn_attention_bwd_workspace_bytes(self, B, H, L): return B * H * L * 4
+
+    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, causal, ws, wsb, stream):
         if hd != 48 or L % 32 or L > 256:
             return -2
         Q, K, V, O, DO, DQ, DK, DV = [np.array(a) if i < 5 else a for i, a in
