@@ -132,8 +132,7 @@ int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* 
  * the GEMM + softmax path). */
 int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
-                          int causal, void* workspace, int64_t workspace_bytes, void* stream);
-int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = rowsum(dO * O) */
+                          int causal, void* stream);
 int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                           const float* d_o, const float* lse, float* dq, float* dk, float* dv, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
