@@ -269,7 +269,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
 }
 
 template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM>
-__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, 2) void gemm_f32_mfma_kernel(GemmParams p) {
+__global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ? 3 : 2) void gemm_f32_mfma_kernel(GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
   using LA = TileLoader<BM, BK, A_KIN, VEC, NT>;
@@ -944,6 +944,7 @@ static const TileCfg kCfgs[] = {
     {1, 4, 3, 2, 16, 0.70f},  // 9:  96 x 256
     {2, 1, 1, 3, 32, 0.78f},  // 10: 64 x  96   (2 waves: finer quantisation for N = 288)
     {1, 2, 3, 1, 32, 0.70f},  // 11: 96 x  64
+    {4, 1, 1, 3, 16, 1.15f},  // 12: 128 x 96, BK 16: 51 KB of LDS -> three workgroups per CU (offered selectively)
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kScalarCfg = 5;
@@ -1091,6 +1092,9 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
     const int bk = kCfgs[c].bk;
     const int64_t tiles = cdiv64(M, BM) * cdiv64(N, BN) * nbatch;
+    // 128x96 with BK 16 keeps THREE workgroups per CU: worth it exactly when two-per-CU would
+    // leave a half-empty last round of short blocks (measured: 73 -> 58 us on 32768x288x288)
+    if (c == 12 && !(tiles > 512 && tiles <= 768 && K <= 1024 && a_kin && !b_kin)) continue;
     const int ktiles = (int)cdiv64(K > 0 ? K : 1, bk);
     for (int s = 1; s <= 64; s *= 2) {
       if (s > 1 && b_colsum) break;
@@ -1176,6 +1180,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       case 9: launch_layout<1, 4, 3, 2, 16, true>(p, a_kin, b_kin, grid, st); break;
       case 10: launch_layout<2, 1, 1, 3, 32, true>(p, a_kin, b_kin, grid, st); break;
       case 11: launch_layout<1, 2, 3, 1, 32, true>(p, a_kin, b_kin, grid, st); break;
+      case 12: launch_layout<4, 1, 1, 3, 16, true>(p, a_kin, b_kin, grid, st); break;
       default: launch_layout<2, 2, 1, 1, 32, true>(p, a_kin, b_kin, grid, st); break;
     }
   } else {
