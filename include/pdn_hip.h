@@ -172,11 +172,14 @@ int pdn_cross_entropy_bwd_f32(const float* logits, const int64_t* targets, const
  * (N, C, kh, kw, oh, ow) -- bit-exact with `as_strided(...).copy()` (:211-222).  col2im is the
  * adjoint of `xp.add.at` on the overlapping view (:224-232) as a deterministic gather.
  * Pooling (mode 0 = max, 1 = avg) works on the zero-padded input like the reference; max
- * backward sends the gradient to every tied position (core/tensor.py:744-750). */
+ * backward sends the gradient to every tied position (core/tensor.py:744-750).
+ * col is (N, col_rows, oh*ow): rows [0, C*k*k) are the reference layout, the rest pad the
+ * contraction (zeros; row C*k*k = ones when ones_row, pairing with a bias column of the packed
+ * weight so that `+ bias` (functional.py:279) and its gradient ride inside the GEMMs). */
 int pdn_im2col2d_f32(const float* x, int N, int C, int H, int W, int k, int stride, int pad,
-                     float* col, void* stream);
+                     float* col, int col_rows, int ones_row, void* stream);
 int pdn_col2im2d_f32(const float* dcol, int N, int C, int H, int W, int k, int stride, int pad,
-                     float* dx, void* stream);
+                     float* dx, int col_rows, void* stream);
 int pdn_pool2d_fwd_f32(const float* x, int N, int C, int H, int W, int k, int stride, int pad,
                        int mode, float* y, void* stream);
 int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, int C, int H, int W,

@@ -503,11 +503,11 @@ class cross_entropy(_Operator):
 class conv2d(_Operator):
     """Square-kernel 2-D convolution = im2col + ONE batched GEMM (nn/functional.py:254-281).
 
-    The im2col buffer keeps the reference layout (N, C, kh, kw, oh, ow); per image it is read by
-    the GEMM as an M-contiguous A operand, the kernel tensor (O, C*k*k) as a K-contiguous B
-    operand, and the product lands in an NHWC buffer that is returned as an NCHW view -- the
-    same (non-contiguous) memory layout the reference produces.  Optional bias (1, O, 1, 1) is
-    fused into the GEMM epilogue."""
+    The im2col buffer keeps the reference layout (N, C, kh, kw, oh, ow) in its first C*k*k rows and
+    pads the contraction to a multiple of 4; per image the packed weight (O, Kp) multiplies it
+    into a contiguous NCHW output (the reference returns an NHWC buffer viewed as NCHW: same
+    values).  The bias (1, O, 1, 1) is column K of the packed weight against a row of ones, so
+    `+ bias` and its gradient ride inside the GEMMs; nothing downstream sees a strided tensor."""
 
     def __init__(self, x, kernel, bias=None, padding=0, stride=1):
         self.padding, self.stride = int(padding), int(stride)
@@ -532,23 +532,39 @@ class conv2d(_Operator):
     def forward_(self, x, kernel, bias=None):
         N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
         if self.xp is np:
-            self._col = self._im2col_np(x.data, k)
-            a = self._col.transpose(0, 4, 5, 1, 2, 3).reshape(N * oh * ow, -1)
+            self._col_np = self._im2col_np(x.data, k)
+            a = self._col_np.transpose(0, 4, 5, 1, 2, 3).reshape(N * oh * ow, -1)
             out = a @ kernel.data.reshape(O, -1).T
             if bias is not None:
                 out = out + bias.data.reshape(1, O)
             return out.reshape(N, oh, ow, O).transpose(0, 3, 1, 2)
         hp, L = _hip(), _L()
         xd = _contig(x.data)
-        col = hp.empty((N, C, k, k, oh, ow), np.float32)
-        L.call("pdn_im2col2d_f32", xd._ptr, N, C, H, W, k, self.stride, self.padding, col._ptr, hp.stream())
-        self._col = col
-        K = C * k * k
-        out = hp.empty((N, oh, ow, O), np.float32)
-        w2 = _contig(kernel.data).reshape(O, K)
-        hp.gemm(col.reshape(N, K, oh * ow).transpose(0, 2, 1), w2.T, out.reshape(N, oh * ow, O),
-                bias=_contig(bias.data).reshape(-1) if bias is not None else None)
-        return out.transpose(0, 3, 1, 2)
+        K, M = C * k * k, oh * ow
+        # contraction padded to a multiple of 4 (16-byte GEMM path); with a bias, row K of the
+        # im2col buffer is ones and column K of the packed weight is the bias
+        Kp = (K + (1 if bias is not None else 0) + 3) // 4 * 4
+        colp = hp.empty((N, Kp, M), np.float32)
+        L.call("pdn_im2col2d_f32", xd._ptr, N, C, H, W, k, self.stride, self.padding, colp._ptr, Kp,
+               1 if bias is not None else 0, hp.stream())
+        self._colp, self._Kp = colp, Kp
+        wp = hp.zeros((O, Kp), np.float32)
+        wp[:, :K] = kernel.data.reshape(O, K)
+        if bias is not None:
+            wp[:, K] = bias.data.reshape(O)
+        self._wp = wp
+        out = hp.empty((N, O, oh, ow), np.float32)                 # NCHW, contiguous
+        hp.gemm(wp, colp, out.reshape(N, O, M))                    # per image (O,Kp) @ (Kp,M)
+        return out
+
+    @property
+    def _col(self):
+        """The im2col buffer in the reference layout (N, C, kh, kw, oh, ow) (a view on the HIP path)."""
+        if hasattr(self, "_colp"):
+            x, kernel = self.last[0], self.last[1]
+            N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+            return self._colp[:, :C * k * k].reshape(N, C, k, k, oh, ow)
+        return self._col_np
 
     def backward_all(self, g):
         x, kernel = self.last[0], self.last[1]
@@ -558,7 +574,7 @@ class conv2d(_Operator):
         grads = [None] * len(self.last)
         if self.xp is np:
             g2 = g.transpose(0, 2, 3, 1).reshape(N * M, O)
-            a = self._col.transpose(0, 4, 5, 1, 2, 3).reshape(N * M, K)
+            a = self._col_np.transpose(0, 4, 5, 1, 2, 3).reshape(N * M, K)
             if kernel.requires_grad:
                 grads[1] = (g2.T @ a).reshape(kernel.shape)
             if bias is not None and bias.requires_grad:
@@ -573,20 +589,24 @@ class conv2d(_Operator):
                 grads[0] = dxp[:, :, p:p + H, p:p + W] if p else dxp
             return grads
         hp, L = _hip(), _L()
-        g2 = _contig(g.transpose(0, 2, 3, 1)).reshape(N, M, O)          # NHWC rows
-        w2 = _contig(kernel.data).reshape(O, K)
-        colT = self._col.reshape(N, K, M)
-        if kernel.requires_grad:
-            part = hp.empty((N, O, K), np.float32)
-            hp.gemm(g2.transpose(0, 2, 1), colT.transpose(0, 2, 1), part)     # per image g^T col
-            grads[1] = part.sum(0).reshape(kernel.shape)
-        if bias is not None and bias.requires_grad:
-            grads[2] = g2.reshape(N * M, O).sum(0).reshape(bias.shape)
+        Kp = self._Kp
+        g3 = _contig(g).reshape(N, O, M)                                       # NCHW rows
+        need_db = bias is not None and bias.requires_grad
+        if kernel.requires_grad or need_db:
+            # per image g (O,M) @ col^T (M,Kp); column K of the sum is the bias gradient
+            part = hp.empty((N, O, Kp), np.float32)
+            hp.gemm(g3, self._colp.transpose(0, 2, 1), part)
+            dwp = part.sum(0)
+            if kernel.requires_grad:
+                grads[1] = dwp[:, :K].reshape(kernel.shape)
+            if need_db:
+                grads[2] = dwp[:, K].reshape(bias.shape)
         if x.requires_grad:
-            dcol = hp.empty((N, K, M), np.float32)
-            hp.gemm(w2.T, g2.transpose(0, 2, 1), dcol)                        # (K,O) (O,M) per image
+            dcol = hp.empty((N, Kp, M), np.float32)
+            hp.gemm(self._wp.T, g3, dcol)                                      # (Kp,O) @ (O,M) per image
             dx = hp.empty((N, C, H, W), np.float32)
-            L.call("pdn_col2im2d_f32", dcol._ptr, N, C, H, W, k, self.stride, self.padding, dx._ptr, hp.stream())
+            L.call("pdn_col2im2d_f32", dcol._ptr, N, C, H, W, k, self.stride, self.padding, dx._ptr, Kp,
+                   hp.stream())
             grads[0] = dx
         return grads
 

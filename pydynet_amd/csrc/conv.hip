@@ -10,33 +10,39 @@
 #include "common.h"
 
 // col[n][c][i][j][oy][ox] = x[n][c][oy*s + i - p][ox*s + j - p]   (0 outside)
-__global__ void im2col2d_kernel(const float* __restrict__ x, float* __restrict__ col, int N, int C,
-                                int H, int W, int k, int s, int p, int oh, int ow) {
-  const int64_t total = (int64_t)N * C * k * k * oh * ow;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = idx;
-    const int ox = (int)(t % ow); t /= ow;
-    const int oy = (int)(t % oh); t /= oh;
-    const int j = (int)(t % k); t /= k;
-    const int i = (int)(t % k); t /= k;      // t = n*C + c
+// One workgroup row per (image, im2col row): the row -> (c, i, j) split is scalar, a thread only
+// divides its pixel index.  Rows >= C*k*k pad the contraction to `rows` (a multiple of 4 for the
+// GEMM's 16-byte path); row C*k*k holds ones when `ones_row` (it pairs with a bias column in the
+// packed weight, so the bias and its gradient ride inside the GEMMs).
+__global__ void im2col2d_kernel(const float* __restrict__ x, float* __restrict__ col, int C, int H,
+                                int W, int k, int s, int p, int oh, int ow, int rows, int ones_row) {
+  const int M = oh * ow, r = blockIdx.y, n = blockIdx.z, ckk = C * k * k;
+  float* dst = col + ((int64_t)n * rows + r) * M;
+  if (r >= ckk) {
+    const float fill = (ones_row && r == ckk) ? 1.f : 0.f;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) dst[m] = fill;
+    return;
+  }
+  const int c = r / (k * k), i = (r / k) % k, j = r % k;
+  const float* src = x + ((int64_t)n * C + c) * H * W;
+  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+    const int oy = m / ow, ox = m - oy * ow;
     const int y = oy * s + i - p, xx = ox * s + j - p;
-    float v = 0.f;
-    if (y >= 0 && y < H && xx >= 0 && xx < W) v = x[(t * H + y) * W + xx];
-    col[idx] = v;
+    dst[m] = (y >= 0 && y < H && xx >= 0 && xx < W) ? src[y * W + xx] : 0.f;
   }
 }
 
 // dx[n][c][y][x] = sum over (i,j) with (y+p-i) % s == 0, (x+p-j) % s == 0 of dcol[n][c][i][j][oy][ox]
 __global__ void col2im2d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int N, int C,
-                                int H, int W, int k, int s, int p, int oh, int ow) {
+                                int H, int W, int k, int s, int p, int oh, int ow, int rows) {
   const int64_t total = (int64_t)N * C * H * W;
   for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
     int64_t t = idx;
     const int xx = (int)(t % W); t /= W;
     const int y = (int)(t % H); t /= H;      // t = n*C + c
-    const float* base = dcol + t * (int64_t)k * k * oh * ow;
+    const int n = (int)(t / C), c = (int)(t - (int64_t)n * C);
+    const float* base = dcol + ((int64_t)n * rows + (int64_t)c * k * k) * oh * ow;
     float acc = 0.f;
     for (int i = 0; i < k; ++i) {
       const int ny = y + p - i;
@@ -124,24 +130,29 @@ static inline int grid1d(int64_t n) {
   const int oh = (H + 2 * pad - k) / stride + 1, ow = (W + 2 * pad - k) / stride + 1;         \
   PDN_CHECK_ARG(oh > 0 && ow > 0, name ": kernel larger than padded input");
 
+// col: (N, col_rows, oh*ow) with col_rows >= C*k*k (+1 when ones_row); see im2col2d_kernel.
 extern "C" int pdn_im2col2d_f32(const float* x, int N, int C, int H, int W, int k, int stride,
-                                int pad, float* col, void* stream) {
+                                int pad, float* col, int col_rows, int ones_row, void* stream) {
   CONV_ARGS_OK("pdn_im2col2d_f32")
   if (N == 0) return PDN_OK;
   PDN_CHECK_ARG(x && col, "pdn_im2col2d_f32: null operand");
-  hipLaunchKernelGGL(im2col2d_kernel, dim3(grid1d((int64_t)N * C * k * k * oh * ow)), dim3(256), 0,
-                     (hipStream_t)stream, x, col, N, C, H, W, k, stride, pad, oh, ow);
+  PDN_CHECK_ARG(col_rows >= C * k * k + (ones_row ? 1 : 0) && col_rows <= 65535 && N <= 65535,
+                "pdn_im2col2d_f32: col_rows=%d too small for C*k*k=%d (or grid limit)", col_rows, C * k * k);
+  const int M = oh * ow;
+  hipLaunchKernelGGL(im2col2d_kernel, dim3((M + 255) / 256 < 8 ? (M + 255) / 256 : 8, col_rows, N), dim3(256), 0,
+                     (hipStream_t)stream, x, col, C, H, W, k, stride, pad, oh, ow, col_rows, ones_row);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
 
 extern "C" int pdn_col2im2d_f32(const float* dcol, int N, int C, int H, int W, int k, int stride,
-                                int pad, float* dx, void* stream) {
+                                int pad, float* dx, int col_rows, void* stream) {
   CONV_ARGS_OK("pdn_col2im2d_f32")
   if (N == 0) return PDN_OK;
   PDN_CHECK_ARG(dcol && dx, "pdn_col2im2d_f32: null operand");
+  PDN_CHECK_ARG(col_rows >= C * k * k, "pdn_col2im2d_f32: col_rows=%d < C*k*k=%d", col_rows, C * k * k);
   hipLaunchKernelGGL(col2im2d_kernel, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0,
-                     (hipStream_t)stream, dcol, dx, N, C, H, W, k, stride, pad, oh, ow);
+                     (hipStream_t)stream, dcol, dx, N, C, H, W, k, stride, pad, oh, ow, col_rows);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -366,17 +366,22 @@ class EmulatedLib:
         s0, s1, s2, s3 = xp.strides
         return oh, ow, (N, C, k, k, oh, ow), (s0, s1, s2, s3, s2 * s, s3 * s)
 
-    def pdn_im2col2d_f32(self, x, N, C, H, W, k, s, p, col, stream):
+    def pdn_im2col2d_f32(self, x, N, C, H, W, k, s, p, col, rows, ones_row, stream):
         xp = np.pad(flat(x, N * C * H * W).reshape(N, C, H, W), [(0, 0), (0, 0), (p, p), (p, p)])
         oh, ow, shape, strides = self._windows(xp, k, s)
-        flat(col, int(np.prod(shape))).reshape(shape)[...] = np.lib.stride_tricks.as_strided(xp, shape, strides)
+        ckk, M = C * k * k, oh * ow
+        dst = flat(col, N * rows * M).reshape(N, rows, M)
+        dst[:, :ckk] = np.lib.stride_tricks.as_strided(xp, shape, strides).reshape(N, ckk, M)
+        dst[:, ckk:] = 0.0
+        if ones_row:
+            dst[:, ckk] = 1.0
         return 0
 
-    def pdn_col2im2d_f32(self, dcol, N, C, H, W, k, s, p, dx, stream):
+    def pdn_col2im2d_f32(self, dcol, N, C, H, W, k, s, p, dx, rows, stream):
         dxp = np.zeros((N, C, H + 2 * p, W + 2 * p), np.float32)
         oh, ow, shape, strides = self._windows(dxp, k, s)
-        np.add.at(np.lib.stride_tricks.as_strided(dxp, shape, strides), (...,),
-                  flat(dcol, int(np.prod(shape))).reshape(shape))
+        src = flat(dcol, N * rows * oh * ow).reshape(N, rows, oh * ow)[:, :C * k * k]
+        np.add.at(np.lib.stride_tricks.as_strided(dxp, shape, strides), (...,), src.reshape(shape))
         flat(dx, N * C * H * W).reshape(N, C, H, W)[...] = dxp[:, :, p:p + H, p:p + W]
         return 0
 
