@@ -10,25 +10,30 @@
 #include "common.h"
 
 // col[n][c][i][j][oy][ox] = x[n][c][oy*s + i - p][ox*s + j - p]   (0 outside)
-// One workgroup row per (image, im2col row): the row -> (c, i, j) split is scalar, a thread only
-// divides its pixel index.  Rows >= C*k*k pad the contraction to `rows` (a multiple of 4 for the
-// GEMM's 16-byte path); row C*k*k holds ones when `ones_row` (it pairs with a bias column in the
-// packed weight, so the bias and its gradient ride inside the GEMMs).
+// One workgroup per (image, channel): it writes the k*k rows of that channel (consecutive threads ->
+// consecutive output pixels, so both the shifted-window reads and the writes are coalesced; the
+// 4 KB input plane is served by L1).  Rows >= C*k*k pad the contraction to `rows` (a multiple of 4
+// for the GEMM's 16-byte path) and are written by the extra workgroup c == C; row C*k*k holds ones
+// when `ones_row` (it pairs with a bias column in the packed weight, so the bias and its gradient
+// ride inside the GEMMs).
 __global__ void im2col2d_kernel(const float* __restrict__ x, float* __restrict__ col, int C, int H,
                                 int W, int k, int s, int p, int oh, int ow, int rows, int ones_row) {
-  const int M = oh * ow, r = blockIdx.y, n = blockIdx.z, ckk = C * k * k;
-  float* dst = col + ((int64_t)n * rows + r) * M;
-  if (r >= ckk) {
-    const float fill = (ones_row && r == ckk) ? 1.f : 0.f;
-    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) dst[m] = fill;
+  const int M = oh * ow, c = blockIdx.x, n = blockIdx.y, kk = k * k, ckk = C * kk;
+  if (c == C) {                                   // padding rows
+    float* dst = col + ((int64_t)n * rows + ckk) * M;
+    const int total = (rows - ckk) * M;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) dst[e] = (ones_row && e < M) ? 1.f : 0.f;
     return;
   }
-  const int c = r / (k * k), i = (r / k) % k, j = r % k;
   const float* src = x + ((int64_t)n * C + c) * H * W;
-  for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < M; m += gridDim.x * blockDim.x) {
+  float* dst = col + ((int64_t)n * rows + (int64_t)c * kk) * M;
+  const int total = kk * M;
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    const int r = e / M, m = e - r * M;
+    const int i = r / k, j = r - i * k;
     const int oy = m / ow, ox = m - oy * ow;
     const int y = oy * s + i - p, xx = ox * s + j - p;
-    dst[m] = (y >= 0 && y < H && xx >= 0 && xx < W) ? src[y * W + xx] : 0.f;
+    dst[e] = (y >= 0 && y < H && xx >= 0 && xx < W) ? src[y * W + xx] : 0.f;
   }
 }
 
@@ -89,32 +94,42 @@ __global__ void pool2d_fwd_kernel(const float* __restrict__ x, float* __restrict
 __global__ void pool2d_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                   const float* __restrict__ dy, float* __restrict__ dx, int NC, int H,
                                   int W, int k, int s, int p, int oh, int ow, int mode) {
-  const int64_t total = (int64_t)NC * H * W;
-  for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    int64_t t = idx;
-    const int xx = (int)(t % W); t /= W;
-    const int yy = (int)(t % H); t /= H;
-    const float v = x[idx];
-    const float* yp = y + t * (int64_t)oh * ow;
-    const float* gp = dy + t * (int64_t)oh * ow;
-    float acc = 0.f;
-    for (int i = 0; i < k; ++i) {
-      const int ny = yy + p - i;
-      if (ny < 0 || ny % s) continue;
-      const int oy = ny / s;
-      if (oy >= oh) continue;
-      for (int j = 0; j < k; ++j) {
-        const int nx = xx + p - j;
-        if (nx < 0 || nx % s) continue;
-        const int ox = nx / s;
-        if (ox >= ow) continue;
-        const float g = gp[oy * ow + ox];
-        if (mode == 0) acc += (yp[oy * ow + ox] == v) ? g : 0.f;
-        else acc += g / (float)(k * k);
+  // one workgroup per (n, c) plane: 32-bit index math only
+  const int HW = H * W, OM = oh * ow;
+  for (int64_t plane = blockIdx.x; plane < NC; plane += gridDim.x) {
+    const float* xp = x + plane * HW;
+    const float* yp = y + plane * OM;
+    const float* gp = dy + plane * OM;
+    float* dp = dx + plane * HW;
+    for (int e = threadIdx.x; e < HW; e += blockDim.x) {
+      const int yy = e / W, xx = e - yy * W;
+      const float v = xp[e];
+      float acc = 0.f;
+      if (k == s) {                                // non-overlapping windows: exactly one covers a pixel
+        const int oy = (yy + p) / k, ox = (xx + p) / k;
+        if (oy < oh && ox < ow) {
+          const float g = gp[oy * ow + ox];
+          acc = mode == 0 ? ((yp[oy * ow + ox] == v) ? g : 0.f) : g / (float)(k * k);
+        }
+      } else {
+        for (int i = 0; i < k; ++i) {
+          const int ny = yy + p - i;
+          if (ny < 0 || ny % s) continue;
+          const int oy = ny / s;
+          if (oy >= oh) continue;
+          for (int j = 0; j < k; ++j) {
+            const int nx = xx + p - j;
+            if (nx < 0 || nx % s) continue;
+            const int ox = nx / s;
+            if (ox >= ow) continue;
+            const float g = gp[oy * ow + ox];
+            if (mode == 0) acc += (yp[oy * ow + ox] == v) ? g : 0.f;
+            else acc += g / (float)(k * k);
+          }
+        }
       }
+      dp[e] = acc;
     }
-    dx[idx] = acc;
   }
 }
 
@@ -138,8 +153,8 @@ extern "C" int pdn_im2col2d_f32(const float* x, int N, int C, int H, int W, int 
   PDN_CHECK_ARG(x && col, "pdn_im2col2d_f32: null operand");
   PDN_CHECK_ARG(col_rows >= C * k * k + (ones_row ? 1 : 0) && col_rows <= 65535 && N <= 65535,
                 "pdn_im2col2d_f32: col_rows=%d too small for C*k*k=%d (or grid limit)", col_rows, C * k * k);
-  const int M = oh * ow;
-  hipLaunchKernelGGL(im2col2d_kernel, dim3((M + 255) / 256 < 8 ? (M + 255) / 256 : 8, col_rows, N), dim3(256), 0,
+  PDN_CHECK_ARG((int64_t)k * k * oh * ow < (1ll << 31), "pdn_im2col2d_f32: plane too large");
+  hipLaunchKernelGGL(im2col2d_kernel, dim3(C + (col_rows > C * k * k ? 1 : 0), N), dim3(256), 0,
                      (hipStream_t)stream, x, col, C, H, W, k, stride, pad, oh, ow, col_rows, ones_row);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
@@ -174,7 +189,9 @@ extern "C" int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* d
   CONV_ARGS_OK("pdn_pool2d_bwd_f32")
   if (N == 0) return PDN_OK;
   PDN_CHECK_ARG(x && y && dy && dx && (mode == 0 || mode == 1), "pdn_pool2d_bwd_f32: bad arguments");
-  hipLaunchKernelGGL(pool2d_bwd_kernel, dim3(grid1d((int64_t)N * C * H * W)), dim3(256), 0,
+  PDN_CHECK_ARG((int64_t)H * W < (1ll << 31), "pdn_pool2d_bwd_f32: plane too large");
+  const int64_t planes = (int64_t)N * C;
+  hipLaunchKernelGGL(pool2d_bwd_kernel, dim3((unsigned)(planes < (1 << 20) ? planes : (1 << 20))), dim3(256), 0,
                      (hipStream_t)stream, x, y, dy, dx, N * C, H, W, k, stride, pad, oh, ow, mode);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
