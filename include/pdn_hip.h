@@ -201,6 +201,21 @@ int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, i
 int64_t pdn_cross_entropy_colsum_workspace_bytes(int64_t rows, int V);
 int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* scalar_dev, void* stream);
 
+/* ---- GRU cell (nn/modules/rnn.py:537-544): the gate algebra between the four GEMMs.
+ *   [z, r] = sigmoid(g1) with g1 = x Wx1 + h Wh1 + b1 (B, 2H);  rh = r * h
+ *   n = tanh(g2) with g2 = x Wx2 + rh Wh2 + b2 (B, H);          h' = (1 - z) h + z n
+ * backward: out_bwd gives dg2, the z half of dg1 and dh = dh' (1 - z); after drh = dg2 Wh2^T,
+ * gates_bwd fills the r half of dg1 and adds drh * r to dh.  sigmoid / tanh are the reference's
+ * piecewise forms (core/tensor.py:996-1019). */
+int pdn_gru_gates_fwd_f32(const float* g1, const float* h, float* z, float* r, float* rh, int64_t B,
+                          int H, void* stream);
+int pdn_gru_out_fwd_f32(const float* g2, const float* z, const float* h, float* n, float* hnew,
+                        int64_t B, int H, void* stream);
+int pdn_gru_out_bwd_f32(const float* dhnew, const float* z, const float* n, const float* h, float* dg2,
+                        float* dg1, float* dh, int64_t B, int H, void* stream);
+int pdn_gru_gates_bwd_f32(const float* drh, const float* r, const float* h, float* dg1, float* dh,
+                          int64_t B, int H, void* stream);
+
 /* ---- Adam.step for all parameters in one launch (optim/optimizer.py:185-196).
  * chunk_table_dev: device int64[nchunks][5] = {p, g, m, v addresses, n elements}.
  * step = lr*sqrt(1-b2^t)/(1-b1^t) computed on the host as the reference does. */

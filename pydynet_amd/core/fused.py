@@ -663,3 +663,70 @@ class pool2d(_Operator):
         L.call("pdn_pool2d_bwd_f32", self._x._ptr, y._ptr, g._ptr, N, C, H, W,
                self.k, self.stride, self.padding, 0 if self.mode == "max" else 1, dx._ptr, hp.stream())
         return [dx]
+
+
+class gru_cell(_Operator):
+    """One GRU step (nn/modules/rnn.py:537-544) as a single tape node on the HIP device:
+        [z, r] = sigmoid(x Wx1 + h Wh1 + b1);  n = tanh(x Wx2 + (r*h) Wh2 + b2);  h' = (1-z) h + z n
+    4 GEMMs + 2 gate kernels forward, 8 GEMMs + 2 gate kernels backward (the generic composition is
+    ~20 nodes / ~45 launches per step).  Inputs: x (B, in), h (B, H), Wx1, Wh1, Wx2, Wh2[, b1, b2]."""
+
+    def __init__(self, x, h, wx1, wh1, wx2, wh2, b1=None, b2=None):
+        self.has_bias = b1 is not None
+        super().__init__(*((x, h, wx1, wh1, wx2, wh2) + ((b1, b2) if self.has_bias else ())))
+
+    def forward_(self, x, h, wx1, wh1, wx2, wh2, b1=None, b2=None):
+        if self.xp is np:
+            raise NotImplementedError("gru_cell is the HIP fused path; the NumPy device composes generic ops")
+        hp, L = _hip(), _L()
+        B, H = h.shape
+        xd, hd = _contig(x.data), _contig(h.data)
+        g1 = hp.empty((B, 2 * H), np.float32)
+        hp.gemm(xd, wx1.data, g1, bias=b1.data.reshape(-1) if b1 is not None else None)
+        hp.gemm(hd, wh1.data, g1, beta=1.0)
+        z, r, rh = (hp.empty((B, H), np.float32) for _ in range(3))
+        L.call("pdn_gru_gates_fwd_f32", g1._ptr, hd._ptr, z._ptr, r._ptr, rh._ptr, B, H, hp.stream())
+        g2 = hp.empty((B, H), np.float32)
+        hp.gemm(xd, wx2.data, g2, bias=b2.data.reshape(-1) if b2 is not None else None)
+        hp.gemm(rh, wh2.data, g2, beta=1.0)
+        n, hn = hp.empty((B, H), np.float32), hp.empty((B, H), np.float32)
+        L.call("pdn_gru_out_fwd_f32", g2._ptr, z._ptr, hd._ptr, n._ptr, hn._ptr, B, H, hp.stream())
+        self._saved = (xd, hd, z, r, rh, n)
+        return hn
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, h, wx1, wh1, wx2, wh2 = self.last[:6]
+        b1, b2 = (self.last[6], self.last[7]) if self.has_bias else (None, None)
+        xd, hd, z, r, rh, n = self._saved
+        B, H = hd.shape
+        g = _contig(g)
+        dg2, dg1, dh = hp.empty((B, H), np.float32), hp.empty((B, 2 * H), np.float32), hp.empty((B, H), np.float32)
+        L.call("pdn_gru_out_bwd_f32", g._ptr, z._ptr, n._ptr, hd._ptr, dg2._ptr, dg1._ptr, dh._ptr, B, H, hp.stream())
+        drh = hp.empty((B, H), np.float32)
+        hp.gemm(dg2, wh2.data.T, drh)
+        L.call("pdn_gru_gates_bwd_f32", drh._ptr, r._ptr, hd._ptr, dg1._ptr, dh._ptr, B, H, hp.stream())
+        grads = [None] * len(self.last)
+        if h.requires_grad:
+            hp.gemm(dg1, wh1.data.T, dh, beta=1.0)
+            grads[1] = dh
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            hp.gemm(dg2, wx2.data.T, dx)
+            hp.gemm(dg1, wx1.data.T, dx, beta=1.0)
+            grads[0] = dx
+        for idx, (a, d, w) in enumerate(((xd, dg1, wx1), (hd, dg1, wh1), (xd, dg2, wx2), (rh, dg2, wh2)), start=2):
+            if not w.requires_grad:
+                continue
+            if _is_leaf_f32(w):
+                hp.gemm(a.T, d, w.grad, beta=1.0)
+            else:
+                dw = hp.empty(w.shape, np.float32)
+                hp.gemm(a.T, d, dw)
+                grads[idx] = dw
+        if self.has_bias:
+            if b1.requires_grad:
+                grads[6] = dg1.sum(0).reshape(b1.shape)
+            if b2.requires_grad:
+                grads[7] = dg2.sum(0).reshape(b2.shape)
+        return grads

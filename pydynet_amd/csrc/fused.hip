@@ -1054,3 +1054,106 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_reg_kernel(
     }
   }
 }
+
+// ======================================================================================
+// GRU cell gate algebra (nn/modules/rnn.py:537-544):
+//   [z, r] = sigmoid(x Wx1 + h Wh1 + b1);  n = tanh(x Wx2 + (r*h) Wh2 + b2);  h' = (1-z) h + z n
+// The four matrix products run on the GEMM kernel; these kernels are everything in between, one
+// pass each (the reference spends ~20 tape nodes per step on them).  sigmoid / tanh use the
+// reference's overflow-safe piecewise forms (core/tensor.py:999-1003, 1012-1016).
+// ======================================================================================
+__device__ __forceinline__ float ref_sigmoid(float x) {
+  return x > 0.f ? 1.f / (1.f + expf(-x)) : 1.f - 1.f / (1.f + expf(x));
+}
+__device__ __forceinline__ float ref_tanh(float x) {
+  return x > 0.f ? 2.f / (1.f + expf(-2.f * x)) - 1.f : 1.f - 2.f / (1.f + expf(2.f * x));
+}
+
+__global__ void gru_gates_fwd_kernel(const float* __restrict__ g1, const float* __restrict__ h,
+                                     float* __restrict__ z, float* __restrict__ r,
+                                     float* __restrict__ rh, int64_t n, int H) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / H;
+    const int j = (int)(i - b * H);
+    const float zz = ref_sigmoid(g1[b * 2 * H + j]), rr = ref_sigmoid(g1[b * 2 * H + H + j]);
+    z[i] = zz; r[i] = rr; rh[i] = rr * h[i];
+  }
+}
+
+__global__ void gru_out_fwd_kernel(const float* __restrict__ g2, const float* __restrict__ z,
+                                   const float* __restrict__ h, float* __restrict__ nn,
+                                   float* __restrict__ hnew, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float t = ref_tanh(g2[i]), zz = z[i];
+    nn[i] = t;
+    hnew[i] = (1.f - zz) * h[i] + zz * t;
+  }
+}
+
+// dG2 = dh' z (1 - n^2);  dG1[:, :H] = dh' (n - h) z (1 - z);  dh = dh' (1 - z)
+__global__ void gru_out_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ z,
+                                   const float* __restrict__ nn, const float* __restrict__ h,
+                                   float* __restrict__ dg2, float* __restrict__ dg1,
+                                   float* __restrict__ dh, int64_t n, int H) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / H;
+    const int j = (int)(i - b * H);
+    const float g = dhn[i], zz = z[i], t = nn[i];
+    dg2[i] = (1.f - t * t) * (g * zz);
+    dg1[b * 2 * H + j] = zz * (1.f - zz) * (g * (t - h[i]));
+    dh[i] = g * (1.f - zz);
+  }
+}
+
+// drh = dG2 Wh2^T arrives from the GEMM:  dG1[:, H:] = drh h r (1 - r);  dh += drh r
+__global__ void gru_gates_bwd_kernel(const float* __restrict__ drh, const float* __restrict__ r,
+                                     const float* __restrict__ h, float* __restrict__ dg1,
+                                     float* __restrict__ dh, int64_t n, int H) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / H;
+    const int j = (int)(i - b * H);
+    const float d = drh[i], rr = r[i];
+    dg1[b * 2 * H + H + j] = rr * (1.f - rr) * (d * h[i]);
+    dh[i] += d * rr;
+  }
+}
+
+extern "C" int pdn_gru_gates_fwd_f32(const float* g1, const float* h, float* z, float* r, float* rh,
+                                     int64_t B, int H, void* stream) {
+  if (B == 0 || H == 0) return PDN_OK;
+  PDN_CHECK_ARG(g1 && h && z && r && rh && B > 0 && H > 0, "pdn_gru_gates_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(gru_gates_fwd_kernel, dim3(stream_grid(B * H)), dim3(256), 0, (hipStream_t)stream, g1, h,
+                     z, r, rh, B * H, H);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_gru_out_fwd_f32(const float* g2, const float* z, const float* h, float* n,
+                                   float* hnew, int64_t B, int H, void* stream) {
+  if (B == 0 || H == 0) return PDN_OK;
+  PDN_CHECK_ARG(g2 && z && h && n && hnew && B > 0 && H > 0, "pdn_gru_out_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(gru_out_fwd_kernel, dim3(stream_grid(B * H)), dim3(256), 0, (hipStream_t)stream, g2, z, h,
+                     n, hnew, B * H);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_gru_out_bwd_f32(const float* dhnew, const float* z, const float* n, const float* h,
+                                   float* dg2, float* dg1, float* dh, int64_t B, int H, void* stream) {
+  if (B == 0 || H == 0) return PDN_OK;
+  PDN_CHECK_ARG(dhnew && z && n && h && dg2 && dg1 && dh && B > 0 && H > 0, "pdn_gru_out_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(gru_out_bwd_kernel, dim3(stream_grid(B * H)), dim3(256), 0, (hipStream_t)stream, dhnew, z,
+                     n, h, dg2, dg1, dh, B * H, H);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_gru_gates_bwd_f32(const float* drh, const float* r, const float* h, float* dg1,
+                                     float* dh, int64_t B, int H, void* stream) {
+  if (B == 0 || H == 0) return PDN_OK;
+  PDN_CHECK_ARG(drh && r && h && dg1 && dh && B > 0 && H > 0, "pdn_gru_gates_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(gru_gates_bwd_kernel, dim3(stream_grid(B * H)), dim3(256), 0, (hipStream_t)stream, drh, r,
+                     h, dg1, dh, B * H, H);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

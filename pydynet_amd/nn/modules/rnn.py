@@ -6,6 +6,8 @@ The stacking / bidirectional wiring of the sequence modules is the reference's a
 (deeper layers consume the forward outputs of the layer below, rnn.py:660-694)."""
 import math
 
+import numpy as np
+
 from .module import Module
 from .. import init, functional as F
 from ..parameter import Parameter
@@ -92,6 +94,10 @@ class GRUCell(_Cell):
             h = self.init_hidden(x)
         else:
             self._check(x, h)
+        if x.device.is_hip and x.ndim == 2 and h.ndim == 2 and x.dtype == np.float32 == h.dtype:
+            from ...core.fused import gru_cell          # one tape node: 4 GEMMs + 2 gate kernels
+            return gru_cell(x, h, self.Wx1, self.Wh1, self.Wx2, self.Wh2,
+                            *((self.bias1, self.bias2) if self.has_bias else ()))
         lin1 = x @ self.Wx1 + h @ self.Wh1
         if self.has_bias:
             lin1 = lin1 + self.bias1

@@ -341,6 +341,46 @@ class EmulatedLib:
             flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
         return rc
 
+    # -- GRU gate algebra ------------------------------------------------------------------
+    @staticmethod
+    def _sig(x):
+        with np.errstate(over="ignore"):
+            return np.where(x > 0, 1 / (1 + np.exp(-x)), 1 - 1 / (1 + np.exp(x))).astype(np.float32)
+
+    @staticmethod
+    def _tanh(x):
+        with np.errstate(over="ignore"):
+            return np.where(x > 0, 2 / (1 + np.exp(-2 * x)) - 1, 1 - 2 / (1 + np.exp(2 * x))).astype(np.float32)
+
+    def pdn_gru_gates_fwd_f32(self, g1, h, z, r, rh, B, H, stream):
+        G = flat(g1, B * 2 * H).reshape(B, 2 * H)
+        hh = flat(h, B * H).reshape(B, H)
+        zz, rr = self._sig(G[:, :H]), self._sig(G[:, H:])
+        flat(z, B * H).reshape(B, H)[...] = zz
+        flat(r, B * H).reshape(B, H)[...] = rr
+        flat(rh, B * H).reshape(B, H)[...] = rr * hh
+        return 0
+
+    def pdn_gru_out_fwd_f32(self, g2, z, h, n, hnew, B, H, stream):
+        t = self._tanh(flat(g2, B * H))
+        zz, hh = flat(z, B * H), flat(h, B * H)
+        flat(n, B * H)[...] = t
+        flat(hnew, B * H)[...] = (1 - zz) * hh + zz * t
+        return 0
+
+    def pdn_gru_out_bwd_f32(self, dhn, z, n, h, dg2, dg1, dh, B, H, stream):
+        g, zz, t, hh = (np.array(flat(a, B * H).reshape(B, H)) for a in (dhn, z, n, h))
+        flat(dg2, B * H).reshape(B, H)[...] = (1 - t * t) * (g * zz)
+        flat(dg1, B * 2 * H).reshape(B, 2 * H)[:, :H] = zz * (1 - zz) * (g * (t - hh))
+        flat(dh, B * H).reshape(B, H)[...] = g * (1 - zz)
+        return 0
+
+    def pdn_gru_gates_bwd_f32(self, drh, r, h, dg1, dh, B, H, stream):
+        d, rr, hh = (np.array(flat(a, B * H).reshape(B, H)) for a in (drh, r, h))
+        flat(dg1, B * 2 * H).reshape(B, 2 * H)[:, H:] = rr * (1 - rr) * (d * hh)
+        flat(dh, B * H).reshape(B, H)[...] += d * rr
+        return 0
+
     def pdn_scale_by_device_scalar_f32(self, x, n, scalar, stream):
         s = flat(scalar, 1)[0]
         if s != 1.0:

@@ -72,3 +72,30 @@ for name, cls, shape, flops, batches in CASES:
             conv_bytes = 3 * (12 + 80 + 20 + 50 + 12.5) * 1024     # fwd bytes/sample x ~3 for fwd+bwd
             line += f"  conv traffic {conv_bytes*B/dt/1e9:7.1f} GB/s (algorithmic)"
         print(line, flush=True)
+
+# ---- GRU sequence of examples/pydynet/ts_prediction.py: GRU(1 -> 32), T = 40, batch ~1568 -------------
+if not only or only.startswith("gru"):
+    Graph.clear()
+    np.random.seed(0)
+    T_, B_, Hd = 40, 1568, 32
+    gru = nn.GRU(1, Hd, dtype=np.float32).to("cuda")
+    head = nn.Linear(Hd, 1, dtype=np.float32).to("cuda")
+    opt = Adam(list(gru.parameters()) + list(head.parameters()), lr=1e-3)
+    xs = pdn.Tensor(np.random.rand(T_, B_, 1).astype(np.float32), device="cuda")
+    ys = pdn.Tensor(np.random.rand(B_, 1).astype(np.float32), device="cuda")
+
+    def gstep():
+        out, hn = gru(xs)
+        loss = F.mse_loss(head(hn[0]), ys)
+        opt.zero_grad(); loss.backward(); opt.step()
+        return loss
+
+    for _ in range(3):
+        gstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = gstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(f"gru    T={T_} B={B_} H={Hd}  {dt*1e3:8.3f} ms/step  {B_/dt:12.0f} sequences/s  loss {loss.item():.4f}", flush=True)
