@@ -1120,6 +1120,14 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     }
   }
   PDN_CHECK_ARG(best >= 0 || use_stream, "pdn_gemm_f32: no tile configuration");
+  if (!use_stream && best_splits == 1 && !b_colsum && K >= 8192) {
+    // 2-4 very long blocks per CU: the last one of each CU runs without a co-resident partner to
+    // hide its barriers behind; halving the blocks evens that out (measured -3..4 % on the
+    // 32768 x 288 x 32000 and 288 x 32000 x 32768 products, slab pass included)
+    const int BMb = kCfgs[best].waves_m * kCfgs[best].wm * 32, BNb = kCfgs[best].waves_n * kCfgs[best].wn * 32;
+    const int64_t blocks = cdiv64(M, BMb) * cdiv64(N, BNb) * nbatch;
+    if (blocks > 512 && blocks < 1024 && (int64_t)2 * M * N * nbatch <= ws_cap) best_splits = 2;
+  }
   if (use_stream) best = 0;
   else if (const char* e = getenv("PDN_GEMM_CFG")) {            // tuning override: "<cfg>[,<splits>]"
     int c = -1, sp = 0;
