@@ -730,3 +730,87 @@ class gru_cell(_Operator):
             if b2.requires_grad:
                 grads[7] = dg2.sum(0).reshape(b2.shape)
         return grads
+
+
+class qkv_attention(_Operator):
+    """Training-path self-attention front end as ONE tape node (llm/llama/model.py:92-121):
+    the three bias-free projections (a single batched GEMM when the weights are equally spaced in
+    memory, as `Attention.move` packs them), RoPE on q and k in place (one launch over both), and
+    the fused causal attention.  Backward: attention backward into one (3, T, D) buffer, inverse
+    rotation in place, the three weight gradients as ONE batched wave-streaming GEMM (when the
+    leaf gradients are equally spaced, e.g. in the flat gradient buffer) and dx = sum_i d_i W_i^T
+    accumulated in the GEMM epilogues.  x: (B, L, D); returns the context (B, L, H, hd)."""
+
+    folds_existing = True
+    enabled = True          # class switch: False sends Attention through the separate nodes (tests, A/B)
+
+    def __init__(self, x, wq, wk, wv, cos, sin, n_heads):
+        self._cos, self._sin, self.H = cos, sin, int(n_heads)
+        super().__init__(x, wq, wk, wv)
+
+    @staticmethod
+    def applicable(x, L, hd):
+        return (qkv_attention.enabled and attention.use_flash and x.device.is_hip and x.dtype == np.float32 and x.ndim == 3
+                and hd == 48 and L % 32 == 0 and L <= 256)
+
+    def forward_(self, x, wq, wk, wv):
+        hp, L = _hip(), _L()
+        B, Lq, D = x.shape
+        H, hd, T = self.H, D // self.H, B * Lq
+        x2 = _contig(x.data).reshape(T, D)
+        qkv = hp.empty((3, T, D), np.float32)
+        ws = [_contig(w.data) for w in (wq, wk, wv)]
+        stack = hp.stacked_view(ws)
+        if stack is not None:
+            hp.gemm(x2, stack, qkv)
+        else:
+            for i in range(3):
+                hp.gemm(x2, ws[i], qkv[i])
+        cos, sin = _contig(self._cos.data), _contig(self._sin.data)
+        L.call("pdn_rope_f32", qkv._ptr, cos._ptr, sin._ptr, qkv._ptr, 2 * T, Lq, H, hd, 0, hp.stream())
+        out = hp.empty((B, Lq, H, hd), np.float32)
+        lse = hp.empty((B, H, Lq), np.float32)
+        L.call("pdn_attention_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr, B, H, Lq,
+               hd, D, Lq * D, 1, hp.stream())
+        self._saved = (x2, qkv, lse, cos, sin)
+        return out
+
+    def backward_all(self, do):
+        hp, L = _hip(), _L()
+        x, wq, wk, wv = self.last
+        B, Lq, D = x.shape
+        H, hd, T = self.H, D // self.H, B * Lq
+        x2, qkv, lse, cos, sin = self._saved
+        do = _contig(do)
+        dqkv = hp.empty((3, T, D), np.float32)
+        ws_, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
+        L.call("pdn_attention_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
+               lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, hd, D, Lq * D, 1, ws_, wsb,
+               hp.stream())
+        L.call("pdn_rope_f32", dqkv._ptr, cos._ptr, sin._ptr, dqkv._ptr, 2 * T, Lq, H, hd, 1, hp.stream())
+        grads = [None] * 4
+        weights = (wq, wk, wv)
+        gstack = None
+        if all(w.requires_grad and _is_leaf_f32(w) for w in weights):
+            gstack = hp.stacked_view([w.grad for w in weights])
+        if gstack is not None:
+            hp.gemm(x2.T, dqkv, gstack, beta=1.0)                 # three x^T @ d_i in one launch
+        else:
+            for i, w in enumerate(weights):
+                if not w.requires_grad:
+                    continue
+                if _is_leaf_f32(w):
+                    hp.gemm(x2.T, dqkv[i], w.grad, beta=1.0)
+                else:
+                    dw = hp.empty(w.shape, np.float32)
+                    hp.gemm(x2.T, dqkv[i], dw)
+                    grads[1 + i] = dw
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            dx2 = dx.reshape(T, D)
+            ex = _foldable(self, 0, x)
+            hp.gemm(dqkv[0], wq.data.T, dx2, residual=ex.reshape(T, D) if ex is not None else None)
+            hp.gemm(dqkv[1], wk.data.T, dx2, beta=1.0)
+            hp.gemm(dqkv[2], wv.data.T, dx2, beta=1.0)
+            grads[0] = dx
+        return grads

@@ -523,6 +523,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_tn_stream_kernel(GemmParams p
   }
   const int split = L / tiles, tile = L - split * tiles;
   const int tile_m = tile % p.tiles_m, tile_n = tile / p.tiles_m;
+  const int batch = blockIdx.y, bb1 = batch / p.nb2, bb2 = batch - bb1 * p.nb2;
+  p.A += bb1 * p.a_bs1 + bb2 * p.a_bs2;
+  p.B += bb1 * p.b_bs1 + bb2 * p.b_bs2;
+  p.C += bb1 * p.c_bs1 + bb2 * p.c_bs2;
+  if (p.residual) p.residual += bb1 * p.c_bs1 + bb2 * p.c_bs2;
+  p.ws += (int64_t)batch * p.splits * p.M * p.N;
   const int m0 = tile_m * (TM * 32), n0 = tile_n * (TN * 32);
   const int kw = p.k_per_split / NW;                       // multiple of 8 (host)
   const int k0 = min(p.K, split * p.k_per_split + wave * kw);
@@ -664,6 +670,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_tn_stream_lds_kernel(GemmPara
   }
   const int split = L / tiles, tile = L - split * tiles;
   const int tile_m = tile % p.tiles_m, tile_n = tile / p.tiles_m;
+  const int batch = blockIdx.y, bb1 = batch / p.nb2, bb2 = batch - bb1 * p.nb2;
+  p.A += bb1 * p.a_bs1 + bb2 * p.a_bs2;
+  p.B += bb1 * p.b_bs1 + bb2 * p.b_bs2;
+  p.C += bb1 * p.c_bs1 + bb2 * p.c_bs2;
+  if (p.residual) p.residual += bb1 * p.c_bs1 + bb2 * p.c_bs2;
+  p.ws += (int64_t)batch * p.splits * p.M * p.N;
   const int m0 = tile_m * AW, n0 = tile_n * BW;
   const int kw = p.k_per_split / NW;
   const int k0 = min(p.K, split * p.k_per_split + wave * kw);
@@ -804,6 +816,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_tn_stream_dma_kernel(GemmPara
   }
   const int split = L / tiles, tile = L - split * tiles;
   const int tile_m = tile % p.tiles_m, tile_n = tile / p.tiles_m;
+  const int batch = blockIdx.y, bb1 = batch / p.nb2, bb2 = batch - bb1 * p.nb2;
+  p.A += bb1 * p.a_bs1 + bb2 * p.a_bs2;
+  p.B += bb1 * p.b_bs1 + bb2 * p.b_bs2;
+  p.C += bb1 * p.c_bs1 + bb2 * p.c_bs2;
+  if (p.residual) p.residual += bb1 * p.c_bs1 + bb2 * p.c_bs2;
+  p.ws += (int64_t)batch * p.splits * p.M * p.N;
   const int m0 = tile_m * AW, n0 = tile_n * BW;
   const int kw = p.k_per_split / NW;
   const int k0 = min(p.K, split * p.k_per_split + wave * kw);
@@ -1049,9 +1067,9 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   // ---- weight-gradient form (small output, long K): wave-streaming kernel --------------------
   constexpr int SNW = 8;                                  // waves per streaming workgroup
   bool use_stream = false;
-  if (!a_kin && !b_kin && a_rs == 1 && b_cs == 1 && nbatch == 1 && !b_colsum && K >= 2048 &&
-      (int64_t)M * N <= (1 << 20) && !getenv("PDN_GEMM_NO_STREAM")) {
-    const int tm = (int)cdiv64(M, 96), tn = (int)cdiv64(N, 96), tiles = tm * tn;
+  if (!a_kin && !b_kin && a_rs == 1 && b_cs == 1 && !b_colsum && K >= 2048 &&
+      (int64_t)M * N * nbatch <= (1 << 20) && nbatch <= 64 && !getenv("PDN_GEMM_NO_STREAM")) {
+    const int tm = (int)cdiv64(M, 96), tn = (int)cdiv64(N, 96), tiles = tm * tn * nbatch;
     if (tiles <= 256) {
       // one 8-wave workgroup per CU (2 waves / SIMD): rounds of 256 blocks; each extra slab costs a
       // write + read of the output in the reduce pass (~1.7 KB/clk), plus its launch
@@ -1059,17 +1077,17 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       int best_kps = 0, best_sp = 1;
       const int smax = (int)std::min<int64_t>(64, K / (SNW * 16));
       for (int s = 1; s <= smax; ++s) {
-        if (s > 1 && (int64_t)s * M * N > ws_cap) break;
+        if (s > 1 && (int64_t)s * M * N * nbatch > ws_cap) break;
         const int kw = (int)cdiv64(cdiv64(K, (int64_t)s * SNW), 8) * 8;
         const int kps = kw * SNW, sp = (int)cdiv64(K, kps);
         const double rounds = (double)cdiv64((int64_t)tiles * sp, 256);
         double cost = rounds * (kw * 0.5 * 9 * 64 * (SNW / 4.0) + 6000.0);
-        if (sp > 1) cost += (double)sp * M * N * 8.0 / 1700.0 + 5000.0;
+        if (sp > 1) cost += (double)sp * M * N * nbatch * 8.0 / 1700.0 + 5000.0;
         if (cost < best_cost) { best_cost = cost; best_kps = kps; best_sp = sp; }
       }
       if (const char* e = getenv("PDN_GEMM_STREAM_SPLITS")) {     // tuning override
         const int s = atoi(e);
-        if (s >= 1 && (s == 1 || (int64_t)s * M * N <= ws_cap)) {
+        if (s >= 1 && (s == 1 || (int64_t)s * M * N * nbatch <= ws_cap)) {
           const int kw = (int)cdiv64(cdiv64(K, (int64_t)s * SNW), 8) * 8;
           best_kps = kw * SNW; best_sp = (int)cdiv64(K, best_kps);
         }
@@ -1164,7 +1182,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   }
 
   if (use_stream) {
-    const dim3 sgrid(p.tiles_m * p.tiles_n * p.splits);
+    const dim3 sgrid(p.tiles_m * p.tiles_n * p.splits, nbatch);
     const bool exact = M % 96 == 0 && N % 96 == 0;
     if (vec && !getenv("PDN_GEMM_STREAM_DIRECT")) {      // 16-byte loads staged through LDS
       if (exact && !getenv("PDN_GEMM_STREAM_NODMA"))

@@ -406,6 +406,23 @@ def full(shape, value, dtype=None):
 
 def zeros_like(a, dtype=None): return zeros(a.shape, dtype or a.dtype)
 def ones_like(a, dtype=None): return ones(a.shape, dtype or a.dtype)
+def stacked_view(arrays):
+    """A (n, *shape) view over `arrays` when they are contiguous, alike and equally spaced in memory
+    (e.g. consecutive parameters of a flat buffer), else None.  Lets n GEMMs that share an operand
+    run as one batched launch without copying anything."""
+    a0 = arrays[0]
+    if not all(isinstance(a, ndarray) and a.shape == a0.shape and a.dtype == a0.dtype and a.is_contiguous()
+               for a in arrays):
+        return None
+    if len(arrays) == 1:
+        return a0.reshape((1,) + a0.shape)
+    step = arrays[1]._ptr - a0._ptr
+    if step % 16 or step == 0 or any(arrays[i + 1]._ptr - arrays[i]._ptr != step for i in range(len(arrays) - 1)):
+        return None
+    out = ndarray(a0._buf, a0._ptr, (len(arrays),) + a0.shape, (step // a0.dtype.itemsize,) + a0._strides, a0.dtype)
+    return out
+
+
 def empty_like(a, dtype=None): return empty(a.shape, dtype or a.dtype)
 
 

@@ -13,6 +13,7 @@ import math
 import numpy as np
 
 from .. import nn
+from ..autograd import is_grad_enable
 from ..core import Tensor, fused
 from ..special import zeros
 
@@ -59,9 +60,34 @@ class Attention(nn.Module):
         self.cache_k = nn.Parameter(zeros(shape, dtype=dtype), requires_grad=False)
         self.cache_v = nn.Parameter(zeros(shape, dtype=dtype), requires_grad=False)
 
+    def move(self, device):
+        super().move(device)
+        if device.is_hip:
+            self._pack_qkv()
+        return self
+
+    def _pack_qkv(self):
+        """Re-home the Q/K/V weights in one (3, dim, dim) buffer: each stays a contiguous Parameter,
+        and being equally spaced lets the three projections run as one batched GEMM."""
+        from .. import hipnp as hp
+        ws = [self.Q.weight, self.K.weight, self.V.weight]
+        if hp.stacked_view([w.data for w in ws]) is not None:
+            return
+        buf = hp.empty((3,) + tuple(ws[0].shape), ws[0].dtype)
+        for i, w in enumerate(ws):
+            buf[i] = w.data
+            w.data = buf[i]
+
     def __call__(self, x, start_pos, mask, freqs_cos, freqs_sin, residual=None):
         B, L, _ = x.shape
         H, hd = self.n_heads, self.head_dim
+        if (self._train and start_pos == 0 and mask is not None and is_grad_enable()
+                and fused.qkv_attention.applicable(x, L, hd)):
+            out = fused.qkv_attention(x, self.Q.weight, self.K.weight, self.V.weight, freqs_cos, freqs_sin, H)
+            out = out.reshape(B, L, -1)
+            if residual is None:
+                return self.O(out)
+            return fused.linear(out, self.O.weight, None, residual)
         xq = self.Q(x).reshape(B, L, H, hd)
         xk = self.K(x).reshape(B, L, H, hd)
         xv = self.V(x).reshape(B, L, H, hd)

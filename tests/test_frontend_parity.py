@@ -367,3 +367,42 @@ def test_autograd2d_cpu_config():
         assert np.allclose(x.grad, A.data @ x.data + b.data, rtol=1e-12)   # closed form, autograd2d.py:36-49
         x.data -= 0.1 * x.grad
         x.zero_grad()
+
+
+# ---- fused QKV + RoPE + attention node vs the separate nodes ------------------------------------
+def check_qkv_attention_node_matches_separate_nodes(dev):
+    from pydynet_amd.core import fused
+    from pydynet_amd.llm.llama import Attention, compute_cos_sin_cache
+    from pydynet_amd.optim.flat import flatten_gradients
+    B, L, D, H = 2, 32, 96, 2
+    rng = np.random.default_rng(11)
+    x_np = rng.standard_normal((B, L, D), dtype=np.float32)
+    g_np = rng.standard_normal((B, L, D), dtype=np.float32)
+    results = []
+    for enabled, flat in [(False, False), (True, False), (True, True)]:
+        Graph.clear()
+        np.random.seed(5)
+        att = Attention(D, H, 64, B, np.float32).to(dev)
+        assert dev == "cpu" or att.K.weight.data._ptr - att.Q.weight.data._ptr == \
+            att.V.weight.data._ptr - att.K.weight.data._ptr           # packed by move()
+        cos, sin = compute_cos_sin_cache(D // H, 64, dtype=np.float32)
+        cos, sin = cos[:L].to(dev), sin[:L].to(dev)
+        params = [att.Q.weight, att.K.weight, att.V.weight, att.O.weight]
+        for p_ in params:
+            p_.zero_grad()
+        if flat:
+            flatten_gradients(params[::-1])                       # equally spaced (descending) grads
+        x = T(x_np, dev, True)
+        fused.qkv_attention.enabled = enabled
+        try:
+            out = att(x * 1.0, 0, True, cos, sin)                 # x*1: x is an op node, as in the model
+            (out * T(g_np, dev)).sum().backward()
+        finally:
+            fused.qkv_attention.enabled = True
+        results.append([host(out.data), host(x.grad)] + [host(p_.grad) for p_ in params])
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            assert np.allclose(a, b, rtol=2e-5, atol=2e-6), float(np.abs(a - b).max())
+
+
+device_variants(globals(), check_qkv_attention_node_matches_separate_nodes)
