@@ -129,14 +129,18 @@ int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* 
  * q, k, v, o (and their gradients) are (B, L, H, head_dim) as the projections produce them;
  * lse (B, H, L) = row log-sum-exp saved for the backward, which recomputes the probabilities.
  * Supported: head_dim 48, L a multiple of 32 up to 256 (else PDN_EUNSUPPORTED: the caller uses
- * the GEMM + softmax path). */
+ * the GEMM + softmax path).
+ * rope_cos / rope_sin (nullable pair, (L, head_dim/2)): RoPE (model.py:23-44) fused into the
+ * kernels -- q and k are rotated by their position as they are loaded, and the backward rotates
+ * dq and dk back as it stores them, so the caller keeps (and differentiates) UN-rotated q, k. */
 int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
-                          int causal, void* stream);
+                          int causal, const float* rope_cos, const float* rope_sin, void* stream);
 int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                           const float* d_o, const float* lse, float* dq, float* dk, float* dv, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
-                          int causal, void* workspace, int64_t workspace_bytes, void* stream);
+                          int causal, const float* rope_cos, const float* rope_sin, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = rowsum(dO * O) */
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);

@@ -340,7 +340,8 @@ class attention(_Operator):
             out = hp.empty((B, Lq, H, hd), np.float32)
             self._lse = hp.empty((B, H, Lq), np.float32)
             L.call("pdn_attention_fwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, out._ptr, self._lse._ptr,
-                   B, H, Lq, hd, H * hd, Lq * H * hd, 1 if (self.causal and Lq > 1) else 0, hp.stream())
+                   B, H, Lq, hd, H * hd, Lq * H * hd, 1 if (self.causal and Lq > 1) else 0, None, None,
+                   hp.stream())
             return out
         p = hp.empty((B, H, Lq, Lk), np.float32)
         hp.gemm(q.data.transpose(0, 2, 1, 3), k.data.transpose(0, 2, 3, 1), p)
@@ -362,7 +363,7 @@ class attention(_Operator):
             ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
             L.call("pdn_attention_bwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, self.data._ptr, do._ptr,
                    self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd,
-                   1 if (self.causal and Lq > 1) else 0, ws, wsb, hp.stream())
+                   1 if (self.causal and Lq > 1) else 0, None, None, ws, wsb, hp.stream())
             return [dq, dk, dv]
         p = self._p
         if self.xp is np:
@@ -735,9 +736,9 @@ class gru_cell(_Operator):
 class qkv_attention(_Operator):
     """Training-path self-attention front end as ONE tape node (llm/llama/model.py:92-121):
     the three bias-free projections (a single batched GEMM when the weights are equally spaced in
-    memory, as `Attention.move` packs them), RoPE on q and k in place (one launch over both), and
-    the fused causal attention.  Backward: attention backward into one (3, T, D) buffer, inverse
-    rotation in place, the three weight gradients as ONE batched wave-streaming GEMM (when the
+    memory, as `Attention.move` packs them) and the fused causal attention with RoPE applied inside
+    its kernels.  Backward: attention backward into one (3, T, D) buffer (dq, dk already rotated
+    back), the three weight gradients as ONE batched wave-streaming GEMM (when the
     leaf gradients are equally spaced, e.g. in the flat gradient buffer) and dx = sum_i d_i W_i^T
     accumulated in the GEMM epilogues.  x: (B, L, D); returns the context (B, L, H, hd)."""
 
@@ -766,12 +767,13 @@ class qkv_attention(_Operator):
         else:
             for i in range(3):
                 hp.gemm(x2, ws[i], qkv[i])
+        # RoPE rides inside the attention kernels (q, k rotated as they are loaded; dq, dk rotated
+        # back as they are stored), so `qkv` keeps the un-rotated projections
         cos, sin = _contig(self._cos.data), _contig(self._sin.data)
-        L.call("pdn_rope_f32", qkv._ptr, cos._ptr, sin._ptr, qkv._ptr, 2 * T, Lq, H, hd, 0, hp.stream())
         out = hp.empty((B, Lq, H, hd), np.float32)
         lse = hp.empty((B, H, Lq), np.float32)
         L.call("pdn_attention_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr, B, H, Lq,
-               hd, D, Lq * D, 1, hp.stream())
+               hd, D, Lq * D, 1, cos._ptr, sin._ptr, hp.stream())
         self._saved = (x2, qkv, lse, cos, sin)
         return out
 
@@ -785,9 +787,8 @@ class qkv_attention(_Operator):
         dqkv = hp.empty((3, T, D), np.float32)
         ws_, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
         L.call("pdn_attention_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
-               lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, hd, D, Lq * D, 1, ws_, wsb,
-               hp.stream())
-        L.call("pdn_rope_f32", dqkv._ptr, cos._ptr, sin._ptr, dqkv._ptr, 2 * T, Lq, H, hd, 1, hp.stream())
+               lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, hd, D, Lq * D, 1, cos._ptr,
+               sin._ptr, ws_, wsb, hp.stream())
         grads = [None] * 4
         weights = (wq, wk, wv)
         gstack = None

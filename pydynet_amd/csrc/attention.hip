@@ -41,12 +41,29 @@ __device__ __forceinline__ int att_owner(int i) { return ((i >> 2) & 1) ? 3 - (i
 // zig-zag owner: wave w (8 per workgroup) takes tile w (w < 4) or 11 - w; SIMD s = w % 4 hosts tiles s and 7 - s
 __device__ __forceinline__ int att_tile_of_wave(int w) { return w < 4 ? w : 11 - w; }
 
+// RoPE on one float4 = two interleaved pairs (llm/llama/model.py:23-44): (r, i) -> (r c - i s, r s + i c);
+// sign = -1 rotates back (the gradient).  cs / sn: (L, HD/2) tables, `pair0` even.
+__device__ __forceinline__ float4 att_rot(float4 v, const float* __restrict__ cs, const float* __restrict__ sn,
+                                          int pos, int pair0, int half, float sign) {
+  const float2 c = *reinterpret_cast<const float2*>(cs + pos * half + pair0);
+  float2 s = *reinterpret_cast<const float2*>(sn + pos * half + pair0);
+  s.x *= sign; s.y *= sign;
+  float4 o;
+  o.x = v.x * c.x - v.y * s.x; o.y = v.x * s.x + v.y * c.x;
+  o.z = v.z * c.y - v.w * s.y; o.w = v.z * s.y + v.w * c.y;
+  return o;
+}
+
 // Stage two [L][HD] row-major matrices (row stride `row_stride` floats) into padded LDS images
 // [L][HD+4]; every thread issues all of its global loads before the first LDS write.
+// `rot0` / `rot1` rotate rows of matrix 0 / 1 by their position (RoPE fused into the load) when the
+// tables are given.
 template <int HD, int NT>
 __device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __restrict__ s1,
                                               const float* __restrict__ g0, const float* __restrict__ g1,
-                                              int L, int64_t row_stride, int tid) {
+                                              int L, int64_t row_stride, int tid,
+                                              const float* __restrict__ cs, const float* __restrict__ sn,
+                                              bool rot0, bool rot1) {
   constexpr int LD = ATT_LD(HD), F4 = HD / 4;
   constexpr int NP = (ATT_MAX_TILES * 32 * F4 + NT - 1) / NT;
   float4 r0[NP], r1[NP];
@@ -56,8 +73,10 @@ __device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __r
     if (u < L * F4) {
       const int row = u / F4, c4 = u % F4;
       // component-wise: a whole-float4 store into the array defeats SROA (scratch) on hipcc 7.2
-      const float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)row * row_stride + 4 * c4);
-      const float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride + 4 * c4);
+      float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)row * row_stride + 4 * c4);
+      float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride + 4 * c4);
+      if (cs && rot0) a = att_rot(a, cs, sn, row, 2 * c4, HD / 2, 1.f);
+      if (cs && rot1) c = att_rot(c, cs, sn, row, 2 * c4, HD / 2, 1.f);
       r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
       r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
     }
@@ -77,7 +96,8 @@ template <int HD>
 __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
-    int64_t batch_stride, float sqrt_hd, int causal) {
+    int64_t batch_stride, float sqrt_hd, int causal, const float* __restrict__ RC,
+    const float* __restrict__ RS) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;                    // k-groups of 8 along the head dim
   constexpr int F4 = HD / 4;
@@ -94,7 +114,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   const float* Qb = Q + base;
   float* Ob = O + base;
 
-  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid);
+  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS, true, false);
   __syncthreads();
 
   const int ntile = L / 32;
@@ -109,7 +129,10 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     {
       const float* qrow = Qb + (int64_t)(qt * 32 + li) * row_stride + 4 * lh;
 #pragma unroll
-      for (int t = 0; t < NT8; ++t) qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+      for (int t = 0; t < NT8; ++t) {
+        qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+        if (RC) qf[t] = att_rot(qf[t], RC, RS, qt * 32 + li, 4 * t + 2 * lh, HD / 2, 1.f);
+      }
     }
     // ---- S^T tiles ---------------------------------------------------------------------
     f32x16 s[ATT_MAX_TILES];
@@ -204,9 +227,12 @@ extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
 extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o,
                                      float* lse, int B, int H, int L, int head_dim,
                                      int64_t row_stride, int64_t batch_stride, int causal,
-                                     void* stream) {
+                                     const float* rope_cos, const float* rope_sin, void* stream) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
   PDN_CHECK_ARG(q && k && v && o && lse, "pdn_attention_fwd_f32: null operand");
+  PDN_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) &&
+                    ((((uintptr_t)rope_cos | (uintptr_t)rope_sin) & 7) == 0),
+                "pdn_attention_fwd_f32: rope tables must come as an 8-byte aligned pair");
   if (head_dim != 48 || L % 32 != 0 || L > 32 * ATT_MAX_TILES) {
     pdn_set_error("pdn_attention_fwd_f32: fused path supports head_dim 48, L multiple of 32 and <= %d",
                   32 * ATT_MAX_TILES);
@@ -223,7 +249,8 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
     attr_set = true;
   }
   hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(512), shm, (hipStream_t)stream, q, k,
-                     v, o, lse, H, L, row_stride, batch_stride, sqrtf((float)head_dim), causal);
+                     v, o, lse, H, L, row_stride, batch_stride, sqrtf((float)head_dim), causal, rope_cos,
+                     rope_sin);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -248,7 +275,8 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
 template <int HD>
 __device__ __forceinline__ void att_store_tile_T(float* slot, const f32x16& t0, const f32x16& t1,
                                                  float* dst_rows, int64_t row_stride, int li, int lh,
-                                                 int lane, float scale) {
+                                                 int lane, float scale, const float* __restrict__ cs = nullptr,
+                                                 const float* __restrict__ sn = nullptr, int pos0 = 0) {
   // t0/t1 hold X^T[d][row]: lane = row, registers = d.  Stage as [row][d] and write rows.
   constexpr int LD = ATT_LD(HD);
   constexpr int F4 = HD / 4;
@@ -262,8 +290,9 @@ __device__ __forceinline__ void att_store_tile_T(float* slot, const f32x16& t0, 
   __builtin_amdgcn_wave_barrier();
   for (int u = lane; u < 32 * F4; u += 64) {
     const int row = u / F4, c4 = u % F4;
-    *reinterpret_cast<float4*>(dst_rows + (int64_t)row * row_stride + 4 * c4) =
-        *reinterpret_cast<const float4*>(slot + row * LD + 4 * c4);
+    float4 v = *reinterpret_cast<const float4*>(slot + row * LD + 4 * c4);
+    if (cs) v = att_rot(v, cs, sn, pos0 + row, 2 * c4, HD / 2, -1.f);   // gradient of RoPE: rotate back
+    *reinterpret_cast<float4*>(dst_rows + (int64_t)row * row_stride + 4 * c4) = v;
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);
   __builtin_amdgcn_wave_barrier();
@@ -274,7 +303,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
     float* __restrict__ dQ, float* __restrict__ Delta, int H, int L, int64_t row_stride,
-    int64_t batch_stride, float sqrt_hd, int causal) {
+    int64_t batch_stride, float sqrt_hd, int causal, const float* __restrict__ RC,
+    const float* __restrict__ RS) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -290,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   const float* Qb = Q + base; const float* Ob = O + base; const float* dOb = dO + base;
   float* dQb = dQ + base;
 
-  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid);
+  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS, true, false);
   __syncthreads();
 
   const int ntile = L / 32;
@@ -309,6 +339,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+      if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
       gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
       const float4 ov = *reinterpret_cast<const float4*>(orow + 8 * t);
       dpart += (ov.x * gf[t].x + ov.y * gf[t].y) + (ov.z * gf[t].z + ov.w * gf[t].w);
@@ -357,7 +388,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     }
   }
   att_store_tile_T<HD>(slots + wave * (32 * LD), dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride,
-                       row_stride, li, lh, lane, 1.f);
+                       row_stride, li, lh, lane, 1.f, RC, RS, qt * 32);
 }
 
 template <int HD>
@@ -365,7 +396,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Delta,
     float* __restrict__ dK, float* __restrict__ dV, int H, int L, int64_t row_stride,
-    int64_t batch_stride, float sqrt_hd, int causal) {
+    int64_t batch_stride, float sqrt_hd, int causal, const float* __restrict__ RC,
+    const float* __restrict__ RS) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -383,7 +415,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const float* Kb = K + base; const float* Vb = V + base;
   float* dKb = dK + base; float* dVb = dV + base;
 
-  att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + base, L, row_stride, tid);
+  att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + base, L, row_stride, tid, RC, RS, true, false);
   for (int q = tid; q < L; q += 512) {
     lse_s[q] = LSE[(int64_t)bh * L + q];
     delta_s[q] = Delta[(int64_t)bh * L + q];
@@ -403,6 +435,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
+      if (RC) kf[t] = att_rot(kf[t], RC, RS, kpos, 4 * t + 2 * lh, HD / 2, 1.f);
       vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
     }
   }
@@ -451,7 +484,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     }
   }
   float* slot = slots + wave * (32 * LD);
-  att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+  att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f,
+                       RC, RS, kt * 32);
   att_store_tile_T<HD>(slot, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
 }
 
@@ -468,8 +502,12 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
                                      const float* d_o, const float* lse, float* dq, float* dk,
                                      float* dv, int B, int H, int L, int head_dim,
                                      int64_t row_stride, int64_t batch_stride, int causal,
-                                     void* workspace, int64_t workspace_bytes, void* stream) {
+                                     const float* rope_cos, const float* rope_sin, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
+  PDN_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) &&
+                    ((((uintptr_t)rope_cos | (uintptr_t)rope_sin) & 7) == 0),
+                "pdn_attention_bwd_f32: rope tables must come as an 8-byte aligned pair");
   PDN_CHECK_ARG(q && k && v && o && d_o && lse && dq && dk && dv, "pdn_attention_bwd_f32: null operand");
   if (head_dim != 48 || L % 32 != 0 || L > 32 * ATT_MAX_TILES) {
     pdn_set_error("pdn_attention_bwd_f32: fused path supports head_dim 48, L multiple of 32 and <= %d",
@@ -496,11 +534,11 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
   const float sq = sqrtf((float)head_dim);
   hipLaunchKernelGGL((attention_bwd_dq_kernel<48>), dim3(B * H), dim3(512),
                      (size_t)pdn_attention_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
-                     lse, dq, delta, H, L, row_stride, batch_stride, sq, causal);
+                     lse, dq, delta, H, L, row_stride, batch_stride, sq, causal, rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL((attention_bwd_dkv_kernel<48>), dim3(B * H), dim3(512),
                      (size_t)pdn_attention_bwd_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, d_o,
-                     lse, delta, dk, dv, H, L, row_stride, batch_stride, sq, causal);
+                     lse, delta, dk, dv, H, L, row_stride, batch_stride, sq, causal, rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

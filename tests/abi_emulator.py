@@ -302,10 +302,23 @@ class EmulatedLib:
     def pdn_attention_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4
     def pdn_attention_bwd_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4 + 8 * L
 
-    def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, causal, stream):
+    @staticmethod
+    def _rot(a, cos, sin, L, hd, sign):
+        """RoPE on (B, H, L, hd) host arrays; cos/sin pointers to (L, hd/2) tables or None."""
+        if not cos:
+            return a
+        c = flat(cos, L * hd // 2).reshape(1, 1, L, hd // 2)
+        s = sign * flat(sin, L * hd // 2).reshape(1, 1, L, hd // 2)
+        out = np.empty_like(a)
+        out[..., 0::2] = a[..., 0::2] * c - a[..., 1::2] * s
+        out[..., 1::2] = a[..., 0::2] * s + a[..., 1::2] * c
+        return out
+
+    def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, causal, rc, rsn, stream):
         if hd != 48 or L % 32 or L > 256:
             return -2
         Q, K, V, O = self._att_views([q, k, v, o], B, H, L, hd, rs, bs)
+        Q, K = self._rot(np.array(Q), rc, rsn, L, hd, 1.0), self._rot(np.array(K), rc, rsn, L, hd, 1.0)
         p, ls = self._att_probs(np.array(Q), np.array(K), L, hd, causal)
         O[...] = np.matmul(p, np.array(V))
         flat(lse, B * H * L).reshape(B, H, L)[...] = ls
@@ -313,11 +326,13 @@ class EmulatedLib:
 
     def pdn_attention_bwd_workspace_bytes(self, B, H, L): return B * H * L * 4
 
-    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, causal, ws, wsb, stream):
+    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, causal, rc, rsn,
+                              ws, wsb, stream):
         if hd != 48 or L % 32 or L > 256:
             return -2
         Q, K, V, O, DO, DQ, DK, DV = [np.array(a) if i < 5 else a for i, a in
                                       enumerate(self._att_views([q, k, v, o, do, dq, dk, dv], B, H, L, hd, rs, bs))]
+        Q, K = self._rot(Q, rc, rsn, L, hd, 1.0), self._rot(K, rc, rsn, L, hd, 1.0)
         s = np.matmul(Q, K.swapaxes(-1, -2)) / np.float32(math.sqrt(hd))
         p = np.exp(s - flat(lse, B * H * L).reshape(B, H, L, 1))
         if causal:
@@ -326,8 +341,8 @@ class EmulatedLib:
         dp = np.matmul(DO, V.swapaxes(-1, -2))
         ds = p * (dp - delta) / np.float32(math.sqrt(hd))
         DV[...] = np.matmul(p.swapaxes(-1, -2), DO)
-        DQ[...] = np.matmul(ds, K)
-        DK[...] = np.matmul(ds.swapaxes(-1, -2), Q)
+        DQ[...] = self._rot(np.matmul(ds, K), rc, rsn, L, hd, -1.0)
+        DK[...] = self._rot(np.matmul(ds.swapaxes(-1, -2), Q), rc, rsn, L, hd, -1.0)
         return 0
 
     def pdn_cross_entropy_colsum_workspace_bytes(self, rows, V):
