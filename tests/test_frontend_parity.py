@@ -402,7 +402,7 @@ def check_qkv_attention_node_matches_separate_nodes(dev):
         results.append([host(out.data), host(x.grad)] + [host(p_.grad) for p_ in params])
     for other in results[1:]:
         for a, b in zip(results[0], other):
-            assert np.allclose(a, b, rtol=2e-5, atol=2e-6), float(np.abs(a - b).max())
+            assert np.allclose(a, b, rtol=1e-4, atol=1e-5), float(np.abs(a - b).max())   # north-star tolerance
 
 
 device_variants(globals(), check_qkv_attention_node_matches_separate_nodes)
