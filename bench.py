@@ -64,6 +64,10 @@ def main():
     hipnp.set_device(local)
     rank, world = init_process_group("nccl", local) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    force_dp = world == 1 and os.environ.get("PDN_BENCH_FORCE_DP") == "1"   # exercise the RCCL path on one GPU
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
     dev = f"hip:{local}"
     B = args.batch
 
@@ -72,7 +76,7 @@ def main():
     model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     model.to(dev)
     opt = Adam(model.parameters(), lr=1e-4)
-    dp = DataParallel(model, opt) if world > 1 else None
+    dp = DataParallel(model, opt, always_reduce=force_dp) if (world > 1 or force_dp) else None
     if dp is None:
         opt.flatten_grads()                                 # one flat gradient buffer: zero_grad is a single fill
     rng = np.random.default_rng(1000 + rank)                # each rank owns its shard of the global batch
@@ -80,12 +84,19 @@ def main():
     tgt = pdn.Tensor(rng.integers(0, V, (B * L,)), dtype=np.int64, device=dev)
     model.train(True)
 
+    comm_events = []
+
     def step():
         opt.zero_grad()
         loss = model.loss(ids, tgt)
         loss.backward()
         if dp is not None:
+            # time the compute stream spends blocked on the gradient all-reduce (= exposed communication)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             dp.finish()
+            e1.record()
+            comm_events.append((e0, e1))
         opt.step()
         return loss
 
@@ -98,6 +109,7 @@ def main():
     for _ in range(args.warmup):
         prev = step()
     fence()
+    comm_events.clear()
     if not args.no_gemm_prof:
         lib.call("pdn_gemm_prof_enable", 1)
     losses = []
@@ -138,11 +150,16 @@ def main():
         "final_loss": losses[-1],
         "roofline": roof,
     }
+    if dp is not None:
+        exposed = sum(a.elapsed_time(b) for a, b in comm_events) / max(len(comm_events), 1)
+        out["comm"] = {"collective": "all-reduce(sum) of flat fp32 gradient buckets, RCCL", "buckets": len(dp.buckets),
+                       "payload_MB_per_step": dp.flat.size * 4 / 1e6, "exposed_ms_per_step": exposed,
+                       "note": "exposed = compute-stream time blocked in DataParallel.finish(); the rest overlaps backward"}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
 
 
