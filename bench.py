@@ -155,12 +155,19 @@ def main():
         out["comm"] = {"collective": "all-reduce(sum) of flat fp32 gradient buckets, RCCL", "buckets": len(dp.buckets),
                        "payload_MB_per_step": dp.flat.size * 4 / 1e6, "exposed_ms_per_step": exposed,
                        "note": "exposed = compute-stream time blocked in DataParallel.finish(); the rest overlaps backward"}
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
     if world > 1 or force_dp:
         torch.distributed.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio (block-buffered when piped): push it out first
+        # so that the JSON record is the last line of stdout
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
