@@ -7,8 +7,11 @@ contract is: an N-rank step on N shards of a batch == a 1-rank step on the conca
 Design for MI355X (8 GPUs fully connected, 7 xGMI links x ~153 GB/s each):
   * all trainable gradients live in ONE flat fp32 buffer laid out in reverse registration order
     (lm_head first, tok_embedding last) -- the order backward finalises them;
-  * the buffer is cut into buckets (default 25 MB: a ring all-reduce is per-link bound, so few
-    large messages beat many small ones); each parameter's `.grad` is a view into its bucket;
+  * the buffer is cut into buckets (default 12 MB: a ring all-reduce is per-link bound, so few
+    large messages beat many small ones, but a bucket can only start once its LAST gradient exists --
+    12 MB lets the transformer blocks' 24 MB go out in two pieces during backward and leaves only the
+    embedding table, whose gradient is the final one, exposed); each parameter's `.grad` is a view
+    into its bucket;
   * the tape engine fires a grad-ready hook when a leaf has received its last contribution;
     when every parameter of bucket k is ready (and buckets < k are already in flight) the
     bucket's `all_reduce(SUM)` is issued asynchronously -- RCCL runs it on its own stream, so
@@ -62,7 +65,7 @@ class DataParallel:
         optimizer.zero_grad(); loss = model.loss(...); loss.backward(); dp.finish(); optimizer.step()
     """
 
-    def __init__(self, module, optimizer=None, bucket_mb: float = 25.0, process_group=None,
+    def __init__(self, module, optimizer=None, bucket_mb: float = 12.0, process_group=None,
                  broadcast_parameters=True, always_reduce=False):
         dist = _dist()
         self.module = module
