@@ -205,6 +205,20 @@ int pdn_cross_entropy_fwd_bwd_f32(const float* logits, const int64_t* targets, i
 int64_t pdn_cross_entropy_colsum_workspace_bytes(int64_t rows, int V);
 int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* scalar_dev, void* stream);
 
+/* ---- reference LayerNorm / BatchNorm1d (nn/modules/norm.py:60-74, 203-218): statistics per COLUMN
+ * of x (rows, cols) -- the reference's LayerNorm reduces over the leading axes -- biased variance,
+ * y = (x - mean) * rstd * w + b; running_{mean,var} (nullable) <- (1-m) * running + m * stat.
+ * mean / rstd (cols,) are saved for the backward: db = sum dy, dw = sum dy*xhat,
+ * dx = w * rstd * (dy - db/R - xhat * dw/R); dx / dw / db are each optional, dw/db (+)= when
+ * accumulate.  Workspace: pdn_colnorm_workspace_bytes. */
+int pdn_colnorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                        float* running_mean, float* running_var, float momentum, float eps,
+                        int64_t rows, int cols, void* workspace, int64_t workspace_bytes, void* stream);
+int pdn_colnorm_bwd_f32(const float* x, const float* w, const float* mean, const float* rstd,
+                        const float* dy, float* dx, float* dw, float* db, int accumulate, int64_t rows,
+                        int cols, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pdn_colnorm_workspace_bytes(int64_t rows, int cols);
+
 /* ---- GRU cell (nn/modules/rnn.py:537-544): the gate algebra between the four GEMMs.
  *   [z, r] = sigmoid(g1) with g1 = x Wx1 + h Wh1 + b1 (B, 2H);  rh = r * h
  *   n = tanh(g2) with g2 = x Wx2 + rh Wh2 + b2 (B, H);          h' = (1 - z) h + z n

@@ -815,3 +815,54 @@ class qkv_attention(_Operator):
             hp.gemm(dqkv[2], wv.data.T, dx2, beta=1.0)
             grads[0] = dx
         return grads
+
+
+class col_norm(_Operator):
+    """Reference LayerNorm / BatchNorm1d in training mode (nn/modules/norm.py:60-74, 203-218):
+    per-column statistics of x viewed as (rows, cols) -- the reference's LayerNorm reduces over the
+    LEADING axes -- then `(x - mean) / sqrt(var + eps) * scale + shift`, with the running statistics
+    updated in the same launch sequence.  HIP device only; the NumPy device composes generic ops."""
+
+    def __init__(self, x, scale, shift, running_mean, running_var, eps, momentum, cols):
+        self._rm, self._rv, self.eps, self.momentum, self.cols = running_mean, running_var, float(eps), float(momentum), int(cols)
+        super().__init__(x, scale, shift)
+
+    def forward_(self, x, scale, shift):
+        if self.xp is np:
+            raise NotImplementedError("col_norm is the HIP fused path")
+        hp, L = _hip(), _L()
+        cols = self.cols
+        xd = _contig(x.data)
+        rows = xd.size // cols
+        y = hp.empty(x.shape, np.float32)
+        mean, rstd = hp.empty((cols,), np.float32), hp.empty((cols,), np.float32)
+        ws, wsb = hp.workspace(L.query("pdn_colnorm_workspace_bytes", rows, cols))
+        rm, rv = self._rm.data, self._rv.data
+        L.call("pdn_colnorm_fwd_f32", xd._ptr, _contig(scale.data)._ptr, _contig(shift.data)._ptr, y._ptr,
+               mean._ptr, rstd._ptr, rm._ptr, rv._ptr, self.momentum, self.eps, rows, cols, ws, wsb, hp.stream())
+        self._saved = (xd, mean, rstd, rows)
+        return y
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, scale, shift = self.last
+        xd, mean, rstd, rows = self._saved
+        cols = self.cols
+        g = _contig(g)
+        dx = hp.empty(x.shape, np.float32) if x.requires_grad else None
+        grads = [dx, None, None]
+        direct_w = scale.requires_grad and _is_leaf_f32(scale)
+        direct_b = shift.requires_grad and _is_leaf_f32(shift)
+        acc = direct_w or direct_b
+        # leaf buffers are accumulated into directly; otherwise fresh arrays are returned
+        dw = scale.grad if direct_w else (hp.zeros((cols,), np.float32) if scale.requires_grad else None)
+        db = shift.grad if direct_b else (hp.zeros((cols,), np.float32) if shift.requires_grad else None)
+        ws, wsb = hp.workspace(L.query("pdn_colnorm_workspace_bytes", rows, cols))
+        L.call("pdn_colnorm_bwd_f32", xd._ptr, _contig(scale.data)._ptr, mean._ptr, rstd._ptr, g._ptr,
+               dx._ptr if dx is not None else None, dw.reshape(-1)._ptr if dw is not None else None,
+               db.reshape(-1)._ptr if db is not None else None, 1 if acc else 0, rows, cols, ws, wsb, hp.stream())
+        if scale.requires_grad and not direct_w:
+            grads[1] = dw.reshape(scale.shape)
+        if shift.requires_grad and not direct_b:
+            grads[2] = db.reshape(shift.shape)
+        return grads

@@ -1157,3 +1157,191 @@ extern "C" int pdn_gru_gates_bwd_f32(const float* drh, const float* r, const flo
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
+
+// ======================================================================================
+// Column-statistics normalisation: the reference's LayerNorm (nn/modules/norm.py:203-218 -- its
+// statistics run over the LEADING axes, i.e. per feature over all tokens, with running averages)
+// and BatchNorm1d on (N, C) (norm.py:60-74).  x is (rows, cols) row-major.
+//   mean_c = sum_r x / R;  var_c = sum_r (x - mean_c)^2 / R;  y = (x - mean_c) / sqrt(var_c + eps) * w + b
+//   running = (1 - m) * running + m * stat                       (norm.py:211-214)
+// backward:  db = sum_r dy;  dw = sum_r dy * xhat;  dx = w * rstd * (dy - db/R - xhat * dw/R)
+// Statistics: per 256-row chunk shifted sums (shift = first row of the chunk, so the squares do
+// not cancel), chunks merged in a fixed order with the pairwise-variance formula.
+// ======================================================================================
+#define CN_ROWS 256      // rows per chunk
+#define CN_COLS 32       // columns per workgroup (x 8 row lanes)
+
+__global__ __launch_bounds__(256) void colnorm_stat_partial_kernel(const float* __restrict__ x, int64_t rows, int cols,
+                                                                   float* __restrict__ part) {
+  __shared__ float sm[8][CN_COLS], sq[8][CN_COLS];
+  const int tx = threadIdx.x & (CN_COLS - 1), ty = threadIdx.x / CN_COLS;
+  const int c = blockIdx.x * CN_COLS + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * CN_ROWS;
+  const int64_t r1 = r0 + CN_ROWS < rows ? r0 + CN_ROWS : rows;
+  float s = 0.f, q = 0.f, shift = 0.f;
+  if (c < cols) {
+    shift = x[r0 * cols + c];
+    for (int64_t r = r0 + ty; r < r1; r += 8) {
+      const float d = x[r * cols + c] - shift;
+      s += d; q += d * d;
+    }
+  }
+  sm[ty][tx] = s; sq[ty][tx] = q;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float S = sm[0][tx], Q = sq[0][tx];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { S += sm[k][tx]; Q += sq[k][tx]; }
+    const float n = (float)(r1 - r0);
+    float* dst = part + ((int64_t)blockIdx.y * cols + c) * 2;
+    dst[0] = shift + S / n;            // chunk mean
+    dst[1] = Q - S * S / n;            // chunk sum of squared deviations
+  }
+}
+
+__global__ void colnorm_stat_finish_kernel(const float* __restrict__ part, int64_t rows, int cols, int nchunks,
+                                           float eps, float momentum, float* __restrict__ mean,
+                                           float* __restrict__ rstd, float* __restrict__ run_mean,
+                                           float* __restrict__ run_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float n = 0.f, mu = 0.f, m2 = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    const int64_t r0 = (int64_t)k * CN_ROWS;
+    const float nb = (float)((r0 + CN_ROWS < rows ? r0 + CN_ROWS : rows) - r0);
+    const float mb = part[((int64_t)k * cols + c) * 2], qb = part[((int64_t)k * cols + c) * 2 + 1];
+    const float tot = n + nb, d = mb - mu;
+    m2 += qb + d * d * (n * nb / tot);
+    mu += d * (nb / tot);
+    n = tot;
+  }
+  const float var = m2 / n;
+  mean[c] = mu;
+  rstd[c] = 1.f / sqrtf(var + eps);
+  if (run_mean) run_mean[c] = run_mean[c] * (1.f - momentum) + momentum * mu;
+  if (run_var) run_var[c] = run_var[c] * (1.f - momentum) + momentum * var;
+}
+
+__global__ void colnorm_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                     const float* __restrict__ b, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, float* __restrict__ y, int64_t n, int cols) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    y[i] = (x[i] - mean[c]) * rstd[c] * w[c] + b[c];
+  }
+}
+
+// partial column sums of dy and dy * xhat per 256-row chunk: part[chunk][{0,1}][cols]
+__global__ __launch_bounds__(256) void colnorm_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                  const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                  int64_t rows, int cols, float* __restrict__ part) {
+  __shared__ float sa[8][CN_COLS], sb[8][CN_COLS];
+  const int tx = threadIdx.x & (CN_COLS - 1), ty = threadIdx.x / CN_COLS;
+  const int c = blockIdx.x * CN_COLS + tx;
+  const int64_t r0 = (int64_t)blockIdx.y * CN_ROWS;
+  const int64_t r1 = r0 + CN_ROWS < rows ? r0 + CN_ROWS : rows;
+  float a = 0.f, bsum = 0.f;
+  if (c < cols) {
+    const float mu = mean[c], rs = rstd[c];
+    for (int64_t r = r0 + ty; r < r1; r += 8) {
+      const float g = dy[r * cols + c];
+      a += g; bsum += g * ((x[r * cols + c] - mu) * rs);
+    }
+  }
+  sa[ty][tx] = a; sb[ty][tx] = bsum;
+  __syncthreads();
+  if (ty == 0 && c < cols) {
+    float A = sa[0][tx], Bv = sb[0][tx];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { A += sa[k][tx]; Bv += sb[k][tx]; }
+    part[((int64_t)blockIdx.y * 2) * cols + c] = A;
+    part[((int64_t)blockIdx.y * 2 + 1) * cols + c] = Bv;
+  }
+}
+
+// sums[0][c] = sum_chunks part[k][0][c] (db), sums[1][c] = ... (dw), fixed order
+__global__ void colnorm_bwd_finish_kernel(const float* __restrict__ part, int cols, int nchunks,
+                                          float* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nchunks; ++k) {
+    a += part[((int64_t)k * 2) * cols + c];
+    b += part[((int64_t)k * 2 + 1) * cols + c];
+  }
+  sums[c] = a; sums[cols + c] = b;
+}
+
+__global__ void colnorm_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                         const float* __restrict__ mean, const float* __restrict__ rstd,
+                                         const float* __restrict__ dy, const float* __restrict__ sums,
+                                         float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
+                                         int accumulate, int64_t rows, int cols) {
+  const int64_t n = rows * cols;
+  const float inv_r = 1.f / (float)rows;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cols);
+    const float rs = rstd[c], xh = (x[i] - mean[c]) * rs;
+    if (dx) dx[i] = w[c] * rs * (dy[i] - sums[c] * inv_r - xh * (sums[cols + c] * inv_r));
+    if (i < cols) {                         // the first row of threads also publishes the parameter gradients
+      if (db) db[c] = accumulate ? db[c] + sums[c] : sums[c];
+      if (dw) dw[c] = accumulate ? dw[c] + sums[cols + c] : sums[cols + c];
+    }
+  }
+}
+
+extern "C" int64_t pdn_colnorm_workspace_bytes(int64_t rows, int cols) {
+  const int64_t chunks = (rows + CN_ROWS - 1) / CN_ROWS;
+  return (chunks * 2 + 2) * (int64_t)cols * 4;
+}
+
+extern "C" int pdn_colnorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean,
+                                   float* rstd, float* running_mean, float* running_var, float momentum,
+                                   float eps, int64_t rows, int cols, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  PDN_CHECK_ARG(x && w && b && y && mean && rstd && rows > 0 && cols > 0, "pdn_colnorm_fwd_f32: bad arguments");
+  if (!workspace || workspace_bytes < pdn_colnorm_workspace_bytes(rows, cols)) {
+    pdn_set_error("pdn_colnorm_fwd_f32: workspace too small");
+    return PDN_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = (int)((rows + CN_ROWS - 1) / CN_ROWS);
+  PDN_CHECK_ARG(chunks <= 65535, "pdn_colnorm_fwd_f32: too many rows (%lld)", (long long)rows);
+  float* part = (float*)workspace;
+  hipLaunchKernelGGL(colnorm_stat_partial_kernel, dim3((cols + CN_COLS - 1) / CN_COLS, chunks), dim3(256), 0, st, x,
+                     rows, cols, part);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colnorm_stat_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, rows, cols, chunks,
+                     eps, momentum, mean, rstd, running_mean, running_var);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colnorm_apply_kernel, dim3(stream_grid(rows * cols)), dim3(256), 0, st, x, w, b, mean, rstd, y,
+                     rows * cols, cols);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+// dx / dw / db are each optional; dw, db: (cols,), (+)= when accumulate.
+extern "C" int pdn_colnorm_bwd_f32(const float* x, const float* w, const float* mean, const float* rstd,
+                                   const float* dy, float* dx, float* dw, float* db, int accumulate,
+                                   int64_t rows, int cols, void* workspace, int64_t workspace_bytes,
+                                   void* stream) {
+  PDN_CHECK_ARG(x && w && mean && rstd && dy && rows > 0 && cols > 0, "pdn_colnorm_bwd_f32: bad arguments");
+  if (!workspace || workspace_bytes < pdn_colnorm_workspace_bytes(rows, cols)) {
+    pdn_set_error("pdn_colnorm_bwd_f32: workspace too small");
+    return PDN_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int chunks = (int)((rows + CN_ROWS - 1) / CN_ROWS);
+  PDN_CHECK_ARG(chunks <= 65535, "pdn_colnorm_bwd_f32: too many rows (%lld)", (long long)rows);
+  float* part = (float*)workspace;
+  float* sums = part + (int64_t)chunks * 2 * cols;
+  hipLaunchKernelGGL(colnorm_bwd_partial_kernel, dim3((cols + CN_COLS - 1) / CN_COLS, chunks), dim3(256), 0, st, x, dy,
+                     mean, rstd, rows, cols, part);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colnorm_bwd_finish_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, part, cols, chunks, sums);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(colnorm_bwd_apply_kernel, dim3(stream_grid(rows * cols)), dim3(256), 0, st, x, w, mean, rstd, dy,
+                     sums, dx, dw, db, accumulate, rows, cols);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

@@ -29,6 +29,13 @@ class _RunningStatNorm(Module):
         init.ones_(self.scale)
 
     def _normalise(self, x, axis, keepdims):
+        if (self._train and not keepdims and x.device.is_hip and x.dtype == np.float32
+                and self.scale.dtype == np.float32 and x.ndim >= 2
+                and tuple(axis if isinstance(axis, tuple) else (axis,)) == tuple(range(x.ndim - self.scale.ndim))
+                and tuple(x.shape[x.ndim - self.scale.ndim:]) == tuple(self.scale.shape)):
+            # statistics over the leading axes of a (rows, cols) view: one fused node (3 launches)
+            return fused.col_norm(x, self.scale, self.shift, self.running_mean, self.running_var,
+                                  self.eps, self.momentum, self.scale.size)
         if self._train:
             mean = x.mean(axis, keepdims) if keepdims else x.mean(axis)
             centred = x - mean

@@ -356,6 +356,37 @@ class EmulatedLib:
             flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
         return rc
 
+    # -- column-statistics normalisation (reference LayerNorm / BatchNorm1d) -----------------
+    def pdn_colnorm_workspace_bytes(self, rows, cols): return ((rows + 255) // 256 * 2 + 2) * cols * 4
+
+    def pdn_colnorm_fwd_f32(self, x, w, b, y, mean, rstd, rmean, rvar, momentum, eps, rows, cols, ws, wsb, stream):
+        a = np.array(flat(x, rows * cols).reshape(rows, cols))
+        mu = a.mean(0)
+        var = np.square(a - mu).mean(0)
+        rs = (1.0 / np.sqrt(var + np.float32(eps))).astype(np.float32)
+        flat(mean, cols)[...] = mu
+        flat(rstd, cols)[...] = rs
+        flat(y, rows * cols).reshape(rows, cols)[...] = (a - mu) * rs * flat(w, cols) + flat(b, cols)
+        if rmean:
+            flat(rmean, cols)[...] = flat(rmean, cols) * np.float32(1 - momentum) + np.float32(momentum) * mu
+        if rvar:
+            flat(rvar, cols)[...] = flat(rvar, cols) * np.float32(1 - momentum) + np.float32(momentum) * var
+        return 0
+
+    def pdn_colnorm_bwd_f32(self, x, w, mean, rstd, dy, dx, dw, db, acc, rows, cols, ws, wsb, stream):
+        a = np.array(flat(x, rows * cols).reshape(rows, cols))
+        g = np.array(flat(dy, rows * cols).reshape(rows, cols))
+        mu, rs = flat(mean, cols), flat(rstd, cols)
+        xh = (a - mu) * rs
+        sdb, sdw = g.sum(0), (g * xh).sum(0)
+        if dx:
+            flat(dx, rows * cols).reshape(rows, cols)[...] = flat(w, cols) * rs * (g - sdb / rows - xh * (sdw / rows))
+        if dw:
+            flat(dw, cols)[...] = flat(dw, cols) + sdw if acc else sdw
+        if db:
+            flat(db, cols)[...] = flat(db, cols) + sdb if acc else sdb
+        return 0
+
     # -- GRU gate algebra ------------------------------------------------------------------
     @staticmethod
     def _sig(x):
