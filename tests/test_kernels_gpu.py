@@ -480,3 +480,67 @@ def test_fused_attention_forward_backward(hip, B, H, L, causal):
     assert rel_err(dk.get(), (ds.swapaxes(-1, -2) @ q64).transpose(0, 2, 1, 3)) < 5e-5
     if causal:                                    # masked probabilities are exactly zero: the first
         assert np.allclose(o.get()[:, 0], v[:, 0], rtol=1e-6)   # query attends only to key 0
+
+
+def test_colnorm_forward_backward_large_offset(hip):
+    """Reference-LayerNorm kernels on the transformer example's shape, with a large common offset
+    (a one-pass E[x^2]-E[x]^2 variance would lose every digit here)."""
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(21)
+    rows, cols, eps, mom = 5632 + 37, 512, 1e-6, 0.1
+    x = (rng.standard_normal((rows, cols)) * 0.5 + 300.0).astype(np.float32)
+    w, b = rng.standard_normal(cols).astype(np.float32), rng.standard_normal(cols).astype(np.float32)
+    dy = rng.standard_normal((rows, cols)).astype(np.float32)
+    rm0, rv0 = rng.standard_normal(cols).astype(np.float32), rng.random(cols).astype(np.float32)
+    X, W, Bb, DY = map(hip.from_numpy, (x, w, b, dy))
+    RM, RV = hip.from_numpy(rm0.copy()), hip.from_numpy(rv0.copy())
+    Y, MU, RS = hip.empty((rows, cols)), hip.empty((cols,)), hip.empty((cols,))
+    ws, wsb = hip.workspace(L.query("pdn_colnorm_workspace_bytes", rows, cols))
+    L.call("pdn_colnorm_fwd_f32", X._ptr, W._ptr, Bb._ptr, Y._ptr, MU._ptr, RS._ptr, RM._ptr, RV._ptr, mom, eps,
+           rows, cols, ws, wsb, hip.stream())
+    x64 = x.astype(np.float64)
+    mu = x64.mean(0); var = ((x64 - mu) ** 2).mean(0); rs = 1 / np.sqrt(var + eps); xh = (x64 - mu) * rs
+    assert np.allclose(MU.get(), mu, rtol=1e-6)
+    assert np.allclose(RS.get(), rs, rtol=2e-4)          # var of (x - 300) in fp32: ~1e-4 relative
+    assert np.allclose(Y.get(), xh * w + b, rtol=1e-3, atol=2e-3)
+    assert np.allclose(RM.get(), rm0 * (1 - mom) + mom * mu, rtol=1e-5, atol=1e-6)
+    assert np.allclose(RV.get(), rv0 * (1 - mom) + mom * var, rtol=2e-4)
+    DX, DW, DB = hip.empty((rows, cols)), hip.from_numpy(np.ones(cols, np.float32)), hip.zeros((cols,), np.float32)
+    L.call("pdn_colnorm_bwd_f32", X._ptr, W._ptr, MU._ptr, RS._ptr, DY._ptr, DX._ptr, DW._ptr, DB._ptr, 1, rows,
+           cols, ws, wsb, hip.stream())
+    g = dy.astype(np.float64)
+    xh32 = (x64 - MU.get()) * RS.get()                    # the statistics the kernel actually used
+    sdb, sdw = g.sum(0), (g * xh32).sum(0)
+    assert np.allclose(DB.get(), sdb, rtol=1e-4, atol=1e-3)
+    assert np.allclose(DW.get(), 1 + sdw, rtol=1e-4, atol=2e-3)
+    dx = w * RS.get() * (g - sdb / rows - xh32 * (sdw / rows))
+    assert np.allclose(DX.get(), dx, rtol=1e-3, atol=1e-4)
+
+
+def test_gru_gate_kernels(hip):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(22)
+    B, H = 1568, 32
+    g1 = (rng.standard_normal((B, 2 * H)) * 3).astype(np.float32)
+    g2 = (rng.standard_normal((B, H)) * 3).astype(np.float32)
+    h = rng.standard_normal((B, H)).astype(np.float32)
+    dhn, drh = rng.standard_normal((B, H)).astype(np.float32), rng.standard_normal((B, H)).astype(np.float32)
+    G1, G2, Hh, DHN, DRH = map(hip.from_numpy, (g1, g2, h, dhn, drh))
+    Z, R, RH, N, HN = (hip.empty((B, H)) for _ in range(5))
+    L.call("pdn_gru_gates_fwd_f32", G1._ptr, Hh._ptr, Z._ptr, R._ptr, RH._ptr, B, H, hip.stream())
+    L.call("pdn_gru_out_fwd_f32", G2._ptr, Z._ptr, Hh._ptr, N._ptr, HN._ptr, B, H, hip.stream())
+    sig = lambda t: 1 / (1 + np.exp(-t.astype(np.float64)))
+    z, r, n = sig(g1[:, :H]), sig(g1[:, H:]), np.tanh(g2.astype(np.float64))
+    assert np.allclose(Z.get(), z, rtol=1e-5, atol=1e-7) and np.allclose(R.get(), r, rtol=1e-5, atol=1e-7)
+    assert np.allclose(RH.get(), r * h, rtol=1e-5, atol=1e-6)
+    assert np.allclose(N.get(), n, rtol=1e-5, atol=1e-6)
+    assert np.allclose(HN.get(), (1 - z) * h + z * n, rtol=1e-5, atol=1e-6)
+    DG2, DG1, DH = hip.empty((B, H)), hip.empty((B, 2 * H)), hip.empty((B, H))
+    L.call("pdn_gru_out_bwd_f32", DHN._ptr, Z._ptr, N._ptr, Hh._ptr, DG2._ptr, DG1._ptr, DH._ptr, B, H, hip.stream())
+    L.call("pdn_gru_gates_bwd_f32", DRH._ptr, R._ptr, Hh._ptr, DG1._ptr, DH._ptr, B, H, hip.stream())
+    assert np.allclose(DG2.get(), dhn * z * (1 - n * n), rtol=1e-4, atol=1e-6)
+    assert np.allclose(DG1.get()[:, :H], dhn * (n - h) * z * (1 - z), rtol=1e-4, atol=1e-6)
+    assert np.allclose(DG1.get()[:, H:], drh * h * r * (1 - r), rtol=1e-4, atol=1e-6)
+    assert np.allclose(DH.get(), dhn * (1 - z) + drh * r, rtol=1e-4, atol=1e-6)
