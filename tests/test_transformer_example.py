@@ -1,0 +1,73 @@
+"""the reference's 1-layer Transformer example (CoLA shape) on this backend, against
+vectors produced by the REAL reference running the same model definition (tests/models_transformer.py,
+tools/gen_golden.py::gen_transformer).  Pins the reference-semantics LayerNorm (leading-axis statistics,
+running averages used in eval), the in-place padding-mask edit under no_grad and Embedding(padding_idx)."""
+import os
+
+import numpy as np
+
+import pydynet_amd as pdn
+import pydynet_amd.nn as nn
+import pydynet_amd.nn.functional as F
+from pydynet_amd.core.tensor import Graph
+from pydynet_amd.optim import Adam
+from tests import models_transformer as mt
+from tests.conftest import device_variants
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+RT = 1e-4
+
+
+def _host(a):
+    return a if isinstance(a, np.ndarray) else a.get()
+
+
+def _run(dev):
+    d = np.load(os.path.join(G, "transformer_example.npz"))
+    Graph.clear()
+    Transformer, loss_fn = mt.build(pdn, nn, F)
+    c = mt.CFG
+    ids, labels, emb = mt.make_inputs()
+    np.random.seed(11)
+    net = Transformer(c["embed"], c["layers"], c["heads"], c["expansion"], c["vocab"], c["max_len"])
+    net.word_embedding.weight.data[...] = emb
+    net.to(dev)
+    opt = Adam(net.parameters(), lr=c["lr"])
+    net.train()
+    losses = []
+    for s in range(c["steps"]):
+        loss = loss_fn(net, pdn.Tensor(ids, device=dev), pdn.Tensor(labels, device=dev))
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+        if s == 0:
+            for n, p in net._parameters.items():
+                if p.requires_grad:
+                    g = _host(p.grad)
+                    ref = float(d[f"gnorm/{n}"])
+                    assert abs(float(np.linalg.norm(g.astype(np.float64))) - ref) <= RT * ref + 1e-6, n
+                    if f"grad1/{n}" in d.files:            # 1e-4 relative error (north_star), norm-wise
+                        r = d[f"grad1/{n}"].astype(np.float64)
+                        assert np.linalg.norm(g - r) <= RT * np.linalg.norm(r) + 1e-6, n
+    assert np.allclose(losses, d["losses"], rtol=RT), (losses, d["losses"])
+    for n, p in net._parameters.items():
+        if f"final/{n}" in d.files:                                   # running statistics of both norms
+            assert np.allclose(_host(p.data), d[f"final/{n}"], rtol=RT, atol=1e-5), n
+        ref = float(d[f"pnorm/{n}"])
+        assert abs(float(np.linalg.norm(_host(p.data).astype(np.float64))) - ref) <= RT * ref + 1e-6, n
+    net.eval()
+    with pdn.no_grad():
+        t = pdn.Tensor(ids, device=dev)
+        out = net(t, pdn.unsqueeze(t.eq(0), (1, 2)).astype(np.float32))
+    pdn.autograd.set_grad_enabled(True)
+    assert np.allclose(_host(out.data), d["eval_out"], rtol=RT, atol=1e-5)
+
+
+def test_transformer_example_cpu():
+    _run("cpu")
+
+
+def check_transformer_example(dev):
+    _run(dev)
+
+
+device_variants(globals(), check_transformer_example)

@@ -333,6 +333,46 @@ def gen_mlp_lenet():
     np.savez_compressed(os.path.join(OUT, "mlp_lenet.npz"), **d)
 
 
+def gen_transformer():
+    """The CoLA-shaped 1-layer Transformer (examples/pydynet/transformer.py) on the real reference:
+    pins leading-axis LayerNorm with running statistics, the in-place padding mask and
+    Embedding(padding_idx)."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import models_transformer as mt
+    fresh()
+    Transformer, loss_fn = mt.build(pdn, nn, F)
+    c = mt.CFG
+    ids, labels, emb = mt.make_inputs()
+    np.random.seed(11)
+    net = Transformer(c["embed"], c["layers"], c["heads"], c["expansion"], c["vocab"], c["max_len"])
+    net.word_embedding.weight.data[...] = emb
+    opt = Adam(net.parameters(), lr=c["lr"])
+    d, losses = {}, []
+    net.train()
+    for s in range(c["steps"]):
+        loss = loss_fn(net, pdn.Tensor(ids), pdn.Tensor(labels))
+        opt.zero_grad(); loss.backward(); opt.step()
+        losses.append(loss.item())
+        if s == 0:
+            for n, p in net._parameters.items():
+                if p.requires_grad:
+                    d[f"gnorm/{n}"] = np.float64(np.linalg.norm(p.grad.astype(np.float64)))
+                    if p.grad.size <= 5000:
+                        d[f"grad1/{n}"] = p.grad.copy()
+    d["losses"] = np.array(losses)
+    for n, p in net._parameters.items():
+        if "running" in n:
+            d[f"final/{n}"] = p.data.copy()
+        d[f"pnorm/{n}"] = np.float64(np.linalg.norm(p.data.astype(np.float64)))
+    net.eval()
+    with pdn.no_grad():
+        mask = pdn.unsqueeze(pdn.Tensor(ids).eq(0), (1, 2)).astype(np.float32)
+        d["eval_out"] = net(pdn.Tensor(ids), mask).data.copy()        # eval mode: running statistics
+    pdn.autograd.set_grad_enabled(True)
+    print("transformer", losses)
+    np.savez_compressed(os.path.join(OUT, "transformer_example.npz"), **d)
+
+
 def gen_autograd2d():
     """examples/pydynet/autograd2d.py:5-33 (config 1): 30 GD steps on 0.5 x^T A x + b^T x."""
     fresh()
@@ -351,7 +391,7 @@ def gen_autograd2d():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d()
+    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer()
     gen_full_llama()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
