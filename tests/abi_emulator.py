@@ -360,10 +360,10 @@ class EmulatedLib:
     def pdn_colnorm_workspace_bytes(self, rows, cols): return ((rows + 255) // 256 * 2 + 2) * cols * 4
 
     def pdn_colnorm_fwd_f32(self, x, w, b, y, mean, rstd, rmean, rvar, momentum, eps, rows, cols, ws, wsb, stream):
-        a = np.array(flat(x, rows * cols).reshape(rows, cols))
+        a = np.array(flat(x, rows * cols).reshape(rows, cols)).astype(np.float64)   # idealised statistics
         mu = a.mean(0)
         var = np.square(a - mu).mean(0)
-        rs = (1.0 / np.sqrt(var + np.float32(eps))).astype(np.float32)
+        rs = 1.0 / np.sqrt(var + eps)
         flat(mean, cols)[...] = mu
         flat(rstd, cols)[...] = rs
         flat(y, rows * cols).reshape(rows, cols)[...] = (a - mu) * rs * flat(w, cols) + flat(b, cols)

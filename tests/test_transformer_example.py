@@ -52,8 +52,10 @@ def _run(dev):
     for n, p in net._parameters.items():
         if f"final/{n}" in d.files:                                   # running statistics of both norms
             assert np.allclose(_host(p.data), d[f"final/{n}"], rtol=RT, atol=1e-5), n
+        # parameters after 3 Adam steps: an entry whose gradient is at round-off level moves by +-lr
+        # in either direction (u = lr * g / (|g| + eps)), so norms are held to 1e-3 only
         ref = float(d[f"pnorm/{n}"])
-        assert abs(float(np.linalg.norm(_host(p.data).astype(np.float64))) - ref) <= RT * ref + 1e-6, n
+        assert abs(float(np.linalg.norm(_host(p.data).astype(np.float64))) - ref) <= 1e-3 * ref + 1e-6, n
     net.eval()
     with pdn.no_grad():
         t = pdn.Tensor(ids, device=dev)
