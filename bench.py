@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "128")), help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-prof", action="store_true")
     args = ap.parse_args()

@@ -6,7 +6,7 @@
 # Summaries worth keeping are copied into profiles/ by hand (gpurun_out/ is scratch).
 set -u
 TAG=${1:-r01}
-B=${2:-64}
+B=${2:-256}
 R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
