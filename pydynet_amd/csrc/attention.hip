@@ -92,7 +92,9 @@ __device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __r
   }
 }
 
-template <int HD>
+// ABLATE (tools/micro/attn_ablate.hip only; 0 in the library): 1 = no K/V staging, 2 = no S^T MFMAs,
+// 4 = no softmax arithmetic, 8 = no PV MFMAs, 16 = no output store -- timing experiments, wrong results.
+template <int HD, int ABLATE = 0>
 __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   const float* Qb = Q + base;
   float* Ob = O + base;
 
-  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS, true, false);
+  if (!(ABLATE & 1)) att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS, true, false);
   __syncthreads();
 
   const int ntile = L / 32;
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      if (kt < nk) {
+      if (kt < nk && !(ABLATE & 2)) {
         const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
 #pragma unroll
         for (int t = 0; t < NT8; ++t) {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-      if (kt < nk) {
+      if (kt < nk && !(ABLATE & 4)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float v = s[kt][r] * inv_sqrt;   // (x * (1/sqrt(hd)): within 1 ulp of the reference division)
@@ -171,7 +173,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-      if (kt < nk) {
+      if (kt < nk && !(ABLATE & 4)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = __expf(s[kt][r] - m);
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     const bool hi_ok = (32 + li) < HD;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-      if (kt < nk) {
+      if (kt < nk && !(ABLATE & 8)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float* vrow = Vs + (kt * 32 + att_krow(r, lh)) * LD;
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     if (lh == 0) LSE[(int64_t)bh * L + qpos] = m + logf(l);
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
-    for (int u = lane; u < 32 * F4; u += 64) {
+    for (int u = lane; u < 32 * F4 && !(ABLATE & 16); u += 64) {
       const int row = u / F4, c4 = u % F4;
       *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * row_stride + 4 * c4) =
           *reinterpret_cast<const float4*>(Ow + row * LD + 4 * c4);
