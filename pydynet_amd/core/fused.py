@@ -125,7 +125,9 @@ class linear(_Operator):
             need_db = False
         # bias gradient = column sums of g: formed inside the dW GEMM (both read g once) when the
         # operands have the aligned x^T @ g layout and the leaf buffers can be accumulated into
-        fuse_db = (need_db and w.requires_grad and _is_leaf_f32(b) and x2.is_contiguous()
+        # (fusing costs ~25 % of the dW GEMM, a separate pass over g one read of it: the fusion only
+        # pays for short contractions, fin < ~8 * MFMA rate / HBM rate ~ 192)
+        fuse_db = (need_db and w.requires_grad and _is_leaf_f32(b) and x2.is_contiguous() and fin < 192
                    and fin % 4 == 0 and fout % 4 == 0 and x2.shape[0] % 4 == 0)
         if w.requires_grad:
             cs = b.grad.reshape(-1) if fuse_db else None
