@@ -142,6 +142,10 @@ int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const 
                           int causal, const float* rope_cos, const float* rope_sin, void* workspace,
                           int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = rowsum(dO * O) */
+/* Decode step (model.py:105-121 in eval mode, L = 1): q, o (B, H, head_dim); the new token attends to
+ * positions [0, T) of the KV cache (max_batch, max_len, H, head_dim); no mask. */
+int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* v_cache, float* o, int B,
+                             int H, int T, int head_dim, int64_t cache_batch_stride, void* stream);
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
 

@@ -544,3 +544,83 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
+
+// ======================================================================================
+// Decode attention (llm/llama/model.py:105-121 in eval mode, one new token per sequence): the query
+// (B, 1, H, hd) against the first T positions of the KV cache (max_batch, max_len, H, hd), no mask
+// (L = 1).  One 256-thread workgroup per (batch, head): scores to LDS, block max / sum, then the
+// probability-weighted sum of the value rows.  Tiny and latency-bound; it replaces two batched GEMMs,
+// a softmax and the cache slicing of the generic path.
+// ======================================================================================
+__global__ __launch_bounds__(256) void attention_decode_kernel(const float* __restrict__ q, const float* __restrict__ kc,
+                                                               const float* __restrict__ vc, float* __restrict__ o,
+                                                               int H, int T, int hd, int64_t cache_batch_stride,
+                                                               float inv_sqrt) {
+  extern __shared__ __attribute__((aligned(16))) float sc[];      // [T] scores, then [21][hd] partial sums
+  __shared__ float red[16];
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const int D = H * hd, f4 = hd / 4;
+  const float4* q4 = reinterpret_cast<const float4*>(q + ((int64_t)b * H + h) * hd);
+  const float* kb = kc + (int64_t)b * cache_batch_stride + (int64_t)h * hd;
+  const float* vb = vc + (int64_t)b * cache_batch_stride + (int64_t)h * hd;
+  float m = -INFINITY;
+  for (int t = tid; t < T; t += 256) {
+    const float4* k4 = reinterpret_cast<const float4*>(kb + (int64_t)t * D);
+    float s = 0.f;
+    for (int c = 0; c < f4; ++c) {
+      const float4 a = q4[c], k = k4[c];
+      s += (a.x * k.x + a.y * k.y) + (a.z * k.z + a.w * k.w);
+    }
+    s *= inv_sqrt;
+    sc[t] = s;
+    m = fmaxf(m, s);
+  }
+  m = block_max(m, red);
+  float l = 0.f;
+  for (int t = tid; t < T; t += 256) {
+    const float pr = expf(sc[t] - m);
+    sc[t] = pr;
+    l += pr;
+  }
+  l = block_sum(l, red);                 // (its barriers also publish the probabilities)
+  // weighted sum of V rows: thread = (key group tg, float4 column c)
+  const int groups = 256 / f4, c = tid % f4, tg = tid / f4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tg < groups) {
+    for (int t = tg; t < T; t += groups) {
+      const float pr = sc[t];
+      const float4 v = *reinterpret_cast<const float4*>(vb + (int64_t)t * D + 4 * c);
+      acc.x += pr * v.x; acc.y += pr * v.y; acc.z += pr * v.z; acc.w += pr * v.w;
+    }
+  }
+  __syncthreads();                       // scores are dead: reuse the buffer for the partial sums
+  float4* part = reinterpret_cast<float4*>(sc);
+  if (tg < groups) part[tg * f4 + c] = acc;
+  __syncthreads();
+  if (tid < f4) {
+    float4 r = part[tid];
+    for (int g = 1; g < groups; ++g) { const float4 t = part[g * f4 + tid]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    const float inv = 1.f / l;
+    r.x *= inv; r.y *= inv; r.z *= inv; r.w *= inv;
+    reinterpret_cast<float4*>(o + ((int64_t)b * H + h) * hd)[tid] = r;
+  }
+}
+
+// q, o: (B, H, head_dim) contiguous; k_cache / v_cache: (max_batch, max_len, H, head_dim) with
+// `cache_batch_stride` floats between sequences; attends to positions [0, T).
+extern "C" int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* v_cache, float* o,
+                                        int B, int H, int T, int head_dim, int64_t cache_batch_stride,
+                                        void* stream) {
+  if (B == 0 || H == 0) return PDN_OK;
+  PDN_CHECK_ARG(q && k_cache && v_cache && o && T > 0, "pdn_attention_decode_f32: bad arguments");
+  PDN_CHECK_ARG(head_dim % 4 == 0 && head_dim <= 256 && (cache_batch_stride % 4) == 0 &&
+                    ((((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)o) & 15) == 0),
+                "pdn_attention_decode_f32: head_dim %% 4, 16-byte alignment required");
+  const int f4 = head_dim / 4, groups = 256 / f4;
+  const size_t shm = sizeof(float) * (size_t)(T > groups * head_dim ? T : groups * head_dim);
+  PDN_CHECK_ARG(shm <= 64 * 1024, "pdn_attention_decode_f32: T=%d too long", T);
+  hipLaunchKernelGGL(attention_decode_kernel, dim3(B * H), dim3(256), shm, (hipStream_t)stream, q, k_cache,
+                     v_cache, o, H, T, head_dim, cache_batch_stride, 1.f / sqrtf((float)head_dim));
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

@@ -943,6 +943,54 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_tn_stream_dma_kernel(GemmPara
   }
 }
 
+// ======================================================================================
+// Skinny product for the decode path: C (MR x N) = A (MR x K, rows contiguous) * B (K x N,
+// N-contiguous), MR <= 4 (one token per sequence).  Pure weight streaming: a workgroup owns 128
+// columns (32 float4 lanes) x 8 k-slices, every lane walks its slice of the K rows with 16-byte
+// loads, the slices are combined through LDS in a fixed order.  No MFMA: 2*MR flops per weight.
+// ======================================================================================
+template <int MR>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmParams p) {
+  __shared__ float4 red[8][MR][32];
+  const int tx = threadIdx.x & 31, ks = threadIdx.x >> 5;
+  const int n = blockIdx.x * 128 + tx * 4;
+  float4 acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) acc[m] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n < p.N) {
+    const float* __restrict__ bp = p.B + n;
+#pragma unroll 4
+    for (int k = ks; k < p.K; k += 8) {
+      const float4 w = *reinterpret_cast<const float4*>(bp + (int64_t)k * p.b_rs);
+#pragma unroll
+      for (int m = 0; m < MR; ++m) {
+        const float a = p.A[(int64_t)m * p.a_rs + k];
+        acc[m].x += a * w.x; acc[m].y += a * w.y; acc[m].z += a * w.z; acc[m].w += a * w.w;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MR; ++m) red[ks][m][tx] = acc[m];
+  __syncthreads();
+  if (ks == 0 && n < p.N) {
+#pragma unroll
+    for (int m = 0; m < MR; ++m) {
+      float4 v = red[0][m][tx];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) {
+        const float4 t = red[q][m][tx];
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      v.x *= p.alpha; v.y *= p.alpha; v.z *= p.alpha; v.w *= p.alpha;
+      float* dst = p.C + (int64_t)m * p.ldc + n;
+      if (p.bias) { const float4 b = *reinterpret_cast<const float4*>(p.bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+      if (p.residual) { const float4 r = *reinterpret_cast<const float4*>(p.residual + (int64_t)m * p.ldc + n); v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w; }
+      if (p.beta != 0.f) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += p.beta * o.x; v.y += p.beta * o.y; v.z += p.beta * o.z; v.w += p.beta * o.w; }
+      *reinterpret_cast<float4*>(dst) = v;
+    }
+  }
+}
+
 // ---- host side ----------------------------------------------------------------------
 struct TileCfg {
   int waves_m, waves_n, wm, wn, bk;
@@ -1062,6 +1110,19 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       pdn_set_error("pdn_gemm_f32: b_colsum needs the x^T @ g layout (A m-contiguous, B n-contiguous, aligned, unbatched)");
       return PDN_EUNSUPPORTED;
     }
+  }
+  // ---- one to four output rows (decode): stream the weight matrix once ----------------------
+  if (M <= 4 && nbatch == 1 && !b_colsum && b_cs == 1 && a_cs == 1 && m4(N) && m4(b_rs) && m4(ldc) &&
+      al16(B) && al16(C) && (!bias || al16(bias)) && (!residual || al16(residual)) && K > 0) {
+    const dim3 g((N + 127) / 128);
+    switch (M) {
+      case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), g, dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((gemm_skinny_kernel<2>), g, dim3(256), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((gemm_skinny_kernel<3>), g, dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((gemm_skinny_kernel<4>), g, dim3(256), 0, st, p); break;
+    }
+    PDN_LAUNCH_CHECK();
+    return PDN_OK;
   }
   const int64_t ws_cap = (workspace && workspace_bytes > 0) ? workspace_bytes / 4 : 0;
   // ---- weight-gradient form (small output, long K): wave-streaming kernel --------------------

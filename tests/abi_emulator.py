@@ -345,6 +345,17 @@ class EmulatedLib:
         DK[...] = self._rot(np.matmul(ds.swapaxes(-1, -2), Q), rc, rsn, L, hd, -1.0)
         return 0
 
+    def pdn_attention_decode_f32(self, q, kc, vc, o, B, H, T, hd, cbs, stream):
+        D = H * hd
+        Q = flat(q, B * D).reshape(B, H, hd)
+        K = view(kc, (B, T, H, hd), (cbs, D, hd, 1), np.float32)
+        V = view(vc, (B, T, H, hd), (cbs, D, hd, 1), np.float32)
+        s = np.einsum("bhd,bthd->bht", Q, K) / np.float32(math.sqrt(hd))
+        e = np.exp(s - s.max(-1, keepdims=True))
+        pr = e / e.sum(-1, keepdims=True)
+        flat(o, B * D).reshape(B, H, hd)[...] = np.einsum("bht,bthd->bhd", pr, V)
+        return 0
+
     def pdn_cross_entropy_colsum_workspace_bytes(self, rows, V):
         return 256 * V * 4 if (V >= 4096 and V % 4 == 0 and V <= 32768 and rows > 0) else 0
 
