@@ -157,17 +157,21 @@ def main():
                        "note": "exposed = compute-stream time blocked in DataParallel.finish(); the rest overlaps backward"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
-    if world > 1 or force_dp:
-        torch.distributed.destroy_process_group()
+    # RCCL writes a version banner through C stdio (block-buffered when piped): every rank pushes its
+    # own out, then all ranks meet, and only then rank 0 prints -- the JSON record stays the last line
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if world > 1:
+        torch.distributed.barrier()
     if rank == 0:
-        # RCCL writes a version banner through C stdio (block-buffered when piped): push it out first
-        # so that the JSON record is the last line of stdout
-        import ctypes
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
         print(json.dumps(out), flush=True)
+    if world > 1 or force_dp:
+        torch.distributed.barrier() if world > 1 else None
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":
