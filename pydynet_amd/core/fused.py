@@ -868,3 +868,91 @@ class col_norm(_Operator):
         if shift.requires_grad and not direct_b:
             grads[2] = db.reshape(shift.shape)
         return grads
+
+
+class gru_sequence(_Operator):
+    """A whole single-layer GRU over T steps as ONE tape node (nn/modules/rnn.py:537-544, 640-694):
+    the input projections of all steps are hoisted into two GEMMs over (T*B, in); each step then costs
+    two (B, H) x (H, .) GEMMs (the hoisted term rides in as the epilogue residual) and the two gate
+    kernels; backward walks the steps in reverse with five launches each and forms every weight
+    gradient with ONE long-K GEMM over the stacked per-step quantities.  The reference runs ~20 tape
+    nodes per step.  Inputs: x (T, B, in), h0 (B, H), Wx1, Wh1, Wx2, Wh2[, b1, b2]; output (T, B, H)."""
+
+    def __init__(self, x, h0, wx1, wh1, wx2, wh2, b1=None, b2=None):
+        self.has_bias = b1 is not None
+        super().__init__(*((x, h0, wx1, wh1, wx2, wh2) + ((b1, b2) if self.has_bias else ())))
+
+    def forward_(self, x, h0, wx1, wh1, wx2, wh2, b1=None, b2=None):
+        if self.xp is np:
+            raise NotImplementedError("gru_sequence is the HIP fused path")
+        hp, L = _hip(), _L()
+        T, B, I = x.shape
+        H = h0.shape[-1]
+        x2 = _contig(x.data).reshape(T * B, I)
+        g1x, g2x = hp.empty((T, B, 2 * H), np.float32), hp.empty((T, B, H), np.float32)
+        hp.gemm(x2, wx1.data, g1x.reshape(T * B, 2 * H), bias=b1.data.reshape(-1) if b1 is not None else None)
+        hp.gemm(x2, wx2.data, g2x.reshape(T * B, H), bias=b2.data.reshape(-1) if b2 is not None else None)
+        out = hp.empty((T, B, H), np.float32)
+        Z, R, RH, N = (hp.empty((T, B, H), np.float32) for _ in range(4))
+        g1, g2 = hp.empty((B, 2 * H), np.float32), hp.empty((B, H), np.float32)
+        h0d = _contig(h0.data)
+        hprev, st = h0d, hp.stream()
+        for t in range(T):
+            hp.gemm(hprev, wh1.data, g1, residual=g1x[t])
+            L.call("pdn_gru_gates_fwd_f32", g1._ptr, hprev._ptr, Z[t]._ptr, R[t]._ptr, RH[t]._ptr, B, H, st)
+            hp.gemm(RH[t], wh2.data, g2, residual=g2x[t])
+            o_t = out[t]
+            L.call("pdn_gru_out_fwd_f32", g2._ptr, Z[t]._ptr, hprev._ptr, N[t]._ptr, o_t._ptr, B, H, st)
+            hprev = o_t
+        self._saved = (x2, h0d, Z, R, RH, N)
+        return out
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, h0, wx1, wh1, wx2, wh2 = self.last[:6]
+        b1, b2 = (self.last[6], self.last[7]) if self.has_bias else (None, None)
+        x2, h0d, Z, R, RH, N = self._saved
+        T, B, H = Z.shape
+        I = x2.shape[1]
+        g = _contig(g)
+        out, st = self.data, hp.stream()
+        dG1, dG2 = hp.empty((T, B, 2 * H), np.float32), hp.empty((T, B, H), np.float32)
+        dh, dh2, drh = hp.zeros((B, H), np.float32), hp.empty((B, H), np.float32), hp.empty((B, H), np.float32)
+        for t in range(T - 1, -1, -1):
+            hprev = out[t - 1] if t > 0 else h0d
+            dh += g[t]                                                   # gradient of h_t: direct + from t+1
+            L.call("pdn_gru_out_bwd_f32", dh._ptr, Z[t]._ptr, N[t]._ptr, hprev._ptr, dG2[t]._ptr, dG1[t]._ptr,
+                   dh2._ptr, B, H, st)
+            hp.gemm(dG2[t], wh2.data.T, drh)
+            L.call("pdn_gru_gates_bwd_f32", drh._ptr, R[t]._ptr, hprev._ptr, dG1[t]._ptr, dh2._ptr, B, H, st)
+            hp.gemm(dG1[t], wh1.data.T, dh2, beta=1.0)
+            dh, dh2 = dh2, dh
+        grads = [None] * len(self.last)
+        if h0.requires_grad:
+            grads[1] = dh
+        d1, d2 = dG1.reshape(T * B, 2 * H), dG2.reshape(T * B, H)
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            hp.gemm(d1, wx1.data.T, dx.reshape(T * B, I))
+            hp.gemm(d2, wx2.data.T, dx.reshape(T * B, I), beta=1.0)
+            grads[0] = dx
+        hprev_all = hp.empty((T, B, H), np.float32)                      # h_{t-1} for every step, stacked
+        hprev_all[0] = h0d
+        if T > 1:
+            hprev_all[1:] = out[:T - 1]
+        stacked = ((x2, d1, wx1), (hprev_all.reshape(T * B, H), d1, wh1), (x2, d2, wx2), (RH.reshape(T * B, H), d2, wh2))
+        for idx, (a, d, w) in enumerate(stacked, start=2):
+            if not w.requires_grad:
+                continue
+            if _is_leaf_f32(w):
+                hp.gemm(a.T, d, w.grad, beta=1.0)
+            else:
+                dw = hp.empty(w.shape, np.float32)
+                hp.gemm(a.T, d, dw)
+                grads[idx] = dw
+        if self.has_bias:
+            if b1.requires_grad:
+                grads[6] = d1.sum(0).reshape(b1.shape)
+            if b2.requires_grad:
+                grads[7] = d2.sum(0).reshape(b2.shape)
+        return grads
