@@ -870,6 +870,14 @@ class col_norm(_Operator):
         return grads
 
 
+def _gemm_raw(L, st, M, N, K, a_ptr, a_rs, a_cs, b, c_ptr, ldc, beta=0.0, residual_ptr=None, b_transposed=False):
+    """pdn_gemm_f32 on raw pointers (time loops: skips the per-call view / workspace bookkeeping of
+    hipnp.gemm); `b` is a 2-D hipnp array, used as b or b.T."""
+    rs, cs = (b._strides[1], b._strides[0]) if b_transposed else (b._strides[0], b._strides[1])
+    L.call("pdn_gemm_f32", M, N, K, 1.0, a_ptr, a_rs, a_cs, b._ptr, rs, cs, beta, c_ptr, ldc, None, 1, 1,
+           0, 0, 0, 0, 0, 0, residual_ptr, None, 0, None, 0, st)
+
+
 class gru_sequence(_Operator):
     """A whole single-layer GRU over T steps as ONE tape node (nn/modules/rnn.py:537-544, 640-694):
     the input projections of all steps are hoisted into two GEMMs over (T*B, in); each step then costs
@@ -896,14 +904,17 @@ class gru_sequence(_Operator):
         Z, R, RH, N = (hp.empty((T, B, H), np.float32) for _ in range(4))
         g1, g2 = hp.empty((B, 2 * H), np.float32), hp.empty((B, H), np.float32)
         h0d = _contig(h0.data)
-        hprev, st = h0d, hp.stream()
+        st = hp.stream()
+        wh1d, wh2d = wh1.data, wh2.data
+        sH, s2H = B * H * 4, B * 2 * H * 4                           # bytes per time step
+        hprev = h0d._ptr
         for t in range(T):
-            hp.gemm(hprev, wh1.data, g1, residual=g1x[t])
-            L.call("pdn_gru_gates_fwd_f32", g1._ptr, hprev._ptr, Z[t]._ptr, R[t]._ptr, RH[t]._ptr, B, H, st)
-            hp.gemm(RH[t], wh2.data, g2, residual=g2x[t])
-            o_t = out[t]
-            L.call("pdn_gru_out_fwd_f32", g2._ptr, Z[t]._ptr, hprev._ptr, N[t]._ptr, o_t._ptr, B, H, st)
-            hprev = o_t
+            z, r, rh, n, o = Z._ptr + t * sH, R._ptr + t * sH, RH._ptr + t * sH, N._ptr + t * sH, out._ptr + t * sH
+            _gemm_raw(L, st, B, 2 * H, H, hprev, H, 1, wh1d, g1._ptr, 2 * H, residual_ptr=g1x._ptr + t * s2H)
+            L.call("pdn_gru_gates_fwd_f32", g1._ptr, hprev, z, r, rh, B, H, st)
+            _gemm_raw(L, st, B, H, H, rh, H, 1, wh2d, g2._ptr, H, residual_ptr=g2x._ptr + t * sH)
+            L.call("pdn_gru_out_fwd_f32", g2._ptr, z, hprev, n, o, B, H, st)
+            hprev = o
         self._saved = (x2, h0d, Z, R, RH, N)
         return out
 
@@ -918,14 +929,18 @@ class gru_sequence(_Operator):
         out, st = self.data, hp.stream()
         dG1, dG2 = hp.empty((T, B, 2 * H), np.float32), hp.empty((T, B, H), np.float32)
         dh, dh2, drh = hp.zeros((B, H), np.float32), hp.empty((B, H), np.float32), hp.empty((B, H), np.float32)
+        wh1d, wh2d = wh1.data, wh2.data
+        sH, s2H = B * H * 4, B * 2 * H * 4
         for t in range(T - 1, -1, -1):
-            hprev = out[t - 1] if t > 0 else h0d
-            dh += g[t]                                                   # gradient of h_t: direct + from t+1
-            L.call("pdn_gru_out_bwd_f32", dh._ptr, Z[t]._ptr, N[t]._ptr, hprev._ptr, dG2[t]._ptr, dG1[t]._ptr,
-                   dh2._ptr, B, H, st)
-            hp.gemm(dG2[t], wh2.data.T, drh)
-            L.call("pdn_gru_gates_bwd_f32", drh._ptr, R[t]._ptr, hprev._ptr, dG1[t]._ptr, dh2._ptr, B, H, st)
-            hp.gemm(dG1[t], wh1.data.T, dh2, beta=1.0)
+            hprev = out._ptr + (t - 1) * sH if t > 0 else h0d._ptr
+            z, r, n = Z._ptr + t * sH, R._ptr + t * sH, N._ptr + t * sH
+            dg1, dg2 = dG1._ptr + t * s2H, dG2._ptr + t * sH
+            # dh += g[t]: gradient of h_t = direct + from step t+1
+            dh += g[t]
+            L.call("pdn_gru_out_bwd_f32", dh._ptr, z, n, hprev, dg2, dg1, dh2._ptr, B, H, st)
+            _gemm_raw(L, st, B, H, H, dg2, H, 1, wh2d, drh._ptr, H, b_transposed=True)
+            L.call("pdn_gru_gates_bwd_f32", drh._ptr, r, hprev, dg1, dh2._ptr, B, H, st)
+            _gemm_raw(L, st, B, H, 2 * H, dg1, 2 * H, 1, wh1d, dh2._ptr, H, beta=1.0, b_transposed=True)
             dh, dh2 = dh2, dh
         grads = [None] * len(self.last)
         if h0.requires_grad:
