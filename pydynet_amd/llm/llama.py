@@ -5,8 +5,11 @@ Same constructor signature, same registered parameter names (`layers.{i}.attenti
 `layers.{i}.ffn.gate.weight`, `lm_head.bias`, ...), same construction order (so a seeded NumPy
 RNG yields the reference's initial weights), same `forward_logits / finetune_step / forward /
 generate` entry points.  What differs is the number of tape nodes per block: 62 in the
-reference, 12 here (rms_norm, 3x linear, 2x rope, attention, linear, add, rms_norm, 2x linear,
-swiglu, linear, add), each one HIP kernel or GEMM per direction.
+reference, 8 here on the training path (rms_norm, qkv_attention [3 projections + RoPE + causal
+attention], linear+residual, rms_norm, 2x linear, swiglu, linear+residual), each a handful of HIP
+kernels / GEMMs per direction; the separate linear / rope / attention nodes remain for shapes the
+fused attention kernels do not cover and for the KV-cache path, whose per-token step bypasses the
+tape altogether (`_decode_step_hip`).
 """
 import math
 
