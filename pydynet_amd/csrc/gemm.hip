@@ -26,7 +26,10 @@
 //   * XCD-aware tile order: each XCD walks a contiguous run of 8x8 super-tiles so the A and
 //     B panels it touches stay in its private 4 MiB L2;
 //   * split-K (workspace + deterministic reduce) when the output has too few tiles to
-//     fill 256 CUs (weight gradients: M,N ~ 288..768, K = tokens).
+//     fill 256 CUs.
+// Besides the tiled kernel this file holds the wave-streaming kernels for weight gradients
+// (small output, K = tokens: gemm_tn_stream_*), the skinny kernel for one to four output rows
+// (decode: gemm_skinny_kernel) and the host-side selection between them (pdn_gemm_f32).
 // f32 MFMA is an exact k-ordered fmaf chain, so results match a scalar fp32 dot product
 // in a different summation order only (tolerance documented in tests/).
 #include "common.h"
