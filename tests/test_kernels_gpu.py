@@ -544,3 +544,58 @@ def test_gru_gate_kernels(hip):
     assert np.allclose(DG1.get()[:, :H], dhn * (n - h) * z * (1 - z), rtol=1e-4, atol=1e-6)
     assert np.allclose(DG1.get()[:, H:], drh * h * r * (1 - r), rtol=1e-4, atol=1e-6)
     assert np.allclose(DH.get(), dhn * (1 - z) + drh * r, rtol=1e-4, atol=1e-6)
+
+
+def test_gemm_batched_weight_gradients_one_launch(hip):
+    # three x^T @ d_i products sharing x, written into equally spaced (descending) leaf buffers with
+    # beta = 1: the batched form of the wave-streaming kernel used by the fused QKV node
+    rng = np.random.default_rng(31)
+    T_, D = 4096 + 24, 96
+    x = rng.standard_normal((T_, D), dtype=np.float32)
+    d = rng.standard_normal((3, T_, D), dtype=np.float32)
+    g0 = rng.standard_normal((3, D, D), dtype=np.float32)
+    X, Dq = hip.from_numpy(x), hip.from_numpy(d)
+    flat = hip.from_numpy(g0.reshape(-1).copy())
+    views = [flat[(2 - i) * D * D:(3 - i) * D * D].reshape(D, D) for i in range(3)]   # descending addresses
+    stack = hip.stacked_view(views)
+    assert stack is not None and stack._strides[0] == -D * D
+    hip.gemm(X.T, Dq, stack, beta=1.0)
+    for i in range(3):
+        ref = g0[2 - i] + x.T.astype(np.float64) @ d[i].astype(np.float64)
+        assert rel_err(views[i].get(), ref) < 2e-5
+    assert hip.stacked_view([views[0], views[2]]) is not None and hip.stacked_view([views[0], views[1][:, :4]]) is None
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+def test_gemm_skinny_rows(hip, M):
+    rng = np.random.default_rng(40 + M)
+    K, N = 288, 32000
+    a = rng.standard_normal((M, K), dtype=np.float32)
+    w = rng.standard_normal((K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32)
+    c0 = rng.standard_normal((M, N), dtype=np.float32)
+    A, W, Bv = hip.from_numpy(a), hip.from_numpy(w), hip.from_numpy(bias)
+    ref = a.astype(np.float64) @ w.astype(np.float64)
+    C = hip.from_numpy(c0.copy())
+    hip.gemm(A, W, C, beta=1.0, bias=Bv)
+    assert rel_err(C.get(), ref + bias + c0) < 1e-5
+    C2 = hip.empty((M, N))
+    hip.gemm(A, W, C2, alpha=2.0, residual=hip.from_numpy(c0))
+    assert rel_err(C2.get(), 2 * ref + c0) < 1e-5
+
+
+@pytest.mark.parametrize("T_", [1, 7, 300, 1024])
+def test_attention_decode_kernel(hip, T_):
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(50 + T_)
+    B, H, hd, maxL = 2, 6, 48, 1024
+    q = rng.standard_normal((B, H, hd), dtype=np.float32)
+    kc = rng.standard_normal((B, maxL, H, hd), dtype=np.float32)
+    vc = rng.standard_normal((B, maxL, H, hd), dtype=np.float32)
+    Q, KC, VC, O = hip.from_numpy(q), hip.from_numpy(kc), hip.from_numpy(vc), hip.empty((B, H, hd))
+    L.call("pdn_attention_decode_f32", Q._ptr, KC._ptr, VC._ptr, O._ptr, B, H, T_, hd, maxL * H * hd, hip.stream())
+    s = np.einsum("bhd,bthd->bht", q.astype(np.float64), kc[:, :T_].astype(np.float64)) / math.sqrt(hd)
+    p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
+    ref = np.einsum("bht,bthd->bhd", p, vc[:, :T_].astype(np.float64))
+    assert rel_err(O.get(), ref) < 1e-5
