@@ -36,6 +36,7 @@
 #include <vector>
 #include <mutex>
 #include <stdlib.h>
+#include <stdio.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1218,6 +1219,9 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       if (sp >= 1 && (sp == 1 || ((int64_t)sp * M * N * nbatch <= ws_cap && !b_colsum))) best_splits = sp;
     }
   }
+  if (getenv("PDN_GEMM_DEBUG"))
+    fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d nb=%d akin=%d bkin=%d vec=%d -> %s cfg=%d splits=%d\n", M, N, K, nbatch,
+            (int)a_kin, (int)b_kin, (int)vec, use_stream ? "stream" : "tiled", best, best_splits);
   const TileCfg& cfg = kCfgs[best];
   const int BM = cfg.waves_m * cfg.wm * 32, BN = cfg.waves_n * cfg.wn * 32;
   if (!use_stream) {
