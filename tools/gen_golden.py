@@ -373,6 +373,17 @@ def gen_transformer():
     np.savez_compressed(os.path.join(OUT, "transformer_example.npz"), **d)
 
 
+def gen_dropout_bn():
+    """examples/pydynet/dropout_bn.py: plain / Dropout / BatchNorm1d classifiers trained jointly."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import models_dropout_bn as md
+    fresh()
+    np.random.seed(42)
+    d = md.run(pdn, nn, F, Adam)
+    print("dropout_bn", d["losses"][-1])
+    np.savez_compressed(os.path.join(OUT, "dropout_bn.npz"), **d)
+
+
 def gen_autograd2d():
     """examples/pydynet/autograd2d.py:5-33 (config 1): 30 GD steps on 0.5 x^T A x + b^T x."""
     fresh()
@@ -391,7 +402,7 @@ def gen_autograd2d():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer()
+    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer(); gen_dropout_bn()
     gen_full_llama()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
