@@ -384,6 +384,19 @@ def gen_dropout_bn():
     np.savez_compressed(os.path.join(OUT, "dropout_bn.npz"), **d)
 
 
+def gen_ts_prediction():
+    """examples/pydynet/ts_prediction.py (GRU regressor) and autograd1d.py on the real reference."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import models_ts_prediction as mt
+    fresh()
+    np.random.seed(7)
+    d = mt.run(pdn, nn, Adam)
+    fresh()
+    d["autograd1d"] = mt.autograd1d(pdn)
+    print("ts_prediction", d["losses"], "autograd1d ->", d["autograd1d"][-1])
+    np.savez_compressed(os.path.join(OUT, "ts_prediction.npz"), **d)
+
+
 def gen_autograd2d():
     """examples/pydynet/autograd2d.py:5-33 (config 1): 30 GD steps on 0.5 x^T A x + b^T x."""
     fresh()
@@ -402,7 +415,7 @@ def gen_autograd2d():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer(); gen_dropout_bn()
+    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer(); gen_dropout_bn(); gen_ts_prediction()
     gen_full_llama()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
