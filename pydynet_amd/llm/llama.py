@@ -189,7 +189,7 @@ class Llama(nn.Module):
             if i == 0:
                 logits = self(input_ids, 0)                       # prompt pass: fills the KV caches
                 next_id = logits[:, -1, :].argmax(-1, True)
-            elif (Llama.fast_decode and B == 1 and next_id.device.is_hip and not self._train
+            elif (Llama.fast_decode and next_id.device.is_hip and not self._train
                   and self.lm_head.weight.dtype == np.float32 and (self.embed_dim // self.n_heads) % 4 == 0):
                 next_id = Tensor(self._decode_step_hip(next_id.data, pos), dtype=np.int64, device=next_id.device,
                                  copy=False)
@@ -199,49 +199,53 @@ class Llama(nn.Module):
 
     # -- decode fast path -----------------------------------------------------------
     def _decode_step_hip(self, ids, pos: int):
-        """One greedy decode step for a single sequence without building tape nodes: the same kernels
-        as the module path (RMSNorm, projections as skinny GEMMs writing k / v straight into their cache
-        slots, RoPE in place, decode attention over the cache, SwiGLU), ~77 launches from preallocated
-        buffers.  ids: (1, 1) int64 device array; returns the next id as a (1, 1) int64 device array."""
+        """One greedy decode step (one new token per sequence) without building tape nodes: the same
+        kernels as the module path (RMSNorm, projections as skinny GEMMs writing k / v straight into
+        their cache slots, RoPE in place, decode attention over the cache, SwiGLU), ~77 launches from
+        preallocated buffers.  ids: (B, 1) int64 device array; returns the next ids, (B, 1) int64."""
         from .. import hipnp as hp, _lib
         L, st = _lib.lib(), hp.stream()
         D, H, F, V = self.embed_dim, self.n_heads, self.ffn_dim, self.vocab_size
         hd, half = D // H, D // H // 2
+        B = ids.shape[0]
         ws = getattr(self, "_decode_ws", None)
-        if ws is None or ws["x"].device_index != hp._state["device"]:
-            ws = {n: hp.empty((1, w), np.float32) for n, w in
+        if ws is None or ws["x"].device_index != hp._state["device"] or ws["x"].shape[0] != B:
+            ws = {n: hp.empty((B, w), np.float32) for n, w in
                   (("x", D), ("h", D), ("q", D), ("att", D), ("g", F), ("u", F), ("sw", F), ("logits", V))}
             self._decode_ws = ws
         x, h, q, att, g, u, sw, logits = (ws[n]._ptr for n in ("x", "h", "q", "att", "g", "u", "sw", "logits"))
 
-        def gemv(a_ptr, K, w, c_ptr, N, beta=0.0, bias=None):
+        def gemv(a_ptr, K, w, c_ptr, N, beta=0.0, bias=None, ldc=None):
             wd = w.data
-            L.call("pdn_gemm_f32", 1, N, K, 1.0, a_ptr, K, 1, wd._ptr, wd._strides[0], wd._strides[1], beta, c_ptr, N,
-                   bias, 1, 1, 0, 0, 0, 0, 0, 0, None, None, 0, None, 0, st)
+            L.call("pdn_gemm_f32", B, N, K, 1.0, a_ptr, K, 1, wd._ptr, wd._strides[0], wd._strides[1], beta, c_ptr,
+                   N if ldc is None else ldc, bias, 1, 1, 0, 0, 0, 0, 0, 0, None, None, 0, None, 0, st)
 
         emb = self.tok_embedding.weight.data
-        L.call("pdn_embedding_gather_f32", emb._ptr, V, D, emb._strides[0], ids._ptr, 1, x, hp._err_flag().data_ptr(), st)
+        idc = ids if ids.is_contiguous() else ids.copy()
+        L.call("pdn_embedding_gather_f32", emb._ptr, V, D, emb._strides[0], idc._ptr, B, x, hp._err_flag().data_ptr(), st)
         cos = self.freqs_cos.data._ptr + pos * half * 4
         sin = self.freqs_sin.data._ptr + pos * half * 4
         for layer in self.layers:
             a, f = layer.attention, layer.ffn
             ck, cv = a.cache_k.data, a.cache_v.data
-            kslot, vslot = ck._ptr + pos * D * 4, cv._ptr + pos * D * 4
-            L.call("pdn_rmsnorm_fwd_f32", x, layer.input_norm.weight.data._ptr, h, None, 1, D, layer.input_norm.eps, st)
+            cbs = ck._strides[0]                                          # floats between sequences in the cache
+            kslot, vslot = ck._ptr + pos * D * 4, cv._ptr + pos * D * 4   # row b of the slot is cbs floats further
+            L.call("pdn_rmsnorm_fwd_f32", x, layer.input_norm.weight.data._ptr, h, None, B, D, layer.input_norm.eps, st)
             gemv(h, D, a.Q.weight, q, D)
-            gemv(h, D, a.K.weight, kslot, D)
-            gemv(h, D, a.V.weight, vslot, D)
-            L.call("pdn_rope_f32", q, cos, sin, q, 1, 1, H, hd, 0, st)
-            L.call("pdn_rope_f32", kslot, cos, sin, kslot, 1, 1, H, hd, 0, st)
-            L.call("pdn_attention_decode_f32", q, ck._ptr, cv._ptr, att, 1, H, pos + 1, hd, ck._strides[0], st)
+            gemv(h, D, a.K.weight, kslot, D, ldc=cbs)
+            gemv(h, D, a.V.weight, vslot, D, ldc=cbs)
+            L.call("pdn_rope_f32", q, cos, sin, q, B, 1, H, hd, 0, st)
+            for b in range(B):
+                L.call("pdn_rope_f32", kslot + b * cbs * 4, cos, sin, kslot + b * cbs * 4, 1, 1, H, hd, 0, st)
+            L.call("pdn_attention_decode_f32", q, ck._ptr, cv._ptr, att, B, H, pos + 1, hd, cbs, st)
             gemv(att, D, a.O.weight, x, D, beta=1.0)                      # x += att @ Wo
-            L.call("pdn_rmsnorm_fwd_f32", x, layer.post_attn_norm.weight.data._ptr, h, None, 1, D,
+            L.call("pdn_rmsnorm_fwd_f32", x, layer.post_attn_norm.weight.data._ptr, h, None, B, D,
                    layer.post_attn_norm.eps, st)
             gemv(h, D, f.gate.weight, g, F)
             gemv(h, D, f.up.weight, u, F)
-            L.call("pdn_swiglu_fwd_f32", g, u, sw, F, st)
+            L.call("pdn_swiglu_fwd_f32", g, u, sw, B * F, st)
             gemv(sw, F, f.down.weight, x, D, beta=1.0)                    # x += swiglu @ Wdown
-        L.call("pdn_rmsnorm_fwd_f32", x, self.norm.weight.data._ptr, h, None, 1, D, self.norm.eps, st)
+        L.call("pdn_rmsnorm_fwd_f32", x, self.norm.weight.data._ptr, h, None, B, D, self.norm.eps, st)
         gemv(h, D, self.lm_head.weight, logits, V,
              bias=self.lm_head.bias.data._ptr if getattr(self.lm_head, "bias", None) is not None else None)
         return ws["logits"].argmax(-1, keepdims=True)

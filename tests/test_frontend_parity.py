@@ -413,11 +413,11 @@ def check_decode_fast_path_matches_module_path(dev):
     from pydynet_amd.llm.llama import Llama
     Graph.clear()
     np.random.seed(21)
-    m = Llama(96, 96, 2, 128, 64, 1, 2, np.float32)
+    m = Llama(96, 96, 2, 128, 64, 3, 2, np.float32)
     m.tok_embedding.weight.data[...] = (0.5 * np.random.randn(96, 96)).astype(np.float32)
     m.to(dev)
     m.eval()
-    prompt = np.array([[5, 17, 3, 42, 9]])
+    prompt = np.array([[5, 17, 3, 42, 9], [1, 2, 3, 4, 5], [90, 80, 70, 60, 50]])     # three sequences
     outs = []
     try:
         with pdn.no_grad():
@@ -425,7 +425,7 @@ def check_decode_fast_path_matches_module_path(dev):
                 Llama.fast_decode = fast
                 ids, logits = [], []
                 for tok in m.generate(prompt, 5 + 12):
-                    ids.append(int(host(tok.data)[0, 0]))
+                    ids.append(host(tok.data)[:, 0].tolist())
                     if fast and hasattr(m, "_decode_ws"):
                         logits.append(host(m._decode_ws["logits"]).copy())
                 outs.append((ids, logits))
@@ -439,11 +439,11 @@ def check_decode_fast_path_matches_module_path(dev):
     with pdn.no_grad():
         m.eval()
         Llama.fast_decode = False
-        ref = m(pdn.Tensor(np.array([[outs[0][0][-2]]]), dtype=np.int64, device=dev), 5 + 12 - 1)   # last pos of range(5, 17)
+        ref = m(pdn.Tensor(np.array(outs[0][0][-2])[:, None], dtype=np.int64, device=dev), 5 + 12 - 1)   # last pos of range(5, 17)
         m.train(True)
         pdn.autograd.set_grad_enabled(True)
         Llama.fast_decode = True
-    assert np.allclose(host(ref.data)[0, -1], outs[1][1][-1][0], rtol=1e-4, atol=1e-5)
+    assert np.allclose(host(ref.data)[:, -1], outs[1][1][-1], rtol=1e-4, atol=1e-5)
 
 
 device_variants(globals(), check_decode_fast_path_matches_module_path)
