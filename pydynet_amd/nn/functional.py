@@ -74,8 +74,10 @@ def _as4d(x):
 
 
 def conv1d(x, kernel, padding: int = 0, stride: int = 1):
-    """1-D convolution expressed on the 2-D kernels: (N, C, F) -> (N, C, 1, F) is not square, so
-    this path uses the generic operators (window gather by slicing + matmul)."""
+    """1-D convolution on the generic operators (window gather by slicing + matmul).  Documented
+    deviation: the reference's conv1d contracts the output-position axis of its im2col buffer with the
+    kernel axis (`col @ kernel.transpose(1, 2, 0)`, nn/functional.py:139) and therefore raises for every
+    shape with n_output != kernel_size; this is the convolution that expression was meant to be."""
     N, C, F = x.shape
     O, _, k = kernel.shape
     if padding:
@@ -89,14 +91,19 @@ def conv1d(x, kernel, padding: int = 0, stride: int = 1):
 
 
 def _pool1d(x, kernel_size, stride, padding, reducer):
+    """Windows of the zero-padded input as (N, C, kernel_size, n_out) -- the reference's im2col1d layout
+    (nn/functional.py:61-84) -- reduced over the LAST axis exactly as the reference does
+    (`col.max(-1)` / `col.mean(-1)`, :165, :191).  Reference quirk kept for parity: that axis is the
+    output position, not the window, so the result is (N, C, kernel_size): entry j is the max / mean of
+    the j-th element of every window.  (The 2-D pooling reduces over the window as usual.)"""
     N, C, F = x.shape
     if padding:
         zeros = Tensor(np.zeros((N, C, padding)), dtype=x.dtype, device=x.device)
         x = tensor.concat([zeros, x, zeros], axis=2)
         F = F + 2 * padding
     n_out = (F - kernel_size) // stride + 1
-    cols = [function.unsqueeze(x[:, :, i:i + stride * (n_out - 1) + 1:stride], 3) for i in range(kernel_size)]
-    return reducer(tensor.concat(cols, axis=3))
+    cols = [function.unsqueeze(x[:, :, i:i + stride * (n_out - 1) + 1:stride], 2) for i in range(kernel_size)]
+    return reducer(tensor.concat(cols, axis=2))               # (N, C, k, n_out) -> (N, C, k)
 
 
 def max_pool1d(x, kernel_size, stride, padding=0):

@@ -1,15 +1,25 @@
-"""Learning-rate schedules (surface of pydynet/optim/lr_scheduler.py): host-side scalar logic
-that wraps `optimizer.step` with a step counter."""
+"""Learning-rate schedules with the reference's semantics (pydynet/optim/lr_scheduler.py): host-side
+scalar logic that wraps `optimizer.step` with a step counter; pinned by tests/test_misc_layers.py."""
 import math
 import weakref
+from collections import Counter
 from functools import wraps
 
 
 class _LRScheduler:
+    """Reference protocol (optim/lr_scheduler.py:16-88): `optimizer.initial_lr` is recorded, `optimizer.step`
+    is wrapped with a counter, the constructor performs the first `step()`; every `step()` advances
+    `last_epoch`, remembers the optimizer's current rate as `_last_lr` and installs `get_lr()`.
+    The update rules below are the reference's own -- each is applied to the CURRENT rate, so the
+    exponential and step schedules compound (lr_t = lr_{t-1} * gamma**t): parity keeps that."""
+
     def __init__(self, optimizer, last_epoch: int = -1) -> None:
         self.optimizer = optimizer
-        self.base_lr = optimizer.lr
         self.last_epoch = last_epoch
+        if last_epoch == -1:
+            optimizer.initial_lr = optimizer.lr
+        else:
+            assert hasattr(optimizer, "initial_lr"), "last_epoch=1 but no 'initial_lr' attribute in optimizer!"
         if not getattr(optimizer.step, "_with_counter", False):
             method = optimizer.step
             ref = weakref.ref(optimizer)
@@ -30,10 +40,15 @@ class _LRScheduler:
     def get_lr(self):
         raise NotImplementedError
 
+    def get_last_lr(self):
+        return self._last_lr
+
     def step(self):
         self._step_count += 1
         self.last_epoch += 1
-        self.optimizer.lr = self.get_lr()
+        lr = self.get_lr()
+        self._last_lr = self.optimizer.lr
+        self.optimizer.lr = lr
 
 
 class ExponentialLR(_LRScheduler):
@@ -41,8 +56,8 @@ class ExponentialLR(_LRScheduler):
         self.gamma = gamma
         super().__init__(optimizer, last_epoch)
 
-    def get_lr(self):
-        return self.optimizer.lr if self.last_epoch == 0 else self.optimizer.lr * self.gamma
+    def get_lr(self):                                           # lr_scheduler.py:100-101
+        return self.optimizer.lr * self.gamma ** self.last_epoch
 
 
 class StepLR(_LRScheduler):
@@ -50,19 +65,19 @@ class StepLR(_LRScheduler):
         self.step_size, self.gamma = step_size, gamma
         super().__init__(optimizer, last_epoch)
 
-    def get_lr(self):
-        if self.last_epoch == 0 or self.last_epoch % self.step_size != 0:
-            return self.optimizer.lr
-        return self.optimizer.lr * self.gamma
+    def get_lr(self):                                           # :116-118
+        return self.optimizer.lr * self.gamma ** (self.last_epoch // self.step_size)
 
 
 class MultiStepLR(_LRScheduler):
     def __init__(self, optimizer, milestones, gamma=0.1, last_epoch=-1):
-        self.milestones, self.gamma = set(milestones), gamma
+        self.milestones, self.gamma = Counter(milestones), gamma   # a repeated milestone counts twice
         super().__init__(optimizer, last_epoch)
 
-    def get_lr(self):
-        return self.optimizer.lr * self.gamma if self.last_epoch in self.milestones else self.optimizer.lr
+    def get_lr(self):                                           # :133-136
+        if self.last_epoch not in self.milestones:
+            return self.optimizer.lr
+        return self.optimizer.lr * self.gamma ** self.milestones[self.last_epoch]
 
 
 class CosineAnnealingLR(_LRScheduler):
@@ -70,5 +85,11 @@ class CosineAnnealingLR(_LRScheduler):
         self.T_max, self.eta_min = T_max, eta_min
         super().__init__(optimizer, last_epoch)
 
-    def get_lr(self):
-        return self.eta_min + (self.base_lr - self.eta_min) * (1 + math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+    def get_lr(self):                                           # recursive form of :150-160
+        base, t, T = self.optimizer.initial_lr, self.last_epoch, self.T_max
+        if t == 0:
+            return base
+        if (t - 1 - T) % (2 * T) == 0:
+            return self.get_last_lr() + (base - self.eta_min) * (1 - math.cos(math.pi / T)) / 2
+        return ((1 + math.cos(math.pi * t / T)) / (1 + math.cos(math.pi * (t - 1) / T))
+                * (self.get_last_lr() - self.eta_min) + self.eta_min)

@@ -397,6 +397,18 @@ def gen_ts_prediction():
     np.savez_compressed(os.path.join(OUT, "ts_prediction.npz"), **d)
 
 
+def gen_misc():
+    """pool1d, LSTM, RNN, SGD / Adagrad / Adadelta, LR schedulers on the real reference."""
+    sys.path.insert(0, os.path.dirname(OUT))
+    import models_misc as mm
+    import pydynet.optim as optim
+    from pydynet.optim import lr_scheduler
+    fresh()
+    d = mm.run(pdn, nn, F, optim, lr_scheduler)
+    print("misc", len(d), "arrays; lr/cos", d["lr/cos"][:4])
+    np.savez_compressed(os.path.join(OUT, "misc_layers.npz"), **d)
+
+
 def gen_autograd2d():
     """examples/pydynet/autograd2d.py:5-33 (config 1): 30 GD steps on 0.5 x^T A x + b^T x."""
     fresh()
@@ -415,7 +427,7 @@ def gen_autograd2d():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer(); gen_dropout_bn(); gen_ts_prediction()
+    gen_ops(); gen_functional(); gen_adam(); gen_tiny_llama(); gen_mlp_lenet(); gen_autograd2d(); gen_transformer(); gen_dropout_bn(); gen_ts_prediction(); gen_misc()
     gen_full_llama()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
