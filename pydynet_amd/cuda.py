@@ -108,3 +108,11 @@ class Device:
 
     def __exit__(self, *exc):
         return False
+
+
+def __getattr__(name):
+    # the reference exposes a module-level flag set at import (pydynet/cuda.py:8-12); here it is
+    # evaluated on first use so that importing the package never touches the driver
+    if name == "cuda_available":
+        return is_available()
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
