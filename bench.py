@@ -72,7 +72,7 @@ def main():
     B = args.batch
 
     np.random.seed(0)                                       # identical weights on every rank
-    model = Llama(V, D, H, F_, 1024, B, LAYERS, np.float32)
+    model = Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)           # (max_batch_size only sizes the unused KV caches)
     model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     model.to(dev)
     opt = Adam(model.parameters(), lr=1e-4)
