@@ -42,6 +42,52 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"{n} steps of the same model at batch 1 (seq 256), NumPy/BLAS default threads, after 1 warm-up step"}
 
 
+# Parity gate (SURVEY 8d "parity gate before timing"): numbers the REAL reference produced for this
+# exact model (seed 0, B = 1; tools/gen_golden.py -> tests/golden/llama_full.json, embedded here so the
+# gate does not depend on the fixture file travelling with the script).
+GATE_LOSS = 11.395865440368652
+GATE_GRAD_NORMS = {"lm_head.weight": 1.060440380538923, "tok_embedding.weight": 34.0423977926973,
+                   "layers.0.attention.Q.weight": 5.102858180800156, "layers.5.ffn.down.weight": 0.6188517568614766}
+GATE_RTOL = 1e-4
+
+
+def parity_gate(model, dev, pdn):
+    """One forward + backward of the seed-0 model on the reference's seed-0 batch; raises unless the
+    loss and the gradient norms match what the reference computed (1e-4 relative)."""
+    ids = np.random.randint(0, V, (1, L))               # same RNG stream as the generator: seed 0, model
+    tgt = np.random.randint(0, V, (1, L))               # construction, embedding draw, then ids, tgt
+    gold = os.path.join(ROOT, "tests", "golden", "llama_full.json")
+    norms = dict(GATE_GRAD_NORMS)
+    if os.path.exists(gold):
+        ref = json.load(open(gold))
+        assert abs(ref["losses"][0] - GATE_LOSS) < 1e-9
+        norms = {k: ref["grad1_norm"][k] for k in norms}
+    model.train(True)
+    for p in model.parameters():
+        p.zero_grad()
+    loss = model.loss(ids, tgt)
+    loss.backward()
+    got = float(loss.item())
+    if not abs(got - GATE_LOSS) <= GATE_RTOL * GATE_LOSS:
+        raise SystemExit(f"bench.py parity gate FAILED: loss {got!r} != reference {GATE_LOSS!r} (rtol {GATE_RTOL}); "
+                         "no throughput number is reported for a path that does not match the reference")
+    worst = 0.0
+    params = dict(model.named_parameters())
+    for name, want in norms.items():
+        if want is None:
+            continue
+        g = params[name].grad.get().astype(np.float64)
+        err = abs(float(np.linalg.norm(g)) - want) / want
+        worst = max(worst, err)
+        if err > GATE_RTOL:
+            raise SystemExit(f"bench.py parity gate FAILED: |grad {name}| off by {err:.2e} relative")
+    for p in model.parameters():
+        p.zero_grad()
+    return {"loss": got, "reference_loss": GATE_LOSS, "rel_err": abs(got - GATE_LOSS) / GATE_LOSS,
+            "grad_norms_checked": sum(v is not None for v in norms.values()), "worst_grad_norm_rel_err": worst,
+            "rtol": GATE_RTOL}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +121,7 @@ def main():
     model = Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)           # (max_batch_size only sizes the unused KV caches)
     model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     model.to(dev)
+    gate = parity_gate(model, dev, pdn)                     # refuses to go on if the path is wrong
     opt = Adam(model.parameters(), lr=1e-4)
     dp = DataParallel(model, opt, always_reduce=force_dp) if (world > 1 or force_dp) else None
     if dp is None:
@@ -148,6 +195,7 @@ def main():
                    "seq_len": L, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "model_flops_frac_of_fp32_mfma_peak": FLOP_PER_SAMPLE * value / world / PEAK_FP32_MFMA,
         "final_loss": losses[-1],
+        "parity_gate": gate,
         "roofline": roof,
     }
     if dp is not None:

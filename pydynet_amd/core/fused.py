@@ -38,6 +38,24 @@ def _contig(a):
     return a if a.is_contiguous() else a.copy()
 
 
+def hip_f32(*tensors):
+    """True when these operands may take a fused HIP node: the kernels behind them are float32
+    only, so on a HIP device every (non-None) operand must be float32.  On "cpu" the nodes are NumPy
+    expressions and carry any floating dtype."""
+    dev = next(t for t in tensors if t is not None).device
+    if not dev.is_hip:
+        return True
+    return all(t is None or (t.dtype == np.float32 and t.device == dev) for t in tensors)
+
+
+def _require_f32(node, *tensors):
+    """Fused HIP kernels reinterpret raw buffers as float32: refuse anything else loudly."""
+    for t in tensors:
+        if t is not None and t.dtype != np.float32:
+            raise TypeError(f"{type(node).__name__}: the fused HIP kernel is float32-only, got {t.dtype} "
+                            "(use the generic operators, or cast with .astype(np.float32))")
+
+
 def _foldable(node, idx, t):
     """The gradient input `idx` already holds (handed over by the engine as `node._existing`) if
     this node can add it inside its own kernel; marks the input as folded."""
@@ -81,6 +99,7 @@ class linear(_Operator):
             if b is not None:
                 y = y + b.data
             return y + r.data if r is not None else y
+        _require_f32(self, x, w, b, r)
         hp = _hip()
         fin, fout = w.shape
         x2 = x.data.reshape(-1, fin)
@@ -155,6 +174,7 @@ class rms_norm(_Operator):
         if self.xp is np:
             self._rms = np.sqrt((x.data * x.data).mean(-1, keepdims=True) + np.asarray(self.eps, x.dtype))
             return x.data / self._rms * w.data
+        _require_f32(self, x, w)
         hp, L = _hip(), _L()
         cols = x.shape[-1]
         self._x = _contig(x.data)
@@ -194,6 +214,7 @@ class swiglu(_Operator):
     def forward_(self, gate, up):
         if self.xp is np:
             return gate.data / (1 + np.exp(-gate.data)) * up.data
+        _require_f32(self, gate, up)
         hp, L = _hip(), _L()
         self._g, self._u = _contig(gate.data), _contig(up.data)
         out = hp.empty(gate.shape, np.float32)
@@ -216,6 +237,7 @@ class silu(_Operator):
     def forward_(self, x):
         if self.xp is np:
             return x.data / (1 + np.exp(-x.data))
+        _require_f32(self, x)
         hp, L = _hip(), _L()
         self._x = _contig(x.data)
         out = hp.empty(x.shape, np.float32)
@@ -258,6 +280,7 @@ class softmax(_Operator):
         if self.xp is np:
             e = np.exp(x.data - x.data.max(-1, keepdims=True))
             return e / e.sum(-1, keepdims=True)
+        _require_f32(self, x)
         hp, L = _hip(), _L()
         xd = _contig(x.data)
         cols = x.shape[-1]
@@ -294,6 +317,9 @@ class rope(_Operator):
             out[..., 0::2] = r * c - i * s
             out[..., 1::2] = r * s + i * c
             return out
+        _require_f32(self, self._cos, self._sin)
+        if a.dtype != np.float32:
+            raise TypeError(f"rope: the fused HIP kernel is float32-only, got {a.dtype}")
         hp, L = _hip(), _L()
         a, cos, sin = _contig(a), _contig(cos), _contig(sin)   # locals keep any copies alive
         out = hp.empty(a.shape, np.float32)
@@ -333,6 +359,7 @@ class attention(_Operator):
             e = np.exp(s - s.max(-1, keepdims=True))
             self._p = e / e.sum(-1, keepdims=True)
             return np.ascontiguousarray(np.matmul(self._p, v.data.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3))
+        _require_f32(self, q, k, v)
         hp, L = _hip(), _L()
         self._flash = (attention.use_flash and Lq == Lk and self.start_pos == 0 and hd == 48 and Lq % 32 == 0
                        and Lq <= 256 and q.data.is_contiguous() and k.data.is_contiguous()
@@ -451,6 +478,7 @@ class cross_entropy(_Operator):
             self._lse = np.log(np.exp(x.data - m).sum(-1, keepdims=True)) + m
             rows = self._lse[:, 0] - x.data[np.arange(n), t]
             return rows.mean() if self.reduction == "mean" else rows.sum()
+        _require_f32(self, x)
         hp, L = _hip(), _L()
         if not hasattr(self._t, "_ptr"):
             self._t = hp.from_numpy(np.asarray(self._t).astype(np.int64))
@@ -541,6 +569,7 @@ class conv2d(_Operator):
             if bias is not None:
                 out = out + bias.data.reshape(1, O)
             return out.reshape(N, oh, ow, O).transpose(0, 3, 1, 2)
+        _require_f32(self, x, kernel, bias)
         hp, L = _hip(), _L()
         xd = _contig(x.data)
         K, M = C * k * k, oh * ow
@@ -635,6 +664,7 @@ class pool2d(_Operator):
         if self.xp is np:
             _, win = self._windows(x.data)
             return win.max((-1, -2)) if self.mode == "max" else win.mean((-1, -2))
+        _require_f32(self, x)
         hp, L = _hip(), _L()
         self._x = _contig(x.data)
         oh = (H + 2 * self.padding - self.k) // self.stride + 1
@@ -681,6 +711,7 @@ class gru_cell(_Operator):
     def forward_(self, x, h, wx1, wh1, wx2, wh2, b1=None, b2=None):
         if self.xp is np:
             raise NotImplementedError("gru_cell is the HIP fused path; the NumPy device composes generic ops")
+        _require_f32(self, x, h, wx1, wh1, wx2, wh2, b1, b2)
         hp, L = _hip(), _L()
         B, H = h.shape
         xd, hd = _contig(x.data), _contig(h.data)
@@ -757,6 +788,7 @@ class qkv_attention(_Operator):
                 and hd == 48 and L % 32 == 0 and L <= 256)
 
     def forward_(self, x, wq, wk, wv):
+        _require_f32(self, x, wq, wk, wv, self._cos, self._sin)
         hp, L = _hip(), _L()
         B, Lq, D = x.shape
         H, hd, T = self.H, D // self.H, B * Lq
@@ -832,6 +864,7 @@ class col_norm(_Operator):
     def forward_(self, x, scale, shift):
         if self.xp is np:
             raise NotImplementedError("col_norm is the HIP fused path")
+        _require_f32(self, x, scale, shift, self._rm, self._rv)
         hp, L = _hip(), _L()
         cols = self.cols
         xd = _contig(x.data)
@@ -893,6 +926,7 @@ class gru_sequence(_Operator):
     def forward_(self, x, h0, wx1, wh1, wx2, wh2, b1=None, b2=None):
         if self.xp is np:
             raise NotImplementedError("gru_sequence is the HIP fused path")
+        _require_f32(self, x, h0, wx1, wh1, wx2, wh2, b1, b2)
         hp, L = _hip(), _L()
         T, B, I = x.shape
         H = h0.shape[-1]

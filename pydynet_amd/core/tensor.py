@@ -305,9 +305,12 @@ def _accumulate(t, add_grad, xp):
     fresh = add_grad.shape != tuple(t.shape)
     if fresh:
         add_grad = _unbroadcast(add_grad, t.shape)
-    if not t.last:                       # leaf: always in place into its own buffer
+    if not t.last and t.grad is not None:          # leaf: always in place into its own buffer
         t.grad += add_grad
-    elif t.grad is None:                 # first contribution to an op node: adopt, no copy
+    elif t.grad is None:
+        # first contribution to an op node: adopt, no copy.  (Also an op node whose own graph was
+        # already walked and freed -- e.g. a hidden state carried into the next batch: it is a leaf of
+        # the new graph, the gradient stops here and stays readable, as in the reference.)
         t.grad = add_grad
         t._grad_owned = fresh
     elif t._grad_owned:

@@ -36,6 +36,9 @@ def set_device(device: int) -> None:
     hipnp.set_device(int(device))
 
 
+_previous = []          # stack of GPUs to return to when `with device:` blocks exit (one thread per process)
+
+
 class Device:
     __slots__ = ("device", "device_id")
 
@@ -100,13 +103,21 @@ class Device:
 
     # `with device:` makes it the current GPU for allocations (cuda.py:93-99)
     def __enter__(self):
+        prev = None
         if self.device == "hip":
             from . import hipnp
-            if hipnp.current_device() != self.device_id:
+            cur = hipnp.current_device()
+            if cur != self.device_id:
+                prev = cur
                 hipnp.set_device(self.device_id)
+        _previous.append(prev)
         return self
 
     def __exit__(self, *exc):
+        prev = _previous.pop() if _previous else None
+        if prev is not None:
+            from . import hipnp
+            hipnp.set_device(prev)
         return False
 
 

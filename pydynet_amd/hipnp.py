@@ -882,6 +882,9 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None, residual=None, b_colsum=None, 
     consumed in place).  `residual` must have C's strides; `b_colsum` (N,) receives the column
     sums of B in the same pass (only for the unbatched x^T @ g form)."""
     L = _lib.lib()
+    for name, arr in (("A", A), ("B", B), ("C", C), ("bias", bias), ("residual", residual), ("b_colsum", b_colsum)):
+        if arr is not None and arr.dtype != np.float32:
+            raise TypeError(f"gemm: operand {name} is {arr.dtype}; pdn_gemm_f32 takes float32 buffers only")
     M, K = A.shape[-2:]
     N = B.shape[-1]
     bshape = C.shape[:-2]

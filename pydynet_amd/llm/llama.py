@@ -208,6 +208,14 @@ class Llama(nn.Module):
         D, H, F, V = self.embed_dim, self.n_heads, self.ffn_dim, self.vocab_size
         hd, half = D // H, D // H // 2
         B = ids.shape[0]
+        cache = self.layers[0].attention.cache_k
+        # raw pointers are formed from `pos` below: refuse what the module path would also refuse
+        # (the reference fails with a NumPy broadcast error, model.py:105-110)
+        if pos < 0 or pos >= cache.shape[1] or pos >= self.freqs_cos.shape[0]:
+            raise ValueError(f"decode position {pos} is outside the KV cache / RoPE table "
+                             f"(max_seq_len {cache.shape[1]}, {self.freqs_cos.shape[0]} RoPE rows)")
+        if B > cache.shape[0]:
+            raise ValueError(f"batch {B} exceeds the KV cache's max_batch_size {cache.shape[0]}")
         ws = getattr(self, "_decode_ws", None)
         if ws is None or ws["x"].device_index != hp._state["device"] or ws["x"].shape[0] != B:
             ws = {n: hp.empty((B, w), np.float32) for n, w in

@@ -10,7 +10,8 @@ from ..autograd import no_grad
 
 
 def linear(x, weight, bias):
-    if x.ndim >= 1 and weight.ndim == 2 and x.dtype == weight.dtype and x.ndim >= 2:
+    if (x.ndim >= 2 and weight.ndim == 2 and x.dtype == weight.dtype and np.issubdtype(x.dtype, np.floating)
+            and fused.hip_f32(x, weight, bias)):
         return fused.linear(x, weight, bias)
     affine = x @ weight
     return affine + bias if bias is not None else affine
@@ -30,7 +31,7 @@ def embedding(x, weight, padding_idx):
 
 def sigmoid(x): return tensor.sigmoid(x)
 def tanh(x): return tensor.tanh(x)
-def relu(x): return fused.relu(x)
+def relu(x): return fused.relu(x)          # (generic kernels inside for non-float32 HIP operands)
 def leaky_relu(x, alpha: float): return tensor.maximum(x, alpha * x)
 
 
@@ -58,15 +59,24 @@ def log_softmax(x, axis=None, keepdims=False):
 
 def conv2d(x, kernel, padding: int = 0, stride: int = 1, bias=None):
     """x (N, C, H, W), kernel (O, C, k, k); square kernel / stride / padding only."""
+    if not fused.hip_f32(x, kernel, bias):
+        raise TypeError("conv2d on a HIP device is float32-only (im2col / MFMA GEMM kernels): got "
+                        f"{x.dtype} / {kernel.dtype}; pass dtype=np.float32 or stay on the cpu device")
     return fused.conv2d(x, kernel, bias, padding, stride)
 
 
+def _pool2d(x, kernel_size, stride, padding, mode):
+    if not fused.hip_f32(x):
+        raise TypeError(f"{mode}_pool2d on a HIP device is float32-only: got {x.dtype}")
+    return fused.pool2d(x, kernel_size, stride, padding, mode)
+
+
 def max_pool2d(x, kernel_size: int, stride: int, padding=0):
-    return fused.pool2d(x, kernel_size, stride, padding, "max")
+    return _pool2d(x, kernel_size, stride, padding, "max")
 
 
 def avg_pool2d(x, kernel_size: int, stride: int, padding=0):
-    return fused.pool2d(x, kernel_size, stride, padding, "avg")
+    return _pool2d(x, kernel_size, stride, padding, "avg")
 
 
 def _as4d(x):

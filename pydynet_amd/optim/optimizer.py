@@ -13,6 +13,13 @@ class Optimizer:
     def __init__(self, params) -> None:
         self.params = list(params)
         self._flat_grad = None
+        # data parallel: gradients arrive as the SUM over ranks and every optimizer applies
+        # `grad_scale` = 1 / world_size (Adam folds it into its kernel)
+        self.grad_scale = 1.0
+
+    def _grad(self, p, weight_decay):
+        g = p.grad * self.grad_scale if self.grad_scale != 1.0 else p.grad
+        return g + weight_decay * p.data
 
     def step(self):
         raise NotImplementedError
@@ -58,7 +65,7 @@ class SGD(Optimizer):
     def step(self):
         for p, v in zip(self.params, self.v):
             with p.device:
-                grad = p.grad + self.weight_decay * p.data
+                grad = self._grad(p, self.weight_decay)
                 v *= self.momentum
                 v += self.lr * grad
                 p.data -= v
@@ -77,7 +84,7 @@ class Adagrad(Optimizer):
     def step(self):
         for p, G in zip(self.params, self.G):
             with p.device:
-                grad = p.grad + self.weight_decay * p.data
+                grad = self._grad(p, self.weight_decay)
                 G += grad ** 2
                 p.data -= self.lr * grad / (self.eps + G) ** 0.5
 
@@ -93,7 +100,7 @@ class Adadelta(Optimizer):
     def step(self):
         for i, p in enumerate(self.params):
             with p.device:
-                grad = p.grad + self.weight_decay * p.data
+                grad = self._grad(p, self.weight_decay)
                 self.G[i] = self.rho * self.G[i] + (1 - self.rho) * grad ** 2
                 p.data -= self.lr * grad / (self.G[i] + self.eps) ** 0.5
 
@@ -112,7 +119,6 @@ class Adam(Optimizer):
         self.eps, self.weight_decay = eps, weight_decay
         self.m, self.v = self._state(), self._state()
         self.t = 1
-        self.grad_scale = 1.0          # data parallel: 1/world_size folded into the kernel
         self._table = None
         self._table_key = None
 
@@ -152,8 +158,7 @@ class Adam(Optimizer):
             if i in done:
                 continue
             with p.device:
-                grad = p.grad * self.grad_scale + self.weight_decay * p.data if self.grad_scale != 1.0 \
-                    else p.grad + self.weight_decay * p.data
+                grad = self._grad(p, self.weight_decay)
                 self.m[i] *= self.beta1
                 self.m[i] += (1 - self.beta1) * grad
                 self.v[i] *= self.beta2
