@@ -5,7 +5,9 @@
 
 One step = zero_grad -> forward -> cross entropy -> backward -> (bucketed RCCL all-reduce,
 overlapped) -> Adam, on synthetic token ids resident in HBM, random-init weights, fp32.
-Per-GPU batch is fixed (weak scaling).  Prints ONE JSON line on rank 0.
+Per-GPU batch is fixed (weak scaling).  Prints ONE JSON line on rank 0.  The launcher only has to
+provide RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; this script itself uses no
+PyTorch -- device memory, streams, events and RCCL all come from libpdnhip.so.
 """
 import argparse
 import json
@@ -24,22 +26,48 @@ PEAK_FP32_MFMA = 157.3e12
 
 
 def cpu_baseline(seconds_budget=25.0):
-    """The oracle (NumPy port of the reference's op sequence) timed on this host's cores."""
+    """CPU numbers next to the GPU line (reported baseline, not the target), on this host's cores:
+    `value` = the oracle (NumPy restatement of the reference's op sequence, kind "port") at batch 1;
+    `product_numpy_device` = this package's own "cpu" device (fused nodes evaluated with NumPy) at
+    batch 1 and 8, as BASELINE.md section 3 lists."""
     from oracle import llama as ollama, nn as onn, tape as otape
+
+    def timed(step, budget, max_steps):
+        step()                                          # warm-up (page faults)
+        t0, n = time.perf_counter(), 0
+        while n < 2 or (time.perf_counter() - t0 < budget and n < max_steps):
+            step()
+            n += 1
+        return n, time.perf_counter() - t0
+
     otape.reset_tape()
     np.random.seed(0)
     m = ollama.Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)
     m.params["tok_embedding.weight"].value[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     ids, tgt = np.random.randint(0, V, (1, L)), np.random.randint(0, V, (1, L))
     opt = onn.Adam(m.parameters(), lr=1e-4)
-    m.finetune_step(ids, tgt, opt)                      # warm-up (page faults)
-    t0, n = time.perf_counter(), 0
-    while n < 2 or (time.perf_counter() - t0 < seconds_budget and n < 8):
-        m.finetune_step(ids, tgt, opt)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"{n} steps of the same model at batch 1 (seq 256), NumPy/BLAS default threads, after 1 warm-up step"}
+    n, dt = timed(lambda: m.finetune_step(ids, tgt, opt), seconds_budget * 0.4, 6)
+    out = {"value": n / dt, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"{n} steps of the same model at batch 1 (seq 256), NumPy/BLAS default threads, after 1 warm-up step"}
+    del m, opt
+    import pydynet_amd as pdn  # noqa: F401
+    from pydynet_amd.core.tensor import Graph
+    from pydynet_amd.llm.llama import Llama
+    from pydynet_amd.optim import Adam
+    prod = {}
+    for B, share, cap in ((1, 0.2, 6), (8, 0.4, 3)):
+        Graph.clear()
+        np.random.seed(0)
+        pm = Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)
+        pm.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
+        popt = Adam(pm.parameters(), lr=1e-4)
+        pids, ptgt = np.random.randint(0, V, (B, L)), np.random.randint(0, V, (B, L))
+        n, dt = timed(lambda: pm.finetune_step(pids, ptgt, popt), seconds_budget * share, cap)
+        prod[f"batch_{B}"] = {"samples_per_s": B * n / dt, "steps": n}
+        del pm, popt
+    Graph.clear()
+    out["product_numpy_device"] = prod
+    return out
 
 
 # Parity gate (SURVEY 8d "parity gate before timing"): numbers the REAL reference produced for this
@@ -98,22 +126,24 @@ def main():
     ap.add_argument("--no-gemm-prof", action="store_true")
     args = ap.parse_args()
 
-    import torch
+    import ctypes
     from pydynet_amd import hipnp, _lib
     import pydynet_amd as pdn
+    from pydynet_amd import distributed as pdist
     from pydynet_amd.llm.llama import Llama
     from pydynet_amd.optim import Adam
-    from pydynet_amd.distributed import DataParallel, init_process_group
+    from pydynet_amd.distributed import DataParallel
 
     local = int(os.environ.get("LOCAL_RANK", "0"))
     lib = _lib.lib()                                        # no CPU fallback: fail loudly
     hipnp.set_device(local)
-    rank, world = init_process_group("nccl", local) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
+    # one process per GPU; the communicator is RCCL through the C ABI (no PyTorch anywhere in this script)
+    rank, world = pdist.init_process_group("rccl", local) if int(os.environ.get("WORLD_SIZE", "1")) > 1 else (0, 1)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     force_dp = world == 1 and os.environ.get("PDN_BENCH_FORCE_DP") == "1"   # exercise the RCCL path on one GPU
     if force_dp:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
-        torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(f"cuda:{local}"))
+        pdist.init_process_group("rccl", local)
+    group = pdist.get_group()
     dev = f"hip:{local}"
     B = args.batch
 
@@ -139,18 +169,18 @@ def main():
         loss.backward()
         if dp is not None:
             # time the compute stream spends blocked on the gradient all-reduce (= exposed communication)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0, e1 = group.exposed_wait_events()
+            lib.call("pdn_event_record", e0, hipnp.stream())
             dp.finish()
-            e1.record()
+            lib.call("pdn_event_record", e1, hipnp.stream())
             comm_events.append((e0, e1))
         opt.step()
         return loss
 
     def fence():
         if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+            group.barrier()
+        hipnp.synchronize()
 
     prev = None
     for _ in range(args.warmup):
@@ -172,7 +202,6 @@ def main():
 
     roof = None
     if not args.no_gemm_prof:
-        import ctypes
         ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         lib.call("pdn_gemm_prof_enable", 0)
         lib.call("pdn_gemm_prof_collect", ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
@@ -183,9 +212,7 @@ def main():
                 "launches": cnt.value, "avg_launch_us": 1e3 * ms.value / max(cnt.value, 1),
                 "gemm_time_share_of_step": ms.value * 1e-3 / dt}
     if world > 1:
-        t = torch.tensor([dt], device=f"cuda:{local}", dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = group.all_reduce_scalar(dt, pdist.MAX)              # slowest rank's wall time
     value = world * B * args.steps / dt
     out = {
         "metric": "training-step samples/sec (6L Llama3, seq=256)", "value": value, "unit": "samples/s",
@@ -199,7 +226,11 @@ def main():
         "roofline": roof,
     }
     if dp is not None:
-        exposed = sum(a.elapsed_time(b) for a, b in comm_events) / max(len(comm_events), 1)
+        exposed = 0.0
+        for a, b in comm_events:
+            ms_ = ctypes.c_float()
+            lib.call("pdn_event_elapsed_ms", a, b, ctypes.byref(ms_))
+            exposed += ms_.value / max(len(comm_events), 1)
         out["comm"] = {"collective": "all-reduce(sum) of flat fp32 gradient buckets, RCCL", "buckets": len(dp.buckets),
                        "payload_MB_per_step": dp.flat.size * 4 / 1e6, "exposed_ms_per_step": exposed,
                        "note": "exposed = compute-stream time blocked in DataParallel.finish(); the rest overlaps backward"}
@@ -207,19 +238,20 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     # RCCL writes a version banner through C stdio (block-buffered when piped): every rank pushes its
     # own out, then all ranks meet, and only then rank 0 prints -- the JSON record stays the last line
-    import ctypes
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
     sys.stdout.flush()
     if world > 1:
-        torch.distributed.barrier()
+        group.barrier()
     if rank == 0:
+        out["memory"] = hipnp.memory_stats()
         print(json.dumps(out), flush=True)
-    if world > 1 or force_dp:
-        torch.distributed.barrier() if world > 1 else None
-        torch.distributed.destroy_process_group()
+    if group is not None:
+        if world > 1:
+            group.barrier()
+        pdist.destroy_process_group()
 
 
 if __name__ == "__main__":

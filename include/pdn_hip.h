@@ -46,6 +46,48 @@ int pdn_device_info(int device, char* name, int cap, int* compute_units, int64_t
 /* replaces the implicit sync of cupy `.get()` / `.item()` (pydynet/core/tensor.py:385-393) */
 int pdn_stream_synchronize(void* stream);
 
+/* ---- device runtime: what CuPy does behind pydynet/cuda.py:16-32,89-99 besides arithmetic ----
+ * cp.cuda.Device(id).use() inside `with device:` (cuda.py:93-99) */
+int pdn_set_device(int device);
+int pdn_get_device(int* device);
+int pdn_device_synchronize(void);
+/* cupy's memory pool behind every xp.zeros / xp.array / op output (core/tensor.py:80,90): a caching
+ * allocator (size-class free lists per device; hipMalloc only on a miss; reuse is ordered on the
+ * device's compute stream).  pdn_free returns the block to the cache, never to the driver. */
+int pdn_malloc(void** ptr, int64_t bytes);
+int pdn_free(void* ptr);
+int pdn_empty_cache(void);
+int pdn_mem_stats(int device, int64_t* in_use, int64_t* reserved, int64_t* peak_in_use,
+                  int64_t* device_allocs, int64_t* requests, int64_t* cache_hits);
+/* `xp.asarray(host)` / `.get()` (tensor.py:385-403): *_host pointers are pageable host memory.
+ * h2d returns when the source may be reused, d2h when the data is on the host; d2d and memset are
+ * asynchronous on `stream`. */
+int pdn_memcpy_h2d(void* dst, const void* src_host, int64_t bytes, void* stream);
+int pdn_memcpy_d2h(void* dst_host, const void* src, int64_t bytes, void* stream);
+int pdn_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream);
+int pdn_memset(void* dst, int byte_value, int64_t bytes, void* stream);
+/* streams (non-blocking: no implicit sync with the null stream) and events; the compute stream of
+ * the current device is created on first use and is what the front end passes to every kernel */
+int pdn_compute_stream(void** stream);
+int pdn_stream_create(void** stream, int high_priority);
+int pdn_stream_destroy(void* stream);
+int pdn_stream_wait_event(void* stream, void* event);
+int pdn_event_create(void** event, int timing);
+int pdn_event_record(void* event, void* stream);
+int pdn_event_synchronize(void* event);
+int pdn_event_elapsed_ms(void* start, void* stop, float* ms);
+int pdn_event_destroy(void* event);
+/* ---- collectives over xGMI (RCCL, bound with dlopen at first use).  No counterpart in the
+ * reference: this is the one exchange step of data-parallel training.
+ * One communicator rank per process; id128 = 128 bytes from rank 0's pdn_comm_unique_id, handed to
+ * the other ranks by the host (pydynet_amd/rendezvous.py).  All calls are asynchronous on `stream`. */
+int pdn_comm_unique_id(char* id128);
+int pdn_comm_init(void** comm, int rank, int world, const char* id128);
+int pdn_comm_destroy(void* comm);
+int pdn_comm_allreduce_f32(void* comm, float* buf, int64_t n, int op, void* stream); /* op 0 sum, 1 max */
+int pdn_comm_broadcast(void* comm, void* buf, int64_t bytes, int root, void* stream);
+int pdn_comm_allgather(void* comm, const void* send, void* recv, int64_t bytes_per_rank, void* stream);
+
 /* ---- matmul: `x.data @ y.data`, and `grad @ B^T`, `A^T @ grad` (tensor.py:659,670-675) ----
  * C[b1,b2] = alpha * A[b1,b2](MxK) * B[b1,b2](KxN) + bias[N] + beta * C[b1,b2]
  * A(m,k)=A[m*a_rs+k*a_cs], B(k,n)=B[k*b_rs+n*b_cs], C(m,n)=C[m*ldc+n]; two batch dims with
@@ -151,13 +193,16 @@ int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
 
 /* ---- embedding: `weight[ids]` (nn/functional.py:14-20) and its gradient
  * `full = zeros; full[key] = grad` (tensor.py:937-940: scatter-ASSIGN, last write wins).
- * scatter mode 0: assign, 1: assign-last accumulated into dW, 2: atomic scatter-add. */
+ * scatter mode 0: assign, 1: assign-last accumulated into dW, 2: atomic scatter-add.
+ * row_owner (V floats) / owner_tag: optional data-parallel filter -- a row is written only when
+ * row_owner[id] == owner_tag, i.e. when this rank holds the last occurrence of the id in the
+ * concatenated global batch (NULL = no filter). */
 int pdn_embedding_gather_f32(const float* W, int64_t V, int D, int64_t w_row_stride,
                              const int64_t* ids, int64_t n, float* out, int* err_flag,
                              void* stream);
 int pdn_embedding_scatter_f32(const float* g, const int64_t* ids, int64_t n, float* dW, int64_t V,
-                              int D, int mode, void* workspace, int64_t workspace_bytes,
-                              void* stream);
+                              int D, int mode, const float* row_owner, float owner_tag,
+                              void* workspace, int64_t workspace_bytes, void* stream);
 int64_t pdn_embedding_scatter_workspace_bytes(int64_t V);
 /* `x[range(N), idx]` and its scatter-assign gradient (nn/functional.py:371) */
 int pdn_take_cols_f32(const float* x, int64_t n, int64_t C, int64_t x_row_stride,

@@ -56,11 +56,10 @@ class _Lib:
             raise HipLibraryError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C pydynet_amd/csrc`). The HIP backend has no CPU fallback.")
-        # PyTorch owns the device memory these kernels touch, so both must share ONE HIP runtime:
-        # importing torch first makes libpdnhip.so bind to the libamdhip64 torch already loaded
-        # (loading ours first can pick a different copy that sees no device).
-        import torch  # noqa: F401
-        self.cdll = ctypes.CDLL(LIB_PATH)
+        # The library owns its device runtime (allocator, copies, streams, RCCL): nothing but the
+        # ROCm HIP runtime it is linked against is needed.  RTLD_GLOBAL so that a HIP runtime loaded
+        # later by another package in the same process resolves to the same libamdhip64.
+        self.cdll = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
         self.protos = parse_header()
         self.fn = {}
         for name, (restype, argtypes) in self.protos.items():
@@ -69,6 +68,7 @@ class _Lib:
             f.argtypes = argtypes
             self.fn[name] = f
         self._last_error = self.fn["pdn_last_error"]
+        self.free = self.fn["pdn_free"]              # hot: called from _Buffer.__del__
 
     def call(self, name, *args):
         rc = self.fn[name](*args)

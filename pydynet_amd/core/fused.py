@@ -438,10 +438,19 @@ class embedding(_Operator):
 
     def backward_all(self, g):
         w = self.last[0]
+        # data parallel (distributed.DataParallel): per-row owner rank, so that the summed gradient keeps
+        # the scatter-ASSIGN semantics of the concatenated batch; irrelevant for scatter-add
+        owner = tag = None
+        if getattr(w, "_dp_owner", None) is not None and not self.accumulate:
+            owner, tag = w._dp_owner(self._ids, w.shape[0])
         if self.xp is np:
             full = np.zeros(w.shape, dtype=w.dtype)
             if self.accumulate:
                 np.add.at(full, self._ids, g)
+            elif owner is not None:
+                ids = np.asarray(self._ids).reshape(-1)
+                keep = owner[ids] == tag
+                full[ids[keep]] = g.reshape(ids.size, -1)[keep]
             else:
                 full[self._ids] = g
             return [full]
@@ -450,13 +459,14 @@ class embedding(_Operator):
         g = _contig(g)
         ids = _contig(self._ids)
         ws, wsb = hp.workspace(V * 4)
+        optr, otag = (owner._ptr, tag) if owner is not None else (None, 0.0)
         if _is_leaf_f32(w):
             L.call("pdn_embedding_scatter_f32", g._ptr, ids._ptr, ids.size, w.grad._ptr, V, D,
-                   2 if self.accumulate else 1, ws, wsb, hp.stream())
+                   2 if self.accumulate else 1, optr, otag, ws, wsb, hp.stream())
             return [None]
         full = hp.zeros(w.shape, np.float32)
         L.call("pdn_embedding_scatter_f32", g._ptr, ids._ptr, ids.size, full._ptr, V, D,
-               2 if self.accumulate else 0, ws, wsb, hp.stream())
+               2 if self.accumulate else 0, optr, otag, ws, wsb, hp.stream())
         return [full]
 
 
@@ -501,11 +511,11 @@ class cross_entropy(_Operator):
             ws, wsb = hp.workspace(wsb) if wsb else (None, 0)
             L.call("pdn_cross_entropy_fwd_bwd_f32", self._x._ptr, self._t._ptr, n, V, mean,
                    1.0 / n if mean else 1.0, loss_row._ptr, self._lse._ptr, out._ptr, self._dx._ptr,
-                   cs._ptr if cs is not None else None, ws, wsb, hp._err_flag().data_ptr(), hp.stream())
+                   cs._ptr if cs is not None else None, ws, wsb, hp.err_flag_ptr(), hp.stream())
             self._dx._aux = ("colsum", cs) if cs is not None else None
         else:
             L.call("pdn_cross_entropy_fwd_f32", self._x._ptr, self._t._ptr, n, V, mean, loss_row._ptr,
-                   self._lse._ptr, out._ptr, hp._err_flag().data_ptr(), hp.stream())
+                   self._lse._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
         return out.reshape(())
 
     def backward_all(self, g):

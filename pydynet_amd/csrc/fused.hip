@@ -554,13 +554,15 @@ __global__ void last_occurrence_kernel(const int64_t* __restrict__ ids, int64_t 
 }
 __global__ void scatter_rows_kernel(const float* __restrict__ g, const int64_t* __restrict__ ids,
                                     float* __restrict__ dW, int64_t n, int D, int64_t V,
-                                    const int* __restrict__ last, int mode) {
+                                    const int* __restrict__ last, int mode,
+                                    const float* __restrict__ row_owner, float owner_tag) {
   // mode 0: assign-last into zero (dW = g), 1: assign-last accumulating (dW += g), 2: atomic add
   for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
     int64_t id = ids[r];
     if (id < 0) id += V;
     if (id < 0 || id >= V) continue;
     if (mode != 2 && last[id] != (int)r) continue;
+    if (row_owner && row_owner[id] != owner_tag) continue;   // a later data-parallel rank holds the last occurrence
     const float* src = g + r * (int64_t)D;
     float* dst = dW + id * (int64_t)D;
     if (mode == 0) for (int c = threadIdx.x; c < D; c += blockDim.x) dst[c] = src[c];
@@ -586,9 +588,12 @@ extern "C" int pdn_embedding_gather_f32(const float* W, int64_t V, int D, int64_
 extern "C" int64_t pdn_embedding_scatter_workspace_bytes(int64_t V) { return V * 4; }
 
 // mode: 0 assign (dW rows overwritten), 1 assign-last accumulated into dW (the engine's
-// `grad += full_grad`), 2 atomic scatter-add.  dW is (V, D) contiguous.
+// `grad += full_grad`), 2 atomic scatter-add.  dW is (V, D) contiguous.  row_owner (V floats, may be
+// NULL): rows whose entry differs from owner_tag are skipped -- data parallel: only the rank holding
+// the globally last occurrence of a token id contributes its row.
 extern "C" int pdn_embedding_scatter_f32(const float* g, const int64_t* ids, int64_t n, float* dW,
-                                         int64_t V, int D, int mode, void* workspace,
+                                         int64_t V, int D, int mode, const float* row_owner,
+                                         float owner_tag, void* workspace,
                                          int64_t workspace_bytes, void* stream) {
   if (n == 0 || D == 0) return PDN_OK;
   PDN_CHECK_ARG(g && ids && dW && V > 0 && mode >= 0 && mode <= 2, "pdn_embedding_scatter_f32: bad arguments");
@@ -606,7 +611,8 @@ extern "C" int pdn_embedding_scatter_f32(const float* g, const int64_t* ids, int
   }
   const int threads = D >= 256 ? 256 : (D >= 128 ? 128 : 64);
   const int grid = (int)(n < 65535 ? n : 65535);
-  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(threads), 0, st, g, ids, dW, n, D, V, last, mode);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid), dim3(threads), 0, st, g, ids, dW, n, D, V, last, mode,
+                     row_owner, owner_tag);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

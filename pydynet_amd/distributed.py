@@ -14,39 +14,215 @@ Design for MI355X (8 GPUs fully connected, 7 xGMI links x ~153 GB/s each):
     into its bucket;
   * the tape engine fires a grad-ready hook when a leaf has received its last contribution;
     when every parameter of bucket k is ready (and buckets < k are already in flight) the
-    bucket's `all_reduce(SUM)` is issued asynchronously -- RCCL runs it on its own stream, so
-    layer k's communication overlaps layer k-1's backward kernels;
-  * the 1/N average is not a separate pass: it is folded into the Adam kernel (`grad_scale`).
-`torch.distributed` (backend "nccl" == RCCL on ROCm, "gloo" for CPU tests) is the plumbing.
+    bucket's all-reduce(SUM) is enqueued on a dedicated high-priority COMMUNICATION stream behind an
+    event recorded on the compute stream -- layer k's reduction overlaps layer k-1's backward
+    kernels; `finish()` makes the compute stream wait for the last bucket (no host sync);
+  * the 1/N average is not a separate pass: every optimizer applies `grad_scale` (Adam folds it into
+    its kernel);
+  * the embedding gradient keeps the reference's scatter-ASSIGN semantics across ranks: an
+    all-reduce(MAX) over a (V,) "owner" vector picks, for every token id, the highest rank that saw
+    it (= the last occurrence in the concatenated batch) and only that rank contributes the row.
+Collectives: RCCL through the C ABI (`pdn_comm_*`, include/pdn_hip.h) for HIP devices -- no
+PyTorch involved; `torch.distributed` gloo carries NumPy buffers for the "cpu" device (CPU tests).
 """
 from __future__ import annotations
 
+import ctypes
 import os
 
 import numpy as np
 
-from .core.tensor import Tensor
+from . import rendezvous
+
+SUM, MAX = 0, 1
+_group = None
 
 
-def _dist():
-    import torch.distributed as dist
-    return dist
+class RcclComm:
+    """One RCCL rank bound to the current GPU: collectives run on a communication stream of their
+    own, ordered against the compute stream with events (never with host synchronisation)."""
+
+    backend = "rccl"
+
+    def __init__(self, rank: int, world: int, device_index: int = 0):
+        from . import hipnp, _lib
+        self.rank, self.world = int(rank), int(world)
+        self._hp, self._L = hipnp, _lib.lib()
+        L = self._L
+        hipnp.set_device(device_index)
+        self.device_index = device_index
+        uid = None
+        if self.rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            L.call("pdn_comm_unique_id", buf)
+            uid = buf.raw
+        uid = rendezvous.broadcast_bytes(uid, self.rank, self.world)
+        h = ctypes.c_void_p()
+        L.call("pdn_comm_init", ctypes.byref(h), self.rank, self.world, uid)
+        self._comm = h.value
+        s = ctypes.c_void_p()
+        L.call("pdn_stream_create", ctypes.byref(s), 1)
+        self._stream = s.value
+        self._events = []           # recycled event pairs
+        self._pending = None        # last event recorded on the communication stream
+
+    # -- event plumbing ---------------------------------------------------------------------------
+    def _event(self):
+        if self._events:
+            return self._events.pop()
+        e = ctypes.c_void_p()
+        self._L.call("pdn_event_create", ctypes.byref(e), 0)
+        return e.value
+
+    def _after_compute(self):
+        """Communication stream waits for everything enqueued on the compute stream so far."""
+        e = self._event()
+        self._L.call("pdn_event_record", e, self._hp.stream())
+        self._L.call("pdn_stream_wait_event", self._stream, e)
+        self._events.append(e)          # an event may be re-recorded once the wait is enqueued
+
+    def _mark(self):
+        if self._pending is None:
+            self._pending = self._event()
+        self._L.call("pdn_event_record", self._pending, self._stream)
+
+    # -- collectives (asynchronous) -----------------------------------------------------------------
+    def all_reduce(self, arr, op=SUM):
+        """In place on a contiguous float32 device array."""
+        assert arr.dtype == np.float32 and arr.is_contiguous()
+        self._after_compute()
+        self._L.call("pdn_comm_allreduce_f32", self._comm, arr._ptr, arr.size, op, self._stream)
+        self._mark()
+
+    def broadcast(self, arr, root=0):
+        assert arr.is_contiguous()
+        self._after_compute()
+        self._L.call("pdn_comm_broadcast", self._comm, arr._ptr, arr.nbytes, root, self._stream)
+        self._mark()
+
+    def all_gather(self, send, recv):
+        assert send.is_contiguous() and recv.is_contiguous() and recv.nbytes == send.nbytes * self.world
+        self._after_compute()
+        self._L.call("pdn_comm_allgather", self._comm, send._ptr, recv._ptr, send.nbytes, self._stream)
+        self._mark()
+
+    def wait(self):
+        """Compute stream waits for every collective issued so far (device-side; the host goes on)."""
+        if self._pending is not None:
+            self._L.call("pdn_stream_wait_event", self._hp.stream(), self._pending)
+
+    def exposed_wait_events(self):
+        """(start, stop) timing events bracketing `wait()` on the compute stream -- what bench.py
+        reports as exposed communication."""
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        self._L.call("pdn_event_create", ctypes.byref(e0), 1)
+        self._L.call("pdn_event_create", ctypes.byref(e1), 1)
+        return e0.value, e1.value
+
+    # -- host-synchronous helpers ---------------------------------------------------------------------
+    def barrier(self):
+        t = self._hp.zeros((1,), np.float32)
+        self.all_reduce(t, SUM)
+        self.wait()
+        self._hp.synchronize()
+
+    def all_reduce_scalar(self, value: float, op=MAX) -> float:
+        t = self._hp.from_numpy(np.array([value], np.float32))
+        self.all_reduce(t, op)
+        self.wait()
+        return float(t.get()[0])
+
+    def destroy(self):
+        if self._comm:
+            self._hp.synchronize()
+            self._L.call("pdn_stream_synchronize", self._stream)
+            self._L.call("pdn_comm_destroy", self._comm)
+            self._L.call("pdn_stream_destroy", self._stream)
+            self._comm = None
+
+
+class GlooComm:
+    """torch.distributed (gloo) moving NumPy buffers: the communicator of the "cpu" device.  It exists
+    so that the N > 1 logic runs in GPU-less tests; it is never used with HIP arrays."""
+
+    backend = "gloo"
+
+    def __init__(self, rank: int, world: int):
+        import torch.distributed as dist
+        self._dist = dist
+        if not dist.is_initialized():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._works = []
+
+    def _tensor(self, arr):
+        import torch
+        assert isinstance(arr, np.ndarray) and arr.flags.c_contiguous
+        return torch.from_numpy(arr)
+
+    def all_reduce(self, arr, op=SUM):
+        dist = self._dist
+        self._works.append(dist.all_reduce(self._tensor(arr), async_op=True,
+                                           op=dist.ReduceOp.SUM if op == SUM else dist.ReduceOp.MAX))
+
+    def broadcast(self, arr, root=0):
+        self._works.append(self._dist.broadcast(self._tensor(arr), src=root, async_op=True))
+
+    def all_gather(self, send, recv):
+        import torch
+        parts = list(torch.from_numpy(recv.reshape(self.world, -1)).unbind(0))
+        self._works.append(self._dist.all_gather(parts, self._tensor(send).reshape(-1), async_op=True))
+
+    def wait(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    def barrier(self):
+        self.wait()
+        self._dist.barrier()
+
+    def all_reduce_scalar(self, value: float, op=MAX) -> float:
+        a = np.array([value], np.float64)
+        self.all_reduce(a, op)
+        self.wait()
+        return float(a[0])
+
+    def destroy(self):
+        self.wait()
+        if self._dist.is_initialized():
+            self._dist.destroy_process_group()
 
 
 def init_process_group(backend=None, device_index=None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, world)."""
-    import torch
-    dist = _dist()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    """Create the process-wide communicator from the launcher's environment (RANK, WORLD_SIZE,
+    MASTER_ADDR, MASTER_PORT).  backend: "rccl" (alias "nccl") for HIP devices, "gloo" for the cpu
+    device; default: rccl when a GPU is visible.  Returns (rank, world)."""
+    global _group
+    rank, world = rendezvous.env_rank_world()
+    if _group is None:
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        kw = {}
-        if backend == "nccl" and device_index is not None:
-            kw["device_id"] = torch.device(f"cuda:{device_index}")
-        dist.init_process_group(backend=backend, **kw)
-    return rank, world
+            from . import cuda
+            backend = "rccl" if cuda.is_available() else "gloo"
+        if backend in ("rccl", "nccl"):
+            local = int(os.environ.get("LOCAL_RANK", rank)) if device_index is None else device_index
+            _group = RcclComm(rank, world, local)
+        elif backend == "gloo":
+            _group = GlooComm(rank, world)
+        else:
+            raise ValueError(f"unknown backend {backend!r} (rccl | nccl | gloo)")
+    return _group.rank, _group.world
+
+
+def get_group():
+    return _group
+
+
+def destroy_process_group():
+    global _group
+    if _group is not None:
+        _group.destroy()
+        _group = None
 
 
 def shard_batch(global_batch: int, rank: int, world: int):
@@ -67,18 +243,19 @@ class DataParallel:
 
     def __init__(self, module, optimizer=None, bucket_mb: float = 12.0, process_group=None,
                  broadcast_parameters=True, always_reduce=False):
-        dist = _dist()
         self.module = module
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.group = process_group if process_group is not None else _group
+        self.world = self.group.world if self.group is not None else 1
+        self.rank = self.group.rank if self.group is not None else 0
         # `always_reduce` runs the collectives even on a single rank (used to exercise the RCCL path
         # on a one-GPU box); normally a lone rank skips them
-        self._comm = dist.is_initialized() and (self.world > 1 or always_reduce)
+        self._comm = self.group is not None and (self.world > 1 or always_reduce)
         self.params = [p for p in module.parameters()][::-1]        # reverse registration order
         if not self.params:
             raise ValueError("DataParallel: module has no trainable parameters")
         self.device = self.params[0].device
+        if self._comm and self.device.is_hip != (self.group.backend == "rccl"):
+            raise ValueError(f"DataParallel: {self.group.backend} communicator cannot move {self.device} arrays")
         self._flatten(bucket_mb)
         for i, p in enumerate(self.params):
             p._grad_hook = self._make_hook(i)
@@ -88,6 +265,8 @@ class DataParallel:
             if [id(p) for p in optimizer.params][::-1] == [id(p) for p in self.params]:
                 optimizer._flat_grad, optimizer._flat_offsets = self.flat, self.offsets[::-1]
                 optimizer._flat_views = [p.grad for p in optimizer.params]
+        if self._comm:
+            self._install_embedding_owner()
         if broadcast_parameters and self._comm:
             self.broadcast_parameters()
         self._reset()
@@ -110,18 +289,31 @@ class DataParallel:
             for i in range(lo, hi):
                 self.param_bucket[i] = b
 
-    def _torch_view(self, lo, hi):
-        seg = self.flat[lo:hi]
-        if isinstance(seg, np.ndarray):
-            import torch
-            return torch.from_numpy(seg)
-        return seg.as_torch()
+    # -- embedding tables: scatter-ASSIGN across ranks --------------------------------------------
+    def _install_embedding_owner(self):
+        """`fused.embedding` consults `weight._dp_owner(ids)` before scattering: it returns a (V,)
+        float32 vector holding, per row, 1 + the highest rank whose shard contains that token id, and
+        this rank's own tag; the scatter then skips rows owned by a later rank, so the summed gradient
+        equals the single-process scatter-assign on the concatenated batch (tensor.py:937-940)."""
+        group, rank, device = self.group, self.rank, self.device
+
+        def owner_of(ids, V):
+            xp = device.xp
+            with device:
+                own = xp.zeros((V,), dtype=np.float32)
+                own[ids.reshape(-1)] = float(rank + 1)
+            group.all_reduce(own, MAX)
+            group.wait()
+            return own, float(rank + 1)
+
+        for p in self.params:
+            if p.ndim == 2:
+                p._dp_owner = owner_of           # used only if the parameter feeds fused.embedding
 
     # -- hooks ------------------------------------------------------------------------------------
     def _reset(self):
         self._ready = [0] * len(self.buckets)
         self._next = 0
-        self._works = []
 
     def _make_hook(self, index):
         def hook(_param):
@@ -130,31 +322,23 @@ class DataParallel:
             self._launch_ready()
         return hook
 
-    def _launch_ready(self):
+    def _launch_ready(self, force=False):
         if not self._comm:
             return
-        dist = _dist()
         while self._next < len(self.buckets):
             lo, hi, plo, phi = self.buckets[self._next]
-            if self._ready[self._next] < phi - plo:
+            if not force and self._ready[self._next] < phi - plo:
                 break
-            self._works.append(dist.all_reduce(self._torch_view(lo, hi), op=dist.ReduceOp.SUM,
-                                               group=self.group, async_op=True))
+            self.group.all_reduce(self.flat[lo:hi], SUM)
             self._next += 1
 
     def finish(self):
         """Call after backward(): issues any bucket not yet launched (parameters that received no
-        gradient this step) and waits for all reductions.  Gradients then hold the SUM over ranks;
-        the optimizer divides by the world size through `grad_scale`."""
+        gradient this step) and orders the optimizer behind all reductions.  Gradients then hold the
+        SUM over ranks; the optimizer divides by the world size through `grad_scale`."""
         if self._comm:
-            dist = _dist()
-            while self._next < len(self.buckets):
-                lo, hi, _, _ = self.buckets[self._next]
-                self._works.append(dist.all_reduce(self._torch_view(lo, hi), op=dist.ReduceOp.SUM,
-                                                   group=self.group, async_op=True))
-                self._next += 1
-            for w in self._works:
-                w.wait()
+            self._launch_ready(force=True)
+            self.group.wait()
         self._reset()
 
     def zero_grad(self):
@@ -162,16 +346,12 @@ class DataParallel:
             self.flat[...] = 0.0
 
     def broadcast_parameters(self, src=0):
-        dist = _dist()
         for p in self.module._parameters.values():
-            if isinstance(p.data, np.ndarray):
-                import torch
-                t = torch.from_numpy(p.data)
-            else:
-                t = p.data.as_torch() if p.data.is_contiguous() else None
-                if t is None:
-                    raise ValueError("DataParallel: non-contiguous parameter")
-            dist.broadcast(t, src=src, group=self.group)
+            a = p.data
+            if not (a.flags.c_contiguous if isinstance(a, np.ndarray) else a.is_contiguous()):
+                raise ValueError("DataParallel: non-contiguous parameter")
+            self.group.broadcast(a, src)
+        self.group.wait()
 
     def __call__(self, *a, **kw):
         return self.module(*a, **kw)

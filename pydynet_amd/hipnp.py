@@ -4,8 +4,9 @@ In the reference ``Device.xp`` is ``numpy`` or ``cupy`` (pydynet/cuda.py:89-91) 
 operator is a one-line array expression on ``Tensor.data``.  This module is the MI355X
 counterpart of that seam: an ``ndarray`` living in HBM whose operators, reductions,
 indexing and assignment all lower to the hand-written HIP kernels of ``libpdnhip.so``
-through the C ABI (``include/pdn_hip.h``).  Nothing here computes on the host: PyTorch is
-used only to own device memory (its caching allocator) and to copy host<->device.
+through the C ABI (``include/pdn_hip.h``).  Nothing here computes on the host, and nothing
+here needs PyTorch: device memory comes from the library's caching allocator (pdn_malloc),
+copies from pdn_memcpy_*, ordering from the per-device compute stream (pdn_compute_stream).
 
 Supported dtypes on the device: float32 (the hot path), float64, int64, bool.
 """
@@ -34,32 +35,47 @@ _UOP = dict(copy=0, neg=1, exp=2, log=3, abs=4, sign=5, sqrt=6, square=7, recip=
             sigmoid=9, tanh=10)
 _ROP = dict(sum=0, mean=1, max=2, min=3, argmax=4, argmin=5)
 
-_torch = None
-_state = {"device": 0, "stream": 0}
+_state = {"device": 0, "stream": 0, "streams": {}}
+
+
+class _Buffer:
+    """One block of HBM from the library's caching allocator (pdn_malloc); returned to the cache
+    when the last array viewing it is dropped."""
+
+    __slots__ = ("ptr", "nbytes", "device", "__weakref__")
+
+    def __init__(self, nbytes: int):
+        p = ctypes.c_void_p()
+        _lib.lib().call("pdn_malloc", ctypes.byref(p), int(nbytes))
+        self.ptr = p.value or 0
+        self.nbytes = int(nbytes)
+        self.device = _state["device"]
+
+    def __del__(self):
+        ptr, self.ptr = self.ptr, 0
+        if ptr:
+            try:
+                _lib.lib().free(ptr)
+            except Exception:                      # interpreter shutdown
+                pass
 
 
 def _dev():
-    return f"cuda:{_state['device']}"
-
-
-def _t():
-    global _torch
-    if _torch is None:
-        import torch
-        _torch = torch
-    return _torch
-
-
-def _torch_dtype(dt):
-    t = _t()
-    return {np.dtype(np.float32): t.float32, np.dtype(np.float64): t.float64,
-            np.dtype(np.int64): t.int64, np.dtype(np.bool_): t.bool,
-            np.dtype(np.int32): t.int32}[np.dtype(dt)]
+    return f"hip:{_state['device']}"
 
 
 def set_device(index: int):
-    _state["device"] = int(index)
-    _t().cuda.set_device(int(index))
+    """Make GPU `index` current: allocations, copies and launches go to it and to its compute stream."""
+    index = int(index)
+    L = _lib.lib()
+    L.call("pdn_set_device", index)
+    _state["device"] = index
+    st = _state["streams"].get(index)
+    if st is None:
+        h = ctypes.c_void_p()
+        L.call("pdn_compute_stream", ctypes.byref(h))
+        st = _state["streams"][index] = h.value or 0
+    _state["stream"] = st
 
 
 def current_device() -> int:
@@ -67,16 +83,55 @@ def current_device() -> int:
 
 
 def set_stream(handle: int):
-    """hipStream_t (as int) every kernel is enqueued on; 0 = the null stream (torch default)."""
+    """hipStream_t (as int) every kernel is enqueued on.  The allocator's reuse is ordered on the
+    device's compute stream: route work to another stream only for buffers that outlive it."""
     _state["stream"] = int(handle)
 
 
 def stream() -> int:
+    if not _state["streams"]:
+        set_device(_state["device"])
     return _state["stream"]
 
 
 def synchronize():
-    _lib.lib().call("pdn_stream_synchronize", _state["stream"])
+    _lib.lib().call("pdn_stream_synchronize", stream())
+
+
+class Timer:
+    """HIP-event stopwatch on the compute stream: `with Timer() as t: ...; t.ms`."""
+
+    def __enter__(self):
+        L = _lib.lib()
+        self._e = [ctypes.c_void_p(), ctypes.c_void_p()]
+        for e in self._e:
+            L.call("pdn_event_create", ctypes.byref(e), 1)
+        L.call("pdn_event_record", self._e[0], stream())
+        return self
+
+    def __exit__(self, *exc):
+        L = _lib.lib()
+        L.call("pdn_event_record", self._e[1], stream())
+        L.call("pdn_event_synchronize", self._e[1])
+        ms = ctypes.c_float()
+        L.call("pdn_event_elapsed_ms", self._e[0], self._e[1], ctypes.byref(ms))
+        self.ms = ms.value
+        for e in self._e:
+            L.call("pdn_event_destroy", e)
+        return False
+
+
+def memory_stats(device=None):
+    """Allocator counters of a device: bytes in use / reserved / peak, driver allocations, requests, hits."""
+    vals = [ctypes.c_int64() for _ in range(6)]
+    _lib.lib().call("pdn_mem_stats", _state["device"] if device is None else int(device),
+                    *[ctypes.byref(v) for v in vals])
+    keys = ("in_use", "reserved", "peak_in_use", "device_allocs", "requests", "cache_hits")
+    return {k: v.value for k, v in zip(keys, vals)}
+
+
+def empty_cache():
+    _lib.lib().call("pdn_empty_cache")
 
 
 def _dtcode(dt):
@@ -103,41 +158,44 @@ def _contig_strides(shape):
 # ---------------------------------------------------------------------------------------
 # workspace: one growing scratch buffer per process (kernels never allocate)
 # ---------------------------------------------------------------------------------------
-_ws = {"buf": None, "bytes": 0}
+_ws = {}          # device -> _Buffer
 
 
 def workspace(nbytes: int):
     nbytes = int(nbytes)
     if nbytes <= 0:
         return 0, 0
-    if _ws["bytes"] < nbytes:
-        t = _t()
-        cap = _bi.max(nbytes, 1 << 20)
-        _ws["buf"] = t.empty(cap, dtype=t.uint8, device=_dev())
-        _ws["bytes"] = cap
-    return _ws["buf"].data_ptr(), _ws["bytes"]
+    buf = _ws.get(_state["device"])
+    if buf is None or buf.nbytes < nbytes:
+        _ws[_state["device"]] = buf = _Buffer(_bi.max(nbytes, 1 << 20))
+    return buf.ptr, buf.nbytes
 
 
-_err = {"buf": None}
+_err = {}         # device -> int32[1] array: set by gathers that saw an out-of-range index
 
 
-def _err_flag():
-    if _err["buf"] is None:
-        t = _t()
-        _err["buf"] = t.zeros(1, dtype=t.int32, device=_dev())
-    return _err["buf"]
+def _err_array():
+    a = _err.get(_state["device"])
+    if a is None:
+        a = _err[_state["device"]] = zeros((1,), np.int32)
+    return a
+
+
+def err_flag_ptr() -> int:
+    return _err_array()._ptr
 
 
 def check_index_errors():
     """Raise IndexError if any gather since the last check saw an out-of-range index."""
-    if _err["buf"] is not None and int(_err["buf"].item()) != 0:
-        _err["buf"].zero_()
+    a = _err.get(_state["device"])
+    if a is not None and int(a.get()[0]) != 0:
+        a.fill(0)
         raise IndexError("index out of range in a device gather")
 
 
 # ---------------------------------------------------------------------------------------
 class ndarray:
-    """Strided N-d array in HBM.  `_buf` (a 1-D torch tensor) owns the storage."""
+    """Strided N-d array in HBM.  `_buf` (a `_Buffer`) owns the storage; views share it."""
 
     __slots__ = ("_buf", "_ptr", "shape", "_strides", "dtype", "_aux", "__weakref__")
     __array_priority__ = 1000.0
@@ -181,7 +239,7 @@ class ndarray:
 
     @property
     def device_index(self):
-        return self._buf.device.index
+        return self._buf.device
 
     def is_contiguous(self):
         exp = 1
@@ -203,21 +261,10 @@ class ndarray:
     def get(self) -> np.ndarray:
         """Device -> host copy (synchronises); the counterpart of cupy's `.get()`."""
         a = self if self.is_contiguous() else self.copy()
-        t = _t()
-        flat = t.as_strided(a._typed_buf(), (a.size,), (1,), a._elem_offset())
-        host = flat.cpu().numpy().reshape(a.shape).astype(self.dtype, copy=False)
-        # .cpu() of a host tensor aliases it (only under the test emulator): always hand out a copy
-        return host.copy() if self._buf.device.type == "cpu" else host
-
-    def _typed_buf(self):
-        return self._buf
-
-    def _elem_offset(self):
-        return (self._ptr - self._buf.data_ptr()) // self.dtype.itemsize
-
-    def as_torch(self):
-        """Zero-copy torch view (plumbing for torch.distributed collectives)."""
-        return _t().as_strided(self._buf, self.shape, self._strides, self._elem_offset())
+        host = np.empty(a.shape, dtype=self.dtype)
+        if host.size:
+            _lib.lib().call("pdn_memcpy_d2h", host.ctypes.data, a._ptr, host.nbytes, stream())
+        return host
 
     def item(self):
         if self.size != 1:
@@ -316,7 +363,7 @@ class ndarray:
             v = float(value.item() if hasattr(value, "item") else value)
             shape, (sm, so) = _broadcast([mask, self], out_shape=self.shape)
             _lib.lib().call("pdn_masked_fill", _dtcode(self.dtype), v, len(shape), _i64(shape),
-                            mask._ptr, _i64(sm), self._ptr, _i64(so), _state["stream"])
+                            mask._ptr, _i64(sm), self._ptr, _i64(so), stream())
             return
         view = _basic_index(self, key)
         if view is None:
@@ -380,10 +427,9 @@ def empty(shape, dtype=np.float32):
     shape = tuple(int(s) for s in shape)
     dtype = np.dtype(dtype if dtype is not None else np.float64)
     _dtcode(dtype)
-    t = _t()
     n = int(math.prod(shape))
-    buf = t.empty(_bi.max(n, 1), dtype=_torch_dtype(dtype), device=_dev())
-    return ndarray(buf, buf.data_ptr(), shape, _contig_strides(shape), dtype)
+    buf = _Buffer(_bi.max(n, 1) * dtype.itemsize)
+    return ndarray(buf, buf.ptr, shape, _contig_strides(shape), dtype)
 
 
 def zeros(shape, dtype=np.float64):
@@ -429,11 +475,10 @@ def empty_like(a, dtype=None): return empty(a.shape, dtype or a.dtype)
 def from_numpy(a: np.ndarray) -> ndarray:
     a = np.asarray(a, order="C")          # (np.ascontiguousarray would turn 0-d into 1-d)
     _dtcode(a.dtype)
-    t = _t()
-    buf = t.from_numpy(a.reshape(-1) if a.size else np.zeros(1, a.dtype))
-    dev = _dev()
-    buf = buf.to(dev) if dev != "cpu" else buf.clone()   # "cpu" only under the test emulator
-    return ndarray(buf, buf.data_ptr(), a.shape, _contig_strides(a.shape), a.dtype)
+    buf = _Buffer(_bi.max(a.size, 1) * a.dtype.itemsize)
+    if a.size:
+        _lib.lib().call("pdn_memcpy_h2d", buf.ptr, a.ctypes.data, a.nbytes, stream())
+    return ndarray(buf, buf.ptr, a.shape, _contig_strides(a.shape), a.dtype)
 
 
 def array(obj, dtype=None, copy=True):
@@ -524,12 +569,12 @@ def _broadcast(arrs, out_shape=None):
 def _cast_into(src: ndarray, dst: ndarray):
     shape, (ss, sd) = _broadcast([src, dst], out_shape=dst.shape)
     _lib.lib().call("pdn_cast", _dtcode(src.dtype), _dtcode(dst.dtype), len(shape), _i64(shape),
-                    src._ptr, _i64(ss), dst._ptr, _i64(sd), _state["stream"])
+                    src._ptr, _i64(ss), dst._ptr, _i64(sd), stream())
 
 
 def _fill(dst: ndarray, value):
     _lib.lib().call("pdn_fill", _dtcode(dst.dtype), float(value), dst.ndim, _i64(dst.shape),
-                    dst._ptr, _i64(dst._strides), _state["stream"])
+                    dst._ptr, _i64(dst._strides), stream())
 
 
 def _is_scalar(o):
@@ -562,7 +607,7 @@ def _binary(op, a, b, out=None):
         res = out if out is not None else empty(arr.shape, np.bool_ if cmp else dt)
         shape, (sa, so) = _broadcast([arr, res], out_shape=res.shape)
         L.call("pdn_ew_binary", _dtcode(dt), code, mode, len(shape), _i64(shape), arr._ptr, _i64(sa),
-               None, None, float(sc_np), res._ptr, _i64(so), _state["stream"])
+               None, None, float(sc_np), res._ptr, _i64(so), stream())
         return res
     dt = np.result_type(a.dtype, b.dtype) if out is None else out.dtype
     if a.dtype != dt:
@@ -573,7 +618,7 @@ def _binary(op, a, b, out=None):
     res = out if out is not None else empty(shape, np.bool_ if cmp else dt)
     shape, (sa, sb, so) = _broadcast([a, b, res], out_shape=res.shape)
     L.call("pdn_ew_binary", _dtcode(dt), code, 0, len(shape), _i64(shape), a._ptr, _i64(sa),
-           b._ptr, _i64(sb), 0.0, res._ptr, _i64(so), _state["stream"])
+           b._ptr, _i64(sb), 0.0, res._ptr, _i64(so), stream())
     return res
 
 
@@ -583,7 +628,7 @@ def _unary(op, a, out=None):
         a = a.astype(np.float64)
     res = out if out is not None else empty(a.shape, a.dtype)
     _lib.lib().call("pdn_ew_unary", _dtcode(a.dtype), _UOP[op], a.ndim, _i64(a.shape), a._ptr,
-                    _i64(a._strides), res._ptr, _i64(res._strides), _state["stream"])
+                    _i64(a._strides), res._ptr, _i64(res._strides), stream())
     return res
 
 
@@ -622,7 +667,7 @@ def _reduce(op, a, axis=None, keepdims=False):
     outn = _bi.max(int(math.prod(kept)), 1)
     ws_ptr, ws_bytes = workspace(outn * 1024 * 16 + 4096 if outn <= 4096 else outn * 16 * 64)
     _lib.lib().call("pdn_reduce", _dtcode(src.dtype), _ROP[op], src.ndim, _i64(src.shape),
-                    _i64(src._strides), flags, src._ptr, out._ptr, ws_ptr, ws_bytes, _state["stream"])
+                    _i64(src._strides), flags, src._ptr, out._ptr, ws_ptr, ws_bytes, stream())
     if keepdims:
         out = out.reshape(tuple(1 if i in axes else s for i, s in enumerate(a.shape)))
     return out
@@ -702,7 +747,7 @@ def _advanced_get(a: ndarray, key):
         out = empty((a.shape[0],), a.dtype)
         idx = ascontiguousarray(idx)
         L.call("pdn_take_cols_f32", src._ptr, a.shape[0], a.shape[1], src._strides[0],
-               idx._ptr, out._ptr, _err_flag().data_ptr(), _state["stream"])
+               idx._ptr, out._ptr, err_flag_ptr(), stream())
         return out
     # integer array on axis 0 (embedding lookup), trailing basic keys applied afterwards
     if (a.ndim >= 1 and not _is_basic(key[0]) and all(_is_basic(k) for k in key[1:])
@@ -714,7 +759,7 @@ def _advanced_get(a: ndarray, key):
         row_stride = src._strides[0] if src.shape[0] > 1 else _bi.max(D, 1)
         out = empty(idx.shape + a.shape[1:], a.dtype)
         L.call("pdn_embedding_gather_f32", src._ptr, a.shape[0], D, row_stride, idx._ptr, idx.size,
-               out._ptr, _err_flag().data_ptr(), _state["stream"])
+               out._ptr, err_flag_ptr(), stream())
         if len(key) > 1:
             out = out[(slice(None),) * idx.ndim + tuple(key[1:])]
         return out
@@ -739,7 +784,7 @@ def _advanced_set(a: ndarray, key, value):
             and _is_arange(key[0], a.shape[0]) and not _is_basic(key[1])):
         idx = ascontiguousarray(_index_array(key[1]))
         v = ascontiguousarray(broadcast_to(value, (a.shape[0],)))
-        L.call("pdn_put_cols_f32", v._ptr, idx._ptr, a._ptr, a.shape[0], a.shape[1], _state["stream"])
+        L.call("pdn_put_cols_f32", v._ptr, idx._ptr, a._ptr, a.shape[0], a.shape[1], stream())
         return
     if len(key) == 1 and a.dtype == np.float32 and a.is_contiguous() and a.ndim >= 1:
         idx = ascontiguousarray(_index_array(key[0]))
@@ -747,7 +792,7 @@ def _advanced_set(a: ndarray, key, value):
         v = ascontiguousarray(broadcast_to(value, idx.shape + a.shape[1:]))
         ws_ptr, ws_bytes = workspace(a.shape[0] * 4)
         L.call("pdn_embedding_scatter_f32", v._ptr, idx._ptr, idx.size, a._ptr, a.shape[0], D, 0,
-               ws_ptr, ws_bytes, _state["stream"])
+               None, 0.0, ws_ptr, ws_bytes, stream())
         return
     raise NotImplementedError(f"HIP backend: unsupported advanced assignment key {key!r}")
 
@@ -924,7 +969,7 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None, residual=None, b_colsum=None, 
            bias._ptr if bias is not None else None, n1, n2, a1, a2, b1, b2, c1, c2,
            residual._ptr if residual is not None else None,
            b_colsum._ptr if b_colsum is not None else None, 1 if colsum_accumulate else 0,
-           ws_ptr, ws_bytes, _state["stream"])
+           ws_ptr, ws_bytes, stream())
     return C
 
 

@@ -230,7 +230,7 @@ class Llama(nn.Module):
 
         emb = self.tok_embedding.weight.data
         idc = ids if ids.is_contiguous() else ids.copy()
-        L.call("pdn_embedding_gather_f32", emb._ptr, V, D, emb._strides[0], idc._ptr, B, x, hp._err_flag().data_ptr(), st)
+        L.call("pdn_embedding_gather_f32", emb._ptr, V, D, emb._strides[0], idc._ptr, B, x, hp.err_flag_ptr(), st)
         cos = self.freqs_cos.data._ptr + pos * half * 4
         sin = self.freqs_sin.data._ptr + pos * half * 4
         for layer in self.layers:

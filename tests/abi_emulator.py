@@ -43,6 +43,7 @@ class EmulatedLib:
     def __init__(self):
         self.protos = _lib.parse_header()
         self.calls = []
+        self._blocks, self._handles = {}, 1000
 
     # -- dispatch -------------------------------------------------------------------------
     def call(self, name, *args):
@@ -61,6 +62,98 @@ class EmulatedLib:
     def pdn_device_count(self): return 1
     def pdn_abi_version(self): return 1
     def pdn_stream_synchronize(self, stream): return 0
+
+    # -- device runtime: "HBM" is host memory owned by NumPy arrays kept alive in a table -------------
+    def free(self, ptr):                      # the fast path _Buffer.__del__ uses
+        self._blocks.pop(int(ptr), None)
+        return 0
+
+    def pdn_set_device(self, device): return 0 if device == 0 else 101
+    def pdn_device_synchronize(self): return 0
+
+    def pdn_malloc(self, out, nbytes):
+        block = np.empty(max(int(nbytes), 1) + 64, np.uint8)
+        ptr = (block.ctypes.data + 63) & ~63
+        self._blocks[ptr] = block
+        ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = ptr
+        return 0
+
+    def pdn_free(self, ptr): return self.free(ptr)
+    def pdn_empty_cache(self): return 0
+
+    def pdn_mem_stats(self, device, *outs):
+        vals = (sum(b.size for b in self._blocks.values()), 0, 0, len(self._blocks), 0, 0)
+        for o, v in zip(outs, vals):
+            ctypes.cast(o, ctypes.POINTER(ctypes.c_int64))[0] = v
+        return 0
+
+    def _copy(self, dst, src, n):
+        ctypes.memmove(int(dst), int(src), int(n))
+        return 0
+
+    def pdn_memcpy_h2d(self, dst, src, n, stream): return self._copy(dst, src, n)
+    def pdn_memcpy_d2h(self, dst, src, n, stream): return self._copy(dst, src, n)
+    def pdn_memcpy_d2d(self, dst, src, n, stream): return self._copy(dst, src, n)
+
+    def pdn_memset(self, dst, value, n, stream):
+        ctypes.memset(int(dst), int(value), int(n))
+        return 0
+
+    def _handle(self, out):
+        self._handles += 1
+        ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = self._handles
+        return 0
+
+    def pdn_compute_stream(self, out): return self._handle(out)
+    def pdn_stream_create(self, out, prio): return self._handle(out)
+    def pdn_stream_destroy(self, s): return 0
+    def pdn_stream_wait_event(self, s, e): return 0
+    def pdn_event_create(self, out, timing): return self._handle(out)
+    def pdn_event_record(self, e, s): return 0
+    def pdn_event_synchronize(self, e): return 0
+    def pdn_event_destroy(self, e): return 0
+
+    def pdn_event_elapsed_ms(self, a, b, out):
+        ctypes.cast(out, ctypes.POINTER(ctypes.c_float))[0] = 0.0
+        return 0
+
+    # -- RCCL stands in as torch.distributed gloo on the host buffers (collectives run synchronously) --
+    def pdn_comm_unique_id(self, out):
+        ctypes.memmove(out, bytes(range(128)), 128)
+        return 0
+
+    def pdn_comm_init(self, out, rank, world, uid):
+        import torch.distributed as dist
+        assert bytes(ctypes.string_at(uid, 128) if not isinstance(uid, bytes) else uid[:128]) == bytes(range(128))
+        if not dist.is_initialized():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        return self._handle(out)
+
+    def pdn_comm_destroy(self, comm):
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        return 0
+
+    def pdn_comm_allreduce_f32(self, comm, buf, n, op, stream):
+        import torch
+        import torch.distributed as dist
+        dist.all_reduce(torch.from_numpy(flat(buf, n)), op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+        return 0
+
+    def pdn_comm_broadcast(self, comm, buf, nbytes, root, stream):
+        import torch
+        import torch.distributed as dist
+        dist.broadcast(torch.from_numpy(flat(buf, nbytes, np.uint8)), src=root)
+        return 0
+
+    def pdn_comm_allgather(self, comm, send, recv, nbytes, stream):
+        import torch
+        import torch.distributed as dist
+        world = dist.get_world_size()
+        parts = list(torch.from_numpy(flat(recv, nbytes * world, np.uint8).reshape(world, nbytes)).unbind(0))
+        dist.all_gather(parts, torch.from_numpy(np.array(flat(send, nbytes, np.uint8))))
+        return 0
     def pdn_gemm_f32_workspace_bytes(self, M, N, K, nb): return 64 * M * N * nb * 4
     def pdn_rmsnorm_bwd_workspace_bytes(self, rows, cols): return 1024 * cols * 4
     def pdn_embedding_scatter_workspace_bytes(self, V): return V * 4
@@ -243,10 +336,15 @@ class EmulatedLib:
         flat(out, n * D).reshape(n, D)[...] = w[flat(ids, n, np.int64)]
         return 0
 
-    def pdn_embedding_scatter_f32(self, g, ids, n, dW, V, D, mode, ws, wsb, stream):
+    def pdn_embedding_scatter_f32(self, g, ids, n, dW, V, D, mode, owner, tag, ws, wsb, stream):
         w = flat(dW, V * D).reshape(V, D)
         gg = np.array(flat(g, n * D).reshape(n, D))
         idx = np.array(flat(ids, n, np.int64))
+        if owner and mode != 2:
+            # last occurrence first (over ALL local rows), then the data-parallel owner filter
+            last = {int(i): r for r, i in enumerate(idx)}
+            rows = [r for i, r in sorted(last.items()) if flat(owner, V)[i] == np.float32(tag)]
+            idx, gg = idx[rows], gg[rows]
         if mode == 0:
             w[idx] = gg
         elif mode == 1:
@@ -505,13 +603,12 @@ class EmulatedLib:
 
 
 def install(monkeypatch):
-    """Point hipnp at host memory and the emulated library; returns the emulator."""
+    """Point hipnp at the emulated library (host memory); returns the emulator."""
     from pydynet_amd import hipnp
     emu = EmulatedLib()
     monkeypatch.setattr(_lib, "_LIB", emu)
     monkeypatch.setattr(_lib, "is_built", lambda: True)
-    monkeypatch.setattr(hipnp, "_dev", lambda: "cpu")
-    monkeypatch.setattr(hipnp, "_ws", {"buf": None, "bytes": 0})
-    monkeypatch.setattr(hipnp, "_err", {"buf": None})
-    monkeypatch.setattr(hipnp, "set_device", lambda i: hipnp._state.__setitem__("device", int(i)))
+    monkeypatch.setattr(hipnp, "_ws", {})
+    monkeypatch.setattr(hipnp, "_err", {})
+    monkeypatch.setattr(hipnp, "_state", {"device": 0, "stream": 0, "streams": {}})
     return emu

@@ -13,9 +13,10 @@ def pytest_configure(config):
 
 
 def _gpu_present():
+    """Asked of the product's own library (pdn_device_count): the test suite needs no PyTorch."""
     try:
-        import torch
-        return torch.cuda.is_available()
+        from pydynet_amd import cuda
+        return cuda.is_available()
     except Exception:
         return False
 
@@ -31,7 +32,7 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope="session")
 def hip():
-    """hipnp module bound to cuda:0; fails loudly if the HIP library is not built."""
+    """hipnp module bound to GPU 0; fails loudly if the HIP library is not built."""
     from pydynet_amd import hipnp, _lib
     _lib.lib()
     hipnp.set_device(0)

@@ -10,12 +10,7 @@ import pytest
 
 from pydynet_amd import _lib
 
-NO_GPU = True
-try:
-    import torch
-    NO_GPU = not torch.cuda.is_available()
-except Exception:
-    pass
+NO_GPU = _lib.lib().query("pdn_device_count") == 0
 
 
 def test_library_exports_exactly_the_declared_abi():

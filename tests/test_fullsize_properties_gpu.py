@@ -53,7 +53,7 @@ def test_cross_entropy_full_vocab_properties(hip):
     CS = hip.empty((V,))
     ws, wsb = hip.workspace(wsb)
     Lb.call("pdn_cross_entropy_fwd_bwd_f32", X._ptr, Tt._ptr, rows, V, 1, 1.0 / rows, lr._ptr, lse._ptr, out._ptr,
-            DX._ptr, CS._ptr, ws, wsb, hip._err_flag().data_ptr(), hip.stream())
+            DX._ptr, CS._ptr, ws, wsb, hip.err_flag_ptr(), hip.stream())
     hip.check_index_errors()
     d = DX.get()
     # softmax - onehot: every row sums to zero, the target entry is the only negative one

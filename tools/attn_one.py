@@ -1,7 +1,8 @@
 """Run the fused attention forward/backward a few times (for rocprofv3 --pmc runs).  usage: attn_one.py [iters] [B]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+from pydynet_amd import hipnp as _hpsync
 from pydynet_amd import hipnp as hp, _lib
 hp.set_device(0)
 L_ = _lib.lib()
@@ -18,5 +19,5 @@ for _ in range(it):
             None, None, hp.stream())
     L_.call("pdn_attention_bwd_f32", q._ptr, k._ptr, v._ptr, o._ptr, do._ptr, lse._ptr, dq._ptr, dk._ptr, dv._ptr,
             B, H, L, hd, H * hd, L * H * hd, 1, None, None, ws, wsb, hp.stream())
-torch.cuda.synchronize()
+_hpsync.synchronize()
 print("done")

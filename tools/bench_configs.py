@@ -4,7 +4,8 @@ algorithmic FLOP count, and for LeNet the HBM GB/s of the algorithmic conv bytes
 usage: python tools/bench_configs.py [steps]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+from pydynet_amd import hipnp as _hpsync
 import pydynet_amd as pdn
 import pydynet_amd.nn as nn
 import pydynet_amd.nn.functional as F
@@ -61,11 +62,11 @@ for name, cls, shape, flops, batches in CASES:
 
         for _ in range(3):
             step()
-        torch.cuda.synchronize()
+        _hpsync.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = step()
-        torch.cuda.synchronize()
+        _hpsync.synchronize()
         dt = (time.perf_counter() - t0) / steps
         line = f"{name:6s} B={B:6d}  {dt*1e3:8.3f} ms/step  {B/dt:12.0f} samples/s  {flops*B/dt/1e12:7.2f} TFLOP/s (algorithmic)  loss {loss.item():.4f}"
         if name == "lenet":
@@ -92,10 +93,10 @@ if not only or only.startswith("gru"):
 
     for _ in range(3):
         gstep()
-    torch.cuda.synchronize()
+    _hpsync.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = gstep()
-    torch.cuda.synchronize()
+    _hpsync.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"gru    T={T_} B={B_} H={Hd}  {dt*1e3:8.3f} ms/step  {B_/dt:12.0f} sequences/s  loss {loss.item():.4f}", flush=True)

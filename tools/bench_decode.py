@@ -3,7 +3,8 @@ tokens/s the same way; README.md:23 quotes 300 tok/s for the reference).  Random
 usage: python tools/bench_decode.py [new_tokens] [prompt_len]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
+from pydynet_amd import hipnp as _hpsync
 import pydynet_amd as pdn
 from pydynet_amd.llm.llama import Llama
 
@@ -22,7 +23,7 @@ with pdn.no_grad():
             out = tok[0].numpy().tolist()          # host read-back per token, as infer.py does
             n += 1
             if n == 1:
-                torch.cuda.synchronize(); t0 = time.perf_counter()   # exclude the prompt pass
-        torch.cuda.synchronize()
+                _hpsync.synchronize(); t0 = time.perf_counter()   # exclude the prompt pass
+        _hpsync.synchronize()
         dt = time.perf_counter() - t0
 print(f"decode: {n - 1} tokens in {dt:.3f} s -> {(n - 1) / dt:.0f} tokens/s (batch 1, greedy, KV cache, fp32)")

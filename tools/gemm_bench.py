@@ -2,7 +2,6 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
 from pydynet_amd import hipnp as hp
 
 hp.set_device(0)
@@ -11,14 +10,11 @@ PEAK = 157.3e12
 
 def bench(name, A, B, C, iters=20):
     hp.gemm(A, B, C)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        hp.gemm(A, B, C)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
+    hp.synchronize()
+    with hp.Timer() as t:
+        for _ in range(iters):
+            hp.gemm(A, B, C)
+    ms = t.ms / iters
     M, K = A.shape[-2:]; N = B.shape[-1]
     nb = int(np.prod(C.shape[:-2])) if C.ndim > 2 else 1
     fl = 2.0 * M * N * K * nb

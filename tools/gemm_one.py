@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
+from pydynet_amd import hipnp as _hpsync
 from pydynet_amd import hipnp as hp
 hp.set_device(0)
 it = int(sys.argv[1]) if len(sys.argv) > 1 else 10
@@ -21,5 +21,5 @@ elif len(sys.argv) > 2:      # only the weight-gradient shapes
 for name, A, B, C in cases:
     for _ in range(it):
         hp.gemm(A, B, C)
-torch.cuda.synchronize()
+_hpsync.synchronize()
 print("done")

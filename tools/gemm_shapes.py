@@ -2,7 +2,7 @@
 step: shows where the GEMM time of the step goes (run on the GPU box).  usage: gemm_shapes.py [batch]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
 from pydynet_amd import hipnp as hp
 hp.set_device(0)
 PEAK = 157.3e12
@@ -12,12 +12,10 @@ rnd = lambda *s: hp.from_numpy(np.random.default_rng(0).standard_normal(s, dtype
 
 
 def bench(A, B, C, iters=10, **kw):
-    hp.gemm(A, B, C, **kw); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters): hp.gemm(A, B, C, **kw)
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    hp.gemm(A, B, C, **kw); hp.synchronize()
+    with hp.Timer() as t:
+        for _ in range(iters): hp.gemm(A, B, C, **kw)
+    return t.ms / iters * 1e3
 
 
 x, h768, g288, g768 = rnd(T, 288), rnd(T, 768), rnd(T, 288), rnd(T, 768)

@@ -1,7 +1,7 @@
 """Sweep tile config x split-K for the weight-gradient GEMMs (TN, K = tokens)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import numpy as np
 from pydynet_amd import hipnp as hp
 hp.set_device(0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
@@ -10,12 +10,10 @@ x, h768, g288, g768 = rnd(T, 288), rnd(T, 768), rnd(T, 288), rnd(T, 768)
 
 
 def bench(A, B, C, iters=10):
-    hp.gemm(A, B, C); torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters): hp.gemm(A, B, C)
-    e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e3
+    hp.gemm(A, B, C); hp.synchronize()
+    with hp.Timer() as t:
+        for _ in range(iters): hp.gemm(A, B, C)
+    return t.ms / iters * 1e3
 
 
 for name, A, B, cs in [("dW 288x288", x.T, g288, (288, 288)), ("dW 288x768", x.T, g768, (288, 768)),
