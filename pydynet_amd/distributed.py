@@ -14,7 +14,7 @@ Design for MI355X (8 GPUs fully connected, 7 xGMI links x ~153 GB/s each):
     into its bucket;
   * the tape engine fires a grad-ready hook when a leaf has received its last contribution;
     when every parameter of bucket k is ready (and buckets < k are already in flight) the
-    bucket's all-reduce(SUM) is enqueued on a dedicated high-priority COMMUNICATION stream behind an
+    bucket's all-reduce(SUM) is enqueued on a dedicated COMMUNICATION stream behind an
     event recorded on the compute stream -- layer k's reduction overlaps layer k-1's backward
     kernels; `finish()` makes the compute stream wait for the last bucket (no host sync);
   * the 1/N average is not a separate pass: every optimizer applies `grad_scale` (Adam folds it into
@@ -61,7 +61,10 @@ class RcclComm:
         L.call("pdn_comm_init", ctypes.byref(h), self.rank, self.world, uid)
         self._comm = h.value
         s = ctypes.c_void_p()
-        L.call("pdn_stream_create", ctypes.byref(s), 1)
+        # NORMAL priority on purpose: while a high-priority queue holds a barrier packet waiting for an
+        # event, every kernel of the compute queue runs 10-60 us longer (one-GPU probe, B = 256:
+        # 61.5 -> 68.8 ms per step with no collective issued at all; tools/dp_overhead_probe.py)
+        L.call("pdn_stream_create", ctypes.byref(s), int(os.environ.get("PDN_COMM_HIGH_PRIORITY", "0")))
         self._stream = s.value
         self._events = []           # recycled event pairs
         self._pending = None        # last event recorded on the communication stream
