@@ -233,6 +233,23 @@ int pdn_im2col2d_f32(const float* x, int N, int C, int H, int W, int k, int stri
                      float* col, int col_rows, int ones_row, void* stream);
 int pdn_col2im2d_f32(const float* dcol, int N, int C, int H, int W, int k, int stride, int pad,
                      float* dx, int col_rows, void* stream);
+/* Direct (implicit-GEMM) convolution for small-image / small-channel shapes (the zero-padded image
+ * and the weights fit in LDS): the im2col matrix of nn/functional.py:211-222 exists only as LDS
+ * addresses, MFMA operands are read straight from the staged image, the NCHW result (+ bias, the
+ * `+ self.bias` of nn/modules/conv.py:99-103) leaves the accumulators once.  bwd_data is the
+ * `np.add.at` col2im of :224-232 fused with its GEMM (stride 1); bwd_weight forms dW (O, C, k, k)
+ * and db (O) in one pass (deterministic two-stage reduction through `workspace`).
+ * pdn_conv2d_direct_supported -> bitmask 1 fwd | 2 bwd_data | 4 bwd_weight; other shapes use
+ * pdn_im2col2d_f32 + pdn_gemm_f32 (+ pdn_col2im2d_f32). */
+int pdn_conv2d_direct_supported(int C, int H, int W, int O, int k, int stride, int pad);
+int pdn_conv2d_fwd_f32(const float* x, const float* w, const float* bias, float* y, int N, int C, int H,
+                       int W, int O, int k, int stride, int pad, void* stream);
+int pdn_conv2d_bwd_data_f32(const float* dy, const float* w, float* dx, int N, int C, int H, int W, int O,
+                            int k, int stride, int pad, void* stream);
+int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float* db, int accumulate, int N,
+                              int C, int H, int W, int O, int k, int stride, int pad, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+int64_t pdn_conv2d_bwd_weight_workspace_bytes(int N, int C, int H, int W, int O, int k, int stride, int pad);
 int pdn_pool2d_fwd_f32(const float* x, int N, int C, int H, int W, int k, int stride, int pad,
                        int mode, float* y, void* stream);
 int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, int C, int H, int W,

@@ -542,13 +542,18 @@ class cross_entropy(_Operator):
 
 
 class conv2d(_Operator):
-    """Square-kernel 2-D convolution = im2col + ONE batched GEMM (nn/functional.py:254-281).
+    """Square-kernel 2-D convolution (nn/functional.py:254-281).
 
-    The im2col buffer keeps the reference layout (N, C, kh, kw, oh, ow) in its first C*k*k rows and
-    pads the contraction to a multiple of 4; per image the packed weight (O, Kp) multiplies it
-    into a contiguous NCHW output (the reference returns an NHWC buffer viewed as NCHW: same
-    values).  The bias (1, O, 1, 1) is column K of the packed weight against a row of ones, so
-    `+ bias` and its gradient ride inside the GEMMs; nothing downstream sees a strided tensor."""
+    HIP device, LeNet-class shapes (the padded image and the weights fit in LDS): direct
+    implicit-GEMM kernels -- nothing of the im2col buffer ever exists in HBM (`pdn_conv2d_*`).
+    Other shapes: im2col + ONE batched GEMM per direction: the im2col buffer keeps the reference
+    layout (N, C, kh, kw, oh, ow) in its first C*k*k rows and pads the contraction to a multiple of
+    4; per image the packed weight (O, Kp) multiplies it into a contiguous NCHW output (the reference
+    returns an NHWC buffer viewed as NCHW: same values); the bias (1, O, 1, 1) is column K of the
+    packed weight against a row of ones, so `+ bias` and its gradient ride inside the GEMMs.
+    `node._col` is the reference-layout im2col buffer (formed on demand on the direct path)."""
+
+    use_direct = True       # class switch: False forces the im2col + GEMM path (tests, A/B)
 
     def __init__(self, x, kernel, bias=None, padding=0, stride=1):
         self.padding, self.stride = int(padding), int(stride)
@@ -581,32 +586,61 @@ class conv2d(_Operator):
             return out.reshape(N, oh, ow, O).transpose(0, 3, 1, 2)
         _require_f32(self, x, kernel, bias)
         hp, L = _hip(), _L()
-        xd = _contig(x.data)
-        K, M = C * k * k, oh * ow
-        # contraction padded to a multiple of 4 (16-byte GEMM path); with a bias, row K of the
-        # im2col buffer is ones and column K of the packed weight is the bias
-        Kp = (K + (1 if bias is not None else 0) + 3) // 4 * 4
-        colp = hp.empty((N, Kp, M), np.float32)
-        L.call("pdn_im2col2d_f32", xd._ptr, N, C, H, W, k, self.stride, self.padding, colp._ptr, Kp,
-               1 if bias is not None else 0, hp.stream())
-        self._colp, self._Kp = colp, Kp
-        wp = hp.zeros((O, Kp), np.float32)
-        wp[:, :K] = kernel.data.reshape(O, K)
-        if bias is not None:
-            wp[:, K] = bias.data.reshape(O)
-        self._wp = wp
+        self._xd = _contig(x.data)
+        self._k_shape = tuple(kernel.shape)
+        self._kernel_data = kernel.data
+        self._bias_data = bias.data if bias is not None else None
+        self._colp = self._wp = None
+        self._direct = L.query("pdn_conv2d_direct_supported", C, H, W, O, k, self.stride, self.padding) \
+            if conv2d.use_direct else 0
         out = hp.empty((N, O, oh, ow), np.float32)                 # NCHW, contiguous
-        hp.gemm(wp, colp, out.reshape(N, O, M))                    # per image (O,Kp) @ (Kp,M)
+        if self._direct & 1:
+            wd = _contig(kernel.data)
+            L.call("pdn_conv2d_fwd_f32", self._xd._ptr, wd._ptr,
+                   _contig(bias.data)._ptr if bias is not None else None, out._ptr, N, C, H, W, O, k,
+                   self.stride, self.padding, hp.stream())
+            return out
+        colp, wp = self._ensure_col(), self._ensure_wp()
+        hp.gemm(wp, colp, out.reshape(N, O, oh * ow))              # per image (O,Kp) @ (Kp,M)
         return out
+
+    # -- explicit im2col operands (generic path, and the bit-exact `col` of the parity tests) ------
+    def _ensure_col(self):
+        if getattr(self, "_colp", None) is None:
+            hp, L = _hip(), _L()
+            N, C, H, W = self._xd.shape
+            k = self._k_shape[2]
+            M = ((H + 2 * self.padding - k) // self.stride + 1) * ((W + 2 * self.padding - k) // self.stride + 1)
+            K = C * k * k
+            # contraction padded to a multiple of 4 (16-byte GEMM path); with a bias, row K of the
+            # im2col buffer is ones and column K of the packed weight is the bias
+            self._Kp = (K + (1 if self.has_bias else 0) + 3) // 4 * 4
+            self._colp = hp.empty((N, self._Kp, M), np.float32)
+            L.call("pdn_im2col2d_f32", self._xd._ptr, N, C, H, W, k, self.stride, self.padding, self._colp._ptr,
+                   self._Kp, 1 if self.has_bias else 0, hp.stream())
+        return self._colp
+
+    def _ensure_wp(self):
+        if getattr(self, "_wp", None) is None:
+            hp = _hip()
+            self._ensure_col()
+            O, C, k, _ = self._k_shape
+            K = C * k * k
+            wp = hp.zeros((O, self._Kp), np.float32)
+            wp[:, :K] = self._kernel_data.reshape(O, K)
+            if self.has_bias:
+                wp[:, K] = self._bias_data.reshape(O)
+            self._wp = wp
+        return self._wp
 
     @property
     def _col(self):
         """The im2col buffer in the reference layout (N, C, kh, kw, oh, ow) (a view on the HIP path)."""
-        if hasattr(self, "_colp"):
-            x, kernel = self.last[0], self.last[1]
-            N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
-            return self._colp[:, :C * k * k].reshape(N, C, k, k, oh, ow)
-        return self._col_np
+        if self.xp is np:
+            return self._col_np
+        x, kernel = self.last[0], self.last[1]
+        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        return self._ensure_col()[:, :C * k * k].reshape(N, C, k, k, oh, ow)
 
     def backward_all(self, g):
         x, kernel = self.last[0], self.last[1]
@@ -631,24 +665,49 @@ class conv2d(_Operator):
                 grads[0] = dxp[:, :, p:p + H, p:p + W] if p else dxp
             return grads
         hp, L = _hip(), _L()
-        Kp = self._Kp
-        g3 = _contig(g).reshape(N, O, M)                                       # NCHW rows
+        gc = _contig(g)
+        need_dw = kernel.requires_grad
         need_db = bias is not None and bias.requires_grad
-        if kernel.requires_grad or need_db:
+        if (need_dw or need_db) and self._direct & 4:
+            # dW and db straight into the leaves' gradient buffers when they are float32 leaves
+            direct_w = need_dw and _is_leaf_f32(kernel)
+            direct_b = need_db and _is_leaf_f32(bias)
+            if need_dw and need_db and direct_w != direct_b:
+                direct_w = direct_b = False              # one accumulate flag: keep both on the same side
+            dw = (kernel.grad if direct_w else hp.empty(kernel.shape, np.float32)) if need_dw else None
+            db = (bias.grad if direct_b else hp.empty((O,), np.float32)) if need_db else None
+            ws, wsb = hp.workspace(L.query("pdn_conv2d_bwd_weight_workspace_bytes", N, C, H, W, O, k,
+                                           self.stride, self.padding))
+            L.call("pdn_conv2d_bwd_weight_f32", self._xd._ptr, gc._ptr, dw._ptr if dw is not None else None,
+                   db._ptr if db is not None else None, 1 if (direct_w or direct_b) else 0, N, C, H, W, O, k,
+                   self.stride, self.padding, ws, wsb, hp.stream())
+            if need_dw and not direct_w:
+                grads[1] = dw
+            if need_db and not direct_b:
+                grads[2] = db.reshape(bias.shape)
+        elif need_dw or need_db:
+            colp = self._ensure_col()
+            Kp = self._Kp
             # per image g (O,M) @ col^T (M,Kp); column K of the sum is the bias gradient
             part = hp.empty((N, O, Kp), np.float32)
-            hp.gemm(g3, self._colp.transpose(0, 2, 1), part)
+            hp.gemm(gc.reshape(N, O, M), colp.transpose(0, 2, 1), part)
             dwp = part.sum(0)
-            if kernel.requires_grad:
+            if need_dw:
                 grads[1] = dwp[:, :K].reshape(kernel.shape)
             if need_db:
                 grads[2] = dwp[:, K].reshape(bias.shape)
         if x.requires_grad:
-            dcol = hp.empty((N, Kp, M), np.float32)
-            hp.gemm(self._wp.T, g3, dcol)                                      # (Kp,O) @ (O,M) per image
             dx = hp.empty((N, C, H, W), np.float32)
-            L.call("pdn_col2im2d_f32", dcol._ptr, N, C, H, W, k, self.stride, self.padding, dx._ptr, Kp,
-                   hp.stream())
+            if self._direct & 2:
+                L.call("pdn_conv2d_bwd_data_f32", gc._ptr, _contig(kernel.data)._ptr, dx._ptr, N, C, H, W, O, k,
+                       self.stride, self.padding, hp.stream())
+            else:
+                wp = self._ensure_wp()
+                Kp = self._Kp
+                dcol = hp.empty((N, Kp, M), np.float32)
+                hp.gemm(wp.T, gc.reshape(N, O, M), dcol)                       # (Kp,O) @ (O,M) per image
+                L.call("pdn_col2im2d_f32", dcol._ptr, N, C, H, W, k, self.stride, self.padding, dx._ptr, Kp,
+                       hp.stream())
             grads[0] = dx
         return grads
 

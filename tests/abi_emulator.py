@@ -572,6 +572,64 @@ class EmulatedLib:
             dst[:, ckk] = 1.0
         return 0
 
+    # -- direct convolution (same supported-shape rule as csrc/conv_direct.hip) -------------------------
+    def pdn_conv2d_direct_supported(self, C, H, W, O, k, s, p):
+        if min(C, O, k, s) <= 0 or p < 0 or H + 2 * p < k or W + 2 * p < k:
+            return 0
+        lim, mask = 150 * 1024, 0
+
+        def fwd_lds(cin, h, w, cout, pad):
+            cp, opad = (cin + 1) // 2 * 2, (cout + 31) // 32 * 32
+            return opad <= 64 and 4 * (k * k * cp * opad + cp * (h + 2 * pad) * (w + 2 * pad) + opad) + 64 <= lim
+        if fwd_lds(C, H, W, O, p):
+            mask |= 1
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        if s == 1 and k - 1 - p >= 0 and fwd_lds(O, oh, ow, C, k - 1 - p):
+            mask |= 2
+        opad, kcols = (O + 31) // 32 * 32, (C * k * k + 1 + 31) // 32 * 32
+        if (opad // 32) * (kcols // 32) <= 16 and \
+                4 * (C * (H + 2 * p) * (W + 2 * p) + opad * ((oh * ow) | 1) + oh * ow) + 64 <= lim:
+            mask |= 4
+        return mask
+
+    def _conv_cols(self, x, N, C, H, W, k, s, p):
+        xp = np.pad(flat(x, N * C * H * W).reshape(N, C, H, W), [(0, 0), (0, 0), (p, p), (p, p)])
+        oh, ow, shape, strides = self._windows(xp, k, s)
+        return np.lib.stride_tricks.as_strided(xp, shape, strides).reshape(N, C * k * k, oh * ow), oh, ow
+
+    def pdn_conv2d_fwd_f32(self, x, w, bias, y, N, C, H, W, O, k, s, p, stream):
+        col, oh, ow = self._conv_cols(x, N, C, H, W, k, s, p)
+        out = np.matmul(flat(w, O * C * k * k).reshape(O, -1), col)
+        if bias:
+            out = out + flat(bias, O).reshape(1, O, 1)
+        flat(y, N * O * oh * ow).reshape(N, O, oh * ow)[...] = out
+        return 0
+
+    def pdn_conv2d_bwd_data_f32(self, dy, w, dx, N, C, H, W, O, k, s, p, stream):
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        g = flat(dy, N * O * oh * ow).reshape(N, O, oh * ow)
+        dcol = np.matmul(flat(w, O * C * k * k).reshape(O, -1).T, g)
+        dxp = np.zeros((N, C, H + 2 * p, W + 2 * p), np.float32)
+        _, _, shape, strides = self._windows(dxp, k, s)
+        np.add.at(np.lib.stride_tricks.as_strided(dxp, shape, strides), (...,), dcol.reshape(shape))
+        flat(dx, N * C * H * W).reshape(N, C, H, W)[...] = dxp[:, :, p:p + H, p:p + W]
+        return 0
+
+    def pdn_conv2d_bwd_weight_workspace_bytes(self, N, C, H, W, O, k, s, p): return 4096
+
+    def pdn_conv2d_bwd_weight_f32(self, x, dy, dw, db, acc, N, C, H, W, O, k, s, p, ws, wsb, stream):
+        col, oh, ow = self._conv_cols(x, N, C, H, W, k, s, p)
+        g = flat(dy, N * O * oh * ow).reshape(N, O, oh * ow)
+        if dw:
+            v = np.matmul(g, col.transpose(0, 2, 1)).sum(0).astype(np.float32).reshape(-1)
+            d = flat(dw, O * C * k * k)
+            d[...] = d + v if acc else v
+        if db:
+            v = g.sum((0, 2)).astype(np.float32)
+            d = flat(db, O)
+            d[...] = d + v if acc else v
+        return 0
+
     def pdn_col2im2d_f32(self, dcol, N, C, H, W, k, s, p, dx, rows, stream):
         dxp = np.zeros((N, C, H + 2 * p, W + 2 * p), np.float32)
         oh, ow, shape, strides = self._windows(dxp, k, s)

@@ -20,9 +20,18 @@ def test_flop_count_and_peak_match_the_survey():
 def test_cpu_baseline_record_shape():
     import bench
     rec = bench.cpu_baseline(seconds_budget=0.0)                         # warm-up + the minimum of 2 steps
-    assert set(rec) == {"value", "unit", "cores", "kind", "sample"}
+    assert set(rec) == {"value", "unit", "cores", "kind", "sample", "product_numpy_device"}
+    assert set(rec["product_numpy_device"]) == {"batch_1", "batch_8"}
     assert rec["unit"] == "samples/s" and rec["kind"] == "port" and rec["value"] > 0
     assert rec["cores"] == os.cpu_count() and "batch 1" in rec["sample"]
+
+
+def test_bench_uses_no_pytorch():
+    """Device memory, streams, events and RCCL come from libpdnhip.so: bench.py imports no torch."""
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    mods = {a.name.split(".")[0] for n in ast.walk(tree) if isinstance(n, ast.Import) for a in n.names}
+    mods |= {n.module.split(".")[0] for n in ast.walk(tree) if isinstance(n, ast.ImportFrom) and n.module}
+    assert "torch" not in mods
 
 
 def test_command_line_defaults_and_json_keys():
@@ -38,5 +47,6 @@ def test_command_line_defaults_and_json_keys():
     assert defaults["--gpus"] == 1 and defaults["--steps"] == 10 and defaults["--warmup"] == 3
     for key in ('"metric"', '"value"', '"unit"', '"n_gpus"', '"steps"', '"warmup"', '"ms_per_step"',
                 '"higher_is_better"', '"scaling"', '"vs_baseline"', '"dtype"', '"data"', '"config"',
-                '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"'):
+                '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"',
+                '"parity_gate"'):
         assert key in src, key
