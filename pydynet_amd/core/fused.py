@@ -638,8 +638,10 @@ class conv2d(_Operator):
         """The im2col buffer in the reference layout (N, C, kh, kw, oh, ow) (a view on the HIP path)."""
         if self.xp is np:
             return self._col_np
-        x, kernel = self.last[0], self.last[1]
-        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        N, C, H, W = self._xd.shape                      # (the node's edges are gone after backward)
+        k = self._k_shape[2]
+        oh = (H + 2 * self.padding - k) // self.stride + 1
+        ow = (W + 2 * self.padding - k) // self.stride + 1
         return self._ensure_col()[:, :C * k * k].reshape(N, C, k, k, oh, ow)
 
     def backward_all(self, g):

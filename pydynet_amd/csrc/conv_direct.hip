@@ -59,8 +59,47 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ src, float
   }
 }
 
-template <int OT, int CH>
-__global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restrict__ x,
+// Register prefetch of a (C, H, W) block whose rows are float4-aligned: `issue` starts the global loads
+// (NV float4 per thread cover 256 * NV * 4 floats), `commit` writes them into the padded LDS frame.
+// Issued one image ahead of the MFMA phase, the HBM latency hides behind compute instead of in front.
+__device__ __forceinline__ void lds_store4(float* __restrict__ d, const float4& v) {
+  // (rotating the component order per lane group to dodge the 4-way bank conflict of these stores was
+  // measured SLOWER: the selects cost more than the conflicts -- the stores are not on the critical path)
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+
+template <int NV>
+struct TilePrefetch {
+  float4 v[NV > 0 ? NV : 1];
+  __device__ __forceinline__ void issue(const float* __restrict__ src, int total) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (threadIdx.x + i * 256) * 4;
+      if (e < total) v[i] = *reinterpret_cast<const float4*>(src + e);
+    }
+  }
+  // (c, y, x) of element e in a (C, H, W) block -> frame[(c * PH + y + pad) * PW + x + pad]
+  __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
+                                               int pad) {
+    const int plane = H * W;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (threadIdx.x + i * 256) * 4;
+      if (e < total) {
+        const int c = e / plane, rem = e - c * plane;
+        const int y = rem / W, x = rem - y * W;
+        lds_store4(frame + (c * PH + y + pad) * PW + x + pad, v[i]);
+      }
+    }
+  }
+};
+
+// KS = compile-time tap extent (1, 3, 5) or 0 for a runtime extent.  With KS known the taps*(OT+CH)
+// LDS reads of one channel pair are issued as a block ahead of the MFMAs that consume them, and the
+// block of the NEXT channel pair is in flight while the current one is multiplied (one wave per SIMD
+// has no partner to hide the ~100-cycle ds_read latency behind, so the prefetch is explicit).
+template <int OT, int CH, int KS, int NV>
+__global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
                                                            float* __restrict__ y, ConvGeom g) {
@@ -85,11 +124,32 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
   for (int e = threadIdx.x; e < img_elems; e += blockDim.x) img[e] = 0.f;   // halo + padded channel stay 0
   __syncthreads();
 
+  float breg[OT][16];
+  unsigned rowmask[OT];
+#pragma unroll
+  for (int o = 0; o < OT; ++o) {
+    rowmask[o] = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int oc = o * 32 + acc_row(r, half);
+      breg[o][r] = bs[oc];
+      rowmask[o] |= (oc < g.Cout ? 1u : 0u) << r;
+    }
+  }
   const int chunks = (M + 31) / 32, per_pass = 4 * CH, passes = (chunks + per_pass - 1) / per_pass;
-  const int plane = g.PH * g.PW;
+  const int plane = g.PH * g.PW, npair = g.Cp / 2, wstep = 2 * g.OPAD, tapw = g.Cp * g.OPAD;
+  const int in_elems = g.Cin * g.Hin * g.Win;
+  TilePrefetch<NV> pf;
+  if (NV > 0 && blockIdx.x < g.N) pf.issue(x + (int64_t)blockIdx.x * in_elems, in_elems);
   for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
-    stage_image(x + (int64_t)n * g.Cin * g.Hin * g.Win, img, g, g.pad);
-    __syncthreads();
+    if (NV > 0) {
+      pf.commit_image(img, in_elems, g.Hin, g.Win, g.PH, g.PW, g.pad);
+      __syncthreads();
+      if (n + (int)gridDim.x < g.N) pf.issue(x + (int64_t)(n + gridDim.x) * in_elems, in_elems);
+    } else {
+      stage_image(x + (int64_t)n * in_elems, img, g, g.pad);
+      __syncthreads();
+    }
     float* yn = y + (int64_t)n * g.Cout * M;
     for (int pass = 0; pass < passes; ++pass) {
       int poff[CH], pos[CH];
@@ -110,33 +170,73 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[o][c][r] = 0.f;
       const float* wrow = wt + half * g.OPAD + l31;
-      for (int tap = 0; tap < taps; ++tap) {
-        const int kh = tap / g.k, kw = tap - kh * g.k;
-        const float* ib = img + kh * g.PW + kw;
-        const float* wb = wrow + tap * g.Cp * g.OPAD;
-        for (int c2 = 0; c2 < g.Cp; c2 += 2) {
-          float a[OT], b[CH];
+      if constexpr (KS > 0) {
+        // software pipeline over steps s = (channel pair, tap row): the KS*(OT+CH) ds_reads of step s+1 are
+        // in flight while step s is multiplied; <= 15 newer LDS operations are ever outstanding, so the
+        // lgkmcnt waits in front of the MFMAs stay exact
+        float a0[KS][OT], b0[KS][CH], a1[KS][OT], b1[KS][CH];
+        int c2l = 0, khl = 0;                           // position of the NEXT load
+        auto load = [&](float (&a)[KS][OT], float (&b)[KS][CH]) {
+          const float* wp = wrow + khl * KS * tapw + c2l * wstep;
+          const float* ip = img + c2l * 2 * plane + khl * g.PW;
 #pragma unroll
-          for (int o = 0; o < OT; ++o) a[o] = wb[c2 * g.OPAD + o * 32];
+          for (int t = 0; t < KS; ++t) {
 #pragma unroll
-          for (int c = 0; c < CH; ++c) b[c] = ib[c2 * plane + poff[c]];
+            for (int o = 0; o < OT; ++o) a[t][o] = wp[t * tapw + o * 32];
 #pragma unroll
-          for (int o = 0; o < OT; ++o)
+            for (int c = 0; c < CH; ++c) b[t][c] = ip[t + poff[c]];
+          }
+          if (++khl == KS) { khl = 0; ++c2l; }
+        };
+        auto mul = [&](float (&a)[KS][OT], float (&b)[KS][CH]) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-              acc[o][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[o], b[c], acc[o][c], 0, 0, 0);
+          for (int t = 0; t < KS; ++t)
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+#pragma unroll
+              for (int c = 0; c < CH; ++c)
+                acc[o][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][o], b[t][c], acc[o][c], 0, 0, 0);
+        };
+        const int steps = npair * KS;
+        load(a0, b0);
+        int st = 0;
+        for (; st + 2 <= steps; st += 2) {
+          load(a1, b1);
+          mul(a0, b0);
+          if (st + 2 < steps) load(a0, b0);
+          mul(a1, b1);
+        }
+        if (st < steps) mul(a0, b0);
+      } else {
+        for (int tap = 0; tap < taps; ++tap) {
+          const int kh = tap / g.k, kw = tap - kh * g.k;
+          const float* ib = img + kh * g.PW + kw;
+          const float* wb = wrow + tap * tapw;
+          for (int c2 = 0; c2 < npair; ++c2) {
+            float a[OT], b[CH];
+#pragma unroll
+            for (int o = 0; o < OT; ++o) a[o] = wb[c2 * wstep + o * 32];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) b[c] = ib[c2 * 2 * plane + poff[c]];
+#pragma unroll
+            for (int o = 0; o < OT; ++o)
+#pragma unroll
+              for (int c = 0; c < CH; ++c)
+                acc[o][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[o], b[c], acc[o][c], 0, 0, 0);
+          }
         }
       }
+      // epilogue: rows of this lane's accumulator registers are fixed -> bias and row validity come
+      // from registers set up once per kernel (no LDS read, no branch per store)
 #pragma unroll
       for (int o = 0; o < OT; ++o)
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
           if (pos[c] >= M) continue;
+          float* yp = yn + pos[c];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int oc = o * 32 + acc_row(r, half);
-            if (oc < g.Cout) yn[(int64_t)oc * M + pos[c]] = acc[o][c][r] + bs[oc];
-          }
+          for (int r = 0; r < 16; ++r)
+            if (rowmask[o] >> r & 1) yp[(int64_t)(o * 32 + acc_row(r, half)) * M] = acc[o][c][r] + breg[o][r];
         }
     }
     __syncthreads();                                  // everyone is done with this image
@@ -146,37 +246,36 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float* __restric
 struct WgradGeom {
   int N, C, H, W, O, k, stride, pad, OH, OW;
   int PH, PW, OPAD, K1, KCOLS;   // K1 = C*k*k + 1 (bias column), KCOLS = K1 rounded up to 32
+  int MB;                        // output positions staged per pass (a multiple of 8, or all of them)
   int DYS;                       // LDS row stride of the dy tile (odd)
   int per_block;                 // images per workgroup
 };
 
 // WT = tiles per wave; PS = 1: waves share all tiles and split the positions, 0: waves split tiles.
-template <int WT, int PS>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ x,
+// The dy tile holds O + 1 rows (row O stays zero and serves the padded output channels).
+template <int WT, int PS, int NVX, int NVD>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ dy,
                                                           float* __restrict__ partial, WgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;                                   // [C][PH][PW]
-  float* dyl = img + g.C * g.PH * g.PW;               // [OPAD][DYS]
-  int* ptab = reinterpret_cast<int*>(dyl + g.OPAD * g.DYS);   // [M] image offset of each output position
+  float* dyl = img + g.C * g.PH * g.PW;               // [O + 1][DYS]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
   const int M = g.OH * g.OW, taps = g.k * g.k, KT = g.KCOLS / 32, T = (g.OPAD / 32) * KT;
   const int plane = g.PH * g.PW;
+  constexpr int G = WT >= 3 ? 2 : (WT == 2 ? 3 : 4);  // position pairs per prefetch group (<= 14 ds_reads)
 
   for (int e = threadIdx.x; e < g.C * plane; e += blockDim.x) img[e] = 0.f;
-  for (int e = threadIdx.x; e < g.OPAD * g.DYS; e += blockDim.x) dyl[e] = 0.f;
-  for (int e = threadIdx.x; e < M; e += blockDim.x) {
-    const int oy = e / g.OW, ox = e - oy * g.OW;
-    ptab[e] = oy * g.stride * g.PW + ox * g.stride;
-  }
+  for (int e = threadIdx.x; e < (g.O + 1) * g.DYS; e += blockDim.x) dyl[e] = 0.f;
   // per-lane column of every owned tile: j = c*taps + tap (the layout of the (O, C, k, k) weight)
-  int coff[WT], row0[WT], kind[WT];                   // kind 0 = gather, 1 = ones (bias column), 2 = zero
+  int coff[WT], arow[WT], kind[WT];                   // kind 0 = gather, 1 = ones (bias column), 2 = zero
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
-    const int t = PS ? i : wave + 4 * i;
+    const int t = PS ? i : wave * WT + i;
     const int ot = t / KT, kt = t - ot * KT;
     const int j = kt * 32 + l31;
-    row0[i] = ot * 32;
+    const int o = ot * 32 + l31;
+    arow[i] = (o < g.O ? o : g.O) * g.DYS;
     kind[i] = (t >= T || j >= g.K1) ? 2 : (j == g.K1 - 1 ? 1 : 0);
     const int c = j / taps, tap = j - c * taps, kh = tap / g.k, kw = tap - kh * g.k;
     coff[i] = kind[i] == 0 ? c * plane + kh * g.PW + kw : 0;
@@ -189,50 +288,128 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   __syncthreads();
 
   const int n0 = blockIdx.x * g.per_block, n1 = min(g.N, n0 + g.per_block);
-  const int pairs = (M + 1) / 2;
-  for (int n = n0; n < n1; ++n) {
-    // image into the padded LDS frame, dy rows into [o][pos]
-    {
-      ConvGeom cg;
-      cg.Cin = g.C; cg.Hin = g.H; cg.Win = g.W; cg.PH = g.PH; cg.PW = g.PW;
-      stage_image(x + (int64_t)n * g.C * g.H * g.W, img, cg, g.pad);
-    }
-    const float* dyn = dy + (int64_t)n * g.O * M;
-    if ((M & 3) == 0) {
-      for (int e = threadIdx.x * 4; e < g.O * M; e += blockDim.x * 4) {
-        const float4 v = *reinterpret_cast<const float4*>(dyn + e);
-        const int o = e / M, p = e - o * M;
-        float* d = dyl + o * g.DYS + p;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    } else {
-      for (int e = threadIdx.x; e < g.O * M; e += blockDim.x) {
-        const int o = e / M, p = e - o * M;
-        dyl[o * g.DYS + p] = dyn[e];
-      }
-    }
-    __syncthreads();
-    for (int pp = PS ? wave : 0; pp < pairs; pp += PS ? 4 : 1) {
-      const int pos = 2 * pp + half;
-      const bool valid = pos < M;
-      const int pc = valid ? pos : M - 1;
-      const int po = ptab[pc];
+  const int pstep = PS ? 4 : 1;                       // pairs between this wave's consecutive iterations
+  const int nblk = (M + g.MB - 1) / g.MB, items = (n1 - n0) * nblk, x_elems = g.C * g.H * g.W;
+  TilePrefetch<NVX> px;
+  float4 dv[NVD > 0 ? NVD : 1];
+  // dy[:, m0 : m0 + mb] of image n as float4 pieces: piece e -> row e / q, columns 4 * (e % q)
+  auto issue = [&](int it) {
+    const int n = n0 + it / nblk, m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
+    if (m0 == 0) px.issue(x + (int64_t)n * x_elems, x_elems);
+    const float* dyn = dy + (int64_t)n * g.O * M + m0;
 #pragma unroll
-      for (int i = 0; i < WT; ++i) {
-        float a = dyl[(row0[i] + l31) * g.DYS + pc];
-        float b = kind[i] == 0 ? img[coff[i] + po] : (kind[i] == 1 ? 1.f : 0.f);
-        a = valid ? a : 0.f;
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NVD; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < g.O * q) {
+        const int o = e / q, p = (e - o * q) * 4;
+        dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)o * M + p);
       }
     }
-    __syncthreads();
+  };
+  auto commit = [&](int it) {
+    const int m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
+    if (m0 == 0) px.commit_image(img, x_elems, g.H, g.W, g.PH, g.PW, g.pad);
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < g.O * q) {
+        const int o = e / q, p = (e - o * q) * 4;
+        lds_store4(dyl + o * g.DYS + p, dv[i]);
+      }
+    }
+  };
+  if (NVD > 0 && items > 0) issue(0);
+  for (int it = 0; it < items; ++it) {
+    const int n = n0 + it / nblk, m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0);
+    if (it) __syncthreads();                          // previous item fully consumed
+    if (NVD > 0) {
+      commit(it);
+      __syncthreads();
+      if (it + 1 < items) issue(it + 1);              // in flight during this item's MFMAs
+    } else {
+      if (m0 == 0) {
+        ConvGeom cg;
+        cg.Cin = g.C; cg.Hin = g.H; cg.Win = g.W; cg.PH = g.PH; cg.PW = g.PW;
+        stage_image(x + (int64_t)n * x_elems, img, cg, g.pad);
+      }
+      const float* dyn = dy + (int64_t)n * g.O * M;
+      // a ragged last block leaves stale columns that are never read
+      for (int e = threadIdx.x; e < g.O * mb; e += blockDim.x) {
+        const int o = e / mb, p = e - o * mb;
+        dyl[o * g.DYS + p] = dyn[(int64_t)o * M + m0 + p];
+      }
+      __syncthreads();
+    }
+    {
+      const int pairs = (mb + 1) / 2;
+      // this wave's position walk: pair index pp -> local position 2*pp + half -> (oy, ox) of m0 + that
+      int pp = PS ? wave : 0;
+      int lp = 2 * pp + half;                         // local position (may run past mb: masked)
+      int gp = m0 + lp;
+      int oy = gp / g.OW, ox = gp - oy * g.OW;
+      float av[2][G][WT], bv[2][G][WT];
+      auto load = [&](float (&a)[G][WT], float (&b)[G][WT]) {
+#pragma unroll
+        for (int q = 0; q < G; ++q) {
+          const bool valid = lp < mb;
+          const int lpc = valid ? lp : 0;
+          const int po = valid ? oy * g.stride * g.PW + ox * g.stride : 0;
+#pragma unroll
+          for (int i = 0; i < WT; ++i) {
+            const float av_ = dyl[arow[i] + lpc];
+            a[q][i] = valid ? av_ : 0.f;
+            b[q][i] = kind[i] == 0 ? img[coff[i] + po] : (kind[i] == 1 ? 1.f : 0.f);
+          }
+          lp += 2 * pstep;
+          ox += 2 * pstep;
+          while (ox >= g.OW) { ox -= g.OW; ++oy; }
+        }
+      };
+      auto mul = [&](float (&a)[G][WT], float (&b)[G][WT]) {
+#pragma unroll
+        for (int q = 0; q < G; ++q)
+#pragma unroll
+          for (int i = 0; i < WT; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][i], acc[i], 0, 0, 0);
+      };
+      const int iters = (pairs - (PS ? wave : 0) + pstep - 1) / pstep;      // this wave's pair count
+      const int groups = (iters + G - 1) / G;
+      if (groups > 0) load(av[0], bv[0]);
+      for (int gi = 0; gi < groups; gi += 2) {
+        if (gi + 1 < groups) load(av[1], bv[1]);
+        mul(av[0], bv[0]);
+        if (gi + 2 < groups) load(av[0], bv[0]);
+        if (gi + 1 < groups) mul(av[1], bv[1]);
+      }
+    }
   }
-  // partial sums: slab per (workgroup[, wave]); layout [OPAD][KCOLS]
-  const int slab = PS ? blockIdx.x * 4 + wave : blockIdx.x;
-  float* out = partial + (int64_t)slab * g.OPAD * g.KCOLS;
+  __syncthreads();
+  // partial sums: slab per workgroup; with PS the four waves' slabs are summed through LDS first
+  float* out = partial + (int64_t)blockIdx.x * g.OPAD * g.KCOLS;
+  if (PS) {
+    float* red = lds;                                 // [4][WT][64][16] floats, reuses the image space
+#pragma unroll
+    for (int i = 0; i < WT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[((wave * WT + i) * 16 + r) * 64 + lane] = acc[i][r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int i = 0; i < WT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float s = 0.f;
+#pragma unroll
+          for (int wv = 0; wv < 4; ++wv) s += red[((wv * WT + i) * 16 + r) * 64 + lane];
+          acc[i][r] = s;
+        }
+    } else {
+      return;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < WT; ++i) {
-    const int t = PS ? i : wave + 4 * i;
+    const int t = PS ? i : wave * WT + i;
     if (t >= T) continue;
     const int ot = t / KT, kt = t - ot * KT;
 #pragma unroll
@@ -241,20 +418,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   }
 }
 
-// dw[o][j] (+)= sum_slabs partial[slab][o][j] (j < K), db[o] (+)= column K; fixed order: deterministic
-__global__ void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int OPAD, int KCOLS,
-                                         int O, int K, float* __restrict__ dw, float* __restrict__ db,
-                                         int accumulate) {
+// dw[o][j] (+)= sum_slabs partial[slab][o][j] (j < K), db[o] (+)= column K.  A workgroup owns 32
+// consecutive elements; its 8 thread groups sum interleaved slabs and combine through LDS in a fixed
+// order: deterministic, and 8x the memory parallelism of one thread per element.
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int slabs,
+                                                                 int OPAD, int KCOLS, int O, int K,
+                                                                 float* __restrict__ dw, float* __restrict__ db,
+                                                                 int accumulate) {
+  __shared__ float red[8][32];
   const int total = O * (K + 1);
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    const int o = e / (K + 1), j = e - o * (K + 1);
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  float s = 0.f;
+  int o = 0, j = 0;
+  if (e < total) {
+    o = e / (K + 1); j = e - o * (K + 1);
     const float* p = partial + (int64_t)o * KCOLS + j;
-    float s = 0.f;
-    for (int b = 0; b < slabs; ++b) s += p[(int64_t)b * OPAD * KCOLS];
+    const int64_t stride = (int64_t)OPAD * KCOLS;
+    for (int b = grp; b < slabs; b += 8) s += p[b * stride];
+  }
+  red[grp][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (grp == 0 && e < total) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x];
     if (j < K) {
-      if (dw) dw[(int64_t)o * K + j] = accumulate ? dw[(int64_t)o * K + j] + s : s;
+      if (dw) dw[(int64_t)o * K + j] = accumulate ? dw[(int64_t)o * K + j] + t : t;
     } else if (db) {
-      db[o] = accumulate ? db[o] + s : s;
+      db[o] = accumulate ? db[o] + t : t;
     }
   }
 }
@@ -284,13 +475,30 @@ int launch_direct(const float* x, const float* w, const float* bias, float* y, c
   int grid = 256 * (per_cu > 4 ? 4 : per_cu);
   if (grid > g.N) grid = g.N;
   const int M = g.OH * g.OW, chunks = (M + 31) / 32;
-#define PDN_CONV_LAUNCH(OT, CH)                                                                        \
+  // float4 per thread that hold one input image in registers (0: rows not float4-aligned / too large)
+  const int in_elems = g.Cin * g.Hin * g.Win;
+  int nv = ((g.Win & 3) == 0 && in_elems <= 16 * 1024) ? (in_elems / 4 + 255) / 256 : 0;
+#define PDN_CONV_LAUNCH_KN(OT, CH, KS, NV)                                                             \
   do {                                                                                                 \
-    auto kern = conv_direct_kernel<OT, CH>;                                                            \
+    auto kern = conv_direct_kernel<OT, CH, KS, NV>;                                                    \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                        (int)lds);                                                      \
     if (e != hipSuccess) { pdn_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, w, bias, y, g);                        \
+  } while (0)
+#define PDN_CONV_LAUNCH_K(OT, CH, KS)                                                                  \
+  do {                                                                                                 \
+    if (nv == 0 || KS != 3) PDN_CONV_LAUNCH_KN(OT, CH, KS, 0);                                         \
+    else if (nv <= 4) PDN_CONV_LAUNCH_KN(OT, CH, 3, 4);                                                \
+    else if (nv <= 8) PDN_CONV_LAUNCH_KN(OT, CH, 3, 8);                                                \
+    else PDN_CONV_LAUNCH_KN(OT, CH, 3, 16);                                                            \
+  } while (0)
+#define PDN_CONV_LAUNCH(OT, CH)                                                                        \
+  do {                                                                                                 \
+    if (g.k == 3) PDN_CONV_LAUNCH_K(OT, CH, 3);                                                        \
+    else if (g.k == 5 && OT * CH <= 2) PDN_CONV_LAUNCH_K(OT, CH, 5);                                   \
+    else if (g.k == 1) PDN_CONV_LAUNCH_K(OT, CH, 1);                                                   \
+    else PDN_CONV_LAUNCH_K(OT, CH, 0);                                                                 \
   } while (0)
   if (g.OPAD == 64) {
     if (chunks >= 8) PDN_CONV_LAUNCH(2, 2); else PDN_CONV_LAUNCH(2, 1);
@@ -298,6 +506,8 @@ int launch_direct(const float* x, const float* w, const float* bias, float* y, c
     if (chunks >= 16) PDN_CONV_LAUNCH(1, 4); else if (chunks >= 8) PDN_CONV_LAUNCH(1, 2); else PDN_CONV_LAUNCH(1, 1);
   }
 #undef PDN_CONV_LAUNCH
+#undef PDN_CONV_LAUNCH_K
+#undef PDN_CONV_LAUNCH_KN
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -310,11 +520,18 @@ bool wgrad_geom(WgradGeom& g, int N, int C, int H, int W, int O, int k, int stri
   g.OPAD = (O + 31) / 32 * 32;
   g.K1 = C * k * k + 1;
   g.KCOLS = (g.K1 + 31) / 32 * 32;
-  g.DYS = (g.OH * g.OW) | 1;
+  // stage all positions of an image at once when two workgroups per CU still fit, else blocks of 512
+  const int M = g.OH * g.OW;
+  g.MB = M;
+  const int64_t img_b = 4ll * C * g.PH * g.PW;
+  if (img_b + 4ll * (O + 1) * (M | 1) > 78 * 1024 && M > 512) g.MB = 512;
+  g.DYS = g.MB | 1;
   return g.OH > 0 && g.OW > 0;
 }
 int64_t wgrad_lds(const WgradGeom& g) {
-  return 4ll * ((int64_t)g.C * g.PH * g.PW + (int64_t)g.OPAD * g.DYS + (int64_t)g.OH * g.OW) + 64;
+  int64_t b = 4ll * ((int64_t)g.C * g.PH * g.PW + (int64_t)(g.O + 1) * g.DYS) + 64;
+  const int64_t red = 4ll * 4 * 3 * 16 * 64;          // cross-wave reduction scratch of the position-split form
+  return b > red ? b : red;
 }
 int wgrad_tiles(const WgradGeom& g) { return (g.OPAD / 32) * (g.KCOLS / 32); }
 bool wgrad_ok(const WgradGeom& g) { return wgrad_tiles(g) <= 16 && wgrad_lds(g) <= kMaxLds; }
@@ -378,7 +595,7 @@ int pdn_conv2d_bwd_data_f32(const float* dy, const float* w, float* dx, int N, i
 int64_t pdn_conv2d_bwd_weight_workspace_bytes(int N, int C, int H, int W, int O, int k, int stride, int pad) {
   WgradGeom g;
   if (!wgrad_geom(g, N, C, H, W, O, k, stride, pad) || !wgrad_ok(g)) return 0;
-  return 4ll * wgrad_blocks(g) * 4 * g.OPAD * g.KCOLS;
+  return 4ll * wgrad_blocks(g) * g.OPAD * g.KCOLS;
 }
 
 /* dw (O, C, k, k) and db (O) [either may be NULL]; accumulate != 0 adds into them */
@@ -397,7 +614,7 @@ int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float*
   const int used = (N + g.per_block - 1) / g.per_block;
   const int T = wgrad_tiles(g);
   const int ps = T < 4 ? 1 : 0;
-  const int slabs = used * (ps ? 4 : 1);
+  const int slabs = used;
   if (!workspace || workspace_bytes < 4ll * slabs * g.OPAD * g.KCOLS) {
     pdn_set_error("pdn_conv2d_bwd_weight_f32: workspace too small");
     return PDN_EWORKSPACE;
@@ -405,9 +622,16 @@ int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float*
   hipStream_t st = (hipStream_t)stream;
   const int64_t lds = wgrad_lds(g);
   float* partial = (float*)workspace;
+  const int M = g.OH * g.OW;
+  const bool pre = (W & 3) == 0 && (M & 3) == 0 && (g.MB & 3) == 0 && C * H * W <= 8 * 1024 &&
+                   O * (g.MB < M ? g.MB : M) <= 16 * 1024;
 #define PDN_WGRAD_LAUNCH(WT, PS)                                                                       \
   do {                                                                                                 \
-    auto kern = conv_wgrad_kernel<WT, PS>;                                                             \
+    if (pre) PDN_WGRAD_LAUNCH_N(WT, PS, 8, 16); else PDN_WGRAD_LAUNCH_N(WT, PS, 0, 0);                 \
+  } while (0)
+#define PDN_WGRAD_LAUNCH_N(WT, PS, NVX, NVD)                                                           \
+  do {                                                                                                 \
+    auto kern = conv_wgrad_kernel<WT, PS, NVX, NVD>;                                                   \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                        (int)lds);                                                      \
     if (e != hipSuccess) { pdn_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
@@ -421,9 +645,10 @@ int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float*
     else if (wt == 3) PDN_WGRAD_LAUNCH(3, 0); else PDN_WGRAD_LAUNCH(4, 0);
   }
 #undef PDN_WGRAD_LAUNCH
+#undef PDN_WGRAD_LAUNCH_N
   PDN_LAUNCH_CHECK();
   const int total = O * g.K1;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partial, slabs,
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, partial, slabs,
                      g.OPAD, g.KCOLS, O, g.K1 - 1, dw, db, accumulate);
   PDN_LAUNCH_CHECK();
   return PDN_OK;

@@ -587,8 +587,9 @@ class EmulatedLib:
         if s == 1 and k - 1 - p >= 0 and fwd_lds(O, oh, ow, C, k - 1 - p):
             mask |= 2
         opad, kcols = (O + 31) // 32 * 32, (C * k * k + 1 + 31) // 32 * 32
-        if (opad // 32) * (kcols // 32) <= 16 and \
-                4 * (C * (H + 2 * p) * (W + 2 * p) + opad * ((oh * ow) | 1) + oh * ow) + 64 <= lim:
+        M, img_b = oh * ow, 4 * C * (H + 2 * p) * (W + 2 * p)
+        mb = 512 if (img_b + 4 * (O + 1) * (M | 1) > 78 * 1024 and M > 512) else M
+        if (opad // 32) * (kcols // 32) <= 16 and max(img_b + 4 * (O + 1) * (mb | 1) + 64, 49152) <= lim:
             mask |= 4
         return mask
 
