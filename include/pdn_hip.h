@@ -191,6 +191,28 @@ int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* 
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
 
+/* General streaming attention (csrc/attention_stream.hip): any Lq / Lk, head_dim in {24, 32, 48, 64,
+ * 96, 128}, causal with a start position (KV-cache prefill, llm/llama/model.py:105-117) and / or an
+ * additive mask (the padding mask of examples/pydynet/transformer.py:120-128, the causal mask tensor of
+ * llm/clip/model.py:8-13,54-55), q and k/v with their own strides (views into a packed QKV projection
+ * or into a cache).  Key tiles stream through LDS with an online softmax; nothing of size Lq x Lk
+ * touches HBM.  mask element (b, h, q, k) = mask[b*sb + h*sh + q*sq + k*sk] (stride 0 broadcasts). */
+int pdn_attention_stream_supported(int head_dim);
+int pdn_attention_stream_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
+                                 int H, int Lq, int Lk, int head_dim, int64_t q_row_stride,
+                                 int64_t q_batch_stride, int64_t kv_row_stride, int64_t kv_batch_stride,
+                                 int causal, int start_pos, const float* mask, int64_t mask_sb,
+                                 int64_t mask_sh, int64_t mask_sq, int64_t mask_sk, const float* rope_cos,
+                                 const float* rope_sin, void* stream);
+int pdn_attention_stream_bwd_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                                 const float* lse, float* dq, float* dk, float* dv, int B, int H, int Lq, int Lk,
+                                 int head_dim, int64_t q_row_stride, int64_t q_batch_stride,
+                                 int64_t kv_row_stride, int64_t kv_batch_stride, int causal, int start_pos,
+                                 const float* mask, int64_t mask_sb, int64_t mask_sh, int64_t mask_sq,
+                                 int64_t mask_sk, const float* rope_cos, const float* rope_sin, void* workspace,
+                                 int64_t workspace_bytes, void* stream);
+int64_t pdn_attention_stream_bwd_workspace_bytes(int B, int H, int Lq);
+
 /* ---- embedding: `weight[ids]` (nn/functional.py:14-20) and its gradient
  * `full = zeros; full[key] = grad` (tensor.py:937-940: scatter-ASSIGN, last write wins).
  * scatter mode 0: assign, 1: assign-last accumulated into dW, 2: atomic scatter-add.

@@ -334,48 +334,121 @@ class rope(_Operator):
         return [self._apply(dy, -1.0)]
 
 
+def _attn_layout(x):
+    """(row_stride, batch_stride) of a (B, L, H, hd) device array the attention kernels can read in
+    place: unit stride along hd, heads packed (stride hd), 16-byte aligned; else None."""
+    B, Lx, H, hd = x.shape
+    st = x._strides
+    if st[3] != 1 or (H > 1 and st[2] != hd) or st[1] % 4 or (B > 1 and st[0] % 4) or x._ptr % 16:
+        return None
+    return st[1], (st[0] if B > 1 else 0)
+
+
+def _attn_mask_args(mask, B, H, Lq, Lk):
+    """Pointer and (b, h, q, k) element strides of an additive mask broadcastable to (B, H, Lq, Lk)."""
+    if mask is None:
+        return None, 0, 0, 0, 0, None
+    m = mask
+    if m.dtype != np.float32:
+        m = m.astype(np.float32)
+    shape = (1,) * (4 - m.ndim) + tuple(m.shape)
+    if m.ndim > 4 or any(s not in (1, t) for s, t in zip(shape, (B, H, Lq, Lk))):
+        raise ValueError(f"attention mask of shape {mask.shape} does not broadcast to {(B, H, Lq, Lk)}")
+    m = _contig(m).reshape(shape)
+    st = [0 if s == 1 else k for s, k in zip(shape, m._strides)]
+    return m._ptr, st[0], st[1], st[2], st[3], m
+
+
+def _attn_kernel(B, H, hd, Lq, Lk, start_pos, has_mask, layouts):
+    """'resident' (K/V of a head held in LDS: hd 48, L <= 256, the benchmark shape), 'stream' (general
+    kernels) or None (GEMM + softmax composition)."""
+    if not attention.use_flash or any(l is None for l in layouts):
+        return None
+    ql, kl, vl = layouts
+    dense = (H * hd, Lq * H * hd if B > 1 else 0)
+    if (Lq == Lk and start_pos == 0 and hd == 48 and Lq % 32 == 0 and Lq <= 256 and not has_mask
+            and attention.use_resident and ql == kl == vl == dense):
+        return "resident"
+    if _L().query("pdn_attention_stream_supported", hd) and kl == vl:
+        return "stream"
+    return None
+
+
 class attention(_Operator):
-    """softmax(q k^T / sqrt(hd) + causal_mask) v  per (batch, head).
+    """softmax(q k^T / sqrt(hd) + causal_mask + mask) v  per (batch, head).
 
     q: (B, L, H, hd); k, v: (B, Lk, H, hd) -- the layout the Q/K/V projections produce, consumed
-    through strides (no transposes, no copies).  Output (B, L, H, hd).  `causal` applies the
-    additive -inf upper-triangular mask of llm/llama/model.py:199-203 with `start_pos`."""
+    through strides (no transposes, no copies; views into a packed QKV projection or a KV cache are
+    fine).  Output (B, L, H, hd).  `causal` applies the additive -inf upper-triangular mask of
+    llm/llama/model.py:199-203 with `start_pos`; `mask` is an optional constant additive mask
+    broadcastable to (B, H, L, Lk) (padding masks, llm/clip's causal mask tensor)."""
 
     use_flash = True      # class switch: False forces the GEMM + softmax path (A/B and tests)
+    use_resident = True   # class switch: False sends the benchmark shape through the streaming kernels too
 
-    def __init__(self, q, k, v, causal=True, start_pos=0):
+    def __init__(self, q, k, v, causal=True, start_pos=0, mask=None):
         self.causal, self.start_pos = bool(causal), int(start_pos)
-        self._flash = False
+        self._mask = mask.data if isinstance(mask, Tensor) else mask
+        self._kind = None
         super().__init__(q, k, v)
+
+    def _np_mask(self, Lq, Lk, dtype):
+        add = None
+        if self.causal and Lq > 1:
+            m = np.triu(np.full((Lq, Lq), float("-inf")), k=1)
+            add = np.concatenate([np.zeros((Lq, self.start_pos)), m], axis=1).astype(dtype)
+        if self._mask is not None:
+            mk = np.asarray(self._mask, dtype=dtype)
+            add = mk if add is None else add + mk
+        return add
 
     def forward_(self, q, k, v):
         B, Lq, H, hd = q.shape
         Lk = k.shape[1]
         if self.xp is np:
             s = np.matmul(q.data.transpose(0, 2, 1, 3), k.data.transpose(0, 2, 3, 1)) / np.asarray(math.sqrt(hd), q.dtype)
-            if self.causal and Lq > 1:
-                m = np.triu(np.full((Lq, Lq), float("-inf")), k=1)
-                s = s + np.concatenate([np.zeros((Lq, self.start_pos)), m], axis=1).astype(q.dtype)
+            add = self._np_mask(Lq, Lk, q.dtype)
+            if add is not None:
+                s = s + add
             e = np.exp(s - s.max(-1, keepdims=True))
             self._p = e / e.sum(-1, keepdims=True)
             return np.ascontiguousarray(np.matmul(self._p, v.data.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3))
         _require_f32(self, q, k, v)
         hp, L = _hip(), _L()
-        self._flash = (attention.use_flash and Lq == Lk and self.start_pos == 0 and hd == 48 and Lq % 32 == 0
-                       and Lq <= 256 and q.data.is_contiguous() and k.data.is_contiguous()
-                       and v.data.is_contiguous())
-        if self._flash:
+        causal = 1 if (self.causal and Lq > 1) else 0
+        layouts = (_attn_layout(q.data), _attn_layout(k.data), _attn_layout(v.data))
+        self._kind = _attn_kernel(B, H, hd, Lq, Lk, self.start_pos, self._mask is not None, layouts)
+        if self._kind == "resident":
             # scores stay in registers: one kernel, nothing of size L x L in HBM; lse kept for backward
             out = hp.empty((B, Lq, H, hd), np.float32)
             self._lse = hp.empty((B, H, Lq), np.float32)
             L.call("pdn_attention_fwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, out._ptr, self._lse._ptr,
-                   B, H, Lq, hd, H * hd, Lq * H * hd, 1 if (self.causal and Lq > 1) else 0, None, None,
-                   hp.stream())
+                   B, H, Lq, hd, H * hd, Lq * H * hd, causal, None, None, hp.stream())
+            return out
+        if self._kind == "stream":
+            out = hp.empty((B, Lq, H, hd), np.float32)
+            self._lse = hp.empty((B, H, Lq), np.float32)
+            mp, sb, sh, sq, sk, self._mask_dev = _attn_mask_args(
+                hp.asarray(self._mask) if self._mask is not None else None, B, H, Lq, Lk)
+            # the output is written with the QUERY strides: give the kernel a q-shaped contiguous view
+            if layouts[0] != (H * hd, Lq * H * hd if B > 1 else 0):
+                self._q_used = q.data.copy()
+                layouts = (_attn_layout(self._q_used), layouts[1], layouts[2])
+            else:
+                self._q_used = q.data
+            self._lay = layouts
+            L.call("pdn_attention_stream_fwd_f32", self._q_used._ptr, k.data._ptr, v.data._ptr, out._ptr,
+                   self._lse._ptr, B, H, Lq, Lk, hd, layouts[0][0], layouts[0][1], layouts[1][0], layouts[1][1],
+                   causal, self.start_pos, mp, sb, sh, sq, sk, None, None, hp.stream())
             return out
         p = hp.empty((B, H, Lq, Lk), np.float32)
         hp.gemm(q.data.transpose(0, 2, 1, 3), k.data.transpose(0, 2, 3, 1), p)
-        L.call("pdn_softmax_fwd_f32", p._ptr, p._ptr, B * H * Lq, Lk, math.sqrt(hd),
-               Lq if (self.causal and Lq > 1) else 0, self.start_pos, hp.stream())
+        div = math.sqrt(hd)
+        if self._mask is not None:
+            p = p / np.float32(div) + hp.asarray(self._mask).astype(np.float32)
+            div = 1.0
+        L.call("pdn_softmax_fwd_f32", p._ptr, p._ptr, B * H * Lq, Lk, div,
+               Lq if causal else 0, self.start_pos, hp.stream())
         self._p = p
         out = hp.empty((B, Lq, H, hd), np.float32)
         hp.gemm(p, v.data.transpose(0, 2, 1, 3), out.transpose(0, 2, 1, 3))
@@ -385,14 +458,32 @@ class attention(_Operator):
         q, k, v = self.last
         B, Lq, H, hd = q.shape
         Lk = k.shape[1]
-        if self.xp is not np and self._flash:
+        causal = 1 if (self.causal and Lq > 1) else 0
+        if self.xp is not np and self._kind == "resident":
             hp, L = _hip(), _L()
             do = _contig(do)
             dq, dk, dv = (hp.empty(q.shape, np.float32) for _ in range(3))
             ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
             L.call("pdn_attention_bwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, self.data._ptr, do._ptr,
                    self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd,
-                   1 if (self.causal and Lq > 1) else 0, None, None, ws, wsb, hp.stream())
+                   causal, None, None, ws, wsb, hp.stream())
+            return [dq, dk, dv]
+        if self.xp is not np and self._kind == "stream":
+            hp, L = _hip(), _L()
+            do = _contig(do)
+            dq = hp.empty(q.shape, np.float32)
+            # dk / dv are written with the key strides: contiguous gradients need contiguous k / v
+            ksrc, vsrc = _contig(k.data), _contig(v.data)
+            dk, dv = hp.empty(k.shape, np.float32), hp.empty(v.shape, np.float32)
+            klay = (H * hd, Lk * H * hd if B > 1 else 0)
+            mp, sb, sh, sq, sk, keep = _attn_mask_args(self._mask_dev, B, H, Lq, Lk) \
+                if self._mask is not None else (None, 0, 0, 0, 0, None)
+            ws, wsb = hp.workspace(L.query("pdn_attention_stream_bwd_workspace_bytes", B, H, Lq))
+            qlay = (H * hd, Lq * H * hd if B > 1 else 0)
+            qsrc = self._q_used
+            L.call("pdn_attention_stream_bwd_f32", qsrc._ptr, ksrc._ptr, vsrc._ptr, self.data._ptr, do._ptr,
+                   self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, Lk, hd, qlay[0], qlay[1], klay[0], klay[1],
+                   causal, self.start_pos, mp, sb, sh, sq, sk, None, None, ws, wsb, hp.stream())
             return [dq, dk, dv]
         p = self._p
         if self.xp is np:
@@ -854,9 +945,15 @@ class qkv_attention(_Operator):
         super().__init__(x, wq, wk, wv)
 
     @staticmethod
+    def _resident(L, hd):
+        return attention.use_resident and hd == 48 and L % 32 == 0 and L <= 256
+
+    @staticmethod
     def applicable(x, L, hd):
-        return (qkv_attention.enabled and attention.use_flash and x.device.is_hip and x.dtype == np.float32 and x.ndim == 3
-                and hd == 48 and L % 32 == 0 and L <= 256)
+        if not (qkv_attention.enabled and attention.use_flash and x.device.is_hip and x.dtype == np.float32
+                and x.ndim == 3):
+            return False
+        return qkv_attention._resident(L, hd) or bool(_L().query("pdn_attention_stream_supported", hd))
 
     def forward_(self, x, wq, wk, wv):
         _require_f32(self, x, wq, wk, wv, self._cos, self._sin)
@@ -877,8 +974,13 @@ class qkv_attention(_Operator):
         cos, sin = _contig(self._cos.data), _contig(self._sin.data)
         out = hp.empty((B, Lq, H, hd), np.float32)
         lse = hp.empty((B, H, Lq), np.float32)
-        L.call("pdn_attention_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr, B, H, Lq,
-               hd, D, Lq * D, 1, cos._ptr, sin._ptr, hp.stream())
+        if qkv_attention._resident(Lq, hd):
+            L.call("pdn_attention_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr, B, H, Lq,
+                   hd, D, Lq * D, 1, cos._ptr, sin._ptr, hp.stream())
+        else:                   # any length / head dim: key tiles stream through LDS, RoPE still in the loads
+            L.call("pdn_attention_stream_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr,
+                   B, H, Lq, Lq, hd, D, Lq * D, D, Lq * D, 1 if Lq > 1 else 0, 0, None, 0, 0, 0, 0,
+                   cos._ptr, sin._ptr, hp.stream())
         self._saved = (x2, qkv, lse, cos, sin)
         return out
 
@@ -891,9 +993,14 @@ class qkv_attention(_Operator):
         do = _contig(do)
         dqkv = hp.empty((3, T, D), np.float32)
         ws_, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
-        L.call("pdn_attention_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
-               lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, hd, D, Lq * D, 1, cos._ptr,
-               sin._ptr, ws_, wsb, hp.stream())
+        if qkv_attention._resident(Lq, hd):
+            L.call("pdn_attention_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
+                   lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, hd, D, Lq * D, 1, cos._ptr,
+                   sin._ptr, ws_, wsb, hp.stream())
+        else:
+            L.call("pdn_attention_stream_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
+                   lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, Lq, hd, D, Lq * D, D, Lq * D,
+                   1 if Lq > 1 else 0, 0, None, 0, 0, 0, 0, cos._ptr, sin._ptr, ws_, wsb, hp.stream())
         grads = [None] * 4
         weights = (wq, wk, wv)
         gstack = None

@@ -443,6 +443,52 @@ class EmulatedLib:
         DK[...] = self._rot(np.matmul(ds.swapaxes(-1, -2), Q), rc, rsn, L, hd, -1.0)
         return 0
 
+    # -- general streaming attention -----------------------------------------------------------------
+    def pdn_attention_stream_supported(self, hd): return 1 if hd in (24, 32, 48, 64, 96, 128) else 0
+    def pdn_attention_stream_bwd_workspace_bytes(self, B, H, Lq): return 4 * B * H * Lq
+
+    def _stream_scores(self, Q, K, B, H, Lq, Lk, hd, causal, start, mask, sb, sh, sq, sk):
+        s = np.matmul(Q, K.swapaxes(-1, -2)) / np.float32(math.sqrt(hd))
+        if causal:
+            qi, ki = np.arange(Lq)[:, None], np.arange(Lk)[None, :]
+            s = s + np.where(ki > qi + start, -np.inf, 0.0).astype(np.float32)
+        if mask:
+            s = s + view(mask, (B, H, Lq, Lk), (sb, sh, sq, sk), np.float32)
+        return s
+
+    def pdn_attention_stream_fwd_f32(self, q, k, v, o, lse, B, H, Lq, Lk, hd, qrs, qbs, krs, kbs, causal, start,
+                                     mask, sb, sh, sq, sk, rc, rsn, stream):
+        if not self.pdn_attention_stream_supported(hd) or (rc and start):
+            return -2
+        Q, O = [view(p, (B, H, Lq, hd), (qbs, hd, qrs, 1), np.float32) for p in (q, o)]
+        K, V = [np.array(view(p, (B, H, Lk, hd), (kbs, hd, krs, 1), np.float32)) for p in (k, v)]
+        Q, K = self._rot(np.array(Q), rc, rsn, Lq, hd, 1.0), self._rot(K, rc, rsn, Lk, hd, 1.0)
+        s = self._stream_scores(Q, K, B, H, Lq, Lk, hd, causal, start, mask, sb, sh, sq, sk)
+        m = s.max(-1, keepdims=True)
+        e = np.exp(s - m)
+        l = e.sum(-1, keepdims=True)
+        O[...] = np.matmul(e / l, V)
+        flat(lse, B * H * Lq).reshape(B, H, Lq)[...] = (m + np.log(l))[..., 0]
+        return 0
+
+    def pdn_attention_stream_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, Lq, Lk, hd, qrs, qbs, krs, kbs,
+                                     causal, start, mask, sb, sh, sq, sk, rc, rsn, ws, wsb, stream):
+        if not self.pdn_attention_stream_supported(hd) or (rc and start):
+            return -2
+        qv = lambda p: view(p, (B, H, Lq, hd), (qbs, hd, qrs, 1), np.float32)
+        kv = lambda p: view(p, (B, H, Lk, hd), (kbs, hd, krs, 1), np.float32)
+        Q, O, DO, K, V = np.array(qv(q)), np.array(qv(o)), np.array(qv(do)), np.array(kv(k)), np.array(kv(v))
+        Q, K = self._rot(Q, rc, rsn, Lq, hd, 1.0), self._rot(K, rc, rsn, Lk, hd, 1.0)
+        s = self._stream_scores(Q, K, B, H, Lq, Lk, hd, causal, start, mask, sb, sh, sq, sk)
+        p = np.exp(s - flat(lse, B * H * Lq).reshape(B, H, Lq, 1))
+        delta = (DO * O).sum(-1, keepdims=True)
+        dp = np.matmul(DO, V.swapaxes(-1, -2))
+        ds = p * (dp - delta) / np.float32(math.sqrt(hd))
+        kv(dv)[...] = np.matmul(p.swapaxes(-1, -2), DO)
+        qv(dq)[...] = self._rot(np.matmul(ds, K), rc, rsn, Lq, hd, -1.0)
+        kv(dk)[...] = self._rot(np.matmul(ds.swapaxes(-1, -2), Q), rc, rsn, Lk, hd, -1.0)
+        return 0
+
     def pdn_attention_decode_f32(self, q, kc, vc, o, B, H, T, hd, cbs, stream):
         D = H * hd
         Q = flat(q, B * D).reshape(B, H, hd)
