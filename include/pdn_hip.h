@@ -16,7 +16,8 @@
  *     scratch is passed in as `workspace`, sized by the matching *_workspace_bytes query.
  *   - launches are asynchronous on `stream`; nothing synchronises except
  *     pdn_stream_synchronize and pdn_gemm_prof_collect.
- *   - dtype codes: 0 = float32, 1 = float64, 2 = int64, 3 = bool (uint8 0/1), 4 = int32.
+ *   - dtype codes: 0 = float32, 1 = float64, 2 = int64, 3 = bool (uint8 0/1), 4 = int32,
+ *     5 = float16 (storage type of the elementwise / cast / fill entry points; math in float32).
  */
 #ifndef PDN_HIP_H
 #define PDN_HIP_H
@@ -30,7 +31,7 @@ extern "C" {
 #define PDN_EUNSUPPORTED (-2)
 #define PDN_EWORKSPACE (-3)
 
-enum pdn_dtype { PDN_F32 = 0, PDN_F64 = 1, PDN_I64 = 2, PDN_BOOL = 3, PDN_I32 = 4 };
+enum pdn_dtype { PDN_F32 = 0, PDN_F64 = 1, PDN_I64 = 2, PDN_BOOL = 3, PDN_I32 = 4, PDN_F16 = 5 };
 enum pdn_binary_op { PDN_ADD = 0, PDN_SUB, PDN_MUL, PDN_DIV, PDN_POW, PDN_MAXIMUM, PDN_MINIMUM,
                      PDN_EQ = 16, PDN_NE, PDN_LT, PDN_LE, PDN_GT, PDN_GE };
 enum pdn_unary_op { PDN_COPY = 0, PDN_NEG, PDN_EXP, PDN_LOG, PDN_ABS, PDN_SIGN, PDN_SQRT,
@@ -151,6 +152,19 @@ int pdn_rmsnorm_bwd_f32(const float* x, const float* w, const float* rms, const 
                         int64_t rows, int cols,
                         void* workspace, int64_t workspace_bytes, void* stream);
 int64_t pdn_rmsnorm_bwd_workspace_bytes(int64_t rows, int cols);
+
+/* ---- last-axis LayerNorm (llm/clip/model.py:66-80, CLIPLayerNorm: mean / var over the last axis,
+ * `(x - mean) / sqrt(var + eps) * scale + shift`) and CLIP's sigmoid-gated GELU
+ * `x * sigmoid(1.702 x)` (llm/clip/model.py:92-95).  (The reference's own nn.LayerNorm reduces over the
+ * LEADING axes: that is pdn_colnorm_*.)  bwd: dw (+)= sum_rows dy * xhat, db (+)= sum_rows dy. */
+int pdn_layernorm_fwd_f32(const float* x, const float* w, const float* b, float* y, float* mean, float* rstd,
+                          int64_t rows, int cols, float eps, void* stream);
+int pdn_layernorm_bwd_f32(const float* x, const float* w, const float* mean, const float* rstd, const float* dy,
+                          const float* dx_residual, float* dx, float* dw, float* db, int accumulate, int64_t rows,
+                          int cols, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t pdn_layernorm_bwd_workspace_bytes(int64_t rows, int cols);
+int pdn_gated_sigmoid_fwd_f32(const float* x, float* y, float alpha, int64_t n, void* stream);
+int pdn_gated_sigmoid_bwd_f32(const float* x, const float* dy, float* dx, float alpha, int64_t n, void* stream);
 
 /* ---- SiLU / SwiGLU (nn/functional.py:39-40; llm/llama/model.py:56-58):
  * y = g/(1+exp(-g)) [* u];  u == NULL selects plain SiLU. */

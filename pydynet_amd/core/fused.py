@@ -208,6 +208,93 @@ class rms_norm(_Operator):
         return [dx if x.requires_grad else None, None if direct else dw]
 
 
+class layer_norm(_Operator):
+    """LayerNorm over the LAST axis: (x - mean) / sqrt(var + eps) * scale + shift -- the CLIPLayerNorm of
+    llm/clip/model.py:66-80 (9 generic nodes there).  The reference's own nn.LayerNorm, which reduces
+    over the leading axes, is `col_norm`."""
+
+    folds_existing = True
+
+    def __init__(self, x, scale, shift, eps=1e-5):
+        self.eps = float(eps)
+        super().__init__(x, scale, shift)
+
+    def forward_(self, x, w, b):
+        if self.xp is np:
+            mu = x.data.mean(-1, keepdims=True)
+            self._c = x.data - mu
+            self._sd = np.sqrt(np.square(self._c).mean(-1, keepdims=True) + np.asarray(self.eps, x.dtype))
+            return self._c / self._sd * w.data + b.data
+        _require_f32(self, x, w, b)
+        hp, L = _hip(), _L()
+        cols = x.shape[-1]
+        self._x = _contig(x.data)
+        rows = self._x.size // cols
+        out = hp.empty(x.shape, np.float32)
+        self._mean, self._rstd = hp.empty((rows,), np.float32), hp.empty((rows,), np.float32)
+        L.call("pdn_layernorm_fwd_f32", self._x._ptr, _contig(w.data)._ptr, _contig(b.data)._ptr, out._ptr,
+               self._mean._ptr, self._rstd._ptr, rows, cols, self.eps, hp.stream())
+        return out
+
+    def backward_all(self, g):
+        x, w, b = self.last
+        cols = x.shape[-1]
+        if self.xp is np:
+            xh = self._c / self._sd
+            dz = g * w.data
+            dx = (dz - dz.mean(-1, keepdims=True) - xh * (dz * xh).mean(-1, keepdims=True)) / self._sd
+            return [dx if x.requires_grad else None,
+                    (g * xh).reshape(-1, cols).sum(0).reshape(w.shape) if w.requires_grad else None,
+                    g.reshape(-1, cols).sum(0).reshape(b.shape) if b.requires_grad else None]
+        hp, L = _hip(), _L()
+        rows = self._x.size // cols
+        g = _contig(g)
+        dx = hp.empty(x.shape, np.float32)
+        dw_direct = w.requires_grad and _is_leaf_f32(w)
+        db_direct = b.requires_grad and _is_leaf_f32(b)
+        direct = dw_direct and db_direct            # one accumulate flag for both
+        dw = (w.grad if direct else hp.empty((cols,), np.float32)) if w.requires_grad else None
+        db = (b.grad if direct else hp.empty((cols,), np.float32)) if b.requires_grad else None
+        ws, wsb = hp.workspace(L.query("pdn_layernorm_bwd_workspace_bytes", rows, cols))
+        ex = _foldable(self, 0, x) if x.requires_grad else None
+        L.call("pdn_layernorm_bwd_f32", self._x._ptr, _contig(w.data)._ptr, self._mean._ptr, self._rstd._ptr, g._ptr,
+               ex._ptr if ex is not None else None, dx._ptr, dw.reshape(-1)._ptr if dw is not None else None,
+               db.reshape(-1)._ptr if db is not None else None, 1 if direct else 0, rows, cols, ws, wsb, hp.stream())
+        return [dx if x.requires_grad else None,
+                None if (direct or dw is None) else dw.reshape(w.shape),
+                None if (direct or db is None) else db.reshape(b.shape)]
+
+
+class gated_sigmoid(_Operator):
+    """y = x * sigmoid(alpha * x): CLIP's quick-GELU with alpha = 1.702 (llm/clip/model.py:92-95)."""
+
+    def __init__(self, x, alpha=1.702):
+        self.alpha = float(alpha)
+        super().__init__(x)
+
+    def forward_(self, x):
+        if self.xp is np:
+            return x.data / (1 + np.exp(-np.asarray(self.alpha, x.dtype) * x.data))
+        _require_f32(self, x)
+        hp, L = _hip(), _L()
+        self._x = _contig(x.data)
+        out = hp.empty(x.shape, np.float32)
+        L.call("pdn_gated_sigmoid_fwd_f32", self._x._ptr, out._ptr, self.alpha, out.size, hp.stream())
+        return out
+
+    def backward_all(self, dy):
+        x = self.last[0]
+        if self.xp is np:
+            a = np.asarray(self.alpha, x.dtype)
+            s = 1 / (1 + np.exp(-a * x.data))
+            return [dy * s * (1 + a * x.data * (1 - s))]
+        hp, L = _hip(), _L()
+        dy = _contig(dy)
+        dx = hp.empty(x.shape, np.float32)
+        L.call("pdn_gated_sigmoid_bwd_f32", self._x._ptr, dy._ptr, dx._ptr, self.alpha, dy.size, hp.stream())
+        return [dx]
+
+
 class swiglu(_Operator):
     """y = silu(gate) * up,  silu(g) = g / (1 + exp(-g))."""
 

@@ -11,7 +11,12 @@
 // dimension-collapsed strided index walk.
 #include "common.h"
 
-enum { PDN_F32 = 0, PDN_F64 = 1, PDN_I64 = 2, PDN_BOOL = 3, PDN_I32 = 4 };
+enum { PDN_F32 = 0, PDN_F64 = 1, PDN_I64 = 2, PDN_BOOL = 3, PDN_I32 = 4, PDN_F16 = 5 };
+
+// float16 STORAGE (the reference's tests draw float16 operands, tests/test_tensor_basic.py:16,80-81):
+// + - * / are IEEE half operations (= NumPy's "compute in float32, round once" for a single operation),
+// transcendental functions are evaluated in float32 and rounded to half.
+typedef _Float16 half_t;
 
 enum {
   BOP_ADD = 0, BOP_SUB, BOP_MUL, BOP_DIV, BOP_POW, BOP_MAX, BOP_MIN,
@@ -33,7 +38,9 @@ struct EwDims {
 template <typename T> __device__ __forceinline__ T t_exp(T x);
 template <> __device__ __forceinline__ float t_exp<float>(float x) { return expf(x); }
 template <> __device__ __forceinline__ double t_exp<double>(double x) { return exp(x); }
+template <> __device__ __forceinline__ half_t t_exp<half_t>(half_t x) { return (half_t)expf((float)x); }
 template <typename T> __device__ __forceinline__ T t_log(T x);
+template <> __device__ __forceinline__ half_t t_log<half_t>(half_t x) { return (half_t)logf((float)x); }
 template <> __device__ __forceinline__ float t_log<float>(float x) { return logf(x); }
 template <> __device__ __forceinline__ double t_log<double>(double x) { return log(x); }
 template <typename T> __device__ __forceinline__ T t_pow(T x, T y);
@@ -47,7 +54,11 @@ template <> __device__ __forceinline__ double t_pow<double>(double x, double y) 
   if (y == 2.0) return x * x;
   return pow(x, y);
 }
+template <> __device__ __forceinline__ half_t t_pow<half_t>(half_t x, half_t y) {
+  return (half_t)t_pow<float>((float)x, (float)y);
+}
 template <typename T> __device__ __forceinline__ T t_sqrt(T x);
+template <> __device__ __forceinline__ half_t t_sqrt<half_t>(half_t x) { return (half_t)sqrtf((float)x); }
 template <> __device__ __forceinline__ float t_sqrt<float>(float x) { return sqrtf(x); }
 template <> __device__ __forceinline__ double t_sqrt<double>(double x) { return sqrt(x); }
 
@@ -200,7 +211,7 @@ __global__ void ew_masked_fill_strided(O* out, const uint8_t* __restrict__ mask,
 static size_t dtype_size(int dt) {
   switch (dt) {
     case PDN_F32: return 4; case PDN_F64: return 8; case PDN_I64: return 8;
-    case PDN_BOOL: return 1; case PDN_I32: return 4;
+    case PDN_BOOL: return 1; case PDN_I32: return 4; case PDN_F16: return 2;
   }
   return 0;
 }
@@ -297,6 +308,8 @@ extern "C" int pdn_ew_binary(int dtype, int op, int mode, int ndim, const int64_
     }
   } else if (dtype == PDN_F64) {
     if (cmp) { CMP_CASES(double, L_STRIDED) } else { BIN_CASES(double, double, false, L_STRIDED) }
+  } else if (dtype == PDN_F16) {
+    if (cmp) { CMP_CASES(half_t, L_STRIDED) } else { BIN_CASES(half_t, half_t, false, L_STRIDED) }
   } else if (dtype == PDN_I64) {
     if (cmp) { CMP_CASES(int64_t, L_STRIDED) }
     else {
@@ -361,6 +374,8 @@ extern "C" int pdn_ew_unary(int dtype, int op, int ndim, const int64_t* shape, c
     }
   } else if (dtype == PDN_F64) {
     UN_CASES(double, LU_STRIDED)
+  } else if (dtype == PDN_F16) {
+    UN_CASES(half_t, LU_STRIDED)
   } else {
     pdn_set_error("pdn_ew_unary: dtype %d unsupported", dtype);
     return PDN_EUNSUPPORTED;
@@ -382,6 +397,7 @@ static int cast_from(int dst_dtype, const void* a, void* out, const EwDims& d, i
     case PDN_F64: LC(double); break;
     case PDN_I64: LC(int64_t); break;
     case PDN_I32: LC(int32_t); break;
+    case PDN_F16: LC(half_t); break;
     case PDN_BOOL: {
       // numpy astype(bool): nonzero -> True
       hipLaunchKernelGGL((ew_binary_strided<S, uint8_t, BOP_NE, true>), dim3(grid), dim3(256), 0,
@@ -413,6 +429,7 @@ extern "C" int pdn_cast(int src_dtype, int dst_dtype, int ndim, const int64_t* s
     case PDN_I64: rc = cast_from<int64_t>(dst_dtype, a, out, d, total, st); break;
     case PDN_I32: rc = cast_from<int32_t>(dst_dtype, a, out, d, total, st); break;
     case PDN_BOOL: rc = cast_from<uint8_t>(dst_dtype, a, out, d, total, st); break;
+    case PDN_F16: rc = cast_from<half_t>(dst_dtype, a, out, d, total, st); break;
     default: pdn_set_error("pdn_cast: bad src dtype %d", src_dtype); return PDN_EINVAL;
   }
   if (rc) return rc;
@@ -440,6 +457,7 @@ extern "C" int pdn_fill(int dtype, double value, int ndim, const int64_t* shape,
     case PDN_I64: LF(int64_t); break;
     case PDN_I32: LF(int32_t); break;
     case PDN_BOOL: LF(uint8_t); break;
+    case PDN_F16: LF(half_t); break;
     default: pdn_set_error("pdn_fill: bad dtype %d", dtype); return PDN_EINVAL;
   }
   PDN_LAUNCH_CHECK();
@@ -464,6 +482,7 @@ extern "C" int pdn_masked_fill(int dtype, double value, int ndim, const int64_t*
     case PDN_F64: LMF(double); break;
     case PDN_I64: LMF(int64_t); break;
     case PDN_BOOL: LMF(uint8_t); break;
+    case PDN_F16: LMF(half_t); break;
     default: pdn_set_error("pdn_masked_fill: bad dtype %d", dtype); return PDN_EINVAL;
   }
   PDN_LAUNCH_CHECK();

@@ -8,7 +8,8 @@ through the C ABI (``include/pdn_hip.h``).  Nothing here computes on the host, a
 here needs PyTorch: device memory comes from the library's caching allocator (pdn_malloc),
 copies from pdn_memcpy_*, ordering from the per-device compute stream (pdn_compute_stream).
 
-Supported dtypes on the device: float32 (the hot path), float64, int64, bool.
+Supported dtypes on the device: float32 (the hot path), float64, int64, int32, bool, and float16 as
+a storage type (elementwise math rounds like NumPy's; reductions and matmul compute in float32).
 """
 from __future__ import annotations
 
@@ -22,13 +23,14 @@ import numpy as np
 from . import _lib
 
 # numpy names re-exported so `xp.float32`, `xp.issubdtype(...)` keep working
-float32, float64, int64, int32, bool_, floating = np.float32, np.float64, np.int64, np.int32, np.bool_, np.floating
+float16, float32, float64, int64, int32, bool_, floating = (np.float16, np.float32, np.float64, np.int64, np.int32,
+                                                            np.bool_, np.floating)
 issubdtype = np.issubdtype
 newaxis = None
 pi, inf = np.pi, np.inf
 
 _DT = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int64): 2,
-       np.dtype(np.bool_): 3, np.dtype(np.int32): 4}
+       np.dtype(np.bool_): 3, np.dtype(np.int32): 4, np.dtype(np.float16): 5}
 _BOP = dict(add=0, sub=1, mul=2, div=3, pow=4, maximum=5, minimum=6,
             eq=16, ne=17, lt=18, le=19, gt=20, ge=21)
 _UOP = dict(copy=0, neg=1, exp=2, log=3, abs=4, sign=5, sqrt=6, square=7, recip=8,
@@ -139,7 +141,7 @@ def _dtcode(dt):
         return _DT[np.dtype(dt)]
     except KeyError:
         raise TypeError(f"HIP backend does not support dtype {np.dtype(dt)} "
-                        "(float32, float64, int64, bool only)") from None
+                        "(float16, float32, float64, int32, int64, bool only)") from None
 
 
 def _i64(seq):
@@ -660,6 +662,9 @@ def _reduce(op, a, axis=None, keepdims=False):
         src = a.astype(np.int64)
     if src.dtype == np.int64 and op == "mean":
         src = src.astype(np.float64)
+    if src.dtype == np.float16:                       # float32 accumulation, result rounded to float16
+        r = _reduce(op, src.astype(np.float32), axis, keepdims)
+        return r if op in ("argmax", "argmin") else r.astype(np.float16)
     flags = (ctypes.c_uint8 * _bi.max(a.ndim, 1))(*[1 if i in axes else 0 for i in range(a.ndim)])
     kept = tuple(s for i, s in enumerate(a.shape) if i not in axes)
     odt = np.int64 if op in ("argmax", "argmin") else src.dtype
@@ -884,6 +889,8 @@ def matmul(a, b):
     """NumPy-rule matmul (1-D promotion, batched broadcast) on the fp32 MFMA GEMM."""
     a, b = asarray(a), asarray(b)
     dt = np.result_type(a.dtype, b.dtype)
+    if dt == np.float16:                              # float32 MFMA, result rounded to float16
+        return matmul(a.astype(np.float32), b.astype(np.float32)).astype(np.float16)
     if dt != np.float32:
         raise TypeError(f"HIP backend matmul supports float32 only (got {a.dtype} @ {b.dtype}); "
                         "float64 has no MFMA path in this library")

@@ -14,7 +14,7 @@ import numpy as np
 
 from pydynet_amd import _lib
 
-_NP = {0: np.float32, 1: np.float64, 2: np.int64, 3: np.uint8, 4: np.int32}
+_NP = {0: np.float32, 1: np.float64, 2: np.int64, 3: np.uint8, 4: np.int32, 5: np.float16}
 
 
 def _ints(arr, n):
@@ -510,6 +510,45 @@ class EmulatedLib:
         if colsum:
             flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
         return rc
+
+    # -- last-axis LayerNorm, gated sigmoid -----------------------------------------------------------
+    def pdn_layernorm_bwd_workspace_bytes(self, rows, cols): return 2 * 1024 * cols * 4
+
+    def pdn_layernorm_fwd_f32(self, x, w, b, y, mean, rstd, rows, cols, eps, stream):
+        a = np.array(flat(x, rows * cols).reshape(rows, cols))
+        mu = a.mean(-1, keepdims=True)
+        sd = np.sqrt(np.square(a - mu).mean(-1, keepdims=True) + np.float32(eps))
+        flat(mean, rows)[...] = mu[:, 0]
+        flat(rstd, rows)[...] = 1 / sd[:, 0]
+        flat(y, rows * cols).reshape(rows, cols)[...] = (a - mu) / sd * flat(w, cols) + flat(b, cols)
+        return 0
+
+    def pdn_layernorm_bwd_f32(self, x, w, mean, rstd, dy, res, dx, dw, db, acc, rows, cols, ws, wsb, stream):
+        a = np.array(flat(x, rows * cols).reshape(rows, cols))
+        g = np.array(flat(dy, rows * cols).reshape(rows, cols))
+        mu, rs = flat(mean, rows)[:, None], flat(rstd, rows)[:, None]
+        xh = (a - mu) * rs
+        dz = g * flat(w, cols)
+        r = (dz - dz.mean(-1, keepdims=True) - xh * (dz * xh).mean(-1, keepdims=True)) * rs
+        if res:
+            r = r + flat(res, rows * cols).reshape(rows, cols)
+        flat(dx, rows * cols).reshape(rows, cols)[...] = r
+        for out, v in ((dw, (g * xh).sum(0)), (db, g.sum(0))):
+            if out:
+                d = flat(out, cols)
+                d[...] = d + v if acc else v
+        return 0
+
+    def pdn_gated_sigmoid_fwd_f32(self, x, y, alpha, n, stream):
+        v = flat(x, n)
+        flat(y, n)[...] = v / (1 + np.exp(-np.float32(alpha) * v))
+        return 0
+
+    def pdn_gated_sigmoid_bwd_f32(self, x, dy, dx, alpha, n, stream):
+        v, a = np.array(flat(x, n)), np.float32(alpha)
+        sg = 1 / (1 + np.exp(-a * v))
+        flat(dx, n)[...] = flat(dy, n) * sg * (1 + a * v * (1 - sg))
+        return 0
 
     # -- column-statistics normalisation (reference LayerNorm / BatchNorm1d) -----------------
     def pdn_colnorm_workspace_bytes(self, rows, cols): return ((rows + 255) // 256 * 2 + 2) * cols * 4

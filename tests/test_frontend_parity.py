@@ -71,22 +71,28 @@ def check_reference_generators_binary_matmul(dev):
     with np.errstate(all="ignore"):
         for i in range(8):
             a, b = d[f"bin{i}_a"], d[f"bin{i}_b"]
-            if hip and (a.dtype == np.float16 or b.dtype == np.float16):
-                continue          # the HIP backend carries float32/float64 only
+            f16 = np.result_type(a.dtype, b.dtype) == np.float16
             for n in ["add", "sub", "mul", "div", "pow", "maximum", "minimum"]:
                 out = getattr(pdn, n)(T(a, dev), T(b, dev))
                 ref = d[f"bin{i}_{n}"]
                 assert out.shape == ref.shape and out.dtype == ref.dtype, (n, i)
                 got = host(out)
-                assert np.allclose(got, ref, rtol=1e-5, atol=1e-6, equal_nan=True), (n, i)
+                # float16 results: one float16 ulp (pow goes through powf on the device)
+                rt, at = (2e-3, 1e-3) if f16 else (1e-5, 1e-6)
+                ok = np.isclose(got.astype(np.float64), ref.astype(np.float64), rtol=rt, atol=at, equal_nan=True)
+                ok |= got == ref                          # equal infinities
+                assert ok.all(), (n, i)
         for i in range(8):
             a, b = d[f"mm{i}_a"], d[f"mm{i}_b"]
-            if hip and not (a.dtype == np.float32 and b.dtype == np.float32):
-                continue          # MFMA GEMM is float32
+            if hip and np.result_type(a.dtype, b.dtype) == np.float64:
+                continue          # the MFMA GEMM is float32 (float16 operands compute in float32)
             out = pdn.matmul(T(a, dev), T(b, dev))
             ref = d[f"mm{i}_out"]
             assert out.shape == ref.shape and out.dtype == ref.dtype
-            close(out, ref, 1e-5, 1e-5)
+            if ref.dtype == np.float16:
+                close(out, ref, 2e-3, 2e-3)
+            else:
+                close(out, ref, 1e-5, 1e-5)
 
 
 @all_devices
