@@ -205,8 +205,8 @@ int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* 
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
 
-/* General streaming attention (csrc/attention_stream.hip): any Lq / Lk, head_dim in {24, 32, 48, 64,
- * 96, 128}, causal with a start position (KV-cache prefill, llm/llama/model.py:105-117) and / or an
+/* General streaming attention (csrc/attention_stream.hip): any Lq / Lk, head_dim in {16, 24, 32, 48,
+ * 64, 96, 128}, causal with a start position (KV-cache prefill, llm/llama/model.py:105-117) and / or an
  * additive mask (the padding mask of examples/pydynet/transformer.py:120-128, the causal mask tensor of
  * llm/clip/model.py:8-13,54-55), q and k/v with their own strides (views into a packed QKV projection
  * or into a cache).  Key tiles stream through LDS with an online softmax; nothing of size Lq x Lk

@@ -1,5 +1,5 @@
 // General fused attention (forward + backward) for gfx950, fp32 MFMA: any sequence lengths, head
-// dims 24 / 32 / 48 / 64 / 96 / 128, causal (with a start position) and / or additive masks,
+// dims 16 / 24 / 32 / 48 / 64 / 96 / 128, causal (with a start position) and / or additive masks,
 // separate query and key/value strides -- key tiles STREAM through LDS with an online softmax, so
 // nothing is bounded by what fits on chip and nothing of size Lq x Lk touches HBM.
 //
@@ -460,10 +460,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_stream_kernel(
 namespace {
 int64_t stream_lds(int hd) { return 4ll * (4 * 32 * AS_LD(hd) + 128); }
 
-bool hd_ok(int hd) { return hd == 24 || hd == 32 || hd == 48 || hd == 64 || hd == 96 || hd == 128; }
+bool hd_ok(int hd) { return hd == 16 || hd == 24 || hd == 32 || hd == 48 || hd == 64 || hd == 96 || hd == 128; }
 
 #define AS_DISPATCH(HDV, BODY)                       \
   switch (HDV) {                                     \
+    case 16: { constexpr int HD = 16; BODY; } break; \
     case 24: { constexpr int HD = 24; BODY; } break; \
     case 32: { constexpr int HD = 32; BODY; } break; \
     case 48: { constexpr int HD = 48; BODY; } break; \
@@ -475,7 +476,7 @@ bool hd_ok(int hd) { return hd == 24 || hd == 32 || hd == 48 || hd == 64 || hd =
 int check_common(const char* who, int head_dim, int64_t q_rs, int64_t q_bs, int64_t kv_rs, int64_t kv_bs,
                  const float* rc, const float* rs, int start_pos, uintptr_t ptr_or) {
   if (!hd_ok(head_dim)) {
-    pdn_set_error("%s: head_dim %d not in {24, 32, 48, 64, 96, 128}", who, head_dim);
+    pdn_set_error("%s: head_dim %d not in {16, 24, 32, 48, 64, 96, 128}", who, head_dim);
     return PDN_EUNSUPPORTED;
   }
   if ((q_rs % 4) || (q_bs % 4) || (kv_rs % 4) || (kv_bs % 4) || (ptr_or & 15)) {

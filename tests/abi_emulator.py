@@ -444,7 +444,7 @@ class EmulatedLib:
         return 0
 
     # -- general streaming attention -----------------------------------------------------------------
-    def pdn_attention_stream_supported(self, hd): return 1 if hd in (24, 32, 48, 64, 96, 128) else 0
+    def pdn_attention_stream_supported(self, hd): return 1 if hd in (16, 24, 32, 48, 64, 96, 128) else 0
     def pdn_attention_stream_bwd_workspace_bytes(self, B, H, Lq): return 4 * B * H * Lq
 
     def _stream_scores(self, Q, K, B, H, Lq, Lk, hd, causal, start, mask, sb, sh, sq, sk):

@@ -64,6 +64,7 @@ CASES = [  # B, H, Lq, Lk, hd, causal, start, mask kind, rope
     (1, 2, 513, 513, 96, 1, 0, None, True),         # long, hd 96
     (2, 1, 130, 130, 128, 1, 0, "pad", True),
     (1, 2, 33, 65, 24, 0, 0, None, False),
+    (8, 4, 12, 12, 16, 0, 0, "pad", False),         # the CoLA example as scripted: embed 64, 4 heads
 ]
 
 

@@ -22,7 +22,20 @@ def _host(a):
     return a if isinstance(a, np.ndarray) else a.get()
 
 
-def _run(dev):
+def _fused_self_attention(self, x, mask):
+    """The example's SelfAttention.forward with its five score-matrix nodes replaced by ONE fused
+    attention node (streaming kernels on the GPU): same projections, same in-place mask edit."""
+    from pydynet_amd.core import fused
+    N, L = x.shape[0], x.shape[1]
+    shape = (N, L, self.heads, self.hd)
+    if mask is not None:
+        mask[mask.eq(1)] = np.float32('-inf')
+    out = fused.attention(self.Q(x).reshape(*shape), self.K(x).reshape(*shape), self.V(x).reshape(*shape),
+                          causal=False, mask=mask)
+    return self.O(out.reshape(N, L, -1))
+
+
+def _run(dev, fused_attention=False):
     d = np.load(os.path.join(G, "transformer_example.npz"))
     Graph.clear()
     Transformer, loss_fn = mt.build(pdn, nn, F)
@@ -30,6 +43,27 @@ def _run(dev):
     ids, labels, emb = mt.make_inputs()
     np.random.seed(11)
     net = Transformer(c["embed"], c["layers"], c["heads"], c["expansion"], c["vocab"], c["max_len"])
+    kinds = []
+    if fused_attention:
+        from pydynet_amd.core import fused
+        type(net.layers[0].attention).forward = _fused_self_attention      # (class is local to this build)
+        orig = fused.attention.forward_
+
+        def spy(node, *a):
+            out = orig(node, *a)
+            kinds.append(node._kind)
+            return out
+        fused.attention.forward_ = spy
+    try:
+        _steps(net, loss_fn, c, d, ids, labels, emb, dev)
+    finally:
+        if fused_attention:
+            fused.attention.forward_ = orig
+    if fused_attention and dev != "cpu":
+        assert kinds and all(k == "stream" for k in kinds), kinds
+
+
+def _steps(net, loss_fn, c, d, ids, labels, emb, dev):
     net.word_embedding.weight.data[...] = emb
     net.to(dev)
     opt = Adam(net.parameters(), lr=c["lr"])
@@ -72,4 +106,14 @@ def check_transformer_example(dev):
     _run(dev)
 
 
+def check_transformer_example_fused_attention(dev):
+    """Same vectors from the real reference, attention through the fused node (padding mask (B,1,1,L))."""
+    _run(dev, fused_attention=True)
+
+
+def test_transformer_example_fused_attention_cpu():
+    _run("cpu", fused_attention=True)
+
+
 device_variants(globals(), check_transformer_example)
+device_variants(globals(), check_transformer_example_fused_attention)

@@ -84,10 +84,13 @@ def gen_fused_llama():
 def gen_generate():
     from llm.llama.model import Llama
     d = {}
-    for tag, B, Lp, total in (("b1", 1, 5, 17), ("b2", 2, 7, 15), ("long", 1, 40, 48)):
+    # p512: a 512-token prompt (prefill through multi-tile causal attention with RoPE positions up to 511,
+    # the reference's RoPE table / KV cache go to 1024: llm/llama/model.py:86-93,176-181), then 3 decode steps
+    for tag, B, Lp, total, max_seq in (("b1", 1, 5, 17, 64), ("b2", 2, 7, 15, 64), ("long", 1, 40, 48, 64),
+                                       ("p512", 1, 512, 515, 520)):
         fresh()
         np.random.seed(99)
-        V, D, H, Ff, layers, max_seq = 96, 96, 2, 128, 2, 64
+        V, D, H, Ff, layers = 96, 96, 2, 128, 2
         m = Llama(V, D, H, Ff, max_seq, B, layers, np.float32)
         m.tok_embedding.weight.data[...] = (0.5 * np.random.randn(V, D)).astype(np.float32)
         # sharpen the head so greedy argmax margins sit far above fp32 reassociation noise
@@ -110,6 +113,7 @@ def gen_generate():
             toks = [t.data.copy() for t in m.generate(prompt, total)]
         d[f"{tag}/prompt"] = prompt
         d[f"{tag}/total"] = np.array(total)
+        d[f"{tag}/max_seq"] = np.array(max_seq)
         d[f"{tag}/tokens"] = np.concatenate(toks, axis=1)               # (B, total - Lp)
         d[f"{tag}/logits"] = np.concatenate(logits_log, axis=1)         # (B, total - Lp, V)
         top2 = np.sort(d[f"{tag}/logits"], axis=-1)[..., -2:]
