@@ -171,6 +171,10 @@ int pdn_gated_sigmoid_bwd_f32(const float* x, const float* dy, float* dx, float 
 int pdn_swiglu_fwd_f32(const float* g, const float* u, float* y, int64_t n, void* stream);
 int pdn_swiglu_bwd_f32(const float* g, const float* u, const float* dy, float* dg, float* du,
                        int64_t n, void* stream);
+/* the same on a PACKED projection: gu (rows, 2F) = [gate | up] written by one batched GEMM, y (rows, F),
+ * dgu (rows, 2F) = [dgate | dup] */
+int pdn_swiglu_rows_fwd_f32(const float* gu, float* y, int64_t rows, int F, void* stream);
+int pdn_swiglu_rows_bwd_f32(const float* gu, const float* dy, float* dgu, int64_t rows, int F, void* stream);
 /* grad of relu = maximum(0., x): (out == x) * dy (tensor.py:814-815, functional.py:31-32) */
 int pdn_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
 
@@ -188,13 +192,17 @@ int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* 
  * the GEMM + softmax path).
  * rope_cos / rope_sin (nullable pair, (L, head_dim/2)): RoPE (model.py:23-44) fused into the
  * kernels -- q and k are rotated by their position as they are loaded, and the backward rotates
- * dq and dk back as it stores them, so the caller keeps (and differentiates) UN-rotated q, k. */
+ * dq and dk back as it stores them, so the caller keeps (and differentiates) UN-rotated q, k.
+ * q, k, v, dq, dk, dv share (row_stride, batch_stride) -- e.g. the three column blocks of ONE packed
+ * (B*L, 3*H*hd) projection buffer; o and d_o have (o_row_stride, o_batch_stride). */
 int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                          int64_t o_row_stride, int64_t o_batch_stride,
                           int causal, const float* rope_cos, const float* rope_sin, void* stream);
 int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                           const float* d_o, const float* lse, float* dq, float* dk, float* dv, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                          int64_t o_row_stride, int64_t o_batch_stride,
                           int causal, const float* rope_cos, const float* rope_sin, void* workspace,
                           int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = rowsum(dO * O) */

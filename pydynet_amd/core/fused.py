@@ -510,7 +510,7 @@ class attention(_Operator):
             out = hp.empty((B, Lq, H, hd), np.float32)
             self._lse = hp.empty((B, H, Lq), np.float32)
             L.call("pdn_attention_fwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, out._ptr, self._lse._ptr,
-                   B, H, Lq, hd, H * hd, Lq * H * hd, causal, None, None, hp.stream())
+                   B, H, Lq, hd, H * hd, Lq * H * hd, H * hd, Lq * H * hd, causal, None, None, hp.stream())
             return out
         if self._kind == "stream":
             out = hp.empty((B, Lq, H, hd), np.float32)
@@ -552,7 +552,7 @@ class attention(_Operator):
             dq, dk, dv = (hp.empty(q.shape, np.float32) for _ in range(3))
             ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
             L.call("pdn_attention_bwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, self.data._ptr, do._ptr,
-                   self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd,
+                   self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd, H * hd, Lq * H * hd,
                    causal, None, None, ws, wsb, hp.stream())
             return [dq, dk, dv]
         if self.xp is not np and self._kind == "stream":
@@ -1015,14 +1015,29 @@ class gru_cell(_Operator):
         return grads
 
 
+def _pack_columns(hp, weights):
+    """(in, sum out_i) copy of weights that share `in`: the B operand of ONE input-gradient GEMM
+    dX = [d_1 | d_2 | ...] @ [W_1 | W_2 | ...]^T with the contraction running over all projections at
+    once (a few hundred KB per call: cheaper than accumulating K-split products through dX)."""
+    fin = weights[0].shape[0]
+    outs = [w.shape[1] for w in weights]
+    cat = hp.empty((fin, int(np.sum(outs))), np.float32)
+    pos = 0
+    for w, n in zip(weights, outs):
+        cat[:, pos:pos + n] = w
+        pos += n
+    return cat
+
+
 class qkv_attention(_Operator):
     """Training-path self-attention front end as ONE tape node (llm/llama/model.py:92-121):
-    the three bias-free projections (a single batched GEMM when the weights are equally spaced in
-    memory, as `Attention.move` packs them) and the fused causal attention with RoPE applied inside
-    its kernels.  Backward: attention backward into one (3, T, D) buffer (dq, dk already rotated
-    back), the three weight gradients as ONE batched wave-streaming GEMM (when the
-    leaf gradients are equally spaced, e.g. in the flat gradient buffer) and dx = sum_i d_i W_i^T
-    accumulated in the GEMM epilogues.  x: (B, L, D); returns the context (B, L, H, hd)."""
+    the three bias-free projections write the column blocks of ONE packed (tokens, 3 * dim) buffer
+    (a single batched GEMM when the weights are equally spaced in memory, as `Attention.move` packs
+    them), the fused causal attention reads q / k / v from it through strides with RoPE applied inside
+    its kernels.  Backward: attention backward into one packed (tokens, 3 * dim) buffer (dq, dk already
+    rotated back), the three weight gradients as ONE batched wave-streaming GEMM (when the leaf
+    gradients are equally spaced, e.g. in the flat gradient buffer) and dx as ONE GEMM that contracts
+    over all 3 * dim columns against the column-packed weights.  x: (B, L, D); returns (B, L, H, hd)."""
 
     folds_existing = True
     enabled = True          # class switch: False sends Attention through the separate nodes (tests, A/B)
@@ -1042,31 +1057,43 @@ class qkv_attention(_Operator):
             return False
         return qkv_attention._resident(L, hd) or bool(_L().query("pdn_attention_stream_supported", hd))
 
+    @staticmethod
+    def _blocks(buf, T, D):
+        """The three (T, D) column blocks of a packed (T, 3D) buffer as one (3, T, D) strided view."""
+        hp = _hip()
+        return hp.ndarray(buf._buf, buf._ptr, (3, T, D), (D, 3 * D, 1), buf.dtype)
+
     def forward_(self, x, wq, wk, wv):
         _require_f32(self, x, wq, wk, wv, self._cos, self._sin)
         hp, L = _hip(), _L()
         B, Lq, D = x.shape
         H, hd, T = self.H, D // self.H, B * Lq
         x2 = _contig(x.data).reshape(T, D)
-        qkv = hp.empty((3, T, D), np.float32)
+        qkv = hp.empty((T, 3 * D), np.float32)
+        blocks = self._blocks(qkv, T, D)
         ws = [_contig(w.data) for w in (wq, wk, wv)]
         stack = hp.stacked_view(ws)
         if stack is not None:
-            hp.gemm(x2, stack, qkv)
+            hp.gemm(x2, stack, blocks)
         else:
             for i in range(3):
-                hp.gemm(x2, ws[i], qkv[i])
+                hp.gemm(x2, ws[i], blocks[i])
         # RoPE rides inside the attention kernels (q, k rotated as they are loaded; dq, dk rotated
         # back as they are stored), so `qkv` keeps the un-rotated projections
         cos, sin = _contig(self._cos.data), _contig(self._sin.data)
         out = hp.empty((B, Lq, H, hd), np.float32)
         lse = hp.empty((B, H, Lq), np.float32)
+        q, k, v = qkv._ptr, qkv._ptr + 4 * D, qkv._ptr + 8 * D
         if qkv_attention._resident(Lq, hd):
-            L.call("pdn_attention_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr, B, H, Lq,
-                   hd, D, Lq * D, 1, cos._ptr, sin._ptr, hp.stream())
+            L.call("pdn_attention_fwd_f32", q, k, v, out._ptr, lse._ptr, B, H, Lq, hd, 3 * D, Lq * 3 * D,
+                   D, Lq * D, 1, cos._ptr, sin._ptr, hp.stream())
         else:                   # any length / head dim: key tiles stream through LDS, RoPE still in the loads
-            L.call("pdn_attention_stream_fwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, out._ptr, lse._ptr,
-                   B, H, Lq, Lq, hd, D, Lq * D, D, Lq * D, 1 if Lq > 1 else 0, 0, None, 0, 0, 0, 0,
+            if (3 * D) % 4 or D % 4:
+                raise ValueError("qkv_attention: dim must be a multiple of 4")
+            # (the streaming kernels write o with the query strides: give them a dense q copy)
+            qd = blocks[0].copy()
+            L.call("pdn_attention_stream_fwd_f32", qd._ptr, k, v, out._ptr, lse._ptr,
+                   B, H, Lq, Lq, hd, D, Lq * D, 3 * D, Lq * 3 * D, 1 if Lq > 1 else 0, 0, None, 0, 0, 0, 0,
                    cos._ptr, sin._ptr, hp.stream())
         self._saved = (x2, qkv, lse, cos, sin)
         return out
@@ -1078,40 +1105,123 @@ class qkv_attention(_Operator):
         H, hd, T = self.H, D // self.H, B * Lq
         x2, qkv, lse, cos, sin = self._saved
         do = _contig(do)
-        dqkv = hp.empty((3, T, D), np.float32)
-        ws_, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
+        dqkv = hp.empty((T, 3 * D), np.float32)
+        dblocks = self._blocks(dqkv, T, D)
+        q, k, v = qkv._ptr, qkv._ptr + 4 * D, qkv._ptr + 8 * D
+        dq, dk, dv = dqkv._ptr, dqkv._ptr + 4 * D, dqkv._ptr + 8 * D
         if qkv_attention._resident(Lq, hd):
-            L.call("pdn_attention_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
-                   lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, hd, D, Lq * D, 1, cos._ptr,
-                   sin._ptr, ws_, wsb, hp.stream())
+            ws_, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
+            L.call("pdn_attention_bwd_f32", q, k, v, self.data._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, Lq, hd,
+                   3 * D, Lq * 3 * D, D, Lq * D, 1, cos._ptr, sin._ptr, ws_, wsb, hp.stream())
         else:
-            L.call("pdn_attention_stream_bwd_f32", qkv[0]._ptr, qkv[1]._ptr, qkv[2]._ptr, self.data._ptr, do._ptr,
-                   lse._ptr, dqkv[0]._ptr, dqkv[1]._ptr, dqkv[2]._ptr, B, H, Lq, Lq, hd, D, Lq * D, D, Lq * D,
-                   1 if Lq > 1 else 0, 0, None, 0, 0, 0, 0, cos._ptr, sin._ptr, ws_, wsb, hp.stream())
+            ws_, wsb = hp.workspace(L.query("pdn_attention_stream_bwd_workspace_bytes", B, H, Lq))
+            qd, dqd = self._blocks(qkv, T, D)[0].copy(), hp.empty((T, D), np.float32)
+            L.call("pdn_attention_stream_bwd_f32", qd._ptr, k, v, self.data._ptr, do._ptr, lse._ptr, dqd._ptr, dk, dv,
+                   B, H, Lq, Lq, hd, D, Lq * D, 3 * D, Lq * 3 * D, 1 if Lq > 1 else 0, 0, None, 0, 0, 0, 0,
+                   cos._ptr, sin._ptr, ws_, wsb, hp.stream())
+            dblocks[0] = dqd
         grads = [None] * 4
         weights = (wq, wk, wv)
         gstack = None
         if all(w.requires_grad and _is_leaf_f32(w) for w in weights):
             gstack = hp.stacked_view([w.grad for w in weights])
         if gstack is not None:
-            hp.gemm(x2.T, dqkv, gstack, beta=1.0)                 # three x^T @ d_i in one launch
+            hp.gemm(x2.T, dblocks, gstack, beta=1.0)              # three x^T @ d_i in one launch
         else:
             for i, w in enumerate(weights):
                 if not w.requires_grad:
                     continue
                 if _is_leaf_f32(w):
-                    hp.gemm(x2.T, dqkv[i], w.grad, beta=1.0)
+                    hp.gemm(x2.T, dblocks[i], w.grad, beta=1.0)
                 else:
                     dw = hp.empty(w.shape, np.float32)
-                    hp.gemm(x2.T, dqkv[i], dw)
+                    hp.gemm(x2.T, dblocks[i], dw)
                     grads[1 + i] = dw
         if x.requires_grad:
             dx = hp.empty(x.shape, np.float32)
-            dx2 = dx.reshape(T, D)
             ex = _foldable(self, 0, x)
-            hp.gemm(dqkv[0], wq.data.T, dx2, residual=ex.reshape(T, D) if ex is not None else None)
-            hp.gemm(dqkv[1], wk.data.T, dx2, beta=1.0)
-            hp.gemm(dqkv[2], wv.data.T, dx2, beta=1.0)
+            wcat = _pack_columns(hp, [wq.data, wk.data, wv.data])                  # (D, 3D)
+            hp.gemm(dqkv, wcat.T, dx.reshape(T, D), residual=ex.reshape(T, D) if ex is not None else None)
+            grads[0] = dx
+        return grads
+
+
+class gate_up_swiglu(_Operator):
+    """The FFN front end as ONE tape node (llm/llama/model.py:56-58): h = silu(x Wg) * (x Wu).
+    Both bias-free projections write the halves of ONE packed (tokens, 2 * ffn) buffer (a single batched
+    GEMM when the two weights are equally spaced in memory), the SwiGLU kernel reads the halves through
+    a row stride.  Backward: d[gate | up] into one packed buffer, the two weight gradients as one
+    batched GEMM and dx as ONE GEMM contracting over all 2 * ffn columns (the reference: 2 matmul + 5
+    elementwise nodes forward, 2 separately accumulated input gradients backward)."""
+
+    folds_existing = True
+    enabled = True
+
+    @staticmethod
+    def applicable(x, wg, wu):
+        return (gate_up_swiglu.enabled and x.device.is_hip and x.dtype == np.float32 and wg.dtype == np.float32
+                and wu.dtype == np.float32 and wg.shape == wu.shape and wg.shape[1] % 4 == 0 and x.ndim >= 2)
+
+    def __init__(self, x, w_gate, w_up):
+        super().__init__(x, w_gate, w_up)
+
+    @staticmethod
+    def _halves(buf, T, F):
+        hp = _hip()
+        return hp.ndarray(buf._buf, buf._ptr, (2, T, F), (F, 2 * F, 1), buf.dtype)
+
+    def forward_(self, x, wg, wu):
+        _require_f32(self, x, wg, wu)
+        hp, L = _hip(), _L()
+        fin, F = wg.shape
+        x2 = _contig(x.data).reshape(-1, fin)
+        T = x2.shape[0]
+        gu = hp.empty((T, 2 * F), np.float32)
+        halves = self._halves(gu, T, F)
+        ws = [_contig(wg.data), _contig(wu.data)]
+        stack = hp.stacked_view(ws)
+        if stack is not None:
+            hp.gemm(x2, stack, halves)
+        else:
+            hp.gemm(x2, ws[0], halves[0])
+            hp.gemm(x2, ws[1], halves[1])
+        out = hp.empty(x.shape[:-1] + (F,), np.float32)
+        L.call("pdn_swiglu_rows_fwd_f32", gu._ptr, out._ptr, T, F, hp.stream())
+        self._saved = (x2, gu)
+        return out
+
+    def backward_all(self, dh):
+        hp, L = _hip(), _L()
+        x, wg, wu = self.last
+        fin, F = wg.shape
+        x2, gu = self._saved
+        T = x2.shape[0]
+        dh = _contig(dh)
+        dgu = hp.empty((T, 2 * F), np.float32)
+        L.call("pdn_swiglu_rows_bwd_f32", gu._ptr, dh._ptr, dgu._ptr, T, F, hp.stream())
+        dhalves = self._halves(dgu, T, F)
+        grads = [None] * 3
+        weights = (wg, wu)
+        gstack = None
+        if all(w.requires_grad and _is_leaf_f32(w) for w in weights):
+            gstack = hp.stacked_view([w.grad for w in weights])
+        if gstack is not None:
+            hp.gemm(x2.T, dhalves, gstack, beta=1.0)
+        else:
+            for i, w in enumerate(weights):
+                if not w.requires_grad:
+                    continue
+                if _is_leaf_f32(w):
+                    hp.gemm(x2.T, dhalves[i], w.grad, beta=1.0)
+                else:
+                    dw = hp.empty(w.shape, np.float32)
+                    hp.gemm(x2.T, dhalves[i], dw)
+                    grads[1 + i] = dw
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            ex = _foldable(self, 0, x)
+            wcat = _pack_columns(hp, [wg.data, wu.data])                           # (fin, 2F)
+            hp.gemm(dgu, wcat.T, dx.reshape(T, fin), residual=ex.reshape(T, fin) if ex is not None else None)
             grads[0] = dx
         return grads
 

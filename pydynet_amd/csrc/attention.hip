@@ -61,7 +61,7 @@ __device__ __forceinline__ float4 att_rot(float4 v, const float* __restrict__ cs
 template <int HD, int NT>
 __device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __restrict__ s1,
                                               const float* __restrict__ g0, const float* __restrict__ g1,
-                                              int L, int64_t row_stride, int tid,
+                                              int L, int64_t row_stride, int64_t row_stride1, int tid,
                                               const float* __restrict__ cs, const float* __restrict__ sn,
                                               bool rot0, bool rot1) {
   constexpr int LD = ATT_LD(HD), F4 = HD / 4;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __r
       const int row = u / F4, c4 = u % F4;
       // component-wise: a whole-float4 store into the array defeats SROA (scratch) on hipcc 7.2
       float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)row * row_stride + 4 * c4);
-      float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride + 4 * c4);
+      float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride1 + 4 * c4);
       if (cs && rot0) a = att_rot(a, cs, sn, row, 2 * c4, HD / 2, 1.f);
       if (cs && rot1) c = att_rot(c, cs, sn, row, 2 * c4, HD / 2, 1.f);
       r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
@@ -98,8 +98,8 @@ template <int HD, int ABLATE = 0>
 __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
-    int64_t batch_stride, float sqrt_hd, int causal, const float* __restrict__ RC,
-    const float* __restrict__ RS) {
+    int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
+    const float* __restrict__ RC, const float* __restrict__ RS) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;                    // k-groups of 8 along the head dim
   constexpr int F4 = HD / 4;
@@ -114,9 +114,9 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   const int li = lane & 31, lh = lane >> 5;
   const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
   const float* Qb = Q + base;
-  float* Ob = O + base;
+  float* Ob = O + (int64_t)b * o_batch_stride + (int64_t)h * HD;
 
-  if (!(ABLATE & 1)) att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS, true, false);
+  if (!(ABLATE & 1)) att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, row_stride, tid, RC, RS, true, false);
   __syncthreads();
 
   const int ntile = L / 32;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     __builtin_amdgcn_wave_barrier();
     for (int u = lane; u < 32 * F4 && !(ABLATE & 16); u += 64) {
       const int row = u / F4, c4 = u % F4;
-      *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * row_stride + 4 * c4) =
+      *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * o_row_stride + 4 * c4) =
           *reinterpret_cast<const float4*>(Ow + row * LD + 4 * c4);
     }
   }
@@ -224,11 +224,13 @@ extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
   return ((int64_t)2 * L + 8 * 32) * ATT_LD(head_dim) * 4;
 }
 
-// q, k, v, o: (B, L, H, head_dim) contiguous in head_dim, `row_stride` between consecutive
-// positions, `batch_stride` between batches.  lse: (B, H, L).  causal: keys > query masked.
+// q, k, v (and dq, dk, dv): (B, L, H, head_dim) contiguous in head_dim, `row_stride` between consecutive
+// positions, `batch_stride` between batches -- e.g. column blocks of one packed (B*L, 3*H*hd) projection;
+// o (and d_o) have strides of their own.  lse: (B, H, L).  causal: keys > query masked.
 extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o,
                                      float* lse, int B, int H, int L, int head_dim,
-                                     int64_t row_stride, int64_t batch_stride, int causal,
+                                     int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                                     int64_t o_batch_stride, int causal,
                                      const float* rope_cos, const float* rope_sin, void* stream) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
   PDN_CHECK_ARG(q && k && v && o && lse, "pdn_attention_fwd_f32: null operand");
@@ -240,7 +242,8 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
                   32 * ATT_MAX_TILES);
     return PDN_EUNSUPPORTED;
   }
-  PDN_CHECK_ARG((row_stride % 4) == 0 && (batch_stride % 4) == 0 &&
+  PDN_CHECK_ARG((row_stride % 4) == 0 && (batch_stride % 4) == 0 && (o_row_stride % 4) == 0 &&
+                    (o_batch_stride % 4) == 0 &&
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0),
                 "pdn_attention_fwd_f32: 16-byte alignment required");
   const size_t shm = (size_t)pdn_attention_lds_bytes(L, head_dim);
@@ -251,8 +254,8 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
     attr_set = true;
   }
   hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(512), shm, (hipStream_t)stream, q, k,
-                     v, o, lse, H, L, row_stride, batch_stride, sqrtf((float)head_dim), causal, rope_cos,
-                     rope_sin);
+                     v, o, lse, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride,
+                     sqrtf((float)head_dim), causal, rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -305,8 +308,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
     float* __restrict__ dQ, float* __restrict__ Delta, int H, int L, int64_t row_stride,
-    int64_t batch_stride, float sqrt_hd, int causal, const float* __restrict__ RC,
-    const float* __restrict__ RS) {
+    int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
+    const float* __restrict__ RC, const float* __restrict__ RS) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -319,10 +322,11 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
-  const float* Qb = Q + base; const float* Ob = O + base; const float* dOb = dO + base;
+  const int64_t obase = (int64_t)b * o_batch_stride + (int64_t)h * HD;
+  const float* Qb = Q + base; const float* Ob = O + obase; const float* dOb = dO + obase;
   float* dQb = dQ + base;
 
-  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS, true, false);
+  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, row_stride, tid, RC, RS, true, false);
   __syncthreads();
 
   const int ntile = L / 32;
@@ -336,8 +340,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   float dpart = 0.f;
   {
     const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
-    const float* grow = dOb + (int64_t)qpos * row_stride + 4 * lh;
-    const float* orow = Ob + (int64_t)qpos * row_stride + 4 * lh;
+    const float* grow = dOb + (int64_t)qpos * o_row_stride + 4 * lh;
+    const float* orow = Ob + (int64_t)qpos * o_row_stride + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
@@ -398,8 +402,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Delta,
     float* __restrict__ dK, float* __restrict__ dV, int H, int L, int64_t row_stride,
-    int64_t batch_stride, float sqrt_hd, int causal, const float* __restrict__ RC,
-    const float* __restrict__ RS) {
+    int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
+    const float* __restrict__ RC, const float* __restrict__ RS) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -417,7 +421,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const float* Kb = K + base; const float* Vb = V + base;
   float* dKb = dK + base; float* dVb = dV + base;
 
-  att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + base, L, row_stride, tid, RC, RS, true, false);
+  att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + (int64_t)b * o_batch_stride + (int64_t)h * HD, L, row_stride,
+                         o_row_stride, tid, RC, RS, true, false);
   for (int q = tid; q < L; q += 512) {
     lse_s[q] = LSE[(int64_t)bh * L + q];
     delta_s[q] = Delta[(int64_t)bh * L + q];
@@ -503,7 +508,8 @@ extern "C" int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L) {
 extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
                                      const float* d_o, const float* lse, float* dq, float* dk,
                                      float* dv, int B, int H, int L, int head_dim,
-                                     int64_t row_stride, int64_t batch_stride, int causal,
+                                     int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                                     int64_t o_batch_stride, int causal,
                                      const float* rope_cos, const float* rope_sin, void* workspace,
                                      int64_t workspace_bytes, void* stream) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
@@ -516,7 +522,8 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
                   32 * ATT_MAX_TILES);
     return PDN_EUNSUPPORTED;
   }
-  PDN_CHECK_ARG((row_stride % 4) == 0 && (batch_stride % 4) == 0 &&
+  PDN_CHECK_ARG((row_stride % 4) == 0 && (batch_stride % 4) == 0 && (o_row_stride % 4) == 0 &&
+                    (o_batch_stride % 4) == 0 &&
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o | (uintptr_t)d_o |
                        (uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) & 15) == 0),
                 "pdn_attention_bwd_f32: 16-byte alignment required");
@@ -536,11 +543,13 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
   const float sq = sqrtf((float)head_dim);
   hipLaunchKernelGGL((attention_bwd_dq_kernel<48>), dim3(B * H), dim3(512),
                      (size_t)pdn_attention_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
-                     lse, dq, delta, H, L, row_stride, batch_stride, sq, causal, rope_cos, rope_sin);
+                     lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
+                     rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL((attention_bwd_dkv_kernel<48>), dim3(B * H), dim3(512),
                      (size_t)pdn_attention_bwd_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, d_o,
-                     lse, delta, dk, dv, H, L, row_stride, batch_stride, sq, causal, rope_cos, rope_sin);
+                     lse, delta, dk, dv, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
+                     rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -471,6 +471,55 @@ extern "C" int pdn_swiglu_bwd_f32(const float* g, const float* u, const float* d
   return PDN_OK;
 }
 
+// SwiGLU on a PACKED projection: gu is (rows, 2F) with gate in columns [0, F) and up in [F, 2F) (the two
+// FFN projections written by one batched GEMM); y is (rows, F), dgu is (rows, 2F).  F % 4 == 0.
+__global__ void swiglu_rows_fwd_kernel(const float* __restrict__ gu, float* __restrict__ y, int64_t rows, int F4) {
+  const int64_t total = rows * F4, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / F4;
+    const int c = (int)(i - r * F4);
+    const float4* row = reinterpret_cast<const float4*>(gu) + r * 2 * F4;
+    const float4 a = row[c], b = row[F4 + c];
+    float4 o;
+    o.x = silu_f(a.x) * b.x; o.y = silu_f(a.y) * b.y; o.z = silu_f(a.z) * b.z; o.w = silu_f(a.w) * b.w;
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+__global__ void swiglu_rows_bwd_kernel(const float* __restrict__ gu, const float* __restrict__ dy,
+                                       float* __restrict__ dgu, int64_t rows, int F4) {
+  const int64_t total = rows * F4, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = i / F4;
+    const int c = (int)(i - r * F4);
+    const float4* row = reinterpret_cast<const float4*>(gu) + r * 2 * F4;
+    float4* drow = reinterpret_cast<float4*>(dgu) + r * 2 * F4;
+    const float4 a = row[c], b = row[F4 + c], g = reinterpret_cast<const float4*>(dy)[i];
+    float4 dg, du;
+    dg.x = g.x * b.x * dsilu_f(a.x); dg.y = g.y * b.y * dsilu_f(a.y);
+    dg.z = g.z * b.z * dsilu_f(a.z); dg.w = g.w * b.w * dsilu_f(a.w);
+    du.x = g.x * silu_f(a.x); du.y = g.y * silu_f(a.y); du.z = g.z * silu_f(a.z); du.w = g.w * silu_f(a.w);
+    drow[c] = dg;
+    drow[F4 + c] = du;
+  }
+}
+extern "C" int pdn_swiglu_rows_fwd_f32(const float* gu, float* y, int64_t rows, int F, void* stream) {
+  if (rows == 0 || F == 0) return PDN_OK;
+  PDN_CHECK_ARG(gu && y && F % 4 == 0 && ((((uintptr_t)gu | (uintptr_t)y) & 15) == 0), "pdn_swiglu_rows_fwd_f32: bad arguments");
+  hipLaunchKernelGGL(swiglu_rows_fwd_kernel, dim3(stream_grid(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, gu, y,
+                     rows, F / 4);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+extern "C" int pdn_swiglu_rows_bwd_f32(const float* gu, const float* dy, float* dgu, int64_t rows, int F, void* stream) {
+  if (rows == 0 || F == 0) return PDN_OK;
+  PDN_CHECK_ARG(gu && dy && dgu && F % 4 == 0 && ((((uintptr_t)gu | (uintptr_t)dy | (uintptr_t)dgu) & 15) == 0),
+                "pdn_swiglu_rows_bwd_f32: bad arguments");
+  hipLaunchKernelGGL(swiglu_rows_bwd_kernel, dim3(stream_grid(rows * (F / 4))), dim3(256), 0, (hipStream_t)stream, gu, dy,
+                     dgu, rows, F / 4);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
 // relu backward: dx = (maximum(0,x) == x) ? dy : 0   -> x >= 0 passes (grad at 0 is 1)
 __global__ void relu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                 float* __restrict__ dx, int64_t n) {

@@ -41,8 +41,29 @@ class FeedForward(nn.Module):
         self.gate = nn.Linear(dim, up_dim, bias=False, dtype=dtype)
         self.down = nn.Linear(up_dim, dim, bias=False, dtype=dtype)
 
+    def move(self, device):
+        super().move(device)
+        if device.is_hip:
+            self._pack_gate_up()
+        return self
+
+    def _pack_gate_up(self):
+        """Re-home the gate / up weights in one (2, dim, ffn) buffer: each stays a contiguous Parameter,
+        and being equally spaced lets both projections run as one batched GEMM."""
+        from .. import hipnp as hp
+        ws = [self.gate.weight, self.up.weight]
+        if hp.stacked_view([w.data for w in ws]) is not None:
+            return
+        buf = hp.empty((2,) + tuple(ws[0].shape), ws[0].dtype)
+        for i, w in enumerate(ws):
+            buf[i] = w.data
+            w.data = buf[i]
+
     def forward(self, x, residual=None):
-        h = fused.swiglu(self.gate(x), self.up(x))
+        if fused.gate_up_swiglu.applicable(x, self.gate.weight, self.up.weight):
+            h = fused.gate_up_swiglu(x, self.gate.weight, self.up.weight)
+        else:
+            h = fused.swiglu(self.gate(x), self.up(x))
         if residual is None:
             return self.down(h)
         return fused.linear(h, self.down.weight, None, residual)      # residual add in the GEMM epilogue

@@ -314,6 +314,21 @@ class EmulatedLib:
         flat(dg, n)[...] = r
         return 0
 
+    def pdn_swiglu_rows_fwd_f32(self, gu, y, rows, F, stream):
+        a = flat(gu, rows * 2 * F).reshape(rows, 2 * F)
+        g, u = a[:, :F], a[:, F:]
+        flat(y, rows * F).reshape(rows, F)[...] = g / (1 + np.exp(-g)) * u
+        return 0
+
+    def pdn_swiglu_rows_bwd_f32(self, gu, dy, dgu, rows, F, stream):
+        a = np.array(flat(gu, rows * 2 * F).reshape(rows, 2 * F))
+        g, u, d = a[:, :F], a[:, F:], flat(dy, rows * F).reshape(rows, F)
+        sg = 1 / (1 + np.exp(-g))
+        out = flat(dgu, rows * 2 * F).reshape(rows, 2 * F)
+        out[:, :F] = d * u * sg * (1 + g * (1 - sg))
+        out[:, F:] = d * g * sg
+        return 0
+
     def pdn_relu_bwd_f32(self, x, dy, dx, n, stream):
         a = flat(x, n)
         flat(dx, n)[...] = np.where(np.maximum(0, a) == a, flat(dy, n), 0)
@@ -412,10 +427,11 @@ class EmulatedLib:
         out[..., 1::2] = a[..., 0::2] * s + a[..., 1::2] * c
         return out
 
-    def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, causal, rc, rsn, stream):
+    def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn, stream):
         if hd != 48 or L % 32 or L > 256:
             return -2
-        Q, K, V, O = self._att_views([q, k, v, o], B, H, L, hd, rs, bs)
+        Q, K, V = self._att_views([q, k, v], B, H, L, hd, rs, bs)
+        O, = self._att_views([o], B, H, L, hd, ors, obs)
         Q, K = self._rot(np.array(Q), rc, rsn, L, hd, 1.0), self._rot(np.array(K), rc, rsn, L, hd, 1.0)
         p, ls = self._att_probs(np.array(Q), np.array(K), L, hd, causal)
         O[...] = np.matmul(p, np.array(V))
@@ -424,12 +440,13 @@ class EmulatedLib:
 
     def pdn_attention_bwd_workspace_bytes(self, B, H, L): return B * H * L * 4
 
-    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, causal, rc, rsn,
+    def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn,
                               ws, wsb, stream):
         if hd != 48 or L % 32 or L > 256:
             return -2
-        Q, K, V, O, DO, DQ, DK, DV = [np.array(a) if i < 5 else a for i, a in
-                                      enumerate(self._att_views([q, k, v, o, do, dq, dk, dv], B, H, L, hd, rs, bs))]
+        Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
+        O, DO = [np.array(a) for a in self._att_views([o, do], B, H, L, hd, ors, obs)]
+        DQ, DK, DV = self._att_views([dq, dk, dv], B, H, L, hd, rs, bs)
         Q, K = self._rot(Q, rc, rsn, L, hd, 1.0), self._rot(K, rc, rsn, L, hd, 1.0)
         s = np.matmul(Q, K.swapaxes(-1, -2)) / np.float32(math.sqrt(hd))
         p = np.exp(s - flat(lse, B * H * L).reshape(B, H, L, 1))

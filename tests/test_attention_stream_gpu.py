@@ -126,7 +126,7 @@ def test_stream_kernels_equal_resident_kernels_on_the_benchmark_shape(hip):
     fr = np.outer(np.arange(Lq), inv).astype(np.float32)
     C, S = hip.from_numpy(np.cos(fr)), hip.from_numpy(np.sin(fr))
     o1, o2, l1, l2 = hip.empty((B, Lq, H, hd)), hip.empty((B, Lq, H, hd)), hip.empty((B, H, Lq)), hip.empty((B, H, Lq))
-    L.call("pdn_attention_fwd_f32", q._ptr, k._ptr, v._ptr, o1._ptr, l1._ptr, B, H, Lq, hd, D, Lq * D, 1,
+    L.call("pdn_attention_fwd_f32", q._ptr, k._ptr, v._ptr, o1._ptr, l1._ptr, B, H, Lq, hd, D, Lq * D, D, Lq * D, 1,
            C._ptr, S._ptr, hip.stream())
     L.call("pdn_attention_stream_fwd_f32", q._ptr, k._ptr, v._ptr, o2._ptr, l2._ptr, B, H, Lq, Lq, hd, D, Lq * D,
            D, Lq * D, 1, 0, None, 0, 0, 0, 0, C._ptr, S._ptr, hip.stream())

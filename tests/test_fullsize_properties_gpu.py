@@ -84,7 +84,7 @@ def test_fused_attention_full_length_properties(hip):
     def run(vv, kk=None):
         o, lse = hip.empty((B, L, H, hd)), hip.empty((B, H, L))
         Vv, Kk = hip.from_numpy(vv), (K if kk is None else hip.from_numpy(kk))
-        Lb.call("pdn_attention_fwd_f32", Q._ptr, Kk._ptr, Vv._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd, 1,
+        Lb.call("pdn_attention_fwd_f32", Q._ptr, Kk._ptr, Vv._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd, H * hd, L * H * hd, 1,
                 None, None, hip.stream())
         return o.get()
 

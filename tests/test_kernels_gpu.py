@@ -457,7 +457,7 @@ def test_fused_attention_forward_backward(hip, B, H, L, causal):
     Q, K, V, DO = map(hip.from_numpy, (q, k, v, do))
     lse = hip.empty((B, H, L))
     Lb.call("pdn_attention_fwd_f32", Q._ptr, K._ptr, V._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd,
-            causal, None, None, hip.stream())
+            H * hd, L * H * hd, causal, None, None, hip.stream())
     q64, k64, v64, g64 = (a.astype(np.float64).transpose(0, 2, 1, 3) for a in (q, k, v, do))
     s = q64 @ k64.swapaxes(-1, -2) / math.sqrt(hd)
     if causal:
@@ -470,7 +470,7 @@ def test_fused_attention_forward_backward(hip, B, H, L, causal):
     assert np.allclose(lse.get(), (m + np.log(e.sum(-1, keepdims=True)))[..., 0], rtol=1e-5, atol=1e-5)
     ws, wsb = hip.workspace(Lb.query("pdn_attention_bwd_workspace_bytes", B, H, L))
     Lb.call("pdn_attention_bwd_f32", Q._ptr, K._ptr, V._ptr, o._ptr, DO._ptr, lse._ptr, dq._ptr, dk._ptr, dv._ptr,
-            B, H, L, hd, H * hd, L * H * hd, causal, None, None, ws, wsb, hip.stream())
+            B, H, L, hd, H * hd, L * H * hd, H * hd, L * H * hd, causal, None, None, ws, wsb, hip.stream())
     dp = g64 @ v64.swapaxes(-1, -2)
     ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / math.sqrt(hd)
     assert rel_err(dv.get(), (p.swapaxes(-1, -2) @ g64).transpose(0, 2, 1, 3)) < 5e-5

@@ -15,9 +15,9 @@ o, lse = hp.empty((B, L, H, hd)), hp.empty((B, H, L))
 dq, dk, dv = hp.empty((B, L, H, hd)), hp.empty((B, L, H, hd)), hp.empty((B, L, H, hd))
 ws, wsb = hp.workspace(L_.query("pdn_attention_bwd_workspace_bytes", B, H, L))
 for _ in range(it):
-    L_.call("pdn_attention_fwd_f32", q._ptr, k._ptr, v._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd, 1,
+    L_.call("pdn_attention_fwd_f32", q._ptr, k._ptr, v._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd, H * hd, L * H * hd, 1,
             None, None, hp.stream())
     L_.call("pdn_attention_bwd_f32", q._ptr, k._ptr, v._ptr, o._ptr, do._ptr, lse._ptr, dq._ptr, dk._ptr, dv._ptr,
-            B, H, L, hd, H * hd, L * H * hd, 1, None, None, ws, wsb, hp.stream())
+            B, H, L, hd, H * hd, L * H * hd, H * hd, L * H * hd, 1, None, None, ws, wsb, hp.stream())
 _hpsync.synchronize()
 print("done")
