@@ -78,6 +78,18 @@ int pdn_event_record(void* event, void* stream);
 int pdn_event_synchronize(void* event);
 int pdn_event_elapsed_ms(void* start, void* stop, float* ms);
 int pdn_event_destroy(void* event);
+/* hipGraph capture / replay of a whole step (the reference pays one Python object + >= 1 kernel launch per
+ * scalar-level op, SURVEY 8a-3: at small batch the step is launch-bound).  Buffers a graph refers to by
+ * address come from a PRIVATE pool: while a pool is active every pdn_malloc / pdn_free is served by its
+ * own free lists, and its blocks rejoin the general cache only at pdn_pool_destroy. */
+int pdn_pool_create(int* pool);
+int pdn_pool_activate(int pool);                 /* 0 = back to the general cache */
+int pdn_pool_destroy(int pool);
+int pdn_pool_stats(int pool, int64_t* in_use, int64_t* reserved, int64_t* device_allocs);
+int pdn_graph_begin_capture(void* stream);
+int pdn_graph_end_capture(void* stream, void** graph_exec, int* n_nodes);
+int pdn_graph_launch(void* graph_exec, void* stream);
+int pdn_graph_destroy(void* graph_exec);
 /* ---- collectives over xGMI (RCCL, bound with dlopen at first use).  No counterpart in the
  * reference: this is the one exchange step of data-parallel training.
  * One communicator rank per process; id128 = 128 bytes from rank 0's pdn_comm_unique_id, handed to
@@ -350,6 +362,11 @@ int pdn_gru_gates_bwd_f32(const float* drh, const float* r, const float* h, floa
 int pdn_adam_multi_f32(const int64_t* chunk_table_dev, int nchunks, float step, float beta1,
                        float beta2, float one_minus_beta1, float one_minus_beta2, float eps,
                        float weight_decay, float grad_scale, void* stream);
+/* the same step replayable from a hipGraph: {t, lr} live on the device as doubles in state_dev, a 1-thread
+ * kernel writes step = lr * sqrt(1-b2^t)/(1-b1^t) to step_dev and advances t, the update reads it there */
+int pdn_adam_multi_tick_f32(const int64_t* chunk_table_dev, int nchunks, double* state_dev, float* step_dev,
+                            float beta1, float beta2, float eps, float weight_decay, float grad_scale,
+                            void* stream);
 
 #ifdef __cplusplus
 }

@@ -820,7 +820,8 @@ extern "C" int pdn_cross_entropy_bwd_f32(const float* logits, const int64_t* tar
 // ======================================================================================
 __global__ void adam_multi_kernel(const int64_t* __restrict__ table, float step, float b1,
                                   float b2, float one_m_b1, float one_m_b2, float eps, float wd,
-                                  float grad_scale) {
+                                  float grad_scale, const float* __restrict__ step_dev) {
+  if (step_dev) step = *step_dev;            // replayed from a hipGraph: the step size lives on the device
   const int64_t* e = table + (int64_t)blockIdx.x * 5;
   float* p = (float*)e[0]; const float* g = (const float*)e[1];
   float* m = (float*)e[2]; float* v = (float*)e[3];
@@ -860,7 +861,30 @@ extern "C" int pdn_adam_multi_f32(const int64_t* chunk_table_dev, int nchunks, f
   PDN_CHECK_ARG(chunk_table_dev && nchunks > 0, "pdn_adam_multi_f32: bad arguments");
   hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream,
                      chunk_table_dev, step, beta1, beta2, one_minus_beta1, one_minus_beta2, eps,
-                     weight_decay, grad_scale);
+                     weight_decay, grad_scale, (const float*)nullptr);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+// Step counter on the device, for optimizer steps replayed from a hipGraph (no host value can change
+// between replays): state = {t, lr} as doubles; each launch writes step_out = lr * sqrt(1-b2^t)/(1-b1^t)
+// (optimizer.py:191, the reference's host scalar a_t) and advances t.
+__global__ void adam_tick_kernel(double* __restrict__ state, float* __restrict__ step_out, double b1, double b2) {
+  const double t = state[0], lr = state[1];
+  *step_out = (float)(lr * sqrt(1.0 - pow(b2, t)) / (1.0 - pow(b1, t)));
+  state[0] = t + 1.0;
+}
+extern "C" int pdn_adam_multi_tick_f32(const int64_t* chunk_table_dev, int nchunks, double* state_dev,
+                                       float* step_dev, float beta1, float beta2, float eps, float weight_decay,
+                                       float grad_scale, void* stream) {
+  PDN_CHECK_ARG(state_dev && step_dev, "pdn_adam_multi_tick_f32: null state");
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state_dev, step_dev, (double)beta1,
+                     (double)beta2);
+  PDN_LAUNCH_CHECK();
+  if (nchunks == 0) return PDN_OK;
+  PDN_CHECK_ARG(chunk_table_dev && nchunks > 0, "pdn_adam_multi_tick_f32: bad arguments");
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, chunk_table_dev, 0.f,
+                     beta1, beta2, 1.f - beta1, 1.f - beta2, eps, weight_decay, grad_scale, (const float*)step_dev);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -34,6 +34,7 @@ namespace {
 struct Block {
   size_t bytes;  // size class
   int device;
+  int pool;      // 0 = the device's general cache, > 0 = a hipGraph's private pool
 };
 
 struct Pool {
@@ -43,7 +44,14 @@ struct Pool {
 
 std::mutex g_mu;
 std::unordered_map<void*, Block> g_live;   // every block obtained from hipMalloc (in use or cached)
-std::map<int, Pool> g_pools;
+std::map<int, Pool> g_pools;               // general cache per device
+// Private pools: buffers a captured hipGraph refers to by address must never be handed to anyone else
+// while the graph lives, so everything allocated while a pool is ACTIVE comes from -- and returns to --
+// that pool's own free lists (frees inside the capture are reused inside it: the captured stream
+// order keeps that safe), and the pool's blocks only rejoin the general cache when it is destroyed.
+std::map<int, Pool> g_private;             // pool id -> pool
+std::map<int, int> g_private_device;
+int g_active_pool = 0, g_next_pool = 1;
 std::map<int, hipStream_t> g_streams;      // the per-device compute stream
 
 size_t size_class(size_t n) {
@@ -162,7 +170,8 @@ int pdn_malloc(void** ptr, int64_t bytes) {
   PDN_HIP(hipGetDevice(&device));
   const size_t cls = size_class((size_t)bytes);
   std::lock_guard<std::mutex> lock(g_mu);
-  Pool& pool = g_pools[device];
+  const int pid = g_active_pool;
+  Pool& pool = pid ? g_private[pid] : g_pools[device];
   pool.requests++;
   auto it = pool.free_lists.find(cls);
   void* p = nullptr;
@@ -187,7 +196,7 @@ int pdn_malloc(void** ptr, int64_t bytes) {
     }
     pool.reserved += (int64_t)cls;
     pool.device_allocs++;
-    g_live[p] = Block{cls, device};
+    g_live[p] = Block{cls, device, pid};
   }
   pool.in_use += (int64_t)cls;
   if (pool.in_use > pool.peak) pool.peak = pool.in_use;
@@ -203,9 +212,96 @@ int pdn_free(void* ptr) {
     pdn_set_error("pdn_free: %p was not allocated by pdn_malloc", ptr);
     return PDN_EINVAL;
   }
-  Pool& pool = g_pools[it->second.device];
+  Pool& pool = it->second.pool ? g_private[it->second.pool] : g_pools[it->second.device];
   pool.free_lists[it->second.bytes].push_back(ptr);
   pool.in_use -= (int64_t)it->second.bytes;
+  return 0;
+}
+
+/* ---- private pools + hipGraph capture / replay of a whole training step ------------------------- */
+int pdn_pool_create(int* pool) {
+  PDN_CHECK_ARG(pool != nullptr, "pdn_pool_create: null output");
+  int device = 0;
+  PDN_HIP(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(g_mu);
+  *pool = g_next_pool++;
+  g_private[*pool];
+  g_private_device[*pool] = device;
+  return 0;
+}
+
+/* pool > 0: allocations come from that pool until pdn_pool_activate(0) */
+int pdn_pool_activate(int pool) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  PDN_CHECK_ARG(pool == 0 || g_private.count(pool), "pdn_pool_activate: unknown pool %d", pool);
+  g_active_pool = pool;
+  return 0;
+}
+
+/* hands the pool's blocks back to the device's general cache (blocks still in use follow when freed) */
+int pdn_pool_destroy(int pool) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_private.find(pool);
+  PDN_CHECK_ARG(pool > 0 && it != g_private.end(), "pdn_pool_destroy: unknown pool %d", pool);
+  if (g_active_pool == pool) g_active_pool = 0;
+  Pool& gen = g_pools[g_private_device[pool]];
+  for (auto& kv : it->second.free_lists)
+    for (void* p : kv.second) gen.free_lists[kv.first].push_back(p);          // cached blocks
+  gen.reserved += it->second.reserved;
+  gen.in_use += it->second.in_use;                                              // blocks still held by arrays
+  if (gen.in_use > gen.peak) gen.peak = gen.in_use;
+  for (auto& kv : g_live)
+    if (kv.second.pool == pool) kv.second.pool = 0;
+  g_private.erase(it);
+  g_private_device.erase(pool);
+  return 0;
+}
+
+int pdn_pool_stats(int pool, int64_t* in_use, int64_t* reserved, int64_t* device_allocs) {
+  std::lock_guard<std::mutex> lock(g_mu);
+  auto it = g_private.find(pool);
+  PDN_CHECK_ARG(it != g_private.end(), "pdn_pool_stats: unknown pool %d", pool);
+  if (in_use) *in_use = it->second.in_use;
+  if (reserved) *reserved = it->second.reserved;
+  if (device_allocs) *device_allocs = it->second.device_allocs;
+  return 0;
+}
+
+/* capture everything enqueued on `stream` between begin and end into an executable graph */
+int pdn_graph_begin_capture(void* stream) {
+  PDN_CHECK_ARG(stream != nullptr, "pdn_graph_begin_capture: the null stream cannot be captured");
+  PDN_HIP(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed));
+  return 0;
+}
+
+int pdn_graph_end_capture(void* stream, void** graph_exec, int* n_nodes) {
+  PDN_CHECK_ARG(stream && graph_exec, "pdn_graph_end_capture: null argument");
+  hipGraph_t g = nullptr;
+  PDN_HIP(hipStreamEndCapture((hipStream_t)stream, &g));
+  if (n_nodes) {
+    size_t n = 0;
+    PDN_HIP(hipGraphGetNodes(g, nullptr, &n));
+    *n_nodes = (int)n;
+  }
+  hipGraphExec_t e = nullptr;
+  hipError_t rc = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  if (rc != hipSuccess) {
+    pdn_set_error("hipGraphInstantiate: %s", hipGetErrorString(rc));
+    return (int)rc;
+  }
+  *graph_exec = (void*)e;
+  return 0;
+}
+
+int pdn_graph_launch(void* graph_exec, void* stream) {
+  PDN_CHECK_ARG(graph_exec != nullptr, "pdn_graph_launch: null graph");
+  PDN_HIP(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream));
+  return 0;
+}
+
+int pdn_graph_destroy(void* graph_exec) {
+  if (graph_exec) PDN_HIP(hipGraphExecDestroy((hipGraphExec_t)graph_exec));
   return 0;
 }
 

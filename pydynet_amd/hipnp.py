@@ -123,6 +123,96 @@ class Timer:
         return False
 
 
+_capture = {"graph": None}
+
+
+def capturing():
+    """The Graph being captured right now (or warmed up inside its private pool), else None."""
+    return _capture["graph"]
+
+
+class Graph:
+    """A whole step captured once and replayed as ONE hipGraph launch: the reference pays a Python object
+    and at least one kernel launch per scalar-level operator, which bounds small-batch steps
+    by launch latency; a replay costs one launch and no Python work.
+
+        g = hipnp.Graph()
+        loss = g.capture(step)          # runs `step` twice: once to fill the private pool, once captured
+        for _ in range(n):
+            ids.data[...] = next_batch  # refresh the static input buffers in place (optional)
+            g.replay()                  # `loss` (and anything else `step` returned) is overwritten in place
+
+    Rules for `step`: everything on the device (no `.item()`, no host arrays turned into device tensors,
+    no dropout drawing host random numbers); tensors it allocates live in a pool private to the graph,
+    so the arrays it returns stay valid -- and are rewritten -- across replays.  Optimizers that keep a
+    host-side step counter (Adam) switch to a device-side counter while capturing."""
+
+    def __init__(self):
+        self._exec, self._pool, self.nodes, self._hooks, self._keep = None, None, 0, [], None
+
+    def on_replay(self, fn):
+        """Host bookkeeping to run at every replay (e.g. an optimizer's step counter)."""
+        self._hooks.append(fn)
+
+    def capture(self, step):
+        import gc
+        L = _lib.lib()
+        if _capture["graph"] is not None:
+            raise RuntimeError("a Graph is already being captured")
+        st = stream()
+        pool = ctypes.c_int()
+        L.call("pdn_pool_create", ctypes.byref(pool))
+        self._pool = pool.value
+        _capture["graph"] = self
+        self._warm = True
+        try:
+            L.call("pdn_pool_activate", self._pool)
+            out = step()                                   # fills the pool (driver allocations happen here)
+            L.call("pdn_stream_synchronize", st)
+            del out
+            gc.collect()
+            self._warm = False
+            self._hooks = []
+            L.call("pdn_graph_begin_capture", st)
+            try:
+                out = step()
+            finally:
+                h, n = ctypes.c_void_p(), ctypes.c_int()
+                L.call("pdn_graph_end_capture", st, ctypes.byref(h), ctypes.byref(n))
+            self._exec, self.nodes = h.value, n.value
+        finally:
+            L.call("pdn_pool_activate", 0)
+            _capture["graph"] = None
+        self._keep = out
+        self.replay()                                      # the captured run itself executed nothing
+        return out
+
+    @property
+    def warming(self):
+        return getattr(self, "_warm", False)
+
+    def replay(self):
+        for fn in self._hooks:
+            fn()
+        _lib.lib().call("pdn_graph_launch", self._exec, stream())
+
+    def pool_stats(self):
+        vals = [ctypes.c_int64() for _ in range(3)]
+        _lib.lib().call("pdn_pool_stats", self._pool, *[ctypes.byref(v) for v in vals])
+        return dict(zip(("in_use", "reserved", "device_allocs"), (v.value for v in vals)))
+
+    def destroy(self):
+        L = _lib.lib()
+        if self._exec:
+            L.call("pdn_stream_synchronize", stream())
+            L.call("pdn_graph_destroy", self._exec)
+            self._exec = None
+        if self._pool:
+            L.call("pdn_pool_destroy", self._pool)
+            self._pool = None
+        self._keep = None
+
+
 def memory_stats(device=None):
     """Allocator counters of a device: bytes in use / reserved / peak, driver allocations, requests, hits."""
     vals = [ctypes.c_int64() for _ in range(6)]

@@ -150,9 +150,27 @@ class Adam(Optimizer):
             from .. import hipnp, _lib
             with self.params[fast[0]].device:
                 table = self._chunk_table(fast)
-                _lib.lib().call("pdn_adam_multi_f32", table._ptr, table.shape[0], self.lr * a_t,
-                                self.beta1, self.beta2, 1 - self.beta1, 1 - self.beta2, self.eps,
-                                self.weight_decay, self.grad_scale, hipnp.stream())
+                graph = hipnp.capturing()
+                if graph is not None:
+                    # replayed steps cannot take a host scalar: {t, lr} live on the device, a one-thread
+                    # kernel forms lr * a_t there and advances t (the host counter follows at every replay)
+                    if len(fast) != len(self.params):
+                        raise RuntimeError("Adam inside a hipnp.Graph needs all parameters on the fused HIP path")
+                    if graph.warming:                    # the eager run inside the graph's pool: seed the device state
+                        self._tick = (hipnp.from_numpy(np.array([float(self.t), float(self.lr)])),
+                                      hipnp.empty((1,), np.float32))
+                    else:
+                        def advance(opt=self):
+                            opt.t += 1
+                        graph.on_replay(advance)
+                        self.t -= 1                      # the captured run executes nothing; replay() counts it
+                    _lib.lib().call("pdn_adam_multi_tick_f32", table._ptr, table.shape[0], self._tick[0]._ptr,
+                                    self._tick[1]._ptr, self.beta1, self.beta2, self.eps, self.weight_decay,
+                                    self.grad_scale, hipnp.stream())
+                else:
+                    _lib.lib().call("pdn_adam_multi_f32", table._ptr, table.shape[0], self.lr * a_t,
+                                    self.beta1, self.beta2, 1 - self.beta1, 1 - self.beta2, self.eps,
+                                    self.weight_decay, self.grad_scale, hipnp.stream())
         done = set(fast)
         for i, p in enumerate(self.params):
             if i in done:

@@ -9,12 +9,24 @@ def _make(arr, dtype, device, requires_grad):
     return Tensor(arr, dtype=dtype, device=device, requires_grad=requires_grad)
 
 
+def _filled(value, shape, dtype, device, requires_grad):
+    """zeros / ones on a HIP device are filled THERE (no host array, no host->device copy: such tensors are
+    created inside training steps -- initial hidden states -- and must stay capturable into a hipGraph)."""
+    from .cuda import Device
+    dev = device if isinstance(device, Device) else Device(device)
+    if dev.is_hip:
+        with dev:
+            arr = dev.xp.full(shape, value, dtype=np.dtype(dtype if dtype is not None else np.float64))
+        return Tensor(arr, dtype=arr.dtype, copy=False, device=dev, requires_grad=requires_grad)
+    return _make(np.full(shape, float(value)), dtype, device, requires_grad)
+
+
 def zeros(shape, dtype=None, device=None, requires_grad=False):
-    return _make(np.zeros(shape), dtype, device, requires_grad)
+    return _filled(0.0, shape, dtype, device, requires_grad)
 
 
 def ones(shape, dtype=None, device=None, requires_grad=False):
-    return _make(np.ones(shape), dtype, device, requires_grad)
+    return _filled(1.0, shape, dtype, device, requires_grad)
 
 
 def randn(*shape, dtype=None, device=None, requires_grad=False):

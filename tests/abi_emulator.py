@@ -117,6 +117,11 @@ class EmulatedLib:
         ctypes.cast(out, ctypes.POINTER(ctypes.c_float))[0] = 0.0
         return 0
 
+    # hipGraph capture has no host counterpart: the emulated library refuses it (tests are GPU-only)
+    def pdn_pool_create(self, out): return -2
+    def pdn_pool_activate(self, pool): return -2 if pool else 0
+    def pdn_graph_begin_capture(self, stream): return -2
+
     # -- RCCL stands in as torch.distributed gloo on the host buffers (collectives run synchronously) --
     def pdn_comm_unique_id(self, out):
         ctypes.memmove(out, bytes(range(128)), 128)

@@ -1,0 +1,117 @@
+"""hipGraph capture / replay of whole training steps (hipnp.Graph): a replayed step must be the SAME step
+as the eager one -- same losses, same parameters -- for the MNIST-shaped MLP of examples/pydynet/mnist.py:65-79
+(Linear / ReLU / cross entropy / Adam) and for a small Llama (fused attention, RMSNorm, SwiGLU, embedding
+scatter), with the private pool keeping every buffer the graph refers to alive and no driver allocation
+happening during replays."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mlp():
+    import pydynet_amd.nn as nn
+    import pydynet_amd.nn.functional as F
+
+    class MLP(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer1 = nn.Linear(784, 256, dtype=np.float32)
+            self.layer2 = nn.Linear(256, 256, dtype=np.float32)
+            self.layer3 = nn.Linear(256, 10, dtype=np.float32)
+
+        def forward(self, x):
+            x = x.reshape(x.shape[0], -1)
+            return self.layer3(F.relu(self.layer2(F.relu(self.layer1(x)))))
+    return MLP
+
+
+def test_replayed_mlp_steps_equal_eager_steps(hip):
+    import pydynet_amd as pdn
+    import pydynet_amd.nn.functional as F
+    from pydynet_amd.optim import Adam
+    from pydynet_amd.core.tensor import Graph
+    rng = np.random.default_rng(0)
+    X = rng.random((64, 1, 28, 28), dtype=np.float32)
+    y = rng.integers(0, 10, 64)
+    N = 6
+    results = []
+    for use_graph in (False, True):
+        Graph.clear()
+        np.random.seed(3)
+        net = _mlp()().to("hip:0")
+        opt = Adam(net.parameters(), lr=1e-3)
+        Xd = pdn.Tensor(X, dtype=np.float32, device="hip:0")
+        yd = pdn.Tensor(y, dtype=np.int64, device="hip:0")
+
+        def step():
+            loss = F.cross_entropy_loss(net(Xd), yd)
+            opt.zero_grad(); loss.backward(); opt.step()
+            return loss
+        losses = []
+        if use_graph:
+            g = hip.Graph()
+            before = hip.memory_stats()["device_allocs"]
+            loss = g.capture(step)                      # = two optimizer steps (warm-up + first replay)
+            losses.append(loss.item())
+            mid = hip.memory_stats()["device_allocs"]
+            for _ in range(N - 2):
+                g.replay()
+                losses.append(loss.item())
+            assert hip.memory_stats()["device_allocs"] == mid      # replays allocate nothing
+            assert g.nodes > 10 and opt.t == 1 + N
+            g.destroy()
+        else:
+            for _ in range(N):
+                losses.append(step().item())
+            losses = losses[1:]                         # (the graph run cannot read the warm-up step's loss)
+        results.append((losses, {n: p.numpy() for n, p in net.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert np.allclose(l0, l1, rtol=1e-6), (l0, l1)
+    for n in p0:
+        assert np.allclose(p0[n], p1[n], rtol=1e-4, atol=2e-6), n     # (device-side double a_t vs the host scalar)
+
+
+def test_replayed_llama_steps_equal_eager_steps(hip):
+    import pydynet_amd as pdn
+    from pydynet_amd.llm.llama import Llama
+    from pydynet_amd.optim import Adam
+    from pydynet_amd.core.tensor import Graph
+    rng = np.random.default_rng(1)
+    V, D, H, F_, L, B = 128, 96, 2, 128, 64, 2
+    ids, tgt = rng.integers(0, V, (B, L)), rng.integers(0, V, (B * L,))
+    N = 5
+    results = []
+    for use_graph in (False, True):
+        Graph.clear()
+        np.random.seed(7)
+        m = Llama(V, D, H, F_, 64, B, 2, np.float32)
+        m.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
+        m.to("hip:0")
+        opt = Adam(m.parameters(), lr=1e-3)
+        opt.flatten_grads()
+        idd = pdn.Tensor(ids, dtype=np.int64, device="hip:0")
+        tgd = pdn.Tensor(tgt, dtype=np.int64, device="hip:0")
+        m.train(True)
+
+        def step():
+            opt.zero_grad()
+            loss = m.loss(idd, tgd)
+            loss.backward()
+            opt.step()
+            return loss
+        if use_graph:
+            g = hip.Graph()
+            loss = g.capture(step)
+            losses = [loss.item()]
+            for _ in range(N - 2):
+                g.replay()
+                losses.append(loss.item())
+            g.destroy()
+        else:
+            losses = [step().item() for _ in range(N)][1:]
+        results.append((losses, {n: p.numpy() for n, p in m.named_parameters()}))
+    (l0, p0), (l1, p1) = results
+    assert np.allclose(l0, l1, rtol=1e-6), (l0, l1)
+    for n in p0:
+        assert np.allclose(p0[n], p1[n], rtol=1e-4, atol=2e-6), n     # (device-side double a_t vs the host scalar)
