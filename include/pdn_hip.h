@@ -247,6 +247,18 @@ int pdn_attention_stream_bwd_f32(const float* q, const float* k, const float* v,
                                  int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_stream_bwd_workspace_bytes(int B, int H, int Lq);
 
+/* Persistent GRU sequence (hidden size 32): the Python time loop of nn/modules/rnn.py:640-708 over
+ * GRUCell.forward (:537-544) inside ONE launch per direction.  A wave64 owns 32 sequences for all T steps and
+ * keeps their hidden state in MFMA accumulator registers (transposed formulation: the new h feeds the next
+ * step's MFMA as its B operand unchanged); the caller hoists the input projections g1x = x Wx1 (+ b1),
+ * g2x = x Wx2 (+ b2) of all steps into two GEMMs and forms the weight gradients from dG1 / dG2 the same way. */
+int pdn_gru_seq_supported(int hidden);
+int pdn_gru_seq_fwd_f32(const float* g1x, const float* g2x, const float* h0, const float* wh1, const float* wh2,
+                        float* z, float* r, float* rh, float* n, float* out, int T, int B, int H, void* stream);
+int pdn_gru_seq_bwd_f32(const float* g, const float* z, const float* r, const float* n, const float* out,
+                        const float* h0, const float* wh1, const float* wh2, float* dg1, float* dg2, float* dh0, int T,
+                        int B, int H, void* stream);
+
 /* ---- embedding: `weight[ids]` (nn/functional.py:14-20) and its gradient
  * `full = zeros; full[key] = grad` (tensor.py:937-940: scatter-ASSIGN, last write wins).
  * scatter mode 0: assign, 1: assign-last accumulated into dW, 2: atomic scatter-add.

@@ -1294,6 +1294,8 @@ class gru_sequence(_Operator):
     gradient with ONE long-K GEMM over the stacked per-step quantities.  The reference runs ~20 tape
     nodes per step.  Inputs: x (T, B, in), h0 (B, H), Wx1, Wh1, Wx2, Wh2[, b1, b2]; output (T, B, H)."""
 
+    use_persistent = True      # class switch: False keeps the per-step launches (tests, A/B)
+
     def __init__(self, x, h0, wx1, wh1, wx2, wh2, b1=None, b2=None):
         self.has_bias = b1 is not None
         super().__init__(*((x, h0, wx1, wh1, wx2, wh2) + ((b1, b2) if self.has_bias else ())))
@@ -1311,9 +1313,16 @@ class gru_sequence(_Operator):
         hp.gemm(x2, wx2.data, g2x.reshape(T * B, H), bias=b2.data.reshape(-1) if b2 is not None else None)
         out = hp.empty((T, B, H), np.float32)
         Z, R, RH, N = (hp.empty((T, B, H), np.float32) for _ in range(4))
-        g1, g2 = hp.empty((B, 2 * H), np.float32), hp.empty((B, H), np.float32)
         h0d = _contig(h0.data)
         st = hp.stream()
+        self._persistent = bool(gru_sequence.use_persistent and L.query("pdn_gru_seq_supported", H))
+        if self._persistent:
+            # the whole time loop in ONE launch: a wave owns 32 sequences, h stays in its registers
+            L.call("pdn_gru_seq_fwd_f32", g1x._ptr, g2x._ptr, h0d._ptr, _contig(wh1.data)._ptr, _contig(wh2.data)._ptr,
+                   Z._ptr, R._ptr, RH._ptr, N._ptr, out._ptr, T, B, H, st)
+            self._saved = (x2, h0d, Z, R, RH, N)
+            return out
+        g1, g2 = hp.empty((B, 2 * H), np.float32), hp.empty((B, H), np.float32)
         wh1d, wh2d = wh1.data, wh2.data
         sH, s2H = B * H * 4, B * 2 * H * 4                           # bytes per time step
         hprev = h0d._ptr
@@ -1337,8 +1346,17 @@ class gru_sequence(_Operator):
         g = _contig(g)
         out, st = self.data, hp.stream()
         dG1, dG2 = hp.empty((T, B, 2 * H), np.float32), hp.empty((T, B, H), np.float32)
+        if self._persistent:
+            dh = hp.empty((B, H), np.float32)
+            L.call("pdn_gru_seq_bwd_f32", g._ptr, Z._ptr, R._ptr, N._ptr, out._ptr, h0d._ptr, _contig(wh1.data)._ptr,
+                   _contig(wh2.data)._ptr, dG1._ptr, dG2._ptr, dh._ptr, T, B, H, st)
+        else:
+            dh = self._backward_steps(hp, L, st, g, out, h0d, Z, R, N, dG1, dG2, wh1.data, wh2.data, T, B, H)
+        return self._finish_backward(hp, x, h0, wx1, wh1, wx2, wh2, b1, b2, x2, h0d, out, RH, dG1, dG2, dh, T, B, H, I)
+
+    @staticmethod
+    def _backward_steps(hp, L, st, g, out, h0d, Z, R, N, dG1, dG2, wh1d, wh2d, T, B, H):
         dh, dh2, drh = hp.zeros((B, H), np.float32), hp.empty((B, H), np.float32), hp.empty((B, H), np.float32)
-        wh1d, wh2d = wh1.data, wh2.data
         sH, s2H = B * H * 4, B * 2 * H * 4
         for t in range(T - 1, -1, -1):
             hprev = out._ptr + (t - 1) * sH if t > 0 else h0d._ptr
@@ -1351,6 +1369,9 @@ class gru_sequence(_Operator):
             L.call("pdn_gru_gates_bwd_f32", drh._ptr, r, hprev, dg1, dh2._ptr, B, H, st)
             _gemm_raw(L, st, B, H, 2 * H, dg1, 2 * H, 1, wh1d, dh2._ptr, H, beta=1.0, b_transposed=True)
             dh, dh2 = dh2, dh
+        return dh
+
+    def _finish_backward(self, hp, x, h0, wx1, wh1, wx2, wh2, b1, b2, x2, h0d, out, RH, dG1, dG2, dh, T, B, H, I):
         grads = [None] * len(self.last)
         if h0.requires_grad:
             grads[1] = dh

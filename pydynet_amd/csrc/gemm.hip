@@ -1116,8 +1116,11 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     }
   }
   // ---- one to four output rows (decode): stream the weight matrix once ----------------------
+  // (a workgroup walks ALL of K for its 128 columns: right when the weight matrix is wide, wrong for a
+  //  long-K / narrow-N product such as the input-weight gradient of an RNN with one input feature)
   if (M <= 4 && nbatch == 1 && !b_colsum && b_cs == 1 && a_cs == 1 && m4(N) && m4(b_rs) && m4(ldc) &&
-      al16(B) && al16(C) && (!bias || al16(bias)) && (!residual || al16(residual)) && K > 0) {
+      al16(B) && al16(C) && (!bias || al16(bias)) && (!residual || al16(residual)) && K > 0 &&
+      (K <= 4096 || (int64_t)K <= 4ll * N)) {
     const dim3 g((N + 127) / 128);
     switch (M) {
       case 1: hipLaunchKernelGGL((gemm_skinny_kernel<1>), g, dim3(256), 0, st, p); break;

@@ -133,15 +133,24 @@ __global__ void reduce_col_kernel(const T* __restrict__ x, RedDims d, int64_t R,
   }
 }
 
-// Second pass: combine `chunks` partials per output in fixed order, apply mean scale.
+// Second pass: combine `chunks` partials per output in a fixed order, apply mean scale.  A workgroup owns
+// 64 outputs; its 4 row lanes each merge every fourth partial (independent loads in flight), then the four
+// lane results are merged in lane order -- deterministic, and 4x shorter than one serial walk per output.
 template <typename T, int OP>
 __global__ void reduce_finish_kernel(const T* __restrict__ pv, const int64_t* __restrict__ pi,
                                      int chunks, int64_t outN, T scale, T* out, int64_t* outi) {
-  for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < outN;
-       o += (int64_t)gridDim.x * blockDim.x) {
-    Acc<T, OP> a; a.init();
-    for (int c = 0; c < chunks; ++c)
+  __shared__ T sv[4][64];
+  __shared__ int64_t si[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int64_t o = blockIdx.x * 64ll + tx;
+  Acc<T, OP> a; a.init();
+  if (o < outN)
+    for (int c = ty; c < chunks; c += 4)
       a.merge(pv[(int64_t)c * outN + o], OP >= ROP_ARGMAX ? pi[(int64_t)c * outN + o] : 0);
+  sv[ty][tx] = a.v; si[ty][tx] = a.idx;
+  __syncthreads();
+  if (ty == 0 && o < outN) {
+    for (int w = 1; w < 4; ++w) a.merge(sv[w][tx], si[w][tx]);
     if (OP >= ROP_ARGMAX) outi[o] = a.idx;
     else out[o] = (OP == ROP_MEAN) ? a.v / scale : a.v;
   }
@@ -158,7 +167,7 @@ static int run_reduce(const T* x, const RedDims& d, int64_t outN, int64_t R, boo
     int64_t want = cdiv64(1024, par);
     int64_t maxc = R / per_chunk_min;
     chunks = (int)(want < maxc ? want : maxc);
-    if (chunks > 1024) chunks = 1024;
+    if (chunks > 256) chunks = 256;
   }
   constexpr bool ARG = OP >= ROP_ARGMAX;
   const size_t rec = sizeof(T) + (ARG ? sizeof(int64_t) : 0);
@@ -194,7 +203,7 @@ static int run_reduce(const T* x, const RedDims& d, int64_t outN, int64_t R, boo
   }
   PDN_LAUNCH_CHECK();
   if (!direct) {
-    int g = (int)cdiv64(outN, 256); if (g > 2048) g = 2048; if (g < 1) g = 1;
+    const unsigned g = (unsigned)cdiv64(outN, 64);
     hipLaunchKernelGGL((reduce_finish_kernel<T, OP>), dim3(g), dim3(256), 0, st, (const T*)pv,
                        (const int64_t*)pi, chunks, outN, scale, (T*)out, (int64_t*)out);
     PDN_LAUNCH_CHECK();

@@ -533,6 +533,50 @@ class EmulatedLib:
             flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
         return rc
 
+    # -- persistent GRU sequence -------------------------------------------------------------------------
+    def pdn_gru_seq_supported(self, H): return 1 if H == 32 else 0
+
+    @staticmethod
+    def _sig(v):
+        out = np.empty_like(v); m = v > 0
+        out[m] = 1 / (1 + np.exp(-v[m])); out[~m] = 1 - 1 / (1 + np.exp(v[~m])); return out
+
+    @staticmethod
+    def _tanh(v):
+        out = np.empty_like(v); m = v > 0
+        out[m] = 2 / (1 + np.exp(-2 * v[m])) - 1; out[~m] = 1 - 2 / (1 + np.exp(2 * v[~m])); return out
+
+    def pdn_gru_seq_fwd_f32(self, g1x, g2x, h0, wh1, wh2, z, r, rh, n, out, T, B, H, stream):
+        G1, G2 = flat(g1x, T * B * 2 * H).reshape(T, B, 2 * H), flat(g2x, T * B * H).reshape(T, B, H)
+        W1, W2 = flat(wh1, H * 2 * H).reshape(H, 2 * H), flat(wh2, H * H).reshape(H, H)
+        Z, R, RH, N, O = (flat(p, T * B * H).reshape(T, B, H) for p in (z, r, rh, n, out))
+        h = np.array(flat(h0, B * H).reshape(B, H))
+        for t in range(T):
+            g = self._sig(G1[t] + h @ W1)
+            Z[t], R[t] = g[:, :H], g[:, H:]
+            RH[t] = R[t] * h
+            N[t] = self._tanh(G2[t] + RH[t] @ W2)
+            h = (1 - Z[t]) * h + Z[t] * N[t]
+            O[t] = h
+        return 0
+
+    def pdn_gru_seq_bwd_f32(self, g, z, r, n, out, h0, wh1, wh2, dg1, dg2, dh0, T, B, H, stream):
+        G, Z, R, N, O = (flat(p, T * B * H).reshape(T, B, H) for p in (g, z, r, n, out))
+        W1, W2 = flat(wh1, H * 2 * H).reshape(H, 2 * H), flat(wh2, H * H).reshape(H, H)
+        D1, D2 = flat(dg1, T * B * 2 * H).reshape(T, B, 2 * H), flat(dg2, T * B * H).reshape(T, B, H)
+        dh = np.zeros((B, H), np.float32)
+        for t in range(T - 1, -1, -1):
+            hp_ = O[t - 1] if t > 0 else flat(h0, B * H).reshape(B, H)
+            d = dh + G[t]
+            D2[t] = (1 - N[t] * N[t]) * (d * Z[t])
+            D1[t, :, :H] = Z[t] * (1 - Z[t]) * (d * (N[t] - hp_))
+            drh = D2[t] @ W2.T
+            D1[t, :, H:] = R[t] * (1 - R[t]) * (drh * hp_)
+            dh = d * (1 - Z[t]) + drh * R[t] + D1[t] @ W1.T
+        if dh0:
+            flat(dh0, B * H).reshape(B, H)[...] = dh
+        return 0
+
     # -- last-axis LayerNorm, gated sigmoid -----------------------------------------------------------
     def pdn_layernorm_bwd_workspace_bytes(self, rows, cols): return 2 * 1024 * cols * 4
 

@@ -597,3 +597,33 @@ def test_attention_decode_kernel(hip, T_):
     p = np.exp(s - s.max(-1, keepdims=True)); p /= p.sum(-1, keepdims=True)
     ref = np.einsum("bht,bthd->bhd", p, vc[:, :T_].astype(np.float64))
     assert rel_err(O.get(), ref) < 1e-5
+
+
+def test_persistent_gru_sequence_equals_per_step_path(hip):
+    """pdn_gru_seq_* (the whole time loop in one launch, h in MFMA accumulator registers) against the
+    per-step launches of the same node, forward and every gradient; ragged batch (not a multiple of 32)."""
+    import pydynet_amd as pdn
+    from pydynet_amd.core import fused
+    from pydynet_amd.core.tensor import Graph
+    rng = np.random.default_rng(4)
+    T, B, I, H = 9, 70, 3, 32
+    arrs = dict(x=rng.standard_normal((T, B, I)), h0=rng.standard_normal((B, H)),
+                wx1=0.3 * rng.standard_normal((I, 2 * H)), wh1=0.3 * rng.standard_normal((H, 2 * H)),
+                wx2=0.3 * rng.standard_normal((I, H)), wh2=0.3 * rng.standard_normal((H, H)),
+                b1=0.1 * rng.standard_normal((2 * H,)), b2=0.1 * rng.standard_normal((H,)))
+    w = rng.standard_normal((T, B, H)).astype(np.float32)
+    res = []
+    for persistent in (True, False):
+        Graph.clear()
+        fused.gru_sequence.use_persistent = persistent
+        try:
+            ts = {k: pdn.Tensor(v.astype(np.float32), dtype=np.float32, device="hip:0", requires_grad=True)
+                  for k, v in arrs.items()}
+            node = fused.gru_sequence(ts["x"], ts["h0"], ts["wx1"], ts["wh1"], ts["wx2"], ts["wh2"], ts["b1"], ts["b2"])
+            assert node._persistent == persistent
+            (node * pdn.Tensor(w, dtype=np.float32, device="hip:0")).sum().backward()
+            res.append([node.numpy()] + [ts[k].grad.get() for k in arrs])
+        finally:
+            fused.gru_sequence.use_persistent = True
+    for a, b, name in zip(res[0], res[1], ["out"] + list(arrs)):
+        assert np.allclose(a, b, rtol=2e-5, atol=2e-5 * np.abs(b).max()), name
