@@ -247,6 +247,18 @@ int pdn_attention_stream_bwd_f32(const float* q, const float* k, const float* v,
                                  int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_stream_bwd_workspace_bytes(int B, int H, int Lq);
 
+/* ---- RNN / LSTM cells (nn/modules/rnn.py:35-47, 244-262): the pointwise half after the two GEMMs as one
+ * kernel per direction.  act: 0 tanh, 1 relu.  LSTM: lin (B, 4H) = [f | i | o | g] pre-activations; gates
+ * (B, 4H) = [sigmoid f | sigmoid i | sigmoid o | tanh g] and tanh_c (B, H) are saved for backward;
+ * hc (B, 2H) = [h' | c'];  bwd: dhc (B, 2H) -> dlin (B, 4H), dc_prev (B, H). */
+int pdn_rnn_cell_fwd_f32(const float* lin, float* y, int64_t n, int act, void* stream);
+int pdn_rnn_cell_bwd_f32(const float* lin, const float* y, const float* dy, float* dlin, int64_t n, int act,
+                         void* stream);
+int pdn_lstm_cell_fwd_f32(const float* lin, const float* c, float* gates, float* tanh_c, float* hc, int64_t B, int H,
+                          void* stream);
+int pdn_lstm_cell_bwd_f32(const float* dhc, const float* gates, const float* tanh_c, const float* c, float* dlin,
+                          float* dc_prev, int64_t B, int H, void* stream);
+
 /* Persistent GRU sequence (hidden size 32): the Python time loop of nn/modules/rnn.py:640-708 over
  * GRUCell.forward (:537-544) inside ONE launch per direction.  A wave64 owns 32 sequences for all T steps and
  * keeps their hidden state in MFMA accumulator registers (transposed formulation: the new h feeds the next

@@ -947,6 +947,108 @@ class pool2d(_Operator):
         return [dx]
 
 
+def _cell_grads(node, hp, x, h, wx, wh, bias, xd, hd, dlin, grads, ix=0, ih=1, iwx=2, iwh=3, ib=4):
+    """Gradients every recurrent cell shares once d(pre-activation) is known: dx = dlin Wx^T,
+    dh = dlin Wh^T, dWx += x^T dlin, dWh += h^T dlin, db = column sums of dlin."""
+    if x.requires_grad:
+        dx = hp.empty(x.shape, np.float32)
+        hp.gemm(dlin, wx.data.T, dx)
+        grads[ix] = dx
+    if h.requires_grad:
+        dh = hp.empty(h.shape, np.float32)
+        hp.gemm(dlin, wh.data.T, dh)
+        grads[ih] = dh if grads[ih] is None else grads[ih] + dh
+    for idx, a, w in ((iwx, xd, wx), (iwh, hd, wh)):
+        if not w.requires_grad:
+            continue
+        if _is_leaf_f32(w):
+            hp.gemm(a.T, dlin, w.grad, beta=1.0)
+        else:
+            dw = hp.empty(w.shape, np.float32)
+            hp.gemm(a.T, dlin, dw)
+            grads[idx] = dw
+    if bias is not None and bias.requires_grad:
+        grads[ib] = dlin.sum(0).reshape(bias.shape)
+
+
+class rnn_cell(_Operator):
+    """One Elman step (nn/modules/rnn.py:35-47) as a single tape node on the HIP device:
+    h' = act(x Wx + h Wh + b): 2 GEMMs (the second accumulating, bias in the first's epilogue) + one
+    pointwise kernel forward; one pointwise kernel + 4 GEMMs backward.  act: "tanh" | "relu"."""
+
+    def __init__(self, x, h, wx, wh, bias=None, nonlinearity="tanh"):
+        self.act = {"tanh": 0, "relu": 1}[nonlinearity]
+        self.has_bias = bias is not None
+        super().__init__(*((x, h, wx, wh) + ((bias,) if self.has_bias else ())))
+
+    def forward_(self, x, h, wx, wh, bias=None):
+        if self.xp is np:
+            raise NotImplementedError("rnn_cell is the HIP fused path; the NumPy device composes generic ops")
+        _require_f32(self, x, h, wx, wh, bias)
+        hp, L = _hip(), _L()
+        B, H = h.shape
+        xd, hd = _contig(x.data), _contig(h.data)
+        lin = hp.empty((B, H), np.float32)
+        hp.gemm(xd, wx.data, lin, bias=bias.data.reshape(-1) if bias is not None else None)
+        hp.gemm(hd, wh.data, lin, beta=1.0)
+        y = hp.empty((B, H), np.float32)
+        L.call("pdn_rnn_cell_fwd_f32", lin._ptr, y._ptr, y.size, self.act, hp.stream())
+        self._saved = (xd, hd, lin)
+        return y
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, h, wx, wh = self.last[:4]
+        bias = self.last[4] if self.has_bias else None
+        xd, hd, lin = self._saved
+        g = _contig(g)
+        dlin = hp.empty(lin.shape, np.float32)
+        L.call("pdn_rnn_cell_bwd_f32", lin._ptr, self.data._ptr, g._ptr, dlin._ptr, dlin.size, self.act, hp.stream())
+        grads = [None] * len(self.last)
+        _cell_grads(self, hp, x, h, wx, wh, bias, xd, hd, dlin, grads)
+        return grads
+
+
+class lstm_cell(_Operator):
+    """One LSTM step (nn/modules/rnn.py:244-262) as a single tape node on the HIP device.  The node's value
+    is the packed pair (B, 2H) = [h' | c'] (the module hands out the two halves as views); 2 GEMMs + one
+    pointwise kernel forward (12 generic nodes in the reference), one pointwise kernel + 4 GEMMs backward."""
+
+    def __init__(self, x, h, c, wx, wh, bias=None):
+        self.has_bias = bias is not None
+        super().__init__(*((x, h, c, wx, wh) + ((bias,) if self.has_bias else ())))
+
+    def forward_(self, x, h, c, wx, wh, bias=None):
+        if self.xp is np:
+            raise NotImplementedError("lstm_cell is the HIP fused path; the NumPy device composes generic ops")
+        _require_f32(self, x, h, c, wx, wh, bias)
+        hp, L = _hip(), _L()
+        B, H = h.shape
+        xd, hd, cd = _contig(x.data), _contig(h.data), _contig(c.data)
+        lin = hp.empty((B, 4 * H), np.float32)
+        hp.gemm(xd, wx.data, lin, bias=bias.data.reshape(-1) if bias is not None else None)
+        hp.gemm(hd, wh.data, lin, beta=1.0)
+        gates, tc, hc = hp.empty((B, 4 * H), np.float32), hp.empty((B, H), np.float32), hp.empty((B, 2 * H), np.float32)
+        L.call("pdn_lstm_cell_fwd_f32", lin._ptr, cd._ptr, gates._ptr, tc._ptr, hc._ptr, B, H, hp.stream())
+        self._saved = (xd, hd, cd, gates, tc)
+        return hc
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, h, c, wx, wh = self.last[:5]
+        bias = self.last[5] if self.has_bias else None
+        xd, hd, cd, gates, tc = self._saved
+        B, H = hd.shape
+        g = _contig(g)
+        dlin, dc = hp.empty((B, 4 * H), np.float32), hp.empty((B, H), np.float32)
+        L.call("pdn_lstm_cell_bwd_f32", g._ptr, gates._ptr, tc._ptr, cd._ptr, dlin._ptr, dc._ptr, B, H, hp.stream())
+        grads = [None] * len(self.last)
+        if c.requires_grad:
+            grads[2] = dc
+        _cell_grads(self, hp, x, h, wx, wh, bias, xd, hd, dlin, grads, ix=0, ih=1, iwx=3, iwh=4, ib=5)
+        return grads
+
+
 class gru_cell(_Operator):
     """One GRU step (nn/modules/rnn.py:537-544) as a single tape node on the HIP device:
         [z, r] = sigmoid(x Wx1 + h Wh1 + b1);  n = tanh(x Wx2 + (r*h) Wh2 + b2);  h' = (1-z) h + z n

@@ -65,6 +65,9 @@ class RNNCell(_Cell):
             h = self.init_hidden(x)
         else:
             self._check(x, h)
+        if x.device.is_hip and x.ndim == 2 and h.ndim == 2 and x.dtype == np.float32 == h.dtype == self.Wx.dtype:
+            from ...core.fused import rnn_cell          # one tape node: 2 GEMMs + 1 pointwise kernel
+            return rnn_cell(x, h, self.Wx, self.Wh, self.bias if self.has_bias else None, self.nonlinearity)
         lin = x @ self.Wx + h @ self.Wh
         if self.has_bias:
             lin = lin + self.bias
@@ -128,6 +131,12 @@ class LSTMCell(_Cell):
             h, c = hx
             self._check(x, h)
             self._check(x, c, "cell")
+        if (x.device.is_hip and x.ndim == 2 and h.ndim == 2 and c.ndim == 2
+                and x.dtype == np.float32 == h.dtype == c.dtype == self.Wx.dtype):
+            from ...core.fused import lstm_cell         # one tape node; its value is the packed [h' | c']
+            hc = lstm_cell(x, h, c, self.Wx, self.Wh, self.bias if self.has_bias else None)
+            H = self.hidden_size
+            return hc[:, :H], hc[:, H:]
         lin = x @ self.Wx + h @ self.Wh
         if self.has_bias:
             lin = lin + self.bias

@@ -533,6 +533,44 @@ class EmulatedLib:
             flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
         return rc
 
+    # -- RNN / LSTM cell pointwise halves -----------------------------------------------------------------
+    def pdn_rnn_cell_fwd_f32(self, lin, y, n, act, stream):
+        v = np.array(flat(lin, n))
+        flat(y, n)[...] = self._tanh(v) if act == 0 else np.maximum(np.float32(0), v)
+        return 0
+
+    def pdn_rnn_cell_bwd_f32(self, lin, y, dy, dlin, n, act, stream):
+        yy, g = np.array(flat(y, n)), flat(dy, n)
+        flat(dlin, n)[...] = (1 - yy * yy) * g if act == 0 else (yy == flat(lin, n)) * g
+        return 0
+
+    def pdn_lstm_cell_fwd_f32(self, lin, c, gates, tc, hc, B, H, stream):
+        l = np.array(flat(lin, B * 4 * H).reshape(B, 4 * H))
+        g = flat(gates, B * 4 * H).reshape(B, 4 * H)
+        g[:, :3 * H] = self._sig(l[:, :3 * H])
+        g[:, 3 * H:] = self._tanh(l[:, 3 * H:])
+        cn = g[:, :H] * flat(c, B * H).reshape(B, H) + g[:, H:2 * H] * g[:, 3 * H:]
+        t = self._tanh(cn)
+        flat(tc, B * H).reshape(B, H)[...] = t
+        out = flat(hc, B * 2 * H).reshape(B, 2 * H)
+        out[:, :H], out[:, H:] = g[:, 2 * H:3 * H] * t, cn
+        return 0
+
+    def pdn_lstm_cell_bwd_f32(self, dhc, gates, tc, c, dlin, dc_prev, B, H, stream):
+        d = flat(dhc, B * 2 * H).reshape(B, 2 * H)
+        g = flat(gates, B * 4 * H).reshape(B, 4 * H)
+        f, i, o, tg = g[:, :H], g[:, H:2 * H], g[:, 2 * H:3 * H], g[:, 3 * H:]
+        t, cp = flat(tc, B * H).reshape(B, H), flat(c, B * H).reshape(B, H)
+        dh = d[:, :H]
+        dc = d[:, H:] + dh * o * (1 - t * t)
+        dl = flat(dlin, B * 4 * H).reshape(B, 4 * H)
+        dl[:, :H] = dc * cp * f * (1 - f)
+        dl[:, H:2 * H] = dc * tg * i * (1 - i)
+        dl[:, 2 * H:3 * H] = dh * t * o * (1 - o)
+        dl[:, 3 * H:] = dc * i * (1 - tg * tg)
+        flat(dc_prev, B * H).reshape(B, H)[...] = dc * f
+        return 0
+
     # -- persistent GRU sequence -------------------------------------------------------------------------
     def pdn_gru_seq_supported(self, H): return 1 if H == 32 else 0
 
