@@ -116,6 +116,12 @@ int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
                  float* b_colsum, int colsum_accumulate, void* workspace, int64_t workspace_bytes,
                  void* stream);
 int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
+/* float64 matmul (the reference's default dtype: a script that never says float32 still gets the right numbers
+ * on the HIP device).  v_mfma_f64_16x16x4_f64, same stride / batch conventions, no epilogue fusions. */
+int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_rs, int64_t a_cs,
+                 const double* B, int64_t b_rs, int64_t b_cs, double beta, double* C, int64_t ldc,
+                 int nb1, int nb2, int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
+                 int64_t c_bs1, int64_t c_bs2, void* stream);
 /* per-launch HIP-event timing of the GEMM kernel for bench.py's roofline block */
 int pdn_gemm_prof_enable(int on);
 int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);

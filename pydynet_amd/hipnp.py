@@ -981,9 +981,8 @@ def matmul(a, b):
     dt = np.result_type(a.dtype, b.dtype)
     if dt == np.float16:                              # float32 MFMA, result rounded to float16
         return matmul(a.astype(np.float32), b.astype(np.float32)).astype(np.float16)
-    if dt != np.float32:
-        raise TypeError(f"HIP backend matmul supports float32 only (got {a.dtype} @ {b.dtype}); "
-                        "float64 has no MFMA path in this library")
+    if dt not in (np.float32, np.float64):
+        raise TypeError(f"HIP backend matmul supports floating-point operands (got {a.dtype} @ {b.dtype})")
     if a.dtype != dt: a = a.astype(dt)
     if b.dtype != dt: b = b.astype(dt)
     if a.ndim == 0 or b.ndim == 0:
@@ -1024,9 +1023,13 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None, residual=None, b_colsum=None, 
     consumed in place).  `residual` must have C's strides; `b_colsum` (N,) receives the column
     sums of B in the same pass (only for the unbatched x^T @ g form)."""
     L = _lib.lib()
+    f64 = A.dtype == np.float64 and B.dtype == np.float64 and C.dtype == np.float64
+    if f64 and (bias is not None or residual is not None or b_colsum is not None):
+        raise TypeError("gemm: the float64 product has no fused epilogues")
     for name, arr in (("A", A), ("B", B), ("C", C), ("bias", bias), ("residual", residual), ("b_colsum", b_colsum)):
-        if arr is not None and arr.dtype != np.float32:
-            raise TypeError(f"gemm: operand {name} is {arr.dtype}; pdn_gemm_f32 takes float32 buffers only")
+        if arr is not None and arr.dtype != (np.float64 if f64 else np.float32):
+            raise TypeError(f"gemm: operand {name} is {arr.dtype}; pdn_gemm_f32 takes float32 buffers only "
+                            "(pdn_gemm_f64: all float64)")
     M, K = A.shape[-2:]
     N = B.shape[-1]
     bshape = C.shape[:-2]
@@ -1056,6 +1059,11 @@ def gemm(A, B, C, alpha=1.0, beta=0.0, bias=None, residual=None, b_colsum=None, 
     while len(merged) < 2:
         merged.insert(0, (1, (0, 0, 0)))
     (n1, (a1, b1, c1)), (n2, (a2, b2, c2)) = merged
+    if f64:
+        L.call("pdn_gemm_f64", M, N, K, float(alpha), A._ptr, A._strides[-2], A._strides[-1], B._ptr,
+               B._strides[-2], B._strides[-1], float(beta), C._ptr,
+               C._strides[-2] if M > 1 else _bi.max(C._strides[-2], N), n1, n2, a1, a2, b1, b2, c1, c2, stream())
+        return C
     # split-K scratch: offered whenever the contraction is long; capped at 256 MiB (the library
     # never splits further than the slabs it is given room for)
     ws_ptr, ws_bytes = workspace(_bi.min(L.query("pdn_gemm_f32_workspace_bytes", M, N, K, n1 * n2), 1 << 28)

@@ -186,6 +186,17 @@ class EmulatedLib:
         c[...] = r
         return 0
 
+    def pdn_gemm_f64(self, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, nb1, nb2,
+                     a1, a2, b1, b2, c1, c2, stream):
+        if M == 0 or N == 0 or nb1 == 0 or nb2 == 0:
+            return 0
+        a = view(A, (nb1, nb2, M, K), (a1, a2, a_rs, a_cs), np.float64)
+        b = view(B, (nb1, nb2, K, N), (b1, b2, b_rs, b_cs), np.float64)
+        c = view(C, (nb1, nb2, M, N), (c1, c2, ldc, 1), np.float64)
+        r = alpha * np.matmul(a, b)
+        c[...] = r + beta * c if beta != 0.0 else r
+        return 0
+
     # -- elementwise --------------------------------------------------------------------------
     def pdn_ew_binary(self, dt, op, mode, ndim, shape, a, sa, b, sb, scalar, out, so, stream):
         shp = _ints(shape, ndim)

@@ -84,13 +84,13 @@ def check_reference_generators_binary_matmul(dev):
                 assert ok.all(), (n, i)
         for i in range(8):
             a, b = d[f"mm{i}_a"], d[f"mm{i}_b"]
-            if hip and np.result_type(a.dtype, b.dtype) == np.float64:
-                continue          # the MFMA GEMM is float32 (float16 operands compute in float32)
-            out = pdn.matmul(T(a, dev), T(b, dev))
+            out = pdn.matmul(T(a, dev), T(b, dev))          # float32 / float64 MFMA GEMMs; float16 computes in float32
             ref = d[f"mm{i}_out"]
             assert out.shape == ref.shape and out.dtype == ref.dtype
             if ref.dtype == np.float16:
                 close(out, ref, 2e-3, 2e-3)
+            elif ref.dtype == np.float64:
+                close(out, ref, 1e-12, 1e-12)
             else:
                 close(out, ref, 1e-5, 1e-5)
 
