@@ -116,6 +116,56 @@ def parity_gate(model, dev, pdn):
             "rtol": GATE_RTOL}
 
 
+def pmc_traffic():
+    """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command (FETCH_SIZE x 2 -- the
+    gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, separate --pmc passes; tools/pmc_cmd.sh writes it).
+    Counters cannot be read from inside the timed run, so `traffic` is null when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r02_pmc_bench_b256.json")
+    if not os.path.exists(path):
+        return {}
+    rows = json.load(open(path))
+    out = {"_source": "profiles/r02_pmc_bench_b256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"}
+    for fam in ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "ce_fwd_bwd_reg_kernel", "adam_multi_kernel",
+                "swiglu_rows_bwd_kernel", "rmsnorm_bwd_kernel"):
+        n = tot = 0.0
+        for name, r in rows.items():
+            if name.startswith(fam) and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+                d = r.get("dispatches", 1)
+                n += d
+                tot += d * (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0        # counters are in KiB
+        if n:
+            out[fam] = tot / n
+    return out
+
+
+def hbm_kernels(lib, hp, B, traffic):
+    """The HBM-bound kernels of the step, timed live with HIP events on the launch stream at the step's own
+    shapes: achieved = ALGORITHMIC bytes per launch / average launch duration, against the 8 TB/s HBM3E peak."""
+    import ctypes
+    out = {}
+    T = B * L
+    x = hp.empty((T, V), np.float32)
+    lib.call("pdn_fill", 0, 0.01, 2, (ctypes.c_int64 * 2)(T, V), x._ptr, (ctypes.c_int64 * 2)(V, 1), hp.stream())
+    tgt = hp.from_numpy(np.random.default_rng(0).integers(0, V, T))
+    row, lse, loss, dx, cs = hp.empty((T,)), hp.empty((T,)), hp.empty((1,)), hp.empty((T, V)), hp.empty((V,))
+    wsb = lib.query("pdn_cross_entropy_colsum_workspace_bytes", T, V)
+    ws, wsb = hp.workspace(wsb)
+
+    def ce():
+        lib.call("pdn_cross_entropy_fwd_bwd_f32", x._ptr, tgt._ptr, T, V, 1, 1.0 / T, row._ptr, lse._ptr, loss._ptr,
+                 dx._ptr, cs._ptr, ws, wsb, hp.err_flag_ptr(), hp.stream())
+    for name, fn, nbytes in (("ce_fwd_bwd_reg_kernel", ce, 8.0 * T * V),):
+        fn(); hp.synchronize()
+        with hp.Timer() as t:
+            for _ in range(5):
+                fn()
+        us = t.ms / 5 * 1e3
+        out[name] = {"bound": "hbm", "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
+                     "avg_launch_us": us, "traffic": traffic.get(name)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,15 +252,30 @@ def main():
 
     roof = None
     if not args.no_gemm_prof:
-        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        ms2, fl2, n2 = (ctypes.c_double * 2)(), (ctypes.c_double * 2)(), (ctypes.c_int64 * 2)()
         lib.call("pdn_gemm_prof_enable", 0)
-        lib.call("pdn_gemm_prof_collect", ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt))
-        ach = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        roof = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel (all launches of the timed region)",
-                "achieved": ach, "peak": PEAK_FP32_MFMA / 1e12, "unit": "TFLOP/s",
-                "frac": ach / (PEAK_FP32_MFMA / 1e12), "traffic": None,
-                "launches": cnt.value, "avg_launch_us": 1e3 * ms.value / max(cnt.value, 1),
-                "gemm_time_share_of_step": ms.value * 1e-3 / dt}
+        lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
+        tf = lambda f, m: f / (m * 1e-3) / 1e12 if m > 0 else 0.0
+        peak = PEAK_FP32_MFMA / 1e12
+        traffic = pmc_traffic()
+        # the dominant kernel is the tiled MFMA GEMM (forward / input-gradient products and the lm_head trio);
+        # `achieved` = algorithmic 2MNK of ITS launches / HIP-event time around them, on the launch stream
+        roof = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": tf(fl2[0], ms2[0]), "peak": peak,
+                "unit": "TFLOP/s", "frac": tf(fl2[0], ms2[0]) / peak,
+                "traffic": traffic.get("gemm_f32_mfma_kernel"),
+                "launches": n2[0], "avg_launch_us": 1e3 * ms2[0] / max(n2[0], 1),
+                "time_share_of_step": ms2[0] * 1e-3 / dt,
+                "algorithmic_flop_per_launch": fl2[0] / max(n2[0], 1),
+                "other_gemm_families": {
+                    "gemm_tn_stream_dma_kernel": {"achieved": tf(fl2[1], ms2[1]), "frac": tf(fl2[1], ms2[1]) / peak,
+                                                  "launches": n2[1], "avg_launch_us": 1e3 * ms2[1] / max(n2[1], 1),
+                                                  "time_share_of_step": ms2[1] * 1e-3 / dt,
+                                                  "traffic": traffic.get("gemm_tn_stream_dma_kernel")}},
+                "all_gemm": {"achieved": tf(fl2[0] + fl2[1], ms2[0] + ms2[1]),
+                             "frac": tf(fl2[0] + fl2[1], ms2[0] + ms2[1]) / peak,
+                             "time_share_of_step": (ms2[0] + ms2[1]) * 1e-3 / dt},
+                "traffic_source": traffic.get("_source")}
+        roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic) if rank == 0 else None
     if world > 1:
         dt = group.all_reduce_scalar(dt, pdist.MAX)              # slowest rank's wall time
     value = world * B * args.steps / dt

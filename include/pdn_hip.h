@@ -125,6 +125,9 @@ int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_r
 /* per-launch HIP-event timing of the GEMM kernel for bench.py's roofline block */
 int pdn_gemm_prof_enable(int on);
 int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
+/* the same split by kernel family: [0] gemm_f32_mfma_kernel (tiled, incl. its split-K reduce),
+ * [1] gemm_tn_stream_*_kernel (weight gradients); each argument points to two values */
+int pdn_gemm_prof_collect_families(double* ms2, double* flops2, int64_t* launches2);
 
 /* ---- broadcasting elementwise: + - * / ** maximum minimum, comparisons
  * (tensor.py:548,564,591,612,634,811,820; 289-316).  mode 0: a op b, 1: a op scalar,

@@ -1037,7 +1037,7 @@ static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t e0, e1; double flops; };
+struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel
 static std::vector<ProfRec> g_prof;
 
 extern "C" int pdn_gemm_prof_enable(int on) {
@@ -1046,22 +1046,37 @@ extern "C" int pdn_gemm_prof_enable(int on) {
   return PDN_OK;
 }
 
-extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+// per kernel family: [0] gemm_f32_mfma_kernel (+ its split-K reduce), [1] gemm_tn_stream_*_kernel
+extern "C" int pdn_gemm_prof_collect_families(double* ms2, double* flops2, int64_t* launches2) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  double ms = 0, fl = 0;
+  double ms[2] = {0, 0}, fl[2] = {0, 0};
+  int64_t n[2] = {0, 0};
   for (auto& r : g_prof) {
     PDN_HIP(hipEventSynchronize(r.e1));
     float t = 0.f;
     PDN_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-    ms += t;
-    fl += r.flops;
+    const int f = r.family ? 1 : 0;
+    ms[f] += t; fl[f] += r.flops; n[f]++;
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
   }
-  if (total_ms) *total_ms = ms;
-  if (total_flops) *total_flops = fl;
-  if (launches) *launches = (int64_t)g_prof.size();
+  for (int f = 0; f < 2; ++f) {
+    if (ms2) ms2[f] = ms[f];
+    if (flops2) flops2[f] = fl[f];
+    if (launches2) launches2[f] = n[f];
+  }
   g_prof.clear();
+  return PDN_OK;
+}
+
+extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
+  double ms[2], fl[2];
+  int64_t n[2];
+  int rc = pdn_gemm_prof_collect_families(ms, fl, n);
+  if (rc) return rc;
+  if (total_ms) *total_ms = ms[0] + ms[1];
+  if (total_flops) *total_flops = fl[0] + fl[1];
+  if (launches) *launches = n[0] + n[1];
   return PDN_OK;
 }
 
@@ -1249,6 +1264,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     PDN_HIP(hipEventCreate(&rec.e0));
     PDN_HIP(hipEventCreate(&rec.e1));
     rec.flops = 2.0 * M * N * (double)K * nbatch;
+    rec.family = use_stream ? 1 : 0;
     PDN_HIP(hipEventRecord(rec.e0, st));
   }
 

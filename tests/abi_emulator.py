@@ -163,6 +163,7 @@ class EmulatedLib:
     def pdn_rmsnorm_bwd_workspace_bytes(self, rows, cols): return 1024 * cols * 4
     def pdn_embedding_scatter_workspace_bytes(self, V): return V * 4
     def pdn_gemm_prof_enable(self, on): return 0
+    def pdn_gemm_prof_collect_families(self, ms, fl, n): return 0
 
     # -- gemm -------------------------------------------------------------------------------
     def pdn_gemm_f32(self, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, nb1, nb2,

@@ -24,6 +24,9 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")[:80]
         if flt not in k: continue
         a = agg[k][r["Counter_Name"]]; a[0] += 1; a[1] += float(r["Counter_Value"])
+import json
+json.dump({k: dict({c: x[1] / max(x[0], 1) for c, x in d.items()}, dispatches=max(x[0] for x in d.values()))
+           for k, d in agg.items()}, open(out + "/summary.json", "w"), indent=1)
 for k, d in sorted(agg.items()):
     print(k)
     v = {c: x[1] / max(x[0], 1) for c, x in d.items()}
