@@ -174,6 +174,9 @@ def main():
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "256")), help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-prof", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true",
+                    help="profiling runs only (keeps the batch-1 gate step out of per-kernel counter averages); "
+                         "the JSON line then carries parity_gate = null")
     args = ap.parse_args()
 
     import ctypes
@@ -201,7 +204,7 @@ def main():
     model = Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)           # (max_batch_size only sizes the unused KV caches)
     model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     model.to(dev)
-    gate = parity_gate(model, dev, pdn)                     # refuses to go on if the path is wrong
+    gate = None if args.no_parity_gate else parity_gate(model, dev, pdn)    # refuses to go on if the path is wrong
     opt = Adam(model.parameters(), lr=1e-4)
     dp = DataParallel(model, opt, always_reduce=force_dp) if (world > 1 or force_dp) else None
     if dp is None:

@@ -1015,6 +1015,10 @@ static const TileCfg kCfgs[] = {
     {2, 1, 1, 3, 32, 0.78f},  // 10: 64 x  96   (2 waves: finer quantisation for N = 288)
     {1, 2, 3, 1, 32, 0.70f},  // 11: 96 x  64
     {4, 1, 1, 3, 16, 1.15f},  // 12: 128 x 96, BK 16: 51 KB of LDS -> three workgroups per CU (offered selectively)
+    // (tried in round 2: {4, 1, 1, 9, 16} = 128 x 288, the whole 288-wide row panel in one workgroup so that the
+    //  65536 x 32000 dlogits operand of the lm_head input gradient is read from HBM once instead of 1.76 times
+    //  (PMC: FETCH 14.8 GB vs 8.4 GB algorithmic) -- 10.45 ms against 9.79 ms for the 96 x 128 tile: the product is
+    //  matrix-pipe bound, the re-reads are L2 / MALL hits that cost nothing; not kept)
 };
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kScalarCfg = 5;

@@ -32,8 +32,9 @@ for k, d in sorted(agg.items()):
     v = {c: x[1] / max(x[0], 1) for c, x in d.items()}
     print("   " + "  ".join(f"{c}={x:.4g}" for c, x in sorted(v.items())))
     if "SQ_BUSY_CYCLES" in v and "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE"):
-        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; GRBM_GUI_ACTIVE = shader-clock cycles of the kernel
-        print(f"   MFMA busy = {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] * 256 * 4):.3f} of 1024 SIMDs x kernel cycles")
+        # SQ_VALU_MFMA_BUSY_CYCLES: cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+        # (= 8 x the kernel's shader-clock cycles: 5.46e6 for a 287 us kernel at 2.38 GHz)
+        print(f"   MFMA busy = {v['SQ_VALU_MFMA_BUSY_CYCLES'] / (v['GRBM_GUI_ACTIVE'] / 8 * 1024):.3f} of 1024 SIMDs x kernel cycles")
     if "TCC_HIT_sum" in v:
         print(f"   L2 hit rate = {v['TCC_HIT_sum'] / max(v['TCC_HIT_sum'] + v['TCC_MISS_sum'], 1):.3f}")
     if "FETCH_SIZE" in v:

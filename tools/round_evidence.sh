@@ -9,9 +9,9 @@ python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/
 PDN_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline > $O/bench_force_dp.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --batch 128 > $O/bench_b128.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --batch 64 > $O/bench_b64.json 2>> $O/bench_default.err
-bash tools/prof_cmd.sh r02_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof > $O/bench_kernel_stats.txt 2>&1
+bash tools/prof_cmd.sh r02_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate > $O/bench_kernel_stats.txt 2>&1
 cp gpurun_out/prof_r02_bench/p_kernel_stats.csv $O/bench_b256_kernel_stats.csv 2>/dev/null
-bash tools/pmc_cmd.sh r02_bench kernel python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-prof > $O/bench_pmc.txt 2>&1
+bash tools/pmc_cmd.sh r02_bench kernel python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate > $O/bench_pmc.txt 2>&1
 cp gpurun_out/pmc_r02_bench/summary.json $O/pmc_bench_b256.json 2>/dev/null
 bash tools/prof_cmd.sh r02_lenet python tools/bench_configs.py 10 lenet:4096 > $O/lenet_kernel_stats.txt 2>&1
 bash tools/pmc_cmd.sh r02_lenet conv python tools/bench_configs.py 3 lenet:4096 > $O/lenet_pmc.txt 2>&1
