@@ -74,3 +74,15 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(base, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "abi_emulator" not in src, f
+
+
+def test_integration_snippet_is_the_documented_one_and_needs_no_torch():
+    """tools/integration_snippet.py is INTEGRATION.md section 2 made runnable: same binding lines, no torch."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    src = open(os.path.join(root, "tools", "integration_snippet.py")).read()
+    assert "import torch" not in src and "import torch" not in doc.split("## 3.")[0]
+    for line in ("lib.pdn_malloc.argtypes, lib.pdn_free.argtypes = [ctypes.POINTER(vp), i64], [vp]",
+                 "check(lib.pdn_memcpy_h2d(p, a.ctypes.data, a.nbytes, stream)); return p",
+                 "0, 0, 0, 0, 0, 0, None, None, 0, None, 0, stream))"):
+        assert line in doc and line in src, line

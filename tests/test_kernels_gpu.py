@@ -627,3 +627,14 @@ def test_persistent_gru_sequence_equals_per_step_path(hip):
             fused.gru_sequence.use_persistent = True
     for a, b, name in zip(res[0], res[1], ["out"] + list(arrs)):
         assert np.allclose(a, b, rtol=2e-5, atol=2e-5 * np.abs(b).max()), name
+
+
+def test_integration_snippet_runs_without_torch():
+    """The ctypes-only binding of INTEGRATION.md drives the library in a process that loads neither PyTorch
+    nor this package (device runtime, allocator, copies and GEMM all come from libpdnhip.so)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "integration_snippet.py")], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "torch loaded: False" in r.stdout
