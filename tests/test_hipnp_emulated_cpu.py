@@ -24,7 +24,6 @@ _ALL = [(name, kw) for name, fn in sorted(vars(kernel_tests).items())
 @pytest.mark.parametrize("name,kw", _ALL, ids=[f"{n}-{i}" for i, (n, _) in enumerate(_ALL)])
 def test_kernel_test_body_on_emulator(emulated_hip, name, kw):
     fn = getattr(kernel_tests, name)
-    if "hip" in inspect.signature(fn).parameters:
-        fn(emulated_hip, **kw)
-    else:
-        fn(**kw)
+    if "hip" not in inspect.signature(fn).parameters:
+        pytest.skip("drives the real library in a subprocess; nothing to emulate")
+    fn(emulated_hip, **kw)
