@@ -17,7 +17,9 @@ expression.  Reference chains replaced:
 """
 from __future__ import annotations
 
+import contextlib
 import math
+import os
 
 import numpy as np
 
@@ -68,6 +70,19 @@ def _foldable(node, idx, t):
     return ex
 
 
+two_stream = {"enabled": os.environ.get("PDN_TWO_STREAM", "0") == "1"}
+
+
+def _beside(hp, fin, fout, has_dx):
+    """A `hipnp.side_stream` for the weight-gradient product of a projection, to run beside the
+    input-gradient product.  Opt-in (PDN_TWO_STREAM=1): isolated 768-wide pairs gain 7-8 % (one GEMM's store
+    tail under the other's main loop, `tools/two_stream_probe.py`), but a whole training step measured
+    +-0.5 % (same-box A/B at per-GPU batch 64 / 128 / 256), i.e. nothing."""
+    if not (two_stream["enabled"] and has_dx and 512 <= max(fin, fout) <= 4096) or hp.capturing() is not None:
+        return None
+    return hp.side_stream()
+
+
 def _is_leaf_f32(t):
     return (t.requires_grad and not t.last and t.grad is not None and t.grad.dtype == np.float32
             and (isinstance(t.grad, np.ndarray) or t.grad.is_contiguous()))
@@ -109,6 +124,13 @@ class linear(_Operator):
                 residual=res)
         return out
 
+    def _dx(self, hp, g2, x, w, fin):
+        dx = hp.empty(x.shape, np.float32)
+        ex = _foldable(self, 0, x)
+        hp.gemm(g2, w.data.T, dx.reshape(-1, fin),                         # NT
+                residual=ex.reshape(-1, fin) if ex is not None else None)
+        return dx
+
     def backward_all(self, g):
         x, w, b, r = self._split(self.last)
         fin, fout = w.shape
@@ -127,12 +149,9 @@ class linear(_Operator):
         hp = _hip()
         g2 = _contig(g).reshape(-1, fout)
         x2 = x.data.reshape(-1, fin)
-        if x.requires_grad:
-            dx = hp.empty(x.shape, np.float32)
-            ex = _foldable(self, 0, x)
-            hp.gemm(g2, w.data.T, dx.reshape(-1, fin),                     # NT
-                    residual=ex.reshape(-1, fin) if ex is not None else None)
-            grads[0] = dx
+        side = _beside(hp, fin, fout, x.requires_grad and w.requires_grad)
+        if x.requires_grad and side is None:
+            grads[0] = self._dx(hp, g2, x, w, fin)
         need_db = b is not None and b.requires_grad
         aux = getattr(g, "_aux", None)
         if need_db and aux is not None and aux[0] == "colsum" and aux[1].size == b.size:
@@ -150,12 +169,16 @@ class linear(_Operator):
                    and fin % 4 == 0 and fout % 4 == 0 and x2.shape[0] % 4 == 0)
         if w.requires_grad:
             cs = b.grad.reshape(-1) if fuse_db else None
-            if _is_leaf_f32(w):
-                hp.gemm(x2.T, g2, w.grad, beta=1.0, b_colsum=cs, colsum_accumulate=True)   # TN, += into the leaf
-            else:
-                dw = hp.empty((fin, fout), np.float32)
-                hp.gemm(x2.T, g2, dw, b_colsum=cs, colsum_accumulate=True)
-                grads[1] = dw
+            dw = None if _is_leaf_f32(w) else hp.empty((fin, fout), np.float32)
+            with side or contextlib.nullcontext():
+                if dw is None:
+                    hp.gemm(x2.T, g2, w.grad, beta=1.0, b_colsum=cs, colsum_accumulate=True)   # TN, += into the leaf
+                else:
+                    hp.gemm(x2.T, g2, dw, b_colsum=cs, colsum_accumulate=True)
+                    grads[1] = dw
+        if side is not None:
+            grads[0] = self._dx(hp, g2, x, w, fin)
+            side.join()
         if need_db and not fuse_db:
             grads[2] = g2.sum(0).reshape(b.shape)
         return grads
@@ -1227,24 +1250,29 @@ class qkv_attention(_Operator):
         gstack = None
         if all(w.requires_grad and _is_leaf_f32(w) for w in weights):
             gstack = hp.stacked_view([w.grad for w in weights])
-        if gstack is not None:
-            hp.gemm(x2.T, dblocks, gstack, beta=1.0)              # three x^T @ d_i in one launch
-        else:
-            for i, w in enumerate(weights):
-                if not w.requires_grad:
-                    continue
-                if _is_leaf_f32(w):
-                    hp.gemm(x2.T, dblocks[i], w.grad, beta=1.0)
-                else:
-                    dw = hp.empty(w.shape, np.float32)
-                    hp.gemm(x2.T, dblocks[i], dw)
-                    grads[1 + i] = dw
+        side = _beside(hp, D, 3 * D, x.requires_grad and any(w.requires_grad for w in weights))
+        dws = [hp.empty(w.shape, np.float32) if gstack is None and w.requires_grad and not _is_leaf_f32(w) else None
+               for w in weights]
+        with side or contextlib.nullcontext():
+            if gstack is not None:
+                hp.gemm(x2.T, dblocks, gstack, beta=1.0)              # three x^T @ d_i in one launch
+            else:
+                for i, w in enumerate(weights):
+                    if not w.requires_grad:
+                        continue
+                    if dws[i] is None:
+                        hp.gemm(x2.T, dblocks[i], w.grad, beta=1.0)
+                    else:
+                        hp.gemm(x2.T, dblocks[i], dws[i])
+                        grads[1 + i] = dws[i]
         if x.requires_grad:
             dx = hp.empty(x.shape, np.float32)
             ex = _foldable(self, 0, x)
             wcat = _pack_columns(hp, [wq.data, wk.data, wv.data])                  # (D, 3D)
             hp.gemm(dqkv, wcat.T, dx.reshape(T, D), residual=ex.reshape(T, D) if ex is not None else None)
             grads[0] = dx
+        if side is not None:
+            side.join()
         return grads
 
 
@@ -1307,24 +1335,29 @@ class gate_up_swiglu(_Operator):
         gstack = None
         if all(w.requires_grad and _is_leaf_f32(w) for w in weights):
             gstack = hp.stacked_view([w.grad for w in weights])
-        if gstack is not None:
-            hp.gemm(x2.T, dhalves, gstack, beta=1.0)
-        else:
-            for i, w in enumerate(weights):
-                if not w.requires_grad:
-                    continue
-                if _is_leaf_f32(w):
-                    hp.gemm(x2.T, dhalves[i], w.grad, beta=1.0)
-                else:
-                    dw = hp.empty(w.shape, np.float32)
-                    hp.gemm(x2.T, dhalves[i], dw)
-                    grads[1 + i] = dw
+        side = _beside(hp, fin, 2 * F, x.requires_grad and any(w.requires_grad for w in weights))
+        dws = [hp.empty(w.shape, np.float32) if gstack is None and w.requires_grad and not _is_leaf_f32(w) else None
+               for w in weights]
+        with side or contextlib.nullcontext():
+            if gstack is not None:
+                hp.gemm(x2.T, dhalves, gstack, beta=1.0)
+            else:
+                for i, w in enumerate(weights):
+                    if not w.requires_grad:
+                        continue
+                    if dws[i] is None:
+                        hp.gemm(x2.T, dhalves[i], w.grad, beta=1.0)
+                    else:
+                        hp.gemm(x2.T, dhalves[i], dws[i])
+                        grads[1 + i] = dws[i]
         if x.requires_grad:
             dx = hp.empty(x.shape, np.float32)
             ex = _foldable(self, 0, x)
             wcat = _pack_columns(hp, [wg.data, wu.data])                           # (fin, 2F)
             hp.gemm(dgu, wcat.T, dx.reshape(T, fin), residual=ex.reshape(T, fin) if ex is not None else None)
             grads[0] = dx
+        if side is not None:
+            side.join()
         return grads
 
 

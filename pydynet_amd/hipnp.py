@@ -100,6 +100,47 @@ def synchronize():
     _lib.lib().call("pdn_stream_synchronize", stream())
 
 
+_side = {}        # device -> (side stream, fork event, join event)
+
+
+class side_stream:
+    """Run the launches of the `with` body on a second stream of the current device, concurrently with
+    whatever the compute stream is given next; `join()` makes the compute stream wait for them.
+
+        with hipnp.side_stream() as s:      # side stream waits for everything enqueued so far
+            hipnp.gemm(x.T, g, dw)          # ... runs beside ...
+        hipnp.gemm(g, w.T, dx)              # ... this one
+        s.join()                            # later compute-stream work sees both results
+
+    Lifetime rule (the allocator orders reuse on the compute stream only): join before any buffer the
+    body touched can be released, i.e. before the enclosing operator returns.  Workspaces are per stream."""
+
+    def __enter__(self):
+        L = _lib.lib()
+        dev = _state["device"]
+        ent = _side.get(dev)
+        if ent is None:
+            st, e0, e1 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+            L.call("pdn_stream_create", ctypes.byref(st), 0)
+            L.call("pdn_event_create", ctypes.byref(e0), 0)
+            L.call("pdn_event_create", ctypes.byref(e1), 0)
+            ent = _side[dev] = (st.value, e0, e1)
+        self._main = stream()
+        self._side, self._e0, self._e1 = ent
+        L.call("pdn_event_record", self._e0, self._main)
+        L.call("pdn_stream_wait_event", self._side, self._e0)
+        _state["stream"] = self._side
+        return self
+
+    def __exit__(self, *exc):
+        _state["stream"] = self._main
+        _lib.lib().call("pdn_event_record", self._e1, self._side)
+        return False
+
+    def join(self):
+        _lib.lib().call("pdn_stream_wait_event", self._main, self._e1)
+
+
 class Timer:
     """HIP-event stopwatch on the compute stream: `with Timer() as t: ...; t.ms`."""
 
@@ -250,16 +291,17 @@ def _contig_strides(shape):
 # ---------------------------------------------------------------------------------------
 # workspace: one growing scratch buffer per process (kernels never allocate)
 # ---------------------------------------------------------------------------------------
-_ws = {}          # device -> _Buffer
+_ws = {}          # (device, stream) -> _Buffer
 
 
 def workspace(nbytes: int):
     nbytes = int(nbytes)
     if nbytes <= 0:
         return 0, 0
-    buf = _ws.get(_state["device"])
+    key = (_state["device"], _state["stream"])
+    buf = _ws.get(key)
     if buf is None or buf.nbytes < nbytes:
-        _ws[_state["device"]] = buf = _Buffer(_bi.max(nbytes, 1 << 20))
+        _ws[key] = buf = _Buffer(_bi.max(nbytes, 1 << 20))
     return buf.ptr, buf.nbytes
 
 
