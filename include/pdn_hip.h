@@ -116,6 +116,14 @@ int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
                  float* b_colsum, int colsum_accumulate, void* workspace, int64_t workspace_bytes,
                  void* stream);
 int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
+/* Row-resident product for the layer projections (tall A with contiguous rows, contraction of a few
+ * hundred): C (M x N) = A (M x K) * B + bias[N] + residual[M x N]; B is (K x N) row-major, or with
+ * `b_trans` the (N x K) row-major matrix whose transpose is meant (`grad @ W^T`, tensor.py:670).
+ * A's rows stay in registers, B streams through LDS (csrc/gemm_rowres.hip).  pdn_gemm_f32 routes the
+ * shapes `pdn_gemm_rowres_supported` accepts here by itself; the entry point is exported for tests. */
+int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
+int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                        int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
 /* float64 matmul (the reference's default dtype: a script that never says float32 still gets the right numbers
  * on the HIP device).  v_mfma_f64_16x16x4_f64, same stride / batch conventions, no epilogue fusions. */
 int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_rs, int64_t a_cs,
@@ -126,8 +134,9 @@ int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_r
 int pdn_gemm_prof_enable(int on);
 int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
 /* the same split by kernel family: [0] gemm_f32_mfma_kernel (tiled, incl. its split-K reduce),
- * [1] gemm_tn_stream_*_kernel (weight gradients); each argument points to two values */
-int pdn_gemm_prof_collect_families(double* ms2, double* flops2, int64_t* launches2);
+ * [1] gemm_tn_stream_*_kernel (weight gradients), [2] gemm_rowres_kernel (projections, contraction 288);
+ * each argument points to THREE values */
+int pdn_gemm_prof_collect_families(double* ms3, double* flops3, int64_t* launches3);
 
 /* ---- broadcasting elementwise: + - * / ** maximum minimum, comparisons
  * (tensor.py:548,564,591,612,634,811,820; 289-316).  mode 0: a op b, 1: a op scalar,

@@ -1041,7 +1041,7 @@ static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel
+struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel
 static std::vector<ProfRec> g_prof;
 
 extern "C" int pdn_gemm_prof_enable(int on) {
@@ -1050,39 +1050,47 @@ extern "C" int pdn_gemm_prof_enable(int on) {
   return PDN_OK;
 }
 
-// per kernel family: [0] gemm_f32_mfma_kernel (+ its split-K reduce), [1] gemm_tn_stream_*_kernel
-extern "C" int pdn_gemm_prof_collect_families(double* ms2, double* flops2, int64_t* launches2) {
+// per kernel family: [0] gemm_f32_mfma_kernel (+ its split-K reduce), [1] gemm_tn_stream_*_kernel,
+// [2] gemm_rowres_kernel (csrc/gemm_rowres.hip); the three output arrays have three entries each
+extern "C" int pdn_gemm_prof_collect_families(double* ms3, double* flops3, int64_t* launches3) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  double ms[2] = {0, 0}, fl[2] = {0, 0};
-  int64_t n[2] = {0, 0};
+  double ms[3] = {0, 0, 0}, fl[3] = {0, 0, 0};
+  int64_t n[3] = {0, 0, 0};
   for (auto& r : g_prof) {
     PDN_HIP(hipEventSynchronize(r.e1));
     float t = 0.f;
     PDN_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-    const int f = r.family ? 1 : 0;
+    const int f = r.family < 0 || r.family > 2 ? 0 : r.family;
     ms[f] += t; fl[f] += r.flops; n[f]++;
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
   }
-  for (int f = 0; f < 2; ++f) {
-    if (ms2) ms2[f] = ms[f];
-    if (flops2) flops2[f] = fl[f];
-    if (launches2) launches2[f] = n[f];
+  for (int f = 0; f < 3; ++f) {
+    if (ms3) ms3[f] = ms[f];
+    if (flops3) flops3[f] = fl[f];
+    if (launches3) launches3[f] = n[f];
   }
   g_prof.clear();
   return PDN_OK;
 }
 
 extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
-  double ms[2], fl[2];
-  int64_t n[2];
+  double ms[3], fl[3];
+  int64_t n[3];
   int rc = pdn_gemm_prof_collect_families(ms, fl, n);
   if (rc) return rc;
-  if (total_ms) *total_ms = ms[0] + ms[1];
-  if (total_flops) *total_flops = fl[0] + fl[1];
-  if (launches) *launches = n[0] + n[1];
+  if (total_ms) *total_ms = ms[0] + ms[1] + ms[2];
+  if (total_flops) *total_flops = fl[0] + fl[1] + fl[2];
+  if (launches) *launches = n[0] + n[1] + n[2];
   return PDN_OK;
 }
+
+extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
+extern "C" int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias,
+                                   const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
+                                   int64_t ldc, int b_trans, void* stream);
+int pdn_gemm_rowres_blocks(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int b_trans, int nblocks, int64_t b_block_stride, void* stream);
 
 extern "C" int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch) {
   // Enough for up to 64 splits of one output; pdn_gemm_f32 never uses more than it is given.
@@ -1149,6 +1157,50 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     }
     PDN_LAUNCH_CHECK();
     return PDN_OK;
+  }
+  // ---- tall A, contraction 288, wide-enough output: rows of A resident in registers (gemm_rowres.hip) ----
+  // measured against the tiled kernel at 65536 rows: N 864 +19 %, 1536 +14 %, 768 (either B orientation)
+  // +11..14 %, 32000 +4 %; N 288 equal (left to the tiled kernel); with a residual the tiled epilogue wins
+  // A batch whose members share A and write side by side into one packed buffer (x against Wq | Wk | Wv,
+  // x against Wg | Wu: fused.py) is ONE such product with B in equally spaced column blocks.
+  {
+    const bool one_dim = nb1 == 1 || nb2 == 1;
+    const int64_t a_bs = nb1 == 1 ? a_bs2 : a_bs1, b_bs = nb1 == 1 ? b_bs2 : b_bs1, c_bs = nb1 == 1 ? c_bs2 : c_bs1;
+    const bool blocks = nbatch > 1 && one_dim && a_bs == 0 && c_bs == N && ldc >= (int64_t)nbatch * N && !bias &&
+                        N % 96 == 0 && (b_bs & 3) == 0;
+    const int64_t n_all = (int64_t)N * (blocks ? nbatch : 1);
+    if ((nbatch == 1 || blocks) && K == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum && !residual &&
+        n_all >= 768 && n_all < (1 << 30) && M >= 8192 && al16(A) && al16(B) && !getenv("PDN_GEMM_NO_ROWRES")) {
+      const int bt = (b_rs == 1 && b_cs != 1) ? 1 : 0;
+      const int64_t ldb = bt ? b_cs : b_rs;
+      if ((bt || b_cs == 1) && pdn_gemm_rowres_supported(M, N, K, a_rs, ldb, ldc, bt)) {
+        bool prof;
+        ProfRec rec;
+        {
+          std::lock_guard<std::mutex> lk(g_prof_mu);
+          prof = g_prof_on;
+        }
+        if (prof) {
+          PDN_HIP(hipEventCreate(&rec.e0));
+          PDN_HIP(hipEventCreate(&rec.e1));
+          rec.flops = 2.0 * M * (double)n_all * (double)K;
+          rec.family = 2;
+          PDN_HIP(hipEventRecord(rec.e0, st));
+        }
+        if (getenv("PDN_GEMM_DEBUG"))
+          fprintf(stderr, "pdn_gemm_f32 M=%d N=%lld K=%d -> row-resident (%s, %d block%s)\n", M, (long long)n_all, K,
+                  bt ? "NT" : "NN", blocks ? nbatch : 1, blocks ? "s" : "");
+        const int rc = blocks ? pdn_gemm_rowres_blocks(A, B, C, M, (int)n_all, K, a_rs, ldb, ldc, bt, nbatch, b_bs, stream)
+                              : pdn_gemm_rowres_f32(A, B, C, bias, nullptr, M, N, K, a_rs, ldb, ldc, bt, stream);
+        if (rc) return rc;
+        if (prof) {
+          PDN_HIP(hipEventRecord(rec.e1, st));
+          std::lock_guard<std::mutex> lk(g_prof_mu);
+          g_prof.push_back(rec);
+        }
+        return PDN_OK;
+      }
+    }
   }
   const int64_t ws_cap = (workspace && workspace_bytes > 0) ? workspace_bytes / 4 : 0;
   // ---- weight-gradient form (small output, long K): wave-streaming kernel --------------------

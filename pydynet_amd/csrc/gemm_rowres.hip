@@ -1,0 +1,331 @@
+// Row-resident fp32 GEMM for the layer projections (short contraction, gfx950 only).
+//
+//   C (M x N) = A (M x K, rows contiguous) * B (K x N)  (+ bias[N]) (+ residual[M x N])
+//
+// The products around a transformer block -- x Wq|Wk|Wv, x Wg|Wu, h W_out (llm/llama/model.py:93-121,
+// 56-58, 179: `x @ W` through pydynet/core/tensor.py:657-676) and the input gradients dY W^T that contract
+// over 288 features -- have a contraction of a few hundred and a tall A: a tiled kernel spends its
+// time in per-tile prologues, a barrier every k-tile and LDS traffic for both operands.  Here
+//   * a wave owns 32 rows of A and keeps ALL of their K values in registers as MFMA A operands
+//     (lane (i, h) holds A[row i][8t + 4h .. +3] for t < K/8: K/2 VGPRs, loaded once);
+//   * B is streamed through LDS in 96 (k) x 96 (n) pieces by LDS-DMA (`global_load_lds_dwordx4`: no VGPR
+//     staging, no ds_write), double buffered, shared by the four waves of a workgroup: one barrier
+//     per 144 MFMAs per wave.  The nine DMA instructions a wave contributes to the next piece are
+//     spread over the MFMA stream (issued as one burst after the barrier they back up the address path
+//     and hold all four waves in VMEM issue: 82 -> 86 % of the matrix peak on 65536 x 32064 x 288);
+//   * B row-major [k][n] (forward, `x @ W`): LDS image [k][96], fragments are conflict-free ds_read_b32;
+//     B^T row-major [n][k] (`grad @ W^T`, tensor.py:670): LDS image [n][96] with the 16-byte units of
+//     row n XOR-swizzled by (n >> 1) & 7 -- applied on the SOURCE side of the DMA, whose LDS side is
+//     linear in the lane -- so one ds_read_b128 per four MFMAs is conflict free without padding;
+//   * the accumulator (lane = output column, registers = rows) is stored straight from registers:
+//     every store instruction writes two full 128-byte row segments.
+// A never passes through LDS and there is no k-tile prologue: between barriers a wave issues an
+// unbroken MFMA stream.  Two workgroups (2 x 4 waves) per CU run out of phase.
+// The k-order of every output element is the same as in csrc/gemm.hip (k = 8t + 4h + j inside an MFMA
+// group, groups ascending), so both kernels give bit-identical results.
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct RowResParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* residual;
+  int M, N;
+  int64_t lda, ldb, ldc;
+  int chunks, chunks_per_wg;      // 96-column chunks of N in total / per workgroup (grid.y)
+  int cpb;                        // chunks per column block of B (B may come as several equally spaced
+  int64_t b_bstride;              // matrices side by side: Wq | Wk | Wv); `chunks` when B is one matrix
+};
+
+__device__ __forceinline__ void rr_glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+#define RR_NC 96          // columns per chunk (three 32-wide MFMA tiles)
+#define RR_KP 96          // contraction rows per piece (twelve 8-row groups)
+
+// Accumulator block (three 32 x 32 tiles: lane = column, register r = row (r & 3) + 8 (r >> 2) + 4 h) ->
+// C rows, + bias, + residual.  Wave-uniform 64-bit bases + one running 32-bit lane offset (opaque to the
+// optimiser: hoisting 48 loop-invariant addresses out of the chunk loop costs more registers than exist).
+// `nt` (1..3): tiles of this chunk that lie inside N.
+__device__ __forceinline__ void rr_store(const RowResParams& p, f32x16 (&acc)[3], int m0, int c, int li, int lh,
+                                         bool full, int nt) {
+  float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + c * RR_NC;
+  const float* __restrict__ Rw = p.residual ? p.residual + (int64_t)m0 * p.ldc + c * RR_NC : nullptr;
+  const unsigned ldc = (unsigned)p.ldc;
+  unsigned o0 = (unsigned)(4 * lh) * ldc + li;
+  asm volatile("" : "+v"(o0));
+  float bv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bv[j] = (p.bias && j < nt) ? p.bias[c * RR_NC + 32 * j + li] : 0.f;
+  const int mrem = p.M - m0 - 4 * lh;             // rows rr < mrem exist
+#define RR_ROWS(GUARD, RES)                                                      \
+  {                                                                              \
+    unsigned o = o0;                                                             \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                            \
+        const int r = 4 * q + e;                                                 \
+        if (!GUARD || 8 * q + e < mrem) {                                        \
+          _Pragma("unroll") for (int j = 0; j < 3; ++j) {                        \
+            if (!GUARD || j < nt) {                                              \
+              float v = acc[j][r] + bv[j];                                       \
+              if (RES) v += Rw[o + 32 * j];                                      \
+              Cw[o + 32 * j] = v;                                                \
+            }                                                                    \
+          }                                                                      \
+        }                                                                        \
+        o += (e == 3) ? 5 * ldc : ldc;                                           \
+      }                                                                          \
+    }                                                                            \
+  }
+  if (full && nt == 3) {
+    if (Rw) RR_ROWS(false, true) else RR_ROWS(false, false)
+  } else {
+    if (Rw) RR_ROWS(true, true) else RR_ROWS(true, false)
+  }
+#undef RR_ROWS
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
+// KG = K / 8.  BT: B is given as the row-major (N x K) matrix whose transpose is meant.
+// ABLATE (timing experiments only, 0 in the library): 2 = no B DMA after the first two pieces,
+// 32 = the DMA of a piece issued as one burst.
+// NW: waves per workgroup (4: two workgroups per CU; 8: one -- half the DMA instructions per wave).
+template <int KG, bool BT, int NW, int ABLATE = 0>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(RowResParams p) {
+  constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
+  constexpr int NPK = KG / 12;                    // pieces along K
+  constexpr int PIECE = RR_KP * RR_NC;            // floats
+  static_assert(KG % 12 == 0, "K must be a multiple of 96");
+  __shared__ __attribute__((aligned(16))) float smem[2 * PIECE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = (blockIdx.x * NW + wave) * 32;
+  const int c_begin = blockIdx.y * p.chunks_per_wg;
+  const int c_end = min(p.chunks, c_begin + p.chunks_per_wg);
+  const int nloc = c_end - c_begin;
+  // (walking the chunks in a different order on every XCD, so that 512 workgroups in lockstep do not ask
+  //  for the same 36 KB piece at the same moment, measured neutral to slower: the order stays 0, 1, 2 ...)
+  auto chunk_of = [&](int ci) { return c_begin + ci; };
+  // first element of chunk c in B: column block c / cpb, 96-column (NN) or 96-row (NT) slice c % cpb of it
+  auto chunk_base = [&](int c) -> const float* {
+    const int blk = c / p.cpb, cin = c - blk * p.cpb;
+    return p.B + blk * p.b_bstride + (BT ? (int64_t)(cin * RR_NC) * p.ldb : (int64_t)(cin * RR_NC));
+  };
+  const int c_tail = (p.N % RR_NC) ? p.chunks - 1 : -1;      // the chunk that sticks out of N, if any
+
+  // DMA plan: a piece is 36 wave instructions of 1 KiB; instruction I covers the 16-byte units
+  // 64 I .. 64 I + 63 of the piece = units u = lane + 64 (I % 3) of 8-row group I / 3: row u / 24, unit
+  // u % 24 of that row (wave-uniform 64-bit base + unsigned 32-bit lane offset).  Wave w issues I = w, w + NW, ...
+  // NN: rows are k, units run along n.   NT: rows are n, units run along k, and LDS unit cu' of row n
+  // receives source unit cu' ^ ((n >> 1) & 7).
+  // The last chunk of an N that is not a multiple of 96 (`c_tail`, nt = 1 or 2 tiles inside N) reads
+  // sources folded back into the matrix -- NN: column units modulo 8 nt (`offt`), NT: row groups modulo
+  // 4 nt -- the tiles outside N are computed on repeated data and never stored.  No branches in the
+  // DMA path: it is issued between MFMAs.
+  const int nt_tail = c_tail >= 0 ? (p.N - c_tail * RR_NC) / 32 : 3;
+  // (the lane offset is recomputed per instruction -- ten VALU operations in the shadow of the MFMAs --
+  //  rather than kept in registers: the A block leaves none to spare)
+  const unsigned ldb = (unsigned)p.ldb;
+  // (nt_tail is 1 or 2 when there is a tail chunk, so both folds are masks: no division, no branch)
+  auto lane_off = [&](int j, int gk, int cmask) -> unsigned {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                  // recomputed at every use: hoisting these out of the loops spills
+    const int u = ln + 64 * j, row = u / 24;
+    int cu = u - 24 * row;
+    if (BT) cu ^= (4 * (gk & 1) + (row >> 1)) & 7;
+    else cu &= cmask;
+    return (unsigned)row * ldb + 4u * (unsigned)cu;
+  };
+  // instruction q (0 .. NQ-1) of this wave's share of piece (chunk c, k-piece kc) into buffer `buf`
+  // (I clamped: a repeated instruction is harmless)
+  auto issue_one = [&](int buf, int c, const float* cb, int kc, int q) {
+    const bool tail = c == c_tail;
+    const int I = min(q * NW + wave, 35), gk = I / 3, j = I - 3 * gk;
+    const int gks = BT ? (gk & (tail ? 4 * nt_tail - 1 : 15)) : gk;
+    float* dst = smem + buf * PIECE + I * 256;
+    const float* src = BT ? cb + (int64_t)(gks * 8) * p.ldb + kc * RR_KP
+                          : cb + (int64_t)(kc * RR_KP + gk * 8) * p.ldb;
+    rr_glds16(src + lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31), dst);
+  };
+
+  // A rows of this wave -> registers.  The first piece only needs a[0..11]: they and the first B
+  // piece are requested first, so the MFMAs start when a third of the block has arrived.
+  float4 a[KG];
+  const int arow_i = min(m0 + li, p.M - 1);
+  const float* arow = p.A + (int64_t)arow_i * p.lda + 4 * lh;
+#define RR_LOADA(T0, T1)                                                             \
+  _Pragma("unroll") for (int t = (T0); t < (T1); ++t) {                              \
+    const float4 v = *reinterpret_cast<const float4*>(arow + 8 * t);                 \
+    a[t].x = v.x; a[t].y = v.y; a[t].z = v.z; a[t].w = v.w;                          \
+  }
+  RR_LOADA(0, 12)
+  if (nloc > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) issue_one(0, chunk_of(0), chunk_base(chunk_of(0)), 0, q);
+  }
+  RR_LOADA(12, KG)
+#undef RR_LOADA
+  const bool full = m0 + 32 <= p.M;
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // B fragment addressing (floats, relative to the piece)
+  const int xl = (li >> 1) & 7;
+  int bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = BT ? li * RR_KP + 4 * ((2 * q + lh) ^ xl) : 0;
+  const int bnn = (4 * lh) * RR_NC + li;
+
+  int s = 0;
+  for (int ci = 0; ci < nloc; ++ci) {
+    const int c = chunk_of(ci);
+    const int c_nxt = ci + 1 < nloc ? chunk_of(ci + 1) : c;    // after the last chunk: a redundant fetch into the idle buffer
+    const float* cb = chunk_base(c);
+    const float* cb_nxt = chunk_base(c_nxt);
+#pragma unroll
+    for (int kc = 0; kc < NPK; ++kc, ++s) {
+      const int nb = (s + 1) & 1, nc = kc + 1 < NPK ? c : c_nxt, nk = kc + 1 < NPK ? kc + 1 : 0;
+      const float* ncb = kc + 1 < NPK ? cb : cb_nxt;
+      if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG - 12) : "memory");   // a[12..] may still be in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const bool more = !(ABLATE & 2) || s < 1;
+      if (more && (ABLATE & 32)) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) issue_one(nb, nc, ncb, nk, q);
+      }
+      const float* Bp = smem + (s & 1) * PIECE;
+      // B fragments one 8-row group ahead of the MFMAs that use them (two named sets, pinned by the
+      // scheduling barriers: the compiler would otherwise hoist several groups and spill)
+      float b0[3][4], b1[3][4];
+#define RR_LOADB(BX, G)                                                                    \
+  if (BT) {                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                        \
+      const float4 v = *reinterpret_cast<const float4*>(Bp + bq[(G) & 3] + 32 * ((G) >> 2) + j * (32 * RR_KP)); \
+      BX[j][0] = v.x; BX[j][1] = v.y; BX[j][2] = v.z; BX[j][3] = v.w;                      \
+    }                                                                                      \
+  } else {                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                          \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) BX[j][q] = Bp[bnn + (8 * (G) + q) * RR_NC + 32 * j]; \
+  }
+#define RR_MFMA(BX, G)                                                               \
+  {                                                                                  \
+    const float4 av = a[kc * 12 + (G)];                                              \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, BX[j][0], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, BX[j][1], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, BX[j][2], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, BX[j][3], acc[j], 0, 0, 0); \
+  }
+      // slot t (one per 12 MFMAs) issues DMA instructions PER t .. PER t + PER - 1 of the next piece
+      constexpr int PER = NW == 4 ? 2 : 1;
+#define RR_SLOT(T)                                                                   \
+  if (!(ABLATE & 34) || (more && !(ABLATE & 32))) {                                  \
+    _Pragma("unroll") for (int e = 0; e < PER; ++e)                                  \
+      if (PER * (T) + e < NQ) issue_one(nb, nc, ncb, nk, PER * (T) + e);                       \
+  }
+      RR_LOADB(b0, 0)
+#pragma unroll
+      for (int g = 0; g < 12; g += 2) {
+        RR_LOADB(b1, g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        RR_MFMA(b0, g)
+        __builtin_amdgcn_sched_barrier(0);
+        RR_SLOT(g)
+        __builtin_amdgcn_sched_barrier(0);
+        if (g + 2 < 12) { RR_LOADB(b0, g + 2) }
+        __builtin_amdgcn_sched_barrier(0);
+        RR_MFMA(b1, g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        RR_SLOT(g + 1)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef RR_LOADB
+#undef RR_SLOT
+#undef RR_MFMA
+    }
+    // ---- store the finished 32 x 96 block of this wave -------------------------------------
+    rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
+}
+
+// K = 288 (the model width of the benchmarked Llama), N a multiple of 32 and >= 96, A rows contiguous,
+// B rows contiguous (either orientation), 16-byte aligned rows.
+extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans) {
+  return K == 288 && N % 32 == 0 && N >= RR_NC && M >= 1 && lda % 4 == 0 && ldb % 4 == 0 && lda >= K &&
+         ldb >= (b_trans ? K : N) && ldc >= N && (int64_t)32 * ldc < (1ll << 30);
+}
+
+// B as `nblocks` matrices side by side (block b at B + b * b_block_stride floats; NN: each (K x N / nblocks),
+// NT: each (N / nblocks x K)); nblocks > 1 needs N / nblocks to be a multiple of 96.
+static int rowres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M,
+                         int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, int nblocks,
+                         int64_t b_block_stride, void* stream) {
+  if (M == 0 || N == 0) return PDN_OK;
+  PDN_CHECK_ARG(A && B && C, "pdn_gemm_rowres_f32: null operand");
+  const int nper = nblocks > 0 ? N / nblocks : 0;
+  if (nblocks < 1 || nper * nblocks != N || !pdn_gemm_rowres_supported(M, nper, K, lda, ldb, ldc, b_trans) ||
+      ldc < N || (nblocks > 1 && (nper % RR_NC != 0 || b_block_stride % 4 != 0))) {
+    pdn_set_error("pdn_gemm_rowres_f32: unsupported shape M=%d N=%d K=%d blocks=%d (K 288, N a multiple of 32 >= 96 "
+                  "-- of 96 per block when B comes in blocks --, leading dimensions multiples of 4)", M, N, K, nblocks);
+    return PDN_EUNSUPPORTED;
+  }
+  PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_rowres_f32: 16-byte alignment required");
+  RowResParams p{A, B, C, bias, residual, M, N, lda, ldb, ldc, (N + RR_NC - 1) / RR_NC, 0, 0, b_block_stride};
+  p.cpb = nblocks > 1 ? nper / RR_NC : p.chunks;
+  hipStream_t st = (hipStream_t)stream;
+  static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
+  static const int nw_env = getenv("PDN_ROWRES_NW") ? atoi(getenv("PDN_ROWRES_NW")) : 0;
+  // NN: one 8-wave workgroup per CU (half the DMA instructions per wave) as long as that fills the chip;
+  // NT: two 4-wave workgroups (the 8-wave form measured 63 vs 71 % at N = 1536)
+  const int nw = nw_env ? nw_env : (!b_trans && (M + 255) / 256 >= 192) ? 8 : 4;
+  const int row_blocks = (M + 32 * nw - 1) / (32 * nw), target = nw == 4 ? 512 : 256;
+  // fill every CU (two 4-wave or one 8-wave workgroup each): split the chunks over grid.y
+  int nsplit = 1;
+  while (row_blocks * nsplit < target && nsplit < p.chunks) ++nsplit;
+  p.chunks_per_wg = (p.chunks + nsplit - 1) / nsplit;
+  nsplit = (p.chunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
+  const dim3 grid(row_blocks, nsplit);
+#define RR_LAUNCH(BT_, NW_, AB_) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, AB_>), grid, dim3(NW_ * 64), 0, st, p)
+  if (nw == 8) {
+    if (b_trans) RR_LAUNCH(true, 8, 0); else RR_LAUNCH(false, 8, 0);
+  } else if (b_trans) {
+    RR_LAUNCH(true, 4, 0);
+  } else if (ablate == 2) {
+    RR_LAUNCH(false, 4, 2);
+  } else if (ablate == 32) {
+    RR_LAUNCH(false, 4, 32);
+  } else {
+    RR_LAUNCH(false, 4, 0);
+  }
+#undef RR_LAUNCH
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+extern "C" int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias,
+                                   const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
+                                   int64_t ldc, int b_trans, void* stream) {
+  return rowres_launch(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, b_trans, 1, 0, stream);
+}
+
+// used by pdn_gemm_f32 for a batch that is really one product: the same A against `nblocks` equally spaced
+// weight matrices, the results side by side in one packed buffer (fused QKV, gate | up)
+int pdn_gemm_rowres_blocks(const float* A, const float* B, float* C, int M, int N, int K, int64_t lda, int64_t ldb,
+                           int64_t ldc, int b_trans, int nblocks, int64_t b_block_stride, void* stream) {
+  return rowres_launch(A, B, C, nullptr, nullptr, M, N, K, lda, ldb, ldc, b_trans, nblocks, b_block_stride, stream);
+}

@@ -6,6 +6,7 @@ fp32 math within rtol 2e-5 / atol 2e-6 of NumPy's fp32 result for streams, and w
 differs from OpenBLAS.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -638,3 +639,64 @@ def test_integration_snippet_runs_without_torch():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "torch loaded: False" in r.stdout
+
+
+# ---------------------------------------------------------------------------------------
+# row-resident projection GEMM (csrc/gemm_rowres.hip): A rows in registers, B streamed through LDS
+@pytest.mark.parametrize("M,N,trans,extras", [(8192, 768, 0, 0), (8200, 864, 0, 1), (8192 + 40, 160, 1, 2),
+                                              (8192, 768, 1, 0), (300, 96, 0, 3), (16384, 1120, 0, 0)])
+def test_gemm_row_resident_entry_point(hip, M, N, trans, extras):
+    # extras: 1 = bias, 2 = residual, 3 = both; N = 160 / 1120 leave a partial last 96-column chunk, the
+    # odd M values a partial last 32-row block
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    K = 288
+    rng = np.random.default_rng(M + N + trans)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = 0.1 * rng.standard_normal((N, K) if trans else (K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32) if extras & 1 else None
+    res = rng.standard_normal((M, N), dtype=np.float32) if extras & 2 else None
+    X, W, Y = hip.from_numpy(x), hip.from_numpy(w), hip.empty((M, N), np.float32)
+    Bv = hip.from_numpy(bias) if bias is not None else None
+    Rv = hip.from_numpy(res) if res is not None else None
+    assert L.query("pdn_gemm_rowres_supported", M, N, K, K, w.shape[1], N, trans)
+    L.call("pdn_gemm_rowres_f32", X._ptr, W._ptr, Y._ptr, Bv._ptr if Bv is not None else None,
+           Rv._ptr if Rv is not None else None, M, N, K, K, w.shape[1], N, trans, hip.stream())
+    ref = x.astype(np.float64) @ (w.T if trans else w).astype(np.float64)
+    if bias is not None: ref = ref + bias
+    if res is not None: ref = ref + res
+    assert rel_err(Y.get(), ref) < 1e-5
+    assert not L.query("pdn_gemm_rowres_supported", M, N, 256, 256, w.shape[1], N, trans)     # K = 288 only
+
+
+def test_gemm_row_resident_dispatch_matches_tiled_kernel(hip):
+    # pdn_gemm_f32 routes tall K = 288 products with wide outputs to the row-resident kernel; its k-order per
+    # output element is the tiled kernel's, so the two agree bit for bit -- also for the batch that is
+    # really one product (x against equally spaced weights, results side by side: fused QKV / gate | up)
+    K, M = 288, 8192
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    X = hip.from_numpy(x)
+    for trans, N in ((0, 768), (1, 768)):
+        w = 0.1 * rng.standard_normal((N, K) if trans else (K, N), dtype=np.float32)
+        W = hip.from_numpy(w)
+        Wv = W.T if trans else W
+        y1 = hip.matmul(X, Wv).get()
+        os.environ["PDN_GEMM_NO_ROWRES"] = "1"
+        try:
+            y0 = hip.matmul(X, Wv).get()
+        finally:
+            del os.environ["PDN_GEMM_NO_ROWRES"]
+        assert np.array_equal(y0, y1)
+        assert rel_err(y1, x.astype(np.float64) @ (w.T if trans else w).astype(np.float64)) < 1e-5
+    # three (288 x 288) weights, descending addresses, one packed (M, 864) result
+    ws = 0.1 * rng.standard_normal((3, K, K), dtype=np.float32)
+    flat = hip.from_numpy(ws.reshape(-1).copy())
+    views = [flat[(2 - i) * K * K:(3 - i) * K * K].reshape(K, K) for i in range(3)]
+    stack = hip.stacked_view(views)
+    packed = hip.empty((M, 3 * K), np.float32)
+    blocks = hip.ndarray(packed._buf, packed._ptr, (3, M, K), (K, 3 * K, 1), packed.dtype)
+    hip.gemm(X, stack, blocks)
+    got = packed.get()
+    for i in range(3):
+        assert rel_err(got[:, i * K:(i + 1) * K], x.astype(np.float64) @ ws[2 - i].astype(np.float64)) < 1e-5
