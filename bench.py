@@ -255,7 +255,7 @@ def main():
 
     roof = None
     if not args.no_gemm_prof:
-        ms2, fl2, n2 = (ctypes.c_double * 3)(), (ctypes.c_double * 3)(), (ctypes.c_int64 * 3)()
+        ms2, fl2, n2 = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
         lib.call("pdn_gemm_prof_enable", 0)
         lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
         tf = lambda f, m: f / (m * 1e-3) / 1e12 if m > 0 else 0.0
@@ -266,17 +266,19 @@ def main():
             return {"achieved": tf(fl2[i], ms2[i]), "frac": tf(fl2[i], ms2[i]) / peak, "launches": n2[i],
                     "avg_launch_us": 1e3 * ms2[i] / max(n2[i], 1), "time_share_of_step": ms2[i] * 1e-3 / dt,
                     "algorithmic_flop_per_launch": fl2[i] / max(n2[i], 1), "traffic": traffic.get(name)}
-        # the dominant kernel is the tiled MFMA GEMM (the lm_head input / weight gradient products, the 288-wide
-        # and K > 288 projections); `achieved` = algorithmic 2MNK of ITS launches / HIP-event time around them,
-        # on the launch stream.  The other two GEMM kernels of the step are reported beside it.
-        f0 = family(0, "gemm_f32_mfma_kernel")
-        roof = {"bound": "mfma", "kernel": "gemm_f32_mfma_kernel", "achieved": f0["achieved"], "peak": peak,
+        # four GEMM kernels share the step; the roofline block is that of the one with the largest time share
+        # (`achieved` = algorithmic 2MNK of ITS launches / HIP-event time around them, on the launch stream),
+        # the others are reported beside it
+        names = ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel")
+        fams = {n: family(i, n) for i, n in enumerate(names)}
+        dom = max(names, key=lambda n: fams[n]["time_share_of_step"])
+        f0 = fams[dom]
+        roof = {"bound": "mfma", "kernel": dom, "achieved": f0["achieved"], "peak": peak,
                 "unit": "TFLOP/s", "frac": f0["frac"], "traffic": f0["traffic"],
                 "launches": f0["launches"], "avg_launch_us": f0["avg_launch_us"],
                 "time_share_of_step": f0["time_share_of_step"],
                 "algorithmic_flop_per_launch": f0["algorithmic_flop_per_launch"],
-                "other_gemm_families": {"gemm_tn_stream_dma_kernel": family(1, "gemm_tn_stream_dma_kernel"),
-                                        "gemm_rowres_kernel": family(2, "gemm_rowres_kernel")},
+                "other_gemm_families": {n: fams[n] for n in names if n != dom},
                 "all_gemm": {"achieved": tf(sum(fl2), sum(ms2)), "frac": tf(sum(fl2), sum(ms2)) / peak,
                              "time_share_of_step": sum(ms2) * 1e-3 / dt},
                 "traffic_source": traffic.get("_source")}

@@ -130,13 +130,21 @@ int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_r
                  const double* B, int64_t b_rs, int64_t b_cs, double beta, double* C, int64_t ldc,
                  int nb1, int nb2, int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
                  int64_t c_bs1, int64_t c_bs2, void* stream);
+/* Output-resident product for the GEMMs that end in the model width: C (M x 288) = A (M x K) * B + bias +
+ * residual, K a multiple of 32, A rows contiguous; B (K x 288) row-major or, with `b_trans`, the (288 x K)
+ * row-major matrix whose transpose is meant.  A wave keeps 32 x 288 outputs in accumulators, A is read once
+ * straight into MFMA operand registers, B streams through LDS (csrc/gemm_outres.hip).  pdn_gemm_f32 routes the
+ * shapes it pays for here by itself; the entry point is exported for tests. */
+int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
+int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                        int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
 /* per-launch HIP-event timing of the GEMM kernel for bench.py's roofline block */
 int pdn_gemm_prof_enable(int on);
 int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
 /* the same split by kernel family: [0] gemm_f32_mfma_kernel (tiled, incl. its split-K reduce),
- * [1] gemm_tn_stream_*_kernel (weight gradients), [2] gemm_rowres_kernel (projections, contraction 288);
- * each argument points to THREE values */
-int pdn_gemm_prof_collect_families(double* ms3, double* flops3, int64_t* launches3);
+ * [1] gemm_tn_stream_*_kernel (weight gradients), [2] gemm_rowres_kernel (projections, contraction 288),
+ * [3] gemm_outres_kernel (products ending in the model width); each argument points to FOUR values */
+int pdn_gemm_prof_collect_families(double* ms4, double* flops4, int64_t* launches4);
 
 /* ---- broadcasting elementwise: + - * / ** maximum minimum, comparisons
  * (tensor.py:548,564,591,612,634,811,820; 289-316).  mode 0: a op b, 1: a op scalar,

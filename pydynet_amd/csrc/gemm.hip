@@ -1041,7 +1041,7 @@ static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel
+struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel, 3: output-resident kernel
 static std::vector<ProfRec> g_prof;
 
 extern "C" int pdn_gemm_prof_enable(int on) {
@@ -1051,40 +1051,49 @@ extern "C" int pdn_gemm_prof_enable(int on) {
 }
 
 // per kernel family: [0] gemm_f32_mfma_kernel (+ its split-K reduce), [1] gemm_tn_stream_*_kernel,
-// [2] gemm_rowres_kernel (csrc/gemm_rowres.hip); the three output arrays have three entries each
-extern "C" int pdn_gemm_prof_collect_families(double* ms3, double* flops3, int64_t* launches3) {
+// [2] gemm_rowres_kernel (csrc/gemm_rowres.hip), [3] gemm_outres_kernel (csrc/gemm_outres.hip); the three
+// output arrays have FOUR entries each
+#define PDN_GEMM_FAMILIES 4
+extern "C" int pdn_gemm_prof_collect_families(double* ms4, double* flops4, int64_t* launches4) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  double ms[3] = {0, 0, 0}, fl[3] = {0, 0, 0};
-  int64_t n[3] = {0, 0, 0};
+  double ms[PDN_GEMM_FAMILIES] = {0}, fl[PDN_GEMM_FAMILIES] = {0};
+  int64_t n[PDN_GEMM_FAMILIES] = {0};
   for (auto& r : g_prof) {
     PDN_HIP(hipEventSynchronize(r.e1));
     float t = 0.f;
     PDN_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-    const int f = r.family < 0 || r.family > 2 ? 0 : r.family;
+    const int f = r.family < 0 || r.family >= PDN_GEMM_FAMILIES ? 0 : r.family;
     ms[f] += t; fl[f] += r.flops; n[f]++;
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);
   }
-  for (int f = 0; f < 3; ++f) {
-    if (ms3) ms3[f] = ms[f];
-    if (flops3) flops3[f] = fl[f];
-    if (launches3) launches3[f] = n[f];
+  for (int f = 0; f < PDN_GEMM_FAMILIES; ++f) {
+    if (ms4) ms4[f] = ms[f];
+    if (flops4) flops4[f] = fl[f];
+    if (launches4) launches4[f] = n[f];
   }
   g_prof.clear();
   return PDN_OK;
 }
 
 extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches) {
-  double ms[3], fl[3];
-  int64_t n[3];
+  double ms[PDN_GEMM_FAMILIES], fl[PDN_GEMM_FAMILIES];
+  int64_t n[PDN_GEMM_FAMILIES];
   int rc = pdn_gemm_prof_collect_families(ms, fl, n);
   if (rc) return rc;
-  if (total_ms) *total_ms = ms[0] + ms[1] + ms[2];
-  if (total_flops) *total_flops = fl[0] + fl[1] + fl[2];
-  if (launches) *launches = n[0] + n[1] + n[2];
+  double tm = 0, tf = 0;
+  int64_t tn = 0;
+  for (int f = 0; f < PDN_GEMM_FAMILIES; ++f) { tm += ms[f]; tf += fl[f]; tn += n[f]; }
+  if (total_ms) *total_ms = tm;
+  if (total_flops) *total_flops = tf;
+  if (launches) *launches = tn;
   return PDN_OK;
 }
 
+extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
+extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias,
+                                   const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
+                                   int64_t ldc, int b_trans, void* stream);
 extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 extern "C" int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias,
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -1161,6 +1170,40 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   // ---- tall A, contraction 288, wide-enough output: rows of A resident in registers (gemm_rowres.hip) ----
   // measured against the tiled kernel at 65536 rows: N 864 +19 %, 1536 +14 %, 768 (either B orientation)
   // +11..14 %, 32000 +4 %; N 288 equal (left to the tiled kernel); with a residual the tiled epilogue wins
+  // ---- tall A, output exactly the model width (288), longer contraction: outputs resident in accumulators
+  // (gemm_outres.hip).  Measured against the tiled kernel at 65536 rows: K 768 +6 %, 864 +17 %, 1536 +20 %,
+  // 32000 +15 % (91.7 % of the matrix peak); at 32768 rows (4-wave workgroups, one wave per SIMD) K >= 1536 only.
+  if (nbatch == 1 && N == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum && K >= 768 &&
+      al16(A) && al16(B) && !getenv("PDN_GEMM_NO_OUTRES")) {
+    const int bt = (b_rs == 1 && b_cs != 1) ? 1 : 0;
+    const int64_t ldb = bt ? b_cs : b_rs;
+    const bool big = (M + 255) / 256 >= 224, mid = (M + 127) / 128 >= 224 && K >= 1536;
+    if ((big || mid) && (bt || b_cs == 1) && pdn_gemm_outres_supported(M, N, K, a_rs, ldb, ldc, bt)) {
+      bool prof;
+      ProfRec rec;
+      {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        prof = g_prof_on;
+      }
+      if (prof) {
+        PDN_HIP(hipEventCreate(&rec.e0));
+        PDN_HIP(hipEventCreate(&rec.e1));
+        rec.flops = 2.0 * M * (double)N * (double)K;
+        rec.family = 3;
+        PDN_HIP(hipEventRecord(rec.e0, st));
+      }
+      if (getenv("PDN_GEMM_DEBUG"))
+        fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> output-resident (%s)\n", M, N, K, bt ? "NT" : "NN");
+      const int rc = pdn_gemm_outres_f32(A, B, C, bias, residual, M, N, K, a_rs, ldb, ldc, bt, stream);
+      if (rc) return rc;
+      if (prof) {
+        PDN_HIP(hipEventRecord(rec.e1, st));
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+      }
+      return PDN_OK;
+    }
+  }
   // A batch whose members share A and write side by side into one packed buffer (x against Wq | Wk | Wv,
   // x against Wg | Wu: fused.py) is ONE such product with B in equally spaced column blocks.
   {

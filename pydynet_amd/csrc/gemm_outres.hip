@@ -1,0 +1,261 @@
+// Output-resident fp32 GEMM for products that END in the model width (gfx950 only).
+//
+//   C (M x 288) = A (M x K, rows contiguous) * B (K x 288)  (+ bias[288]) (+ residual[M x 288])
+//
+// Every second product of a transformer block has the model width (288 in the benchmarked Llama) as its
+// OUTPUT and something longer as its contraction: ctx Wo and h W_down forward (llm/llama/model.py:121, 58),
+// the input gradients dqkv Wqkv^T, dgu Wgu^T, dctx Wo^T (`grad @ W^T`, pydynet/core/tensor.py:670) and
+// dlogits W_out (K = 32000).  A tile kernel re-reads A once per column tile (three times at 96 columns) and
+// stages both operands through LDS.  Here
+//   * a wave owns 32 rows of C and keeps ALL 288 columns of them in accumulators (nine 32 x 32 MFMA tiles,
+//     144 registers): A is read exactly once, straight from global memory into MFMA A-operand registers
+//     (lane (i, h) loads A[row i][8t + 4h .. +3]; a four-group ring keeps one k-piece of loads in flight),
+//     and never passes through LDS;
+//   * B is streamed through LDS in 32 (k) x 288 (n) pieces by LDS-DMA (`global_load_lds_dwordx4`), double
+//     buffered, shared by the four waves of a workgroup, its instructions spread over the MFMA stream:
+//     one barrier per 144 MFMAs per wave;
+//   * B row-major [k][n] (`x @ W`): LDS image [32][288], fragments are conflict-free ds_read_b32;
+//     B^T row-major [n][k] (`grad @ W^T`): LDS image [288][32] with the eight 16-byte units of row n
+//     XOR-swizzled by (n >> 1) & 7 on the source side of the DMA: one conflict-free ds_read_b128 per four MFMAs;
+//   * C leaves the accumulators once, every store instruction writing two full 128-byte row segments.
+// The k-order of every output element is that of csrc/gemm.hip (k = 8t + 4h + j inside an MFMA group, groups
+// ascending), so the results are bit-identical to the tiled kernel's when that one does not split K.
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct OutResParams {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* residual;
+  int M, K;
+  int64_t lda, ldb, ldc;
+};
+
+__device__ __forceinline__ void or_glds16(const float* g, float* l) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+#define OR_N 288          // output columns (nine 32-wide MFMA tiles)
+#define OR_KP 32          // contraction rows per piece (four 8-row groups)
+
+// BT: B is given as the row-major (288 x K) matrix whose transpose is meant.  NW: waves per workgroup.
+// ABLATE (timing experiments only): 1 = A loaded once, 2 = no B DMA after the first two pieces.
+// STAGE: the B piece reaches LDS by LDS-DMA (0) or through registers, global_load_dwordx4 + ds_write_b128 (1).
+template <bool BT, int NW, int STAGE, int ABLATE = 0>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(OutResParams p) {
+  constexpr int PIECE = OR_KP * OR_N;             // floats: 36 KiB
+  constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
+  static_assert(NQ <= 9, "the DMA of a piece must be issued within its first three k-groups");
+  __shared__ __attribute__((aligned(16))) float smem[2 * PIECE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int m0 = (blockIdx.x * NW + wave) * 32;
+  const int npieces = p.K / OR_KP;
+  const unsigned ldb = (unsigned)p.ldb;
+
+  // DMA instruction I (0..35) of a piece covers its 16-byte units 64 I .. 64 I + 63 (LDS side linear in the lane).
+  // NN: unit u = row k = u / 72, column unit u % 72.   NT: unit u = row n = u / 8, k unit (u % 8) ^ ((n >> 1) & 7).
+  // (the lane offset is recomputed per instruction, in the shadow of the MFMAs, instead of occupying registers)
+  auto piece_src = [&](int piece, int q, int& I) -> const float* {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    I = min(q * NW + wave, 35);
+    const int u = 64 * I + ln;
+    unsigned o;
+    if (BT) {
+      const int n = u >> 3, cu = (u & 7) ^ ((n >> 1) & 7);
+      o = (unsigned)n * ldb + 4u * (unsigned)cu;
+    } else {
+      const int k = u / 72, n4 = u - 72 * k;
+      o = (unsigned)k * ldb + 4u * (unsigned)n4;
+    }
+    const float* src = BT ? p.B + (int64_t)piece * OR_KP : p.B + (int64_t)piece * OR_KP * p.ldb;
+    return src + o;
+  };
+  float4 rb[STAGE ? NQ : 1];                      // STAGE 1: the wave's share of the next piece on its way to LDS
+  auto issue_one = [&](int buf, int piece, int q) {
+    int I;
+    const float* src = piece_src(piece, q, I);
+    if (STAGE) {
+      const float4 v = *reinterpret_cast<const float4*>(src);
+      rb[q].x = v.x; rb[q].y = v.y; rb[q].z = v.z; rb[q].w = v.w;
+    } else {
+      or_glds16(src, smem + buf * PIECE + I * 256);
+    }
+  };
+  auto park = [&](int buf) {                      // STAGE 1: registers -> LDS (unit 64 I + lane, linear: no conflicts)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int I = min(q * NW + wave, 35);
+      *reinterpret_cast<float4*>(smem + buf * PIECE + I * 256 + 4 * lane) = rb[q];
+    }
+  };
+
+  if (npieces > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) issue_one(0, 0, q);
+    if (STAGE) park(0);
+  }
+  // A operand ring: a[g] holds group g of the current piece, reloaded for the next piece right after use
+  const int arow_i = min(m0 + li, p.M - 1);
+  const float* arow = p.A + (int64_t)arow_i * p.lda + 4 * lh;
+  float4 a[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(arow + 8 * g);
+    a[g].x = v.x; a[g].y = v.y; a[g].z = v.z; a[g].w = v.w;
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // B fragment addressing (floats, relative to the piece)
+  const int xl = (li >> 1) & 7;
+  const int bnn = (4 * lh) * OR_N + li;
+  int bq[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bq[g] = BT ? li * OR_KP + 4 * ((2 * g + lh) ^ xl) : 0;
+
+  for (int s = 0; s < npieces; ++s) {
+    // every DMA of piece s was issued before the last two A loads of the previous piece (vmcnt retires in order)
+    if (STAGE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this wave's ds_writes of the piece
+    else if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    // (a bare s_barrier: __syncthreads() carries a fence that drains vmcnt to 0, i.e. would wait for the A loads
+    //  that were just put in flight; LDS reads of the previous piece were consumed by its MFMAs already)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float* Bp = smem + (s & 1) * PIECE;
+    const int nxt = min(s + 1, npieces - 1);       // after the last piece: a redundant fetch into the idle buffer
+    const float* anext = arow + (int64_t)nxt * OR_KP;
+    // Twelve (k-group, column-triple) steps per piece; the fragments of step n + 1 are read while step n
+    // multiplies (two named sets, pinned by the scheduling barriers: the compiler would hoist more and spill).
+    float b0[3][4], b1[3][4];
+    // fragments of column tiles 3 T .. 3 T + 2 for k-group G of the piece
+#define OR_LOADB(BX, G, T)                                                                       \
+  if (BT) {                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) {                                              \
+      const float4 v = *reinterpret_cast<const float4*>(Bp + bq[G] + (3 * (T) + j) * (32 * OR_KP)); \
+      BX[j][0] = v.x; BX[j][1] = v.y; BX[j][2] = v.z; BX[j][3] = v.w;                            \
+    }                                                                                            \
+  } else {                                                                                       \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) BX[j][q] = Bp[bnn + (8 * (G) + q) * OR_N + 32 * (3 * (T) + j)]; \
+  }
+#define OR_MFMA(BX, AV, T)                                                                       \
+  {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.x, BX[j][0], acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.y, BX[j][1], acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.z, BX[j][2], acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV.w, BX[j][3], acc[3 * (T) + j], 0, 0, 0); \
+  }
+    // one step: read the next step's fragments into BN, multiply this step's from BC
+#define OR_STEP(BC, BN, G, T)                                                                    \
+  if (3 * (G) + (T) + 1 < 12) { OR_LOADB(BN, (3 * (G) + (T) + 1) / 3, (3 * (G) + (T) + 1) % 3) }  \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  OR_MFMA(BC, av, T)                                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+    OR_LOADB(b0, 0, 0)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 av = a[g];
+      // the fetch of the next piece first (three instructions at the head of groups 0..2; spread one per step
+      // it measured 66 instead of 77 % at K = 32000), so that only the A loads of groups 2 and 3 follow its last one
+      if (g < 3 && (!(ABLATE & 2) || s < 1)) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (3 * g + e < NQ) issue_one((s + 1) & 1, nxt, 3 * g + e);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g & 1) {                                  // steps 3g, 3g + 1, 3g + 2: the fragment sets alternate
+        OR_STEP(b1, b0, g, 0) OR_STEP(b0, b1, g, 1) OR_STEP(b1, b0, g, 2)
+      } else {
+        OR_STEP(b0, b1, g, 0) OR_STEP(b1, b0, g, 1) OR_STEP(b0, b1, g, 2)
+      }
+      if (!(ABLATE & 1)) {                          // a[g] is free: fetch group g of the next piece
+        const float4 v = *reinterpret_cast<const float4*>(anext + 8 * g);
+        a[g].x = v.x; a[g].y = v.y; a[g].z = v.z; a[g].w = v.w;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef OR_STEP
+    if (STAGE) park((s + 1) & 1);                   // every wave is past this piece's barrier: that buffer is idle
+#undef OR_LOADB
+#undef OR_MFMA
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
+
+  // ---- C rows: accumulator register r of tile j = row (r & 3) + 8 (r >> 2) + 4 h, column 32 j + lane -----------
+  float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc;
+  const float* __restrict__ Rw = p.residual ? p.residual + (int64_t)m0 * p.ldc : nullptr;
+  const unsigned ldc = (unsigned)p.ldc;
+  const int mrem = p.M - m0 - 4 * lh;               // rows rr < mrem exist
+  const bool full = m0 + 32 <= p.M;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const float bv = p.bias ? p.bias[32 * j + li] : 0.f;
+    unsigned o = (unsigned)(4 * lh) * ldc + li + 32 * j;
+    float rv[16];
+    if (Rw) {
+      unsigned orr = o;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        rv[r] = (full || (r & 3) + 8 * (r >> 2) < mrem) ? Rw[orr] : 0.f;
+        orr += ((r & 3) == 3) ? 5 * ldc : ldc;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[j][r] + bv;
+      if (Rw) v += rv[r];
+      if (full || (r & 3) + 8 * (r >> 2) < mrem) Cw[o] = v;
+      o += ((r & 3) == 3) ? 5 * ldc : ldc;
+    }
+  }
+}
+
+extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans) {
+  return N == OR_N && K >= OR_KP && K % OR_KP == 0 && M >= 1 && lda % 4 == 0 && ldb % 4 == 0 && lda >= K &&
+         ldb >= (b_trans ? K : N) && ldc >= N && (int64_t)OR_N * ldb < (1ll << 30) && (int64_t)32 * ldc < (1ll << 30);
+}
+
+extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias,
+                                   const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
+                                   int64_t ldc, int b_trans, void* stream) {
+  if (M == 0 || N == 0) return PDN_OK;
+  PDN_CHECK_ARG(A && B && C, "pdn_gemm_outres_f32: null operand");
+  if (!pdn_gemm_outres_supported(M, N, K, lda, ldb, ldc, b_trans)) {
+    pdn_set_error("pdn_gemm_outres_f32: unsupported shape M=%d N=%d K=%d (N 288, K a multiple of 32, leading "
+                  "dimensions multiples of 4)", M, N, K);
+    return PDN_EUNSUPPORTED;
+  }
+  PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_outres_f32: 16-byte alignment required");
+  OutResParams p{A, B, C, bias, residual, M, K, lda, ldb, ldc};
+  hipStream_t st = (hipStream_t)stream;
+  static const int nw_env = getenv("PDN_OUTRES_NW") ? atoi(getenv("PDN_OUTRES_NW")) : 0;
+  static const int stage_env = getenv("PDN_OUTRES_STAGE") ? atoi(getenv("PDN_OUTRES_STAGE")) : -1;
+  static const int ablate = getenv("PDN_OUTRES_ABLATE") ? atoi(getenv("PDN_OUTRES_ABLATE")) : 0;
+  // one 8-wave workgroup per CU when that fills the chip, else 4-wave workgroups
+  const int nw = nw_env ? nw_env : ((M + 255) / 256 >= 224 ? 8 : 4);
+  const int stage = stage_env >= 0 ? stage_env : 1;
+  const dim3 grid((M + 32 * nw - 1) / (32 * nw));
+#define OR_LAUNCH(BT_, NW_, ST_, AB_) hipLaunchKernelGGL((gemm_outres_kernel<BT_, NW_, ST_, AB_>), grid, dim3(NW_ * 64), 0, st, p)
+  if (ablate == 1 && b_trans) OR_LAUNCH(true, 4, 1, 1);
+  else if (ablate == 2 && b_trans) OR_LAUNCH(true, 4, 1, 2);
+  else if (nw == 8 && b_trans) { if (stage) OR_LAUNCH(true, 8, 1, 0); else OR_LAUNCH(true, 8, 0, 0); }
+  else if (nw == 8) { if (stage) OR_LAUNCH(false, 8, 1, 0); else OR_LAUNCH(false, 8, 0, 0); }
+  else if (b_trans) { if (stage) OR_LAUNCH(true, 4, 1, 0); else OR_LAUNCH(true, 4, 0, 0); }
+  else { if (stage) OR_LAUNCH(false, 4, 1, 0); else OR_LAUNCH(false, 4, 0, 0); }
+#undef OR_LAUNCH
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

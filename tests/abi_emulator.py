@@ -206,6 +206,25 @@ class EmulatedLib:
         view(C, (M, N), (ldc, 1), np.float32)[...] = r
         return 0
 
+    def pdn_gemm_outres_supported(self, M, N, K, lda, ldb, ldc, b_trans):
+        return int(N == 288 and K >= 32 and K % 32 == 0 and M >= 1 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K
+                   and ldb >= (K if b_trans else N) and ldc >= N and 288 * ldb < (1 << 30) and 32 * ldc < (1 << 30))
+
+    def pdn_gemm_outres_f32(self, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, b_trans, stream):
+        if M == 0 or N == 0:
+            return 0
+        if not self.pdn_gemm_outres_supported(M, N, K, lda, ldb, ldc, b_trans):
+            return -2
+        a = view(A, (M, K), (lda, 1), np.float32)
+        b = view(B, (K, N), (1, ldb) if b_trans else (ldb, 1), np.float32)
+        r = np.matmul(a, b)
+        if bias:
+            r = r + flat(bias, N)
+        if residual:
+            r = r + view(residual, (M, N), (ldc, 1), np.float32)
+        view(C, (M, N), (ldc, 1), np.float32)[...] = r
+        return 0
+
     def pdn_gemm_f64(self, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, nb1, nb2,
                      a1, a2, b1, b2, c1, c2, stream):
         if M == 0 or N == 0 or nb1 == 0 or nb2 == 0:

@@ -700,3 +700,58 @@ def test_gemm_row_resident_dispatch_matches_tiled_kernel(hip):
     got = packed.get()
     for i in range(3):
         assert rel_err(got[:, i * K:(i + 1) * K], x.astype(np.float64) @ ws[2 - i].astype(np.float64)) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------
+# output-resident GEMM (csrc/gemm_outres.hip): 32 x 288 outputs per wave in accumulators, A straight into
+# MFMA operand registers, B through LDS
+@pytest.mark.parametrize("M,K,trans,extras", [(512, 768, 0, 0), (300, 864, 1, 2), (8192 + 40, 1536, 1, 3),
+                                              (256, 32, 0, 1), (1024, 3200, 1, 0)])
+def test_gemm_output_resident_entry_point(hip, M, K, trans, extras):
+    # extras: 1 = bias, 2 = residual, 3 = both; odd M values leave partial 32-row blocks and partial workgroups
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    N = 288
+    rng = np.random.default_rng(M + K + trans)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = 0.1 * rng.standard_normal((N, K) if trans else (K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32) if extras & 1 else None
+    res = rng.standard_normal((M, N), dtype=np.float32) if extras & 2 else None
+    X, W, Y = hip.from_numpy(x), hip.from_numpy(w), hip.empty((M, N), np.float32)
+    Bv = hip.from_numpy(bias) if bias is not None else None
+    Rv = hip.from_numpy(res) if res is not None else None
+    assert L.query("pdn_gemm_outres_supported", M, N, K, K, w.shape[1], N, trans)
+    L.call("pdn_gemm_outres_f32", X._ptr, W._ptr, Y._ptr, Bv._ptr if Bv is not None else None,
+           Rv._ptr if Rv is not None else None, M, N, K, K, w.shape[1], N, trans, hip.stream())
+    ref = x.astype(np.float64) @ (w.T if trans else w).astype(np.float64)
+    if bias is not None: ref = ref + bias
+    if res is not None: ref = ref + res
+    assert rel_err(Y.get(), ref) < 1e-5
+    assert not L.query("pdn_gemm_outres_supported", M, 256, K, K, w.shape[1], 256, trans)     # N = 288 only
+    assert not L.query("pdn_gemm_outres_supported", M, N, K + 8, K + 8, w.shape[1] + 8, N, trans)
+
+
+def test_gemm_output_resident_dispatch_matches_tiled_kernel(hip):
+    # pdn_gemm_f32 sends tall products that end in 288 columns with K >= 768 to the output-resident kernel (also with
+    # the residual of a transformer block folded in); same k-order per element as the tiled kernel: bit-identical
+    M, N = 57344, 288
+    rng = np.random.default_rng(9)
+    for trans, K, with_res in ((0, 768, True), (1, 864, False)):
+        x = rng.standard_normal((M, K), dtype=np.float32)
+        w = 0.1 * rng.standard_normal((N, K) if trans else (K, N), dtype=np.float32)
+        r = rng.standard_normal((M, N), dtype=np.float32) if with_res else None
+        X, W = hip.from_numpy(x), hip.from_numpy(w)
+        R = hip.from_numpy(r) if with_res else None
+        Wv = W.T if trans else W
+        y1 = hip.empty((M, N), np.float32)
+        hip.gemm(X, Wv, y1, residual=R)
+        os.environ["PDN_GEMM_NO_OUTRES"] = "1"
+        try:
+            y0 = hip.empty((M, N), np.float32)
+            hip.gemm(X, Wv, y0, residual=R)
+        finally:
+            del os.environ["PDN_GEMM_NO_OUTRES"]
+        a, b = y0.get(), y1.get()
+        assert np.array_equal(a, b)
+        ref = x[:512].astype(np.float64) @ (w.T if trans else w).astype(np.float64) + (r[:512] if with_res else 0.0)
+        assert rel_err(b[:512], ref) < 1e-5
