@@ -1090,6 +1090,9 @@ extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int6
   return PDN_OK;
 }
 
+extern "C" int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out);
+int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                              int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream);
 extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias,
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -1246,6 +1249,50 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     }
   }
   const int64_t ws_cap = (workspace && workspace_bytes > 0) ? workspace_bytes / 4 : 0;
+  // ---- weight gradient of a wide layer out of the model width: C (288 x N) = x^T (288 x K) g (K x N), K = tokens --
+  // (the lm_head: N = 32000).  Output-resident over the 288 rows, g read once straight into MFMA operands
+  // (gemm_outres_tn_kernel); K split so that the grid fills the chip once, slabs combined (with beta) below.
+  if (nbatch == 1 && M == 288 && a_rs == 1 && a_cs >= 288 && b_cs == 1 && alpha == 1.f && !b_colsum && !bias && !residual &&
+      N >= 8192 && N % 32 == 0 && K % 32 == 0 && K >= 4096 && m4(a_cs) && m4(b_rs) && al16(A) && al16(B) &&
+      (int64_t)288 * ldc < (1ll << 30) && (int64_t)32 * b_rs < (1ll << 30) && !getenv("PDN_GEMM_NO_OUTRES")) {
+    int nw = 8, kps = K;
+    const int splits = pdn_gemm_outres_tn_plan(N, K, &nw, &kps);
+    const bool direct = splits == 1 && beta == 0.f;
+    if (direct || (int64_t)splits * M * N <= ws_cap) {
+      bool prof;
+      ProfRec rec;
+      {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        prof = g_prof_on;
+      }
+      if (prof) {
+        PDN_HIP(hipEventCreate(&rec.e0));
+        PDN_HIP(hipEventCreate(&rec.e1));
+        rec.flops = 2.0 * M * (double)N * (double)K;
+        rec.family = 3;
+        PDN_HIP(hipEventRecord(rec.e0, st));
+      }
+      if (getenv("PDN_GEMM_DEBUG"))
+        fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> output-resident TN (splits %d)\n", M, N, K, splits);
+      int rc = direct ? pdn_gemm_outres_tn_launch(A, B, C, N, K, a_cs, b_rs, ldc, 0, nw, kps, stream)
+                      : pdn_gemm_outres_tn_launch(A, B, (float*)workspace, N, K, a_cs, b_rs, N, (int64_t)M * N, nw, kps, stream);
+      if (rc) return rc;
+      if (!direct) {
+        p.splits = splits;
+        const int64_t total = (int64_t)M * N;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        const int rvec = (ldc % 4 == 0) && al16(C) && al16(workspace);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, 1, rvec);
+        PDN_LAUNCH_CHECK();
+      }
+      if (prof) {
+        PDN_HIP(hipEventRecord(rec.e1, st));
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof.push_back(rec);
+      }
+      return PDN_OK;
+    }
+  }
   // ---- weight-gradient form (small output, long K): wave-streaming kernel --------------------
   constexpr int SNW = 8;                                  // waves per streaming workgroup
   bool use_stream = false;

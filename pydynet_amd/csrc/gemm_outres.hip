@@ -259,3 +259,166 @@ extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, con
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
+
+// ======================================================================================
+// Weight-gradient form with the model width as the OUTPUT ROWS:  C (288 x N) = X^T (288 x K) * G (K x N),
+// X (K x 288) and G (K x N) row-major, K = tokens.  (`A^T @ grad`, tensor.py:672-675: the lm_head weight
+// gradient x^T dlogits with N = 32000.)  The mirror image of the kernel above: a wave owns 32 COLUMNS of C and
+// all 288 rows of them (nine accumulator tiles); G -- the big operand -- is read exactly once, straight from
+// global memory into MFMA B-operand registers (lane (j, h) loads G[8t + 4h + q][n0 + j]: two full 128-byte row
+// segments per instruction; a four-group ring keeps one k-piece in flight); X is streamed through LDS in
+// 32 x 288 pieces, register-staged, shared by the workgroup, and read back as A-operand fragments with
+// conflict-free ds_read_b32.  K is split over grid.y when the columns alone do not fill the chip; the slabs are
+// combined by gemm_splitk_reduce_kernel (csrc/gemm.hip), which also applies beta.
+// ======================================================================================
+struct OutResTnParams {
+  const float* X;
+  const float* G;
+  float* C;                       // slab s at C + s * slab
+  int N, K;
+  int64_t ldx, ldg, ldc, slab;
+  int k_per_split;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kernel(OutResTnParams p) {
+  constexpr int PIECE = OR_KP * OR_N;
+  constexpr int NQ = (36 + NW - 1) / NW;
+  __shared__ __attribute__((aligned(16))) float smem[2 * PIECE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0_raw = (blockIdx.x * NW + wave) * 32;
+  const bool active = n0_raw < p.N;
+  const int n0 = active ? n0_raw : p.N - 32;          // idle waves still stage X and meet the barriers
+  const int k_begin = blockIdx.y * p.k_per_split;
+  const int k_end = min(p.K, k_begin + p.k_per_split);
+  const int npieces = (k_end - k_begin) / OR_KP;
+  const unsigned ldx = (unsigned)p.ldx, ldg = (unsigned)p.ldg;
+  const float* Xk = p.X + (int64_t)k_begin * p.ldx;
+
+  float4 rb[NQ];
+  auto fetch = [&](int piece, int q) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int I = min(q * NW + wave, 35);
+    const int u = 64 * I + ln, k = u / 72, n4 = u - 72 * k;
+    const float4 v = *reinterpret_cast<const float4*>(Xk + (int64_t)piece * OR_KP * p.ldx + (unsigned)k * ldx + 4u * (unsigned)n4);
+    rb[q].x = v.x; rb[q].y = v.y; rb[q].z = v.z; rb[q].w = v.w;
+  };
+  auto park = [&](int buf) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int I = min(q * NW + wave, 35);
+      *reinterpret_cast<float4*>(smem + buf * PIECE + I * 256 + 4 * lane) = rb[q];
+    }
+  };
+  if (npieces > 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) fetch(0, q);
+    park(0);
+  }
+  // G operand ring: gb[g] = G[k0 + 8g + 4h + 0..3][n0 + lane] for the current piece
+  const float* gcol = p.G + (int64_t)(k_begin + 4 * lh) * p.ldg + n0 + li;
+  float4 gb[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    gb[g].x = gcol[(8 * g + 0) * ldg]; gb[g].y = gcol[(8 * g + 1) * ldg];
+    gb[g].z = gcol[(8 * g + 2) * ldg]; gb[g].w = gcol[(8 * g + 3) * ldg];
+  }
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int bnn = (4 * lh) * OR_N + li;
+
+  for (int s = 0; s < npieces; ++s) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const float* Bp = smem + (s & 1) * PIECE;
+    const int nxt = min(s + 1, npieces - 1);
+    const float* gnext = gcol + (int64_t)nxt * OR_KP * p.ldg;
+    float x0[3][4], x1[3][4];
+#define TN_LOADX(BX, G, T)                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                  \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) BX[j][q] = Bp[bnn + (8 * (G) + q) * OR_N + 32 * (3 * (T) + j)];
+#define TN_MFMA(BX, GV, T)                                                                       \
+  {                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][0], GV.x, acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][1], GV.y, acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][2], GV.z, acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][3], GV.w, acc[3 * (T) + j], 0, 0, 0); \
+  }
+#define TN_STEP(BC, BN, G, T)                                                                    \
+  if (3 * (G) + (T) + 1 < 12) { TN_LOADX(BN, (3 * (G) + (T) + 1) / 3, (3 * (G) + (T) + 1) % 3) }  \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  TN_MFMA(BC, gv, T)                                                                             \
+  __builtin_amdgcn_sched_barrier(0);
+    TN_LOADX(x0, 0, 0)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 gv = gb[g];
+      if (g < 3) {
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+          if (3 * g + e < NQ) fetch(nxt, 3 * g + e);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g & 1) {
+        TN_STEP(x1, x0, g, 0) TN_STEP(x0, x1, g, 1) TN_STEP(x1, x0, g, 2)
+      } else {
+        TN_STEP(x0, x1, g, 0) TN_STEP(x1, x0, g, 1) TN_STEP(x0, x1, g, 2)
+      }
+      gb[g].x = gnext[(8 * g + 0) * ldg]; gb[g].y = gnext[(8 * g + 1) * ldg];
+      gb[g].z = gnext[(8 * g + 2) * ldg]; gb[g].w = gnext[(8 * g + 3) * ldg];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef TN_STEP
+#undef TN_LOADX
+#undef TN_MFMA
+    park((s + 1) & 1);
+  }
+  if (!active) return;
+  // accumulator register r of tile i = row 32 i + (r & 3) + 8 (r >> 2) + 4 h, column n0 + lane
+  float* __restrict__ Cw = p.C + (int64_t)blockIdx.y * p.slab + n0 + li;
+  const unsigned ldc = (unsigned)p.ldc;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    unsigned o = (unsigned)(32 * i + 4 * lh) * ldc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      Cw[o] = acc[i][r];
+      o += ((r & 3) == 3) ? 5 * ldc : ldc;
+    }
+  }
+}
+
+// splits of K so that (column workgroups x splits) fills the chip once; k per split a multiple of 32
+extern "C" int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out) {
+  static const int nw_env = getenv("PDN_OUTRES_NW") ? atoi(getenv("PDN_OUTRES_NW")) : 0;
+  const int nw = nw_env ? nw_env : 8;
+  const int col_wgs = (N / 32 + nw - 1) / nw;
+  int splits = (nw == 8 ? 256 : 512) / (col_wgs > 0 ? col_wgs : 1);
+  if (splits < 1) splits = 1;
+  const int pieces = K / OR_KP;
+  if (splits > pieces) splits = pieces > 0 ? pieces : 1;
+  const int kps = ((pieces + splits - 1) / splits) * OR_KP;
+  if (nw_out) *nw_out = nw;
+  if (k_per_split_out) *k_per_split_out = kps;
+  return (K + kps - 1) / kps;
+}
+
+// C slabs: slab s (rows of `ldc` floats) at C + s * slab receives the partial product of split s
+int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                              int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream) {
+  OutResTnParams p{X, G, C, N, K, ldx, ldg, ldc, slab, k_per_split};
+  const int splits = (K + k_per_split - 1) / k_per_split;
+  const dim3 grid((N / 32 + nw - 1) / nw, splits);
+  if (nw == 8) hipLaunchKernelGGL((gemm_outres_tn_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_outres_tn_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}

@@ -755,3 +755,17 @@ def test_gemm_output_resident_dispatch_matches_tiled_kernel(hip):
         assert np.array_equal(a, b)
         ref = x[:512].astype(np.float64) @ (w.T if trans else w).astype(np.float64) + (r[:512] if with_res else 0.0)
         assert rel_err(b[:512], ref) < 1e-5
+
+
+@pytest.mark.parametrize("N,K,beta", [(8192, 4096, 0.0), (8192 + 32, 8192 + 64, 1.0), (16384, 4096, 1.0)])
+def test_gemm_weight_gradient_output_resident(hip, N, K, beta):
+    # x^T @ g with 288 output rows and a wide g (the lm_head weight gradient): output-resident TN kernel, K split
+    # over the grid, slabs combined with beta * C by the split-K reduce
+    rng = np.random.default_rng(N + K)
+    x = rng.standard_normal((K, 288), dtype=np.float32)
+    g = rng.standard_normal((K, N), dtype=np.float32)
+    c0 = rng.standard_normal((288, N), dtype=np.float32)
+    X, G, C = hip.from_numpy(x), hip.from_numpy(g), hip.from_numpy(c0.copy())
+    hip.gemm(X.T, G, C, beta=beta)
+    ref = x.T.astype(np.float64) @ g.astype(np.float64) + beta * c0
+    assert rel_err(C.get(), ref) < 2e-5
