@@ -265,10 +265,11 @@ extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, con
 // X (K x 288) and G (K x N) row-major, K = tokens.  (`A^T @ grad`, tensor.py:672-675: the lm_head weight
 // gradient x^T dlogits with N = 32000.)  The mirror image of the kernel above: a wave owns 32 COLUMNS of C and
 // all 288 rows of them (nine accumulator tiles); G -- the big operand -- is read exactly once, straight from
-// global memory into MFMA B-operand registers (lane (j, h) loads G[8t + 4h + q][n0 + j]: two full 128-byte row
-// segments per instruction; a four-group ring keeps one k-piece in flight); X is streamed through LDS in
-// 32 x 288 pieces, register-staged, shared by the workgroup, and read back as A-operand fragments with
-// conflict-free ds_read_b32.  K is split over grid.y when the columns alone do not fill the chip; the slabs are
+// global memory (four 16-byte loads per lane and k-piece, eight lanes per 128-byte row segment) through a
+// 4 KiB LDS piece PRIVATE to the wave, from which the MFMA B operands are read with conflict-free ds_read_b32
+// (loading the operands directly -- sixteen dword loads per piece -- measured 80 instead of 9x % of the matrix
+// peak: a memory instruction costs the wave's MFMA stream the same whatever its width); X is streamed through LDS
+// in 32 x 288 pieces, register-staged, shared by the workgroup, and read back as A-operand fragments.  K is split over grid.y when the columns alone do not fill the chip; the slabs are
 // combined by gemm_splitk_reduce_kernel (csrc/gemm.hip), which also applies beta.
 // ======================================================================================
 struct OutResTnParams {
@@ -281,10 +282,11 @@ struct OutResTnParams {
 };
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kernel(OutResTnParams p) {
+__global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnParams p) {
   constexpr int PIECE = OR_KP * OR_N;
   constexpr int NQ = (36 + NW - 1) / NW;
-  __shared__ __attribute__((aligned(16))) float smem[2 * PIECE];
+  constexpr int GP = OR_KP * 32;                   // a wave's private 32 (k) x 32 (n) piece of G: 4 KiB
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 2 X pieces, then NW x 2 G pieces
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -296,8 +298,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kerne
   const int npieces = (k_end - k_begin) / OR_KP;
   const unsigned ldx = (unsigned)p.ldx, ldg = (unsigned)p.ldg;
   const float* Xk = p.X + (int64_t)k_begin * p.ldx;
+  float* Gs = smem + 2 * PIECE + wave * (2 * GP);
 
-  float4 rb[NQ];
+  float4 rb[NQ], rg[4];
   auto fetch = [&](int piece, int q) {
     int ln = lane;
     asm volatile("" : "+v"(ln));
@@ -306,25 +309,30 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kerne
     const float4 v = *reinterpret_cast<const float4*>(Xk + (int64_t)piece * OR_KP * p.ldx + (unsigned)k * ldx + 4u * (unsigned)n4);
     rb[q].x = v.x; rb[q].y = v.y; rb[q].z = v.z; rb[q].w = v.w;
   };
+  // G piece: instruction e covers rows 8e .. 8e + 7, eight lanes (128 bytes) per row; LDS image [32 k][32 n] linear
+  const float* gsrc = p.G + (int64_t)(k_begin + (lane >> 3)) * p.ldg + n0 + 4 * (lane & 7);
+  auto fetch_g = [&](int piece) {
+    const float* g = gsrc + (int64_t)piece * OR_KP * p.ldg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float4 v = *reinterpret_cast<const float4*>(g + (unsigned)(8 * e) * ldg);
+      rg[e].x = v.x; rg[e].y = v.y; rg[e].z = v.z; rg[e].w = v.w;
+    }
+  };
   auto park = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int I = min(q * NW + wave, 35);
       *reinterpret_cast<float4*>(smem + buf * PIECE + I * 256 + 4 * lane) = rb[q];
     }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(Gs + buf * GP + e * 256 + 4 * lane) = rg[e];
   };
   if (npieces > 0) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) fetch(0, q);
+    fetch_g(0);
     park(0);
-  }
-  // G operand ring: gb[g] = G[k0 + 8g + 4h + 0..3][n0 + lane] for the current piece
-  const float* gcol = p.G + (int64_t)(k_begin + 4 * lh) * p.ldg + n0 + li;
-  float4 gb[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    gb[g].x = gcol[(8 * g + 0) * ldg]; gb[g].y = gcol[(8 * g + 1) * ldg];
-    gb[g].z = gcol[(8 * g + 2) * ldg]; gb[g].w = gcol[(8 * g + 3) * ldg];
   }
 
   f32x16 acc[9];
@@ -333,24 +341,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kerne
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   const int bnn = (4 * lh) * OR_N + li;
+  const int gnn = (4 * lh) * 32 + li;
 
   for (int s = 0; s < npieces; ++s) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     const float* Bp = smem + (s & 1) * PIECE;
+    const float* Gp = Gs + (s & 1) * GP + gnn;
     const int nxt = min(s + 1, npieces - 1);
-    const float* gnext = gcol + (int64_t)nxt * OR_KP * p.ldg;
     float x0[3][4], x1[3][4];
 #define TN_LOADX(BX, G, T)                                                                       \
   _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                  \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) BX[j][q] = Bp[bnn + (8 * (G) + q) * OR_N + 32 * (3 * (T) + j)];
 #define TN_MFMA(BX, GV, T)                                                                       \
   {                                                                                              \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][0], GV.x, acc[3 * (T) + j], 0, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][1], GV.y, acc[3 * (T) + j], 0, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][2], GV.z, acc[3 * (T) + j], 0, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][3], GV.w, acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][0], GV[0], acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][1], GV[1], acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][2], GV[2], acc[3 * (T) + j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[3 * (T) + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][3], GV[3], acc[3 * (T) + j], 0, 0, 0); \
   }
 #define TN_STEP(BC, BN, G, T)                                                                    \
   if (3 * (G) + (T) + 1 < 12) { TN_LOADX(BN, (3 * (G) + (T) + 1) / 3, (3 * (G) + (T) + 1) % 3) }  \
@@ -358,9 +367,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kerne
   TN_MFMA(BC, gv, T)                                                                             \
   __builtin_amdgcn_sched_barrier(0);
     TN_LOADX(x0, 0, 0)
+    float gn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) gn[q] = Gp[q * 32];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 gv = gb[g];
+      float gv[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gv[q] = gn[q];
+      if (g + 1 < 4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gn[q] = Gp[(8 * (g + 1) + q) * 32];
+      }
+      if (g == 0) fetch_g(nxt);
       if (g < 3) {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
@@ -372,9 +391,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_tn_kerne
       } else {
         TN_STEP(x0, x1, g, 0) TN_STEP(x1, x0, g, 1) TN_STEP(x0, x1, g, 2)
       }
-      gb[g].x = gnext[(8 * g + 0) * ldg]; gb[g].y = gnext[(8 * g + 1) * ldg];
-      gb[g].z = gnext[(8 * g + 2) * ldg]; gb[g].w = gnext[(8 * g + 3) * ldg];
-      __builtin_amdgcn_sched_barrier(0);
     }
 #undef TN_STEP
 #undef TN_LOADX
@@ -417,8 +433,15 @@ int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, i
   OutResTnParams p{X, G, C, N, K, ldx, ldg, ldc, slab, k_per_split};
   const int splits = (K + k_per_split - 1) / k_per_split;
   const dim3 grid((N / 32 + nw - 1) / nw, splits);
-  if (nw == 8) hipLaunchKernelGGL((gemm_outres_tn_kernel<8>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((gemm_outres_tn_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  const size_t shm = (size_t)(2 * OR_KP * OR_N + nw * 2 * OR_KP * 32) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (nw == 8) hipLaunchKernelGGL((gemm_outres_tn_kernel<8>), grid, dim3(512), shm, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_outres_tn_kernel<4>), grid, dim3(256), shm, (hipStream_t)stream, p);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -99,7 +99,9 @@ __device__ __forceinline__ void rr_store(const RowResParams& p, f32x16 (&acc)[3]
 // ABLATE (timing experiments only, 0 in the library): 2 = no B DMA after the first two pieces,
 // 32 = the DMA of a piece issued as one burst.
 // NW: waves per workgroup (4: two workgroups per CU; 8: one -- half the DMA instructions per wave).
-template <int KG, bool BT, int NW, int ABLATE = 0>
+// STAGE: the B piece reaches LDS by LDS-DMA (0) or through registers, global_load_dwordx4 + ds_write_b128 (1):
+// an LDS-DMA instruction holds up the issuing wave's MFMA stream for 50-170 cycles, a plain load far less.
+template <int KG, bool BT, int NW, int STAGE, int ABLATE = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(RowResParams p) {
   constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
   constexpr int NPK = KG / 12;                    // pieces along K
@@ -148,6 +150,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   };
   // instruction q (0 .. NQ-1) of this wave's share of piece (chunk c, k-piece kc) into buffer `buf`
   // (I clamped: a repeated instruction is harmless)
+  // STAGE 1: the wave's share of the next piece on its way to LDS, in two halves (fetched in the first / second
+  // half of the current piece and parked in its middle / at its end): half the staging registers
+  constexpr int RBN = STAGE ? (NQ + 1) / 2 : 1;
+  float4 rb[RBN];
   auto issue_one = [&](int buf, int c, const float* cb, int kc, int q) {
     const bool tail = c == c_tail;
     const int I = min(q * NW + wave, 35), gk = I / 3, j = I - 3 * gk;
@@ -155,7 +161,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
     float* dst = smem + buf * PIECE + I * 256;
     const float* src = BT ? cb + (int64_t)(gks * 8) * p.ldb + kc * RR_KP
                           : cb + (int64_t)(kc * RR_KP + gk * 8) * p.ldb;
-    rr_glds16(src + lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31), dst);
+    if (STAGE) {
+      const float4 v = *reinterpret_cast<const float4*>(src + lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31));
+      rb[q % RBN].x = v.x; rb[q % RBN].y = v.y; rb[q % RBN].z = v.z; rb[q % RBN].w = v.w;
+    } else {
+      rr_glds16(src + lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31), dst);
+    }
+  };
+  auto park = [&](int buf, int half) {            // STAGE 1: registers -> LDS (unit 64 I + lane, linear: no conflicts)
+#pragma unroll
+    for (int e = 0; e < RBN; ++e) {
+      const int q = half * RBN + e;
+      if (q < NQ) {
+        const int I = min(q * NW + wave, 35);
+        *reinterpret_cast<float4*>(smem + buf * PIECE + I * 256 + 4 * lane) = rb[e];
+      }
+    }
   };
 
   // A rows of this wave -> registers.  The first piece only needs a[0..11]: they and the first B
@@ -170,8 +191,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   }
   RR_LOADA(0, 12)
   if (nloc > 0) {
+    if (STAGE) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) issue_one(0, chunk_of(0), chunk_base(chunk_of(0)), 0, q);
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int e = 0; e < RBN; ++e)
+          if (h * RBN + e < NQ) issue_one(0, chunk_of(0), chunk_base(chunk_of(0)), 0, h * RBN + e);
+        park(0, h);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) issue_one(0, chunk_of(0), chunk_base(chunk_of(0)), 0, q);
+    }
   }
   RR_LOADA(12, KG)
 #undef RR_LOADA
@@ -200,9 +231,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
     for (int kc = 0; kc < NPK; ++kc, ++s) {
       const int nb = (s + 1) & 1, nc = kc + 1 < NPK ? c : c_nxt, nk = kc + 1 < NPK ? kc + 1 : 0;
       const float* ncb = kc + 1 < NPK ? cb : cb_nxt;
-      if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG - 12) : "memory");   // a[12..] may still be in flight
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (STAGE) {
+        // a bare barrier: __syncthreads() carries a fence that drains vmcnt, i.e. would wait for loads in flight
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      } else {
+        if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG - 12) : "memory");   // a[12..] may still be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      }
       const bool more = !(ABLATE & 2) || s < 1;
       if (more && (ABLATE & 32)) {
 #pragma unroll
@@ -233,9 +271,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       // slot t (one per 12 MFMAs) issues DMA instructions PER t .. PER t + PER - 1 of the next piece
       constexpr int PER = NW == 4 ? 2 : 1;
 #define RR_SLOT(T)                                                                   \
-  if (!(ABLATE & 34) || (more && !(ABLATE & 32))) {                                  \
+  if (STAGE) {                                                                       \
+    if ((T) < 6) { if ((T) < RBN) issue_one(nb, nc, ncb, nk, (T)); }                  \
+    else if ((T) - 6 < NQ - RBN) issue_one(nb, nc, ncb, nk, RBN + (T) - 6);           \
+    if ((T) == 5) park(nb, 0);                                                       \
+  } else if (!(ABLATE & 34) || (more && !(ABLATE & 32))) {                           \
     _Pragma("unroll") for (int e = 0; e < PER; ++e)                                  \
-      if (PER * (T) + e < NQ) issue_one(nb, nc, ncb, nk, PER * (T) + e);                       \
+      if (PER * (T) + e < NQ) issue_one(nb, nc, ncb, nk, PER * (T) + e);             \
   }
       RR_LOADB(b0, 0)
 #pragma unroll
@@ -256,6 +298,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
 #undef RR_LOADB
 #undef RR_SLOT
 #undef RR_MFMA
+      if (STAGE) park(nb, 1);                       // every wave is past this piece's barrier: that buffer is idle
     }
     // ---- store the finished 32 x 96 block of this wave -------------------------------------
     rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
@@ -290,9 +333,12 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   hipStream_t st = (hipStream_t)stream;
   static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
   static const int nw_env = getenv("PDN_ROWRES_NW") ? atoi(getenv("PDN_ROWRES_NW")) : 0;
-  // NN: one 8-wave workgroup per CU (half the DMA instructions per wave) as long as that fills the chip;
-  // NT: two 4-wave workgroups (the 8-wave form measured 63 vs 71 % at N = 1536)
-  const int nw = nw_env ? nw_env : (!b_trans && (M + 255) / 256 >= 192) ? 8 : 4;
+  static const int stage_env = getenv("PDN_ROWRES_STAGE") ? atoi(getenv("PDN_ROWRES_STAGE")) : -1;
+  // NT: register-staged B (8-wave workgroups: 72.9 vs 68.6 % at N = 768, 87.9 vs 75.8 % at N = 32000); NN keeps the
+  // LDS-DMA -- its ds_read_b32 fragment addressing leaves no registers for the staging (the staged form spills)
+  // one 8-wave workgroup per CU (half the fetch instructions per wave) as long as that fills the chip
+  const int nw = nw_env ? nw_env : ((M + 255) / 256 >= 192) ? 8 : 4;
+  const int stage = stage_env >= 0 ? stage_env : (b_trans && nw == 8 ? 1 : 0);
   const int row_blocks = (M + 32 * nw - 1) / (32 * nw), target = nw == 4 ? 512 : 256;
   // fill every CU (two 4-wave or one 8-wave workgroup each): split the chunks over grid.y
   int nsplit = 1;
@@ -300,7 +346,7 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   p.chunks_per_wg = (p.chunks + nsplit - 1) / nsplit;
   nsplit = (p.chunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
   const dim3 grid(row_blocks, nsplit);
-#define RR_LAUNCH(BT_, NW_, AB_) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, AB_>), grid, dim3(NW_ * 64), 0, st, p)
+#define RR_LAUNCH(BT_, NW_, AB_) if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 1, 0>), grid, dim3(NW_ * 64), 0, st, p); else hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 0, AB_>), grid, dim3(NW_ * 64), 0, st, p)
   if (nw == 8) {
     if (b_trans) RR_LAUNCH(true, 8, 0); else RR_LAUNCH(false, 8, 0);
   } else if (b_trans) {

@@ -19,7 +19,7 @@ def bench(fn, iters=20):
     return t.ms / iters * 1e3
 
 
-for K, trans, extras in ((288, 0, 0), (288, 1, 0), (768, 0, 0), (768, 0, 2), (864, 1, 0), (864, 1, 2), (1536, 1, 2), (32000, 1, 0)):
+for K, trans, extras in ((288, 0, 0), (288, 1, 0), (768, 0, 0), (768, 0, 2), (864, 1, 0), (864, 1, 2), (1536, 1, 2), (32000, 1, 0), (32000, 0, 0)):
     big = K > 4000
     x = hp.empty((T, K)) if big else hp.from_numpy(rng.standard_normal((T, K), dtype=np.float32))
     if big:

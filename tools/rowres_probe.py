@@ -18,7 +18,7 @@ def bench(fn, iters=20):
     return t.ms / iters * 1e3
 
 
-for K, N, trans in ((288, 288, 0), (288, 864, 0), (288, 1536, 0), (288, 768, 0), (288, 288, 1), (288, 768, 1), (288, 1536, 1), (288, 32000, 0), (288, 160, 1)):
+for K, N, trans in ((288, 288, 0), (288, 864, 0), (288, 1536, 0), (288, 768, 0), (288, 288, 1), (288, 768, 1), (288, 1536, 1), (288, 32000, 0), (288, 32000, 1), (288, 160, 1)):
     big = N > 4000 or os.environ.get('NO_EPI') == '1'
     x = hp.from_numpy(rng.standard_normal((T, K), dtype=np.float32))
     w = hp.from_numpy((rng.standard_normal((N, K) if trans else (K, N), dtype=np.float32) * 0.05))
