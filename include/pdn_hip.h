@@ -325,6 +325,20 @@ int pdn_cross_entropy_fwd_f32(const float* logits, const int64_t* targets, int64
 int pdn_cross_entropy_bwd_f32(const float* logits, const int64_t* targets, const float* lse_row,
                               const float* upstream, float gscale, float* dlogits, int64_t rows,
                               int V, void* stream);
+/* Backward of `linear -> cross entropy` (llm/llama/model.py:179 feeding nn/functional.py:364-381) without the
+ * (rows x V) gradient of the logits in memory: both products form
+ *   dlogits[t][v] = (exp(logits[t][v] - lse[t]) - [v == targets[t]]) * gscale * (upstream ? upstream[0] : 1)
+ * from the saved logits and the row statistics of pdn_cross_entropy_fwd_f32 as they consume it:
+ *   dx (rows x in) = dlogits W^T (+ dx_residual);  dW (in x V) = dw_beta dW + x^T dlogits;
+ *   dbias (V) = db_beta dbias + column sums of dlogits.   W (in x V) row-major; any of dx / dW / dbias may be null.
+ * in = 288 only (pdn_linear_ce_supported); other shapes use pdn_cross_entropy_bwd_f32 + pdn_gemm_f32. */
+int pdn_linear_ce_supported(int64_t rows, int V, int in_features);
+int64_t pdn_linear_ce_workspace_bytes(int64_t rows, int V, int in_features);
+int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const float* logits, const float* lse,
+                               const int64_t* targets, float gscale, const float* upstream, const float* W,
+                               float* dx, const float* dx_residual, float* dW, float dw_beta, float* dbias,
+                               float db_beta, int64_t rows, int V, int in_features, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 
 /* ---- Conv2d building blocks (nn/functional.py:194-339).  im2col folds the zero padding of
  * __pad2d (:241-245) into the gather and writes the reference's exact layout

@@ -742,6 +742,89 @@ class cross_entropy(_Operator):
         return [dx]
 
 
+class linear_cross_entropy(_Operator):
+    """loss = cross_entropy(x @ W + b, targets) as ONE tape node (llm/llama/model.py:179 feeding
+    nn/functional.py:364-381): the (rows, V) gradient of the logits never exists in memory.  Forward: the
+    logits GEMM and one read-only pass for the row statistics (log-sum-exp, loss).  Backward: the two products
+    `dlogits @ W^T` and `x^T @ dlogits` (and the column sums for the bias) form
+    dlogits = (softmax - onehot) * scale from the saved logits as they consume it (`pdn_linear_ce_backward_f32`).
+    Versus linear + cross_entropy nodes: one (rows x V) write and none of its re-reads less."""
+
+    folds_existing = True
+    enabled = True
+
+    @staticmethod
+    def applicable(x, w, b, targets, reduction="mean"):
+        if not (linear_cross_entropy.enabled and x.device.is_hip and x.dtype == np.float32 and w.dtype == np.float32
+                and (b is None or b.dtype == np.float32) and reduction in ("mean", "sum") and w.ndim == 2):
+            return False
+        rows = 1
+        for d in x.shape[:-1]:
+            rows *= d
+        t = targets.data if isinstance(targets, Tensor) else targets
+        return (x.shape[-1] == w.shape[0] and getattr(t, "ndim", 0) == 1 and t.shape[0] == rows
+                and bool(_L().query("pdn_linear_ce_supported", rows, w.shape[1], w.shape[0])))
+
+    def __init__(self, x, weight, bias, targets, reduction="mean"):
+        self.reduction = reduction
+        self.has_bias = bias is not None
+        self._t = targets.data if isinstance(targets, Tensor) else targets
+        super().__init__(*([x, weight] + ([bias] if self.has_bias else [])))
+
+    def forward_(self, x, w, b=None):
+        _require_f32(self, x, w, b)
+        hp, L = _hip(), _L()
+        fin, V = w.shape
+        x2 = _contig(x.data).reshape(-1, fin)
+        n = x2.shape[0]
+        if not hasattr(self._t, "_ptr"):
+            self._t = hp.from_numpy(np.asarray(self._t).astype(np.int64))
+        self._t = _contig(self._t)
+        logits = hp.empty((n, V), np.float32)
+        hp.gemm(x2, w.data, logits, bias=b.data.reshape(-1) if b is not None else None)
+        loss_row, lse, out = hp.empty((n,), np.float32), hp.empty((n,), np.float32), hp.empty((1,), np.float32)
+        L.call("pdn_cross_entropy_fwd_f32", logits._ptr, self._t._ptr, n, V, 1 if self.reduction == "mean" else 0,
+               loss_row._ptr, lse._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
+        self._saved = (x2, logits, lse)
+        return out.reshape(())
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, w = self.last[0], self.last[1]
+        b = self.last[2] if self.has_bias else None
+        fin, V = w.shape
+        x2, logits, lse = self._saved
+        self._saved = None
+        n = x2.shape[0]
+        g = _contig(g)
+        grads = [None] * len(self.last)
+        dx = ex = None
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            ex = _foldable(self, 0, x)
+            grads[0] = dx
+        dw, dw_beta = None, 0.0
+        if w.requires_grad:
+            if _is_leaf_f32(w):
+                dw, dw_beta = w.grad, 1.0
+            else:
+                dw = grads[1] = hp.empty((fin, V), np.float32)
+        db, db_beta = None, 0.0
+        if b is not None and b.requires_grad:
+            if _is_leaf_f32(b):
+                db, db_beta = b.grad.reshape(-1), 1.0
+            else:
+                db = hp.empty((V,), np.float32)
+                grads[2] = db.reshape(b.shape)
+        ws, wsb = hp.workspace(L.query("pdn_linear_ce_workspace_bytes", n, V, fin)) if (dw is not None or db is not None) else (None, 0)
+        L.call("pdn_linear_ce_backward_f32", x2._ptr, x2._strides[0], logits._ptr, lse._ptr, self._t._ptr,
+               1.0 / n if self.reduction == "mean" else 1.0, g._ptr, w.data._ptr,
+               dx._ptr if dx is not None else None, ex._ptr if ex is not None else None,
+               dw._ptr if dw is not None else None, dw_beta, db._ptr if db is not None else None, db_beta,
+               n, V, fin, ws, wsb, hp.stream())
+        return grads
+
+
 class conv2d(_Operator):
     """Square-kernel 2-D convolution (nn/functional.py:254-281).
 

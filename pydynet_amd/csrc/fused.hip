@@ -782,6 +782,18 @@ __global__ void ce_reduce_kernel(const float* __restrict__ loss_row, int64_t row
 
 // loss_row / lse_row: (rows,) scratch kept for backward.  loss_out: 1 float =
 // (mean ? 1/rows : 1) * sum(loss_row).
+template <bool COLSUM, bool WRITE = true>
+__global__ void ce_fwd_bwd_reg_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
+                                      float* __restrict__ loss_row, float* __restrict__ lse_row,
+                                      float* __restrict__ dx, float gscale, int64_t rows, int V,
+                                      int* __restrict__ err, float* __restrict__ colsum_part);
+
+#define CE_REG_MAX_V 32768      // 1024 threads x 8 float4 held in registers
+static inline bool ce_reg_row_ok(int V, const void* a, const void* b) {
+  return V >= 4096 && V % 4 == 0 && V <= CE_REG_MAX_V && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+}
+static inline int ce_reg_grid(int64_t rows) { return (int)(rows < 256 ? rows : 256); }
+
 extern "C" int pdn_cross_entropy_fwd_f32(const float* logits, const int64_t* targets, int64_t rows,
                                          int V, int mean, float* loss_row, float* lse_row,
                                          float* loss_out, int* err_flag, void* stream) {
@@ -791,7 +803,11 @@ extern "C" int pdn_cross_entropy_fwd_f32(const float* logits, const int64_t* tar
   // long rows: few, fat workgroups so the rows in flight (grid x V x 4 B) stay within L2 for the re-read pass
   const int ce_threads = V >= 4096 ? 1024 : 256;
   const int g = (int)(V >= 4096 ? (rows < 512 ? rows : 512) : (rows < 65535 ? rows : 65535));
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row, lse_row, rows, V, err_flag);
+  if (ce_reg_row_ok(V, logits, logits))            // one pass, the row held in registers
+    hipLaunchKernelGGL((ce_fwd_bwd_reg_kernel<false, false>), dim3(ce_reg_grid(rows)), dim3(1024), 0, st, logits, targets,
+                       loss_row, lse_row, (float*)nullptr, 1.f, rows, V, err_flag, (float*)nullptr);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel, dim3(g), dim3(ce_threads), 0, st, logits, targets, loss_row, lse_row, rows, V, err_flag);
   PDN_LAUNCH_CHECK();
   hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows,
                      mean ? 1.f / (float)rows : 1.f, loss_out);
@@ -946,17 +962,6 @@ __global__ void ce_fwd_bwd_kernel(const float* __restrict__ x, const int64_t* __
   }
 }
 
-template <bool COLSUM>
-__global__ void ce_fwd_bwd_reg_kernel(const float* __restrict__ x, const int64_t* __restrict__ tgt,
-                                      float* __restrict__ loss_row, float* __restrict__ lse_row,
-                                      float* __restrict__ dx, float gscale, int64_t rows, int V,
-                                      int* __restrict__ err, float* __restrict__ colsum_part);
-
-#define CE_REG_MAX_V 32768      // 1024 threads x 8 float4 held in registers
-static inline bool ce_reg_row_ok(int V, const void* a, const void* b) {
-  return V >= 4096 && V % 4 == 0 && V <= CE_REG_MAX_V && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0);
-}
-static inline int ce_reg_grid(int64_t rows) { return (int)(rows < 256 ? rows : 256); }
 
 // Bytes of workspace needed for the fused column sums of dlogits (the bias gradient of the layer
 // that produced the logits); 0 when this shape takes the generic path, which has no such fusion.
@@ -1038,7 +1043,9 @@ extern "C" int pdn_scale_by_device_scalar_f32(float* x, int64_t n, const float* 
 // read stream overlaps the exp / store work.  Algorithmic traffic = 4 B read + 4 B written per logit.
 // COLSUM: per-thread column sums of dlogits over the workgroup's rows -> one partial row per
 // workgroup (the bias gradient of the vocabulary projection, summed by colsum_partials_kernel).
-template <bool COLSUM>
+// WRITE = false: row statistics only (lse, loss) -- the forward of the fused linear + cross-entropy node, whose
+// backward forms the gradient inside the two GEMMs: one read of the logits, nothing written back.
+template <bool COLSUM, bool WRITE>
 __global__ __launch_bounds__(1024) void ce_fwd_bwd_reg_kernel(
     const float* __restrict__ x, const int64_t* __restrict__ tgt, float* __restrict__ loss_row,
     float* __restrict__ lse_row, float* __restrict__ dx, float gscale, int64_t rows, int V,
@@ -1110,7 +1117,7 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_reg_kernel(
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int i = tid + 1024 * j;
-      if (i < n4) {
+      if (WRITE && i < n4) {
         float4 r;
         r.x = cur[j].x * inv; r.y = cur[j].y * inv; r.z = cur[j].z * inv; r.w = cur[j].w * inv;
         if (i == t4) {

@@ -1090,7 +1090,7 @@ extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int6
   return PDN_OK;
 }
 
-extern "C" int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out);
+int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out);
 int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
                               int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream);
 extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
@@ -1458,6 +1458,87 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     PDN_HIP(hipEventRecord(rec.e1, st));
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(rec);
+  }
+  return PDN_OK;
+}
+
+// ======================================================================================
+// Backward of `linear -> cross entropy` (llm/llama/model.py:179 + nn/functional.py:364-381) without the
+// (rows x V) gradient of the logits in memory: both products form it from the saved logits as they consume it,
+//   dlogits[t][v] = (exp(logits[t][v] - lse[t]) - [v == targets[t]]) * gscale * (upstream ? upstream[0] : 1)
+//   dx (rows x in)  = dlogits W^T (+ dx_residual)          W (in x V) row-major
+//   dW (in x V)     = dw_beta * dW + x^T dlogits           x (rows x in), row stride ldx
+//   dbias (V)       = db_beta * dbias + column sums of dlogits
+// in = 288 (output-resident kernels, csrc/gemm_outres.hip).  The cross-entropy pass then only reads the logits
+// (row statistics) instead of reading them and writing a gradient of the same size.
+// ======================================================================================
+int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, const int64_t* targets, float gscale,
+                            const float* gdev, const float* W, int64_t ldw, float* dx, int64_t ldc,
+                            const float* residual, int M, int V, void* stream);
+int pdn_outres_ce_dw_launch(const float* X, const float* logits, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                            int64_t ldc, int64_t slab, int nw, int k_per_split, const float* lse,
+                            const int64_t* targets, float gscale, const float* gdev, float* colsum, void* stream);
+
+extern "C" int pdn_linear_ce_supported(int64_t rows, int V, int in_features) {
+  return in_features == 288 && V % 32 == 0 && V >= 32 && rows % 32 == 0 && rows >= 32 && rows < (1ll << 31) &&
+         (int64_t)288 * V < (1ll << 30);
+}
+
+extern "C" int64_t pdn_linear_ce_workspace_bytes(int64_t rows, int V, int in_features) {
+  if (!pdn_linear_ce_supported(rows, V, in_features)) return 0;
+  int nw, kps;
+  const int splits = pdn_gemm_outres_tn_plan(V, (int)rows, &nw, &kps);
+  return (int64_t)splits * (in_features + 1) * V * 4;
+}
+
+extern "C" int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const float* logits, const float* lse,
+                                          const int64_t* targets, float gscale, const float* upstream,
+                                          const float* W, float* dx, const float* dx_residual, float* dW,
+                                          float dw_beta, float* dbias, float db_beta, int64_t rows, int V,
+                                          int in_features, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (rows == 0 || V == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && logits && lse && targets && W, "pdn_linear_ce_backward_f32: null operand");
+  if (!pdn_linear_ce_supported(rows, V, in_features)) {
+    pdn_set_error("pdn_linear_ce_backward_f32: unsupported shape rows=%lld V=%d in=%d (in 288, V and rows multiples of 32)",
+                  (long long)rows, V, in_features);
+    return PDN_EUNSUPPORTED;
+  }
+  PDN_CHECK_ARG((ldx & 3) == 0 && ldx >= in_features && ((((uintptr_t)x | (uintptr_t)logits | (uintptr_t)W) & 15) == 0),
+                "pdn_linear_ce_backward_f32: 16-byte alignment required");
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    int rc = pdn_outres_ce_dx_launch(logits, V, lse, targets, gscale, upstream, W, V, dx, in_features, dx_residual,
+                                     (int)rows, V, stream);
+    if (rc) return rc;
+  }
+  if (dW || dbias) {
+    int nw, kps;
+    const int splits = pdn_gemm_outres_tn_plan(V, (int)rows, &nw, &kps);
+    const int64_t need = (int64_t)splits * (in_features + 1) * V * 4;
+    PDN_CHECK_ARG(workspace && workspace_bytes >= need, "pdn_linear_ce_backward_f32: workspace too small (%lld < %lld)",
+                  (long long)workspace_bytes, (long long)need);
+    float* slabs = (float*)workspace;
+    float* cs = slabs + (int64_t)splits * in_features * V;
+    int rc = pdn_outres_ce_dw_launch(x, logits, slabs, V, (int)rows, ldx, V, V, (int64_t)in_features * V, nw, kps, lse,
+                                     targets, gscale, upstream, dbias ? cs : nullptr, stream);
+    if (rc) return rc;
+    GemmParams p{};
+    p.N = V; p.nb2 = 1; p.splits = splits;
+    if (dW) {
+      p.M = in_features; p.C = dW; p.ldc = V; p.ws = slabs; p.beta = dw_beta;
+      const int64_t total = (int64_t)p.M * V;
+      const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+      const int rvec = ((uintptr_t)dW & 15) == 0 && ((uintptr_t)slabs & 15) == 0;
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, 1, rvec);
+      PDN_LAUNCH_CHECK();
+    }
+    if (dbias) {
+      p.M = 1; p.C = dbias; p.ldc = V; p.ws = cs; p.beta = db_beta;
+      const int blocks = (V + 255) / 256 < 2048 ? (V + 255) / 256 : 2048;
+      const int rvec = ((uintptr_t)dbias & 15) == 0 && ((uintptr_t)cs & 15) == 0;
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, 1, rvec);
+      PDN_LAUNCH_CHECK();
+    }
   }
   return PDN_OK;
 }

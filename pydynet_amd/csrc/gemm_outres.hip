@@ -33,7 +33,19 @@ struct OutResParams {
   const float* residual;
   int M, K;
   int64_t lda, ldb, ldc;
+  // CE instantiation: A holds LOGITS and the operand is formed as it is consumed,
+  //   a = (exp(logit - lse[row]) - [column == target[row]]) * gscale * (gdev ? *gdev : 1)
+  // -- the gradient of cross entropy w.r.t. the logits (nn/functional.py:364-381) never exists in memory
+  const float* lse;
+  const int64_t* targets;
+  const float* gdev;
+  float gscale;
 };
+
+// gradient of the mean cross entropy w.r.t. one logit
+__device__ __forceinline__ float ce_grad(float logit, float lse, bool is_target, float sc) {
+  return (__expf(logit - lse) - (is_target ? 1.f : 0.f)) * sc;
+}
 
 __device__ __forceinline__ void or_glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -46,7 +58,7 @@ __device__ __forceinline__ void or_glds16(const float* g, float* l) {
 // BT: B is given as the row-major (288 x K) matrix whose transpose is meant.  NW: waves per workgroup.
 // ABLATE (timing experiments only): 1 = A loaded once, 2 = no B DMA after the first two pieces.
 // STAGE: the B piece reaches LDS by LDS-DMA (0) or through registers, global_load_dwordx4 + ds_write_b128 (1).
-template <bool BT, int NW, int STAGE, int ABLATE = 0>
+template <bool BT, int NW, int STAGE, int ABLATE = 0, bool CE = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(OutResParams p) {
   constexpr int PIECE = OR_KP * OR_N;             // floats: 36 KiB
   constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
@@ -111,6 +123,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
     const float4 v = *reinterpret_cast<const float4*>(arow + 8 * g);
     a[g].x = v.x; a[g].y = v.y; a[g].z = v.z; a[g].w = v.w;
   }
+  float ce_lse = 0.f, ce_sc = 0.f;
+  int ce_rel = 0;                                   // target column relative to this lane's first column (4 h)
+  if (CE) {
+    ce_lse = p.lse[arow_i];
+    ce_rel = (int)p.targets[arow_i] - 4 * lh;
+    ce_sc = p.gscale * (p.gdev ? p.gdev[0] : 1.f);
+  }
 
   f32x16 acc[9];
 #pragma unroll
@@ -167,7 +186,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
     OR_LOADB(b0, 0, 0)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 av = a[g];
+      float4 av = a[g];
+      if (CE) {                                     // this lane's four columns: 32 s + 8 g + 4 h + 0..3
+        const int c0 = ce_rel - (OR_KP * s + 8 * g);
+        av.x = ce_grad(av.x, ce_lse, c0 == 0, ce_sc); av.y = ce_grad(av.y, ce_lse, c0 == 1, ce_sc);
+        av.z = ce_grad(av.z, ce_lse, c0 == 2, ce_sc); av.w = ce_grad(av.w, ce_lse, c0 == 3, ce_sc);
+      }
       // the fetch of the next piece first (three instructions at the head of groups 0..2; spread one per step
       // it measured 66 instead of 77 % at K = 32000), so that only the A loads of groups 2 and 3 follow its last one
       if (g < 3 && (!(ABLATE & 2) || s < 1)) {
@@ -239,7 +263,7 @@ extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, con
     return PDN_EUNSUPPORTED;
   }
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_outres_f32: 16-byte alignment required");
-  OutResParams p{A, B, C, bias, residual, M, K, lda, ldb, ldc};
+  OutResParams p{A, B, C, bias, residual, M, K, lda, ldb, ldc, nullptr, nullptr, nullptr, 0.f};
   hipStream_t st = (hipStream_t)stream;
   static const int nw_env = getenv("PDN_OUTRES_NW") ? atoi(getenv("PDN_OUTRES_NW")) : 0;
   static const int stage_env = getenv("PDN_OUTRES_STAGE") ? atoi(getenv("PDN_OUTRES_STAGE")) : -1;
@@ -256,6 +280,20 @@ extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, con
   else if (b_trans) { if (stage) OR_LAUNCH(true, 4, 1, 0); else OR_LAUNCH(true, 4, 0, 0); }
   else { if (stage) OR_LAUNCH(false, 4, 1, 0); else OR_LAUNCH(false, 4, 0, 0); }
 #undef OR_LAUNCH
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+// dX (M x 288) = dlogits (M x V) * W^T, W (288 x V) row-major, with dlogits formed from the logits on the fly
+// (see OutResParams): the input gradient of `linear -> cross entropy` without the (M x V) gradient in memory.
+int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, const int64_t* targets, float gscale,
+                            const float* gdev, const float* W, int64_t ldw, float* dx, int64_t ldc,
+                            const float* residual, int M, int V, void* stream) {
+  OutResParams p{logits, W, dx, nullptr, residual, M, V, ldl, ldw, ldc, lse, targets, gdev, gscale};
+  const int nw = (M + 255) / 256 >= 224 ? 8 : 4;
+  const dim3 grid((M + 32 * nw - 1) / (32 * nw));
+  if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -279,9 +317,17 @@ struct OutResTnParams {
   int N, K;
   int64_t ldx, ldg, ldc, slab;
   int k_per_split;
+  // CE instantiation: G holds LOGITS (rows = tokens); the operand is (exp(logit - lse[t]) - [n == target[t]]) * scale,
+  // formed as it is read from the wave's LDS piece; lse / targets of a piece's 32 tokens are staged beside X.
+  // colsum (optional): per-split column sums of the formed operand (the bias gradient), [splits][N]
+  const float* lse;
+  const int64_t* targets;
+  const float* gdev;
+  float gscale;
+  float* colsum;
 };
 
-template <int NW>
+template <int NW, bool CE = false>
 __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnParams p) {
   constexpr int PIECE = OR_KP * OR_N;
   constexpr int NQ = (36 + NW - 1) / NW;
@@ -299,6 +345,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
   const unsigned ldx = (unsigned)p.ldx, ldg = (unsigned)p.ldg;
   const float* Xk = p.X + (int64_t)k_begin * p.ldx;
   float* Gs = smem + 2 * PIECE + wave * (2 * GP);
+  float* Ls = smem + 2 * PIECE + NW * 2 * GP;      // CE: [2][32] lse, then [2][32] targets (as int bits)
+  const float ce_sc = CE ? p.gscale * (p.gdev ? p.gdev[0] : 1.f) : 0.f;
+  float ce_row = 0.f;                               // CE, wave 0: lanes 0..31 carry lse[t], lanes 32..63 target[t]
+  float csum = 0.f;
 
   float4 rb[NQ], rg[4];
   auto fetch = [&](int piece, int q) {
@@ -319,6 +369,12 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
       rg[e].x = v.x; rg[e].y = v.y; rg[e].z = v.z; rg[e].w = v.w;
     }
   };
+  auto fetch_rows = [&](int piece) {                // CE: the piece's 32 tokens
+    if (CE && wave == 0) {
+      const int t = k_begin + piece * OR_KP + li;
+      ce_row = lh == 0 ? p.lse[t] : __int_as_float((int)p.targets[t]);
+    }
+  };
   auto park = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
@@ -327,11 +383,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) *reinterpret_cast<float4*>(Gs + buf * GP + e * 256 + 4 * lane) = rg[e];
+    if (CE && wave == 0) Ls[(lh * 2 + buf) * 32 + li] = ce_row;
   };
   if (npieces > 0) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) fetch(0, q);
     fetch_g(0);
+    fetch_rows(0);
     park(0);
   }
 
@@ -375,11 +433,21 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
       float gv[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) gv[q] = gn[q];
+      if (CE) {                                     // rows 8 g + 4 h + q of the piece, column n0 + lane
+        const float4 l4 = *reinterpret_cast<const float4*>(Ls + (s & 1) * 32 + 8 * g + 4 * lh);
+        const float4 t4 = *reinterpret_cast<const float4*>(Ls + (2 + (s & 1)) * 32 + 8 * g + 4 * lh);
+        const int col = n0 + li;
+        gv[0] = ce_grad(gv[0], l4.x, __float_as_int(t4.x) == col, ce_sc);
+        gv[1] = ce_grad(gv[1], l4.y, __float_as_int(t4.y) == col, ce_sc);
+        gv[2] = ce_grad(gv[2], l4.z, __float_as_int(t4.z) == col, ce_sc);
+        gv[3] = ce_grad(gv[3], l4.w, __float_as_int(t4.w) == col, ce_sc);
+        csum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+      }
       if (g + 1 < 4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) gn[q] = Gp[(8 * (g + 1) + q) * 32];
       }
-      if (g == 0) fetch_g(nxt);
+      if (g == 0) { fetch_g(nxt); fetch_rows(nxt); }
       if (g < 3) {
 #pragma unroll
         for (int e = 0; e < 3; ++e)
@@ -398,6 +466,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
     park((s + 1) & 1);
   }
   if (!active) return;
+  if (CE && p.colsum) {                             // both half-waves saw disjoint token rows
+    csum += __shfl_xor(csum, 32, 64);
+    if (lh == 0) p.colsum[(int64_t)blockIdx.y * p.N + n0 + li] = csum;
+  }
   // accumulator register r of tile i = row 32 i + (r & 3) + 8 (r >> 2) + 4 h, column n0 + lane
   float* __restrict__ Cw = p.C + (int64_t)blockIdx.y * p.slab + n0 + li;
   const unsigned ldc = (unsigned)p.ldc;
@@ -413,7 +485,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
 }
 
 // splits of K so that (column workgroups x splits) fills the chip once; k per split a multiple of 32
-extern "C" int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out) {
+int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out) {
   static const int nw_env = getenv("PDN_OUTRES_NW") ? atoi(getenv("PDN_OUTRES_NW")) : 0;
   const int nw = nw_env ? nw_env : 8;
   const int col_wgs = (N / 32 + nw - 1) / nw;
@@ -428,20 +500,41 @@ extern "C" int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_spl
 }
 
 // C slabs: slab s (rows of `ldc` floats) at C + s * slab receives the partial product of split s
-int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
-                              int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream) {
-  OutResTnParams p{X, G, C, N, K, ldx, ldg, ldc, slab, k_per_split};
-  const int splits = (K + k_per_split - 1) / k_per_split;
-  const dim3 grid((N / 32 + nw - 1) / nw, splits);
-  const size_t shm = (size_t)(2 * OR_KP * OR_N + nw * 2 * OR_KP * 32) * sizeof(float);
+static int outres_tn_launch(OutResTnParams& p, int nw, bool ce, void* stream) {
+  const int splits = (p.K + p.k_per_split - 1) / p.k_per_split;
+  const dim3 grid((p.N / 32 + nw - 1) / nw, splits);
+  const size_t shm = (size_t)(2 * OR_KP * OR_N + nw * 2 * OR_KP * 32 + 4 * 32) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  if (nw == 8) hipLaunchKernelGGL((gemm_outres_tn_kernel<8>), grid, dim3(512), shm, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((gemm_outres_tn_kernel<4>), grid, dim3(256), shm, (hipStream_t)stream, p);
+  hipStream_t st = (hipStream_t)stream;
+  if (nw == 8) {
+    if (ce) hipLaunchKernelGGL((gemm_outres_tn_kernel<8, true>), grid, dim3(512), shm, st, p);
+    else hipLaunchKernelGGL((gemm_outres_tn_kernel<8, false>), grid, dim3(512), shm, st, p);
+  } else {
+    if (ce) hipLaunchKernelGGL((gemm_outres_tn_kernel<4, true>), grid, dim3(256), shm, st, p);
+    else hipLaunchKernelGGL((gemm_outres_tn_kernel<4, false>), grid, dim3(256), shm, st, p);
+  }
   PDN_LAUNCH_CHECK();
   return PDN_OK;
+}
+
+// C slabs: slab s (rows of `ldc` floats) at C + s * slab receives the partial product of split s
+int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                              int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream) {
+  OutResTnParams p{X, G, C, N, K, ldx, ldg, ldc, slab, k_per_split, nullptr, nullptr, nullptr, 0.f, nullptr};
+  return outres_tn_launch(p, nw, false, stream);
+}
+
+// the same with G = logits turned into the cross-entropy gradient on the fly; colsum: [splits][N] or null
+int pdn_outres_ce_dw_launch(const float* X, const float* logits, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                            int64_t ldc, int64_t slab, int nw, int k_per_split, const float* lse,
+                            const int64_t* targets, float gscale, const float* gdev, float* colsum, void* stream) {
+  OutResTnParams p{X, logits, C, N, K, ldx, ldg, ldc, slab, k_per_split, lse, targets, gdev, gscale, colsum};
+  return outres_tn_launch(p, nw, true, stream);
 }

@@ -181,12 +181,20 @@ class Llama(nn.Module):
         return trainable, frozen
 
     def loss(self, input_ids, target_ids, criterion=None, start_pos: int = 0):
-        logits = self.forward_logits(input_ids, start_pos)
-        B, L, V = logits.shape
+        h = self._forward_hidden(input_ids, start_pos)
         if isinstance(target_ids, Tensor):
             targets = target_ids.reshape(-1)
         else:
-            targets = Tensor(np.asarray(target_ids).reshape(-1), dtype=np.int64, device=logits.device)
+            targets = Tensor(np.asarray(target_ids).reshape(-1), dtype=np.int64, device=h.device)
+        head = self.lm_head
+        bias = getattr(head, "bias", None)
+        reduction = getattr(criterion, "reduction", "mean") if criterion is not None else "mean"
+        if ((criterion is None or type(criterion) is nn.CrossEntropyLoss) and type(head) is nn.Linear
+                and fused.linear_cross_entropy.applicable(h, head.weight, bias, targets, reduction)):
+            # lm_head + cross entropy as one node: the (tokens, vocab) gradient of the logits is never written
+            return fused.linear_cross_entropy(h, head.weight, bias, targets, reduction)
+        logits = head(h)
+        B, L, V = logits.shape
         return (criterion or nn.CrossEntropyLoss())(logits.reshape(B * L, V), targets)
 
     def finetune_step(self, input_ids, target_ids, optimizer, criterion=None, start_pos: int = 0):

@@ -453,6 +453,36 @@ class EmulatedLib:
         flat(dlogits, rows * V).reshape(rows, V)[...] = sm * gs
         return 0
 
+    def pdn_linear_ce_supported(self, rows, V, fin):
+        return int(fin == 288 and V % 32 == 0 and V >= 32 and rows % 32 == 0 and rows >= 32 and 288 * V < (1 << 30))
+
+    def pdn_linear_ce_workspace_bytes(self, rows, V, fin):
+        return 2 * (fin + 1) * V * 4 if self.pdn_linear_ce_supported(rows, V, fin) else 0
+
+    def pdn_linear_ce_backward_f32(self, x, ldx, logits, lse, targets, gscale, upstream, W, dx, dx_res, dW, dw_beta,
+                                   dbias, db_beta, rows, V, fin, ws, wsb, stream):
+        if not self.pdn_linear_ce_supported(rows, V, fin):
+            return -2
+        a = np.array(flat(logits, rows * V).reshape(rows, V))
+        t = flat(targets, rows, np.int64)
+        sm = np.exp(a - flat(lse, rows)[:, None])
+        sm[np.arange(rows), t] -= 1
+        d = sm * (np.float32(gscale) * (flat(upstream, 1)[0] if upstream else np.float32(1)))
+        xv = view(x, (rows, fin), (ldx, 1), np.float32)
+        w = flat(W, fin * V).reshape(fin, V)
+        if dx:
+            r = d @ w.T
+            if dx_res:
+                r = r + flat(dx_res, rows * fin).reshape(rows, fin)
+            flat(dx, rows * fin).reshape(rows, fin)[...] = r
+        if dW:
+            g = flat(dW, fin * V).reshape(fin, V)
+            g[...] = np.float32(dw_beta) * g + xv.T @ d if dw_beta != 0.0 else xv.T @ d
+        if dbias:
+            bg = flat(dbias, V)
+            bg[...] = np.float32(db_beta) * bg + d.sum(0) if db_beta != 0.0 else d.sum(0)
+        return 0
+
     # -- fused attention (NumPy statement of the same contract) -------------------------------------
     @staticmethod
     def _att_views(ptrs, B, H, L, hd, rs, bs):

@@ -1,0 +1,98 @@
+"""`linear -> cross entropy` as one tape node (pydynet_amd/core/fused.py: linear_cross_entropy; C ABI
+pdn_linear_ce_backward_f32) against (a) the same module with the node disabled -- separate Linear and
+cross-entropy nodes, the (rows, V) gradient of the logits in memory -- and (b) a float64 NumPy statement of
+llm/llama/model.py:179 + nn/functional.py:364-381.  Tolerance: 1e-4 relative (north_star), gradients against
+their own largest entry.  Runs on the emulated C ABI and (``-m gpu``) on a real MI355X."""
+import numpy as np
+
+import pydynet_amd as pdn
+from pydynet_amd import nn
+from pydynet_amd.core import fused
+from pydynet_amd.core.tensor import Graph
+from tests.conftest import device_variants
+
+RT = 1e-4
+
+
+def host(x):
+    return x.numpy() if isinstance(x, pdn.Tensor) else (x if isinstance(x, np.ndarray) else x.get())
+
+
+def close(a, b, what):
+    a, b = np.asarray(host(a), np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    assert float(np.abs(a - b).max()) <= 1e-7 + RT * scale, (what, float(np.abs(a - b).max()), scale)
+
+
+def _case(dev, rows, V, reduction, upstream, seed):
+    D = 288
+    rng = np.random.default_rng(seed)
+    x0 = rng.standard_normal((rows, D)).astype(np.float32)
+    w0 = (0.05 * rng.standard_normal((D, V))).astype(np.float32)
+    b0 = (0.1 * rng.standard_normal(V)).astype(np.float32)
+    t0 = rng.integers(0, V, rows)
+    t0[:3] = (0, V - 1, V // 2)
+    out = {}
+    for fused_on in (True, False):
+        Graph.clear()
+        head = nn.Linear(D, V, dtype=np.float32)
+        head.weight.data[...] = w0
+        head.bias.data[...] = b0
+        head.to(dev)
+        head.weight.zero_grad(); head.bias.zero_grad()
+        x = pdn.Tensor(x0, dtype=np.float32, device=dev, requires_grad=True)
+        t = pdn.Tensor(t0, dtype=np.int64, device=dev)
+        h = x * 1.0                                     # a non-leaf input, as the final norm of the model is
+        if fused_on:
+            assert fused.linear_cross_entropy.applicable(h, head.weight, head.bias, t, reduction)
+            loss = fused.linear_cross_entropy(h, head.weight, head.bias, t, reduction)
+        else:
+            loss = nn.CrossEntropyLoss(reduction=reduction)(head(h), t)
+        (loss * upstream).backward()
+        out[fused_on] = (host(loss), host(x.grad), host(head.weight.grad), host(head.bias.grad))
+    # float64 statement
+    z = x0.astype(np.float64) @ w0.astype(np.float64) + b0
+    m = z.max(-1, keepdims=True)
+    lse = np.log(np.exp(z - m).sum(-1, keepdims=True)) + m
+    per_row = lse[:, 0] - z[np.arange(rows), t0]
+    ref_loss = per_row.mean() if reduction == "mean" else per_row.sum()
+    d = np.exp(z - lse)
+    d[np.arange(rows), t0] -= 1
+    d *= upstream / rows if reduction == "mean" else upstream
+    ref = (ref_loss, d @ w0.astype(np.float64).T, x0.astype(np.float64).T @ d, d.sum(0))
+    for name, i in (("loss", 0), ("dx", 1), ("dW", 2), ("db", 3)):
+        close(out[True][i], ref[i], f"fused {name} vs float64")
+        close(out[True][i], out[False][i], f"fused {name} vs separate nodes")
+
+
+def check_linear_ce_mean(dev):
+    _case(dev, 64, 96, "mean", 1.0, 0)
+
+
+def check_linear_ce_sum_scaled_upstream(dev):
+    _case(dev, 96, 160, "sum", 0.5, 1)
+
+
+def check_linear_ce_many_rows_two_k_splits(dev):
+    # enough rows for the weight-gradient kernel to split the tokens over the grid
+    _case(dev, 4096, 256, "mean", 1.0, 2)
+
+
+def check_linear_ce_not_applicable_falls_back(dev):
+    Graph.clear()
+    head = nn.Linear(96, 64, dtype=np.float32)
+    head.to(dev)
+    x = pdn.Tensor(np.zeros((32, 96), np.float32), device=dev, requires_grad=True)
+    t = pdn.Tensor(np.zeros(32, np.int64), dtype=np.int64, device=dev)
+    assert not fused.linear_cross_entropy.applicable(x, head.weight, head.bias, t)       # in_features != 288
+    head2 = nn.Linear(288, 64, dtype=np.float32)
+    head2.to(dev)
+    x2 = pdn.Tensor(np.zeros((30, 288), np.float32), device=dev, requires_grad=True)
+    t2 = pdn.Tensor(np.zeros(30, np.int64), dtype=np.int64, device=dev)
+    assert not fused.linear_cross_entropy.applicable(x2, head2.weight, head2.bias, t2)   # rows not a multiple of 32
+
+
+for _f in (check_linear_ce_mean, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
+           check_linear_ce_not_applicable_falls_back):
+    device_variants(globals(), _f)
