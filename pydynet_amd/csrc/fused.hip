@@ -1101,7 +1101,11 @@ __global__ __launch_bounds__(1024) void ce_fwd_bwd_reg_kernel(
       const int i = tid + 1024 * j;
       if (i < n4) {
         float4 e;
-        e.x = expf(cur[j].x - m); e.y = expf(cur[j].y - m); e.z = expf(cur[j].z - m); e.w = expf(cur[j].w - m);
+        if (WRITE) {
+          e.x = expf(cur[j].x - m); e.y = expf(cur[j].y - m); e.z = expf(cur[j].z - m); e.w = expf(cur[j].w - m);
+        } else {      // statistics only: the hardware exponential (the pass is VALU-bound with expf: 2.1 G elements)
+          e.x = __expf(cur[j].x - m); e.y = __expf(cur[j].y - m); e.z = __expf(cur[j].z - m); e.w = __expf(cur[j].w - m);
+        }
         cur[j] = e;
         s += (e.x + e.y) + (e.z + e.w);
       }

@@ -1506,11 +1506,36 @@ extern "C" int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const flo
   PDN_CHECK_ARG((ldx & 3) == 0 && ldx >= in_features && ((((uintptr_t)x | (uintptr_t)logits | (uintptr_t)W) & 15) == 0),
                 "pdn_linear_ce_backward_f32: 16-byte alignment required");
   hipStream_t st = (hipStream_t)stream;
+  bool prof;
+  {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof = g_prof_on;
+  }
+  // the two products count as launches of the output-resident family in the GEMM profile (bench.py roofline)
+  auto prof_begin = [&](ProfRec& rec) {
+    if (!prof) return;
+    (void)hipEventCreate(&rec.e0);
+    (void)hipEventCreate(&rec.e1);
+    rec.flops = 2.0 * (double)rows * (double)V * (double)in_features;
+    rec.family = 3;
+    (void)hipEventRecord(rec.e0, st);
+  };
+  auto prof_end = [&](ProfRec& rec) {
+    if (!prof) return;
+    (void)hipEventRecord(rec.e1, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(rec);
+  };
   if (dx) {
+    ProfRec rec;
+    prof_begin(rec);
     int rc = pdn_outres_ce_dx_launch(logits, V, lse, targets, gscale, upstream, W, V, dx, in_features, dx_residual,
                                      (int)rows, V, stream);
     if (rc) return rc;
+    prof_end(rec);
   }
+  ProfRec rec_w;
+  if (dW || dbias) prof_begin(rec_w);
   if (dW || dbias) {
     int nw, kps;
     const int splits = pdn_gemm_outres_tn_plan(V, (int)rows, &nw, &kps);
@@ -1539,6 +1564,7 @@ extern "C" int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const flo
       hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, 1, rvec);
       PDN_LAUNCH_CHECK();
     }
+    prof_end(rec_w);
   }
   return PDN_OK;
 }
