@@ -239,7 +239,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       } else {
         if (s == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KG - 12) : "memory");   // a[12..] may still be in flight
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        __builtin_amdgcn_s_barrier();                 // (bare: __syncthreads() would drain vmcnt to 0 again)
+        asm volatile("" ::: "memory");
       }
       const bool more = !(ABLATE & 2) || s < 1;
       if (more && (ABLATE & 32)) {
