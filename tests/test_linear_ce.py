@@ -27,6 +27,7 @@ def close(a, b, what):
 
 def _case(dev, rows, V, reduction, upstream, seed):
     D = 288
+    fused.linear_cross_entropy.min_rows = 32          # (the model only takes the node from 32768 tokens up)
     rng = np.random.default_rng(seed)
     x0 = rng.standard_normal((rows, D)).astype(np.float32)
     w0 = (0.05 * rng.standard_normal((D, V))).astype(np.float32)

@@ -22,4 +22,7 @@ python tools/gemm_shapes.py 256 > $O/gemm_shapes_b256.txt 2>&1
 python tools/attn_compare.py 256 > $O/attn_compare.txt 2>&1
 python tools/dp_overhead_probe.py dp > $O/dp_probe.txt 2>&1; python tools/dp_overhead_probe.py base >> $O/dp_probe.txt 2>&1
 python tools/two_stream_probe.py 65536 > $O/two_stream.txt 2>&1
+NO_EPI=1 python tools/rowres_probe.py 65536 > $O/rowres_probe.txt 2>&1
+python tools/outres_probe.py 65536 > $O/outres_probe.txt 2>&1
+tools/micro/mfma_sustained.bin > $O/mfma_sustained.txt 2>&1
 ls -la $O
