@@ -27,6 +27,8 @@
 // The head dim (48) is padded to 64 in the O^T product only (two 32-row MFMA tiles).
 // Saved for backward: lse[b,h,q] = rowmax + log(rowsum).
 #include "common.h"
+#include <stdlib.h>
+#include <stdio.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -220,6 +222,19 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   }
 }
 
+// chunked variants (defined below)
+template <int HD> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd2_kernel(const float*, const float*, const float*, float*, float*, int, int,
+                                                        int64_t, int64_t, int64_t, int64_t, float, int, const float*, const float*);
+template <int HD> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dq2_kernel(const float*, const float*, const float*, const float*, const float*,
+                                                           const float*, float*, float*, int, int, int64_t, int64_t, int64_t,
+                                                           int64_t, float, int, const float*, const float*);
+template <int HD> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dkv2_kernel(const float*, const float*, const float*, const float*, const float*,
+                                                            const float*, float*, float*, int, int, int64_t, int64_t, int64_t,
+                                                            int64_t, float, int, const float*, const float*);
+extern "C" int64_t pdn_attention_chunk_lds_bytes(int head_dim);
+// opt-in (PDN_ATTN_CHUNKED=1, read per call): the chunked kernels measured the SAME times as the whole-head ones
+static inline bool att_use_chunked() { return getenv("PDN_ATTN_CHUNKED") != nullptr; }
+
 extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
   return ((int64_t)2 * L + 8 * 32) * ATT_LD(head_dim) * 4;
 }
@@ -253,9 +268,29 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(512), shm, (hipStream_t)stream, q, k,
-                     v, o, lse, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride,
-                     sqrtf((float)head_dim), causal, rope_cos, rope_sin);
+  if (causal && att_use_chunked()) {
+    // four waves per head, K / V in 128-key chunks, two workgroups per CU
+    static bool attr2 = false;
+    if (!attr2) {
+      PDN_HIP(hipFuncSetAttribute((const void*)attention_fwd2_kernel<48>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr2 = true;
+    }
+    if (getenv("PDN_ATTN_DEBUG")) {
+      int nb = -1;
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)attention_fwd2_kernel<48>, 256,
+                                                         (size_t)pdn_attention_chunk_lds_bytes(head_dim));
+      fprintf(stderr, "attention_fwd2_kernel: %d workgroups per CU at %lld bytes of LDS\n", nb,
+              (long long)pdn_attention_chunk_lds_bytes(head_dim));
+    }
+    hipLaunchKernelGGL((attention_fwd2_kernel<48>), dim3(B * H), dim3(256), (size_t)pdn_attention_chunk_lds_bytes(head_dim),
+                       (hipStream_t)stream, q, k, v, o, lse, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride,
+                       sqrtf((float)head_dim), causal, rope_cos, rope_sin);
+  } else {
+    hipLaunchKernelGGL((attention_fwd_kernel<48>), dim3(B * H), dim3(512), shm, (hipStream_t)stream, q, k,
+                       v, o, lse, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride,
+                       sqrtf((float)head_dim), causal, rope_cos, rope_sin);
+  }
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -541,17 +576,481 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
     attr_set = true;
   }
   const float sq = sqrtf((float)head_dim);
-  hipLaunchKernelGGL((attention_bwd_dq_kernel<48>), dim3(B * H), dim3(512),
-                     (size_t)pdn_attention_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
-                     lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
-                     rope_cos, rope_sin);
+  static bool attr2 = false;
+  if (!attr2) {
+    PDN_HIP(hipFuncSetAttribute((const void*)attention_bwd_dq2_kernel<48>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    PDN_HIP(hipFuncSetAttribute((const void*)attention_bwd_dkv2_kernel<48>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr2 = true;
+  }
+  const int ntile = L / 32;
+  const size_t shm2 = (size_t)pdn_attention_chunk_lds_bytes(head_dim);
+  if (causal && att_use_chunked())
+    hipLaunchKernelGGL((attention_bwd_dq2_kernel<48>), dim3(B * H), dim3(256), shm2, (hipStream_t)stream, q, k, v, o, d_o,
+                       lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
+                       rope_cos, rope_sin);
+  else
+    hipLaunchKernelGGL((attention_bwd_dq_kernel<48>), dim3(B * H), dim3(512),
+                       (size_t)pdn_attention_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
+                       lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
+                       rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
-  hipLaunchKernelGGL((attention_bwd_dkv_kernel<48>), dim3(B * H), dim3(512),
-                     (size_t)pdn_attention_bwd_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, d_o,
-                     lse, delta, dk, dv, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
-                     rope_cos, rope_sin);
+  // (the chunked dK/dV kernel keeps one key tile's accumulators live at a time: with 5 or 6 tiles the pair
+  //  (a, ntile - 1 - a) can have both members start in the first query chunk -- those lengths take the whole-head kernel)
+  if (causal && att_use_chunked() && (ntile <= 4 || ntile >= 7))
+    hipLaunchKernelGGL((attention_bwd_dkv2_kernel<48>), dim3(B * H), dim3(256), shm2, (hipStream_t)stream, q, k, v, d_o,
+                       lse, delta, dk, dv, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
+                       rope_cos, rope_sin);
+  else
+    hipLaunchKernelGGL((attention_bwd_dkv_kernel<48>), dim3(B * H), dim3(512),
+                       (size_t)pdn_attention_bwd_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, d_o,
+                       lse, delta, dk, dv, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
+                       rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
+}
+
+// ======================================================================================
+// Chunked variants (opt-in, PDN_ATTN_CHUNKED=1): the same three kernels with FOUR waves per (batch, head) and the
+// LDS-resident pair -- K,V for forward / dQ, Q,dO for dK/dV -- passing through LDS in chunks of 128 rows (53 KB) instead
+// of whole (106 KB + 53 KB of staging = one 160 KB workgroup per CU).  With 80 KB per workgroup TWO workgroups share a CU
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor = 2) and run out of phase.  Measured on the benchmark shape (1536 heads,
+// L 256, hd 48): forward 205 vs 202 us, backward 670 vs 677 us -- the SAME: either way a SIMD hosts two waves, and what
+// limits these kernels is each wave's own dependency chain (LDS operand -> MFMA -> softmax VALU -> MFMA; 49 % of the
+// wave cycles wait on s_waitcnt, PMC), which a second workgroup does not shorten.  Four waves per SIMD need <= 128
+// VGPRs per wave (the dK/dV kernel holds 144 in accumulators and operands alone): not reachable in fp32 at hd 48.
+// A wave owns the tile pair (w, 7 - w) -- nine of the 36 causal tile pairs, as before -- and works through it
+// sequentially; odd (batch, head) indices mirror the assignment so that two co-resident workgroups load the four
+// SIMDs evenly in every chunk phase.  Forward: tile w needs chunk 0 only; tile 7 - w carries (m, l, O) across the
+// chunk switch with ONE online rescale.  Backward recomputes P from the saved log-sum-exp, so its accumulators
+// simply carry over.  Results are those of the single-chunk kernels up to the rescale's rounding.
+// ======================================================================================
+#define ATT_CH 128                      // rows per LDS chunk (four 32-row tiles)
+
+// rows [row0, row0 + nrows) of two [L][HD] matrices -> padded LDS images [nrows][HD+4] (see att_stage_two)
+template <int HD, int NT>
+__device__ __forceinline__ void att_stage_chunk(float* __restrict__ s0, float* __restrict__ s1,
+                                                const float* __restrict__ g0, const float* __restrict__ g1,
+                                                int row0, int nrows, int64_t row_stride, int64_t row_stride1, int tid,
+                                                const float* __restrict__ cs, const float* __restrict__ sn,
+                                                bool rot0, bool rot1) {
+  constexpr int LD = ATT_LD(HD), F4 = HD / 4;
+  constexpr int NP = (ATT_CH * F4 + NT - 1) / NT;
+  float4 r0[NP], r1[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < nrows * F4) {
+      const int row = u / F4, c4 = u % F4;
+      float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)(row0 + row) * row_stride + 4 * c4);
+      float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)(row0 + row) * row_stride1 + 4 * c4);
+      if (cs && rot0) a = att_rot(a, cs, sn, row0 + row, 2 * c4, HD / 2, 1.f);
+      if (cs && rot1) c = att_rot(c, cs, sn, row0 + row, 2 * c4, HD / 2, 1.f);
+      r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
+      r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < nrows * F4) {
+      const int row = u / F4, c4 = u % F4;
+      *reinterpret_cast<float4*>(s0 + row * LD + 4 * c4) = r0[j];
+      *reinterpret_cast<float4*>(s1 + row * LD + 4 * c4) = r1[j];
+    }
+  }
+}
+
+// tile pair of wave w (0..3) of workgroup bh: (a, b) with a < b, or b = -1 (a alone), or a = -1 (idle)
+__device__ __forceinline__ void att_pair_of_wave(int w, int bh, int ntile, int& a, int& b) {
+  const int ww = (bh & 1) ? 3 - w : w;
+  a = ww; b = ntile - 1 - ww;
+  if (a >= ntile || a > b) { a = -1; b = -1; }
+  else if (a == b) b = -1;
+}
+
+extern "C" int64_t pdn_attention_chunk_lds_bytes(int head_dim) {
+  return ((int64_t)2 * ATT_CH + 4 * 32) * ATT_LD(head_dim) * 4 + 2 * ATT_CH * 4;
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_fwd2_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
+    int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
+    const float* __restrict__ RC, const float* __restrict__ RS) {
+  constexpr int LD = ATT_LD(HD);
+  constexpr int NT8 = HD / 8;
+  constexpr int F4 = HD / 4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ks = lds;                               // [ATT_CH][LD]
+  float* Vs = lds + ATT_CH * LD;                 // [ATT_CH][LD]
+  float* Os = Vs + ATT_CH * LD;                  // 4 waves x [32][LD] output staging
+
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
+  const float* Qb = Q + base;
+  float* Ob = O + (int64_t)b * o_batch_stride + (int64_t)h * HD;
+  const int ntile = L / 32, nchunk = (L + ATT_CH - 1) / ATT_CH;
+  int tA, tB;
+  att_pair_of_wave(wave, bh, ntile, tA, tB);
+  const float inv_sqrt = 1.f / sqrt_hd;
+  const bool hi_ok = (32 + li) < HD;
+  float* Ow = Os + wave * (32 * LD);
+
+  // running state of the tile being worked on
+  float4 qf[NT8];
+  f32x16 o0, o1;
+  float m_run = -INFINITY, l_run = 0.f;
+  int qt = -1;
+  auto begin_tile = [&](int t) {
+    qt = t;
+    const float* qrow = Qb + (int64_t)(qt * 32 + li) * row_stride + 4 * lh;
+#pragma unroll
+    for (int t8 = 0; t8 < NT8; ++t8) {
+      qf[t8] = *reinterpret_cast<const float4*>(qrow + 8 * t8);
+      if (RC) qf[t8] = att_rot(qf[t8], RC, RS, qt * 32 + li, 4 * t8 + 2 * lh, HD / 2, 1.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    m_run = -INFINITY; l_run = 0.f;
+  };
+  // key tiles [k_lo, k_hi) of the chunk whose first key tile is c0 (all resident in LDS)
+  auto run_chunk = [&](int c0, int k_lo, int k_hi) {
+    const int qpos = qt * 32 + li;
+    f32x16 s[4];
+    float m = m_run;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[j][r] = 0.f;
+      const int kt = c0 + j;
+      if (kt >= k_lo && kt < k_hi) {
+        const float* krow = Ks + (j * 32 + li) * LD + 4 * lh;
+#pragma unroll
+        for (int t8 = 0; t8 < NT8; ++t8) {
+          const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t8);
+          s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t8].x, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t8].y, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t8].z, s[j], 0, 0, 0);
+          s[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t8].w, s[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = s[j][r] * inv_sqrt;
+          if (causal && kt * 32 + att_krow(r, lh) > qpos) v = -INFINITY;
+          s[j][r] = v;
+          m = fmaxf(m, v);
+        }
+      }
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    // one rescale of what the earlier chunk left (exp(-inf - m) = 0 on the first chunk)
+    const float a = __expf(m_run - m);
+    l_run *= a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] *= a; o1[r] *= a; }
+    m_run = m;
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int kt = c0 + j;
+      if (kt >= k_lo && kt < k_hi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float pv = __expf(s[j][r] - m);
+          s[j][r] = pv;
+          l += pv;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float* vrow = Vs + (j * 32 + att_krow(r, lh)) * LD;
+          const float a0 = vrow[li];
+          const float a1 = hi_ok ? vrow[32 + li] : 0.f;
+          o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[j][r], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[j][r], o1, 0, 0, 0);
+        }
+      }
+    }
+    l_run += l + __shfl_xor(l, 32, 64);
+  };
+  auto end_tile = [&]() {
+    const float inv_l = 1.f / l_run;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int d = att_krow(r, lh);
+      Ow[li * LD + d] = o0[r] * inv_l;
+      if (32 + d < HD) Ow[li * LD + 32 + d] = o1[r] * inv_l;
+    }
+    if (lh == 0) LSE[(int64_t)bh * L + qt * 32 + li] = m_run + logf(l_run);
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    for (int u = lane; u < 32 * F4; u += 64) {
+      const int row = u / F4, c4 = u % F4;
+      *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * o_row_stride + 4 * c4) =
+          *reinterpret_cast<const float4*>(Ow + row * LD + 4 * c4);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  for (int c = 0; c < nchunk; ++c) {
+    const int c0 = 4 * c, rows = min(ATT_CH, L - ATT_CH * c);
+    if (c > 0) __syncthreads();                    // everyone is done reading the previous chunk
+    att_stage_chunk<HD, 256>(Ks, Vs, K + base, V + base, ATT_CH * c, rows, row_stride, row_stride, tid, RC, RS, true, false);
+    __syncthreads();
+    const int c_end = c0 + rows / 32;              // key tiles [c0, c_end) are resident
+    // tile A first (causal: all of its keys lie in the chunk that holds its own rows, so it finishes there),
+    // then tile B, which is resumed in the next chunk
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int t = which == 0 ? tA : tB;
+      if (t < 0) continue;
+      const int nk = t + 1;                        // causal: key tiles [0, t] matter for query tile t
+      if (nk <= c0) continue;                      // finished in an earlier chunk
+      if (qt != t) begin_tile(t);
+      run_chunk(c0, c0, min(nk, c_end));
+      if (nk <= c_end) end_tile();
+    }
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dq2_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
+    float* __restrict__ dQ, float* __restrict__ Delta, int H, int L, int64_t row_stride,
+    int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
+    const float* __restrict__ RC, const float* __restrict__ RS) {
+  constexpr int LD = ATT_LD(HD);
+  constexpr int NT8 = HD / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Ks = lds;                                 // [ATT_CH][LD]
+  float* Vs = Ks + ATT_CH * LD;                    // [ATT_CH][LD]
+  float* slots = Vs + ATT_CH * LD;                 // 4 waves x [32][LD]
+
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
+  const int64_t obase = (int64_t)b * o_batch_stride + (int64_t)h * HD;
+  const float* Qb = Q + base; const float* Ob = O + obase; const float* dOb = dO + obase;
+  float* dQb = dQ + base;
+  const int ntile = L / 32, nchunk = (L + ATT_CH - 1) / ATT_CH;
+  int tA, tB;
+  att_pair_of_wave(wave, bh, ntile, tA, tB);
+  const float inv_sqrt = 1.f / sqrt_hd;
+  const bool hi_ok = (32 + li) < HD;
+
+  float4 qf[NT8], gf[NT8];
+  float delta_q = 0.f, lse_q = 0.f;
+  f32x16 dq0, dq1;
+  int qt = -1;
+  auto begin_tile = [&](int t) {
+    qt = t;
+    const int qpos = qt * 32 + li;
+    const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
+    const float* grow = dOb + (int64_t)qpos * o_row_stride + 4 * lh;
+    const float* orow = Ob + (int64_t)qpos * o_row_stride + 4 * lh;
+    float dpart = 0.f;
+#pragma unroll
+    for (int t8 = 0; t8 < NT8; ++t8) {
+      qf[t8] = *reinterpret_cast<const float4*>(qrow + 8 * t8);
+      if (RC) qf[t8] = att_rot(qf[t8], RC, RS, qpos, 4 * t8 + 2 * lh, HD / 2, 1.f);
+      gf[t8] = *reinterpret_cast<const float4*>(grow + 8 * t8);
+      const float4 ov = *reinterpret_cast<const float4*>(orow + 8 * t8);
+      dpart += (ov.x * gf[t8].x + ov.y * gf[t8].y) + (ov.z * gf[t8].z + ov.w * gf[t8].w);
+    }
+    delta_q = dpart + __shfl_xor(dpart, 32, 64);
+    lse_q = LSE[(int64_t)bh * L + qpos];
+    if (lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+  };
+  auto run_chunk = [&](int c0, int k_hi) {          // key tiles [c0, k_hi), chunk rows start at tile c0
+    const int qpos = qt * 32 + li;
+    for (int kt = c0; kt < k_hi; ++kt) {
+      const int j = kt - c0;
+      f32x16 sv, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sv[r] = 0.f; dp[r] = 0.f; }
+      const float* krow = Ks + (j * 32 + li) * LD + 4 * lh;
+      const float* vrow = Vs + (j * 32 + li) * LD + 4 * lh;
+#pragma unroll
+      for (int t8 = 0; t8 < NT8; ++t8) {
+        const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t8);
+        const float4 vf = *reinterpret_cast<const float4*>(vrow + 8 * t8);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t8].x, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t8].x, dp, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t8].y, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t8].y, dp, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t8].z, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, gf[t8].z, dp, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t8].w, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t8].w, dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const bool masked = causal && (kt * 32 + att_krow(r, lh) > qpos);
+        const float pv = masked ? 0.f : __expf(sv[r] * inv_sqrt - lse_q);
+        sv[r] = pv * (dp[r] - delta_q) * inv_sqrt;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* kr = Ks + (j * 32 + att_krow(r, lh)) * LD;
+        const float a0 = kr[li];
+        const float a1 = hi_ok ? kr[32 + li] : 0.f;
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sv[r], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sv[r], dq1, 0, 0, 0);
+      }
+    }
+  };
+  for (int c = 0; c < nchunk; ++c) {
+    const int c0 = 4 * c, rows = min(ATT_CH, L - ATT_CH * c);
+    if (c > 0) __syncthreads();
+    att_stage_chunk<HD, 256>(Ks, Vs, K + base, V + base, ATT_CH * c, rows, row_stride, row_stride, tid, RC, RS, true, false);
+    __syncthreads();
+    const int c_end = c0 + rows / 32;
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int t = which == 0 ? tA : tB;
+      if (t < 0) continue;
+      const int nk = t + 1;
+      if (nk <= c0) continue;
+      if (qt != t) begin_tile(t);
+      run_chunk(c0, min(nk, c_end));
+      if (nk <= c_end)
+        att_store_tile_T<HD>(slots + wave * (32 * LD), dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride,
+                             row_stride, li, lh, lane, 1.f, RC, RS, qt * 32);
+    }
+  }
+}
+
+// dK / dV: a wave owns key tiles (w, 7 - w); Q and dO pass through LDS in chunks of 128 QUERY rows.  Key tile t needs
+// query tiles t .. ntile - 1: tile A (<= 3) starts in the chunk that holds its own rows and is carried into the
+// next one; tile B lies wholly in the last chunk -- so only one tile's accumulators are live at a time.
+template <int HD>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dkv2_kernel(
+    const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+    const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Delta,
+    float* __restrict__ dK, float* __restrict__ dV, int H, int L, int64_t row_stride,
+    int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
+    const float* __restrict__ RC, const float* __restrict__ RS) {
+  constexpr int LD = ATT_LD(HD);
+  constexpr int NT8 = HD / 8;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* Qs = lds;                                 // [ATT_CH][LD]
+  float* Gs = Qs + ATT_CH * LD;                    // [ATT_CH][LD]   dO
+  float* slots = Gs + ATT_CH * LD;                 // 4 waves x [32][LD]
+  float* lse_s = slots + 4 * 32 * LD;              // [ATT_CH]
+  float* delta_s = lse_s + ATT_CH;                 // [ATT_CH]
+
+  const int bh = blockIdx.x, b = bh / H, h = bh % H;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
+  const float* Kb = K + base; const float* Vb = V + base;
+  float* dKb = dK + base; float* dVb = dV + base;
+  const float* dOb = dO + (int64_t)b * o_batch_stride + (int64_t)h * HD;
+  const int ntile = L / 32, nchunk = (L + ATT_CH - 1) / ATT_CH;
+  int tA, tB;
+  att_pair_of_wave(wave, bh, ntile, tA, tB);
+  const float inv_sqrt = 1.f / sqrt_hd;
+  const bool hi_ok = (32 + li) < HD;
+
+  float4 kf[NT8], vf[NT8];
+  f32x16 dk0, dk1, dv0, dv1;
+  int kt = -1;
+  auto begin_tile = [&](int t) {
+    kt = t;
+    const int kpos = kt * 32 + li;
+    const float* krow = Kb + (int64_t)kpos * row_stride + 4 * lh;
+    const float* vrow = Vb + (int64_t)kpos * row_stride + 4 * lh;
+#pragma unroll
+    for (int t8 = 0; t8 < NT8; ++t8) {
+      kf[t8] = *reinterpret_cast<const float4*>(krow + 8 * t8);
+      if (RC) kf[t8] = att_rot(kf[t8], RC, RS, kpos, 4 * t8 + 2 * lh, HD / 2, 1.f);
+      vf[t8] = *reinterpret_cast<const float4*>(vrow + 8 * t8);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.f; dk1[r] = 0.f; dv0[r] = 0.f; dv1[r] = 0.f; }
+  };
+  auto run_chunk = [&](int c0, int q_lo, int q_hi) {     // query tiles [q_lo, q_hi), chunk rows start at tile c0
+    const int kpos = kt * 32 + li;
+    for (int qt = q_lo; qt < q_hi; ++qt) {
+      const int j = qt - c0;
+      f32x16 sv, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sv[r] = 0.f; dp[r] = 0.f; }
+      const float* qrow = Qs + (j * 32 + li) * LD + 4 * lh;
+      const float* grow = Gs + (j * 32 + li) * LD + 4 * lh;
+#pragma unroll
+      for (int t8 = 0; t8 < NT8; ++t8) {
+        const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * t8);
+        const float4 g4 = *reinterpret_cast<const float4*>(grow + 8 * t8);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t8].x, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t8].x, dp, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[t8].y, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.y, vf[t8].y, dp, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[t8].z, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.z, vf[t8].z, dp, 0, 0, 0);
+        sv = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[t8].w, sv, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.w, vf[t8].w, dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ql = j * 32 + att_krow(r, lh);             // row inside the chunk
+        const bool masked = causal && (kpos > c0 * 32 + ql);
+        const float pv = masked ? 0.f : __expf(sv[r] * inv_sqrt - lse_s[ql]);
+        sv[r] = pv;
+        dp[r] = pv * (dp[r] - delta_s[ql]) * inv_sqrt;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qr = j * 32 + att_krow(r, lh);
+        const float g0 = Gs[qr * LD + li], q0 = Qs[qr * LD + li];
+        const float g1 = hi_ok ? Gs[qr * LD + 32 + li] : 0.f;
+        const float q1 = hi_ok ? Qs[qr * LD + 32 + li] : 0.f;
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, sv[r], dv0, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, dp[r], dk0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, sv[r], dv1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, dp[r], dk1, 0, 0, 0);
+      }
+    }
+  };
+  auto end_tile = [&]() {
+    float* slot = slots + wave * (32 * LD);
+    att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f,
+                         RC, RS, kt * 32);
+    att_store_tile_T<HD>(slot, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+  };
+  for (int c = 0; c < nchunk; ++c) {
+    const int c0 = 4 * c, rows = min(ATT_CH, L - ATT_CH * c);
+    if (c > 0) __syncthreads();
+    att_stage_chunk<HD, 256>(Qs, Gs, Q + base, dOb, ATT_CH * c, rows, row_stride, o_row_stride, tid, RC, RS, true, false);
+    for (int q = tid; q < rows; q += 256) {
+      lse_s[q] = LSE[(int64_t)bh * L + ATT_CH * c + q];
+      delta_s[q] = Delta[(int64_t)bh * L + ATT_CH * c + q];
+    }
+    __syncthreads();
+    const int c_end = c0 + rows / 32;              // query tiles [c0, c_end) are resident
+    const bool last = c == nchunk - 1;
+    // causal: key tile t needs query tiles [t, ntile).  A tile is started in the chunk that holds its own rows.
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const int t = which == 0 ? tA : tB;
+      if (t < 0 || t >= c_end) continue;           // its queries start in a later chunk
+      if (kt != t) begin_tile(t);
+      run_chunk(c0, max(t, c0), c_end);
+      if (last) end_tile();
+    }
+  }
 }
 
 // ======================================================================================

@@ -161,3 +161,40 @@ def test_attention_node_on_strided_views_and_cache_prefill(hip):
             fused.attention.use_flash = True
     for a, b in zip(res[0], res[1]):
         assert np.allclose(a, b, rtol=1e-4, atol=1e-5 * np.abs(b).max())
+
+
+@pytest.mark.gpu
+def test_chunked_resident_attention_matches_whole_head_kernels(hip):
+    """PDN_ATTN_CHUNKED=1: four waves per head, K,V / Q,dO through LDS in 128-row chunks, two workgroups per CU
+    (csrc/attention.hip) -- same results as the whole-head kernels up to the one online rescale (1e-5)."""
+    import os
+    from pydynet_amd import _lib
+    Lb = _lib.lib()
+    B, H, L, hd = 3, 6, 256, 48
+    D = H * hd
+    rng = np.random.default_rng(11)
+    qkv = hip.from_numpy(rng.standard_normal((B * L, 3 * D), dtype=np.float32))
+    do = hip.from_numpy(rng.standard_normal((B, L, H, hd), dtype=np.float32))
+    inv = 1.0 / (10000 ** (np.arange(0, hd, 2) / hd))
+    fr = np.outer(np.arange(L), inv).astype(np.float32)
+    C, S = hip.from_numpy(np.cos(fr)), hip.from_numpy(np.sin(fr))
+    q, k, v = qkv._ptr, qkv._ptr + 4 * D, qkv._ptr + 8 * D
+    ws, wsb = hip.workspace(4 * B * H * L)
+    out = {}
+    for chunked in (False, True):
+        if chunked:
+            os.environ["PDN_ATTN_CHUNKED"] = "1"
+        try:
+            o, lse = hip.empty((B, L, H, hd)), hip.empty((B, H, L))
+            dqkv = hip.empty((B * L, 3 * D))
+            dq, dk, dv = dqkv._ptr, dqkv._ptr + 4 * D, dqkv._ptr + 8 * D
+            Lb.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1,
+                    C._ptr, S._ptr, hip.stream())
+            Lb.call("pdn_attention_bwd_f32", q, k, v, o._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, L, hd, 3 * D,
+                    L * 3 * D, D, L * D, 1, C._ptr, S._ptr, ws, wsb, hip.stream())
+            out[chunked] = (o.get(), lse.get(), dqkv.get())
+        finally:
+            os.environ.pop("PDN_ATTN_CHUNKED", None)
+    for a, b, what in zip(out[True], out[False], ("o", "lse", "dqkv")):
+        err = np.abs(a - b).max() / np.abs(b).max()
+        assert err < 1e-5, (what, err)
