@@ -1093,6 +1093,8 @@ extern "C" int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int6
 int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out);
 int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
                               int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream);
+int pdn_gemm_outres_tn_blocks_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                                     int nb_cols, int nw, int k_per_split, void* stream);
 extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias,
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -1291,6 +1293,54 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
         g_prof.push_back(rec);
       }
       return PDN_OK;
+    }
+  }
+  // ---- the packed weight gradients of a transformer block out of the model width: x^T (288 x K) against dq | dk | dv
+  // (three 288-column blocks of one (K x 864) matrix) or dgate | dup (two 768-column blocks), one output per block.
+  // The same output-resident TN kernel, K split 40-64 ways so that the grid fills the chip, slabs in the batched
+  // layout of the split-K reduce (which adds beta * C).  Against the wave-streaming kernel: 864 columns -16 %,
+  // 1536 columns -11 % (60 instead of 170 operand bytes per MFMA; the slab pass costs 30-40 us).
+  {
+    const bool one_dim = nb1 == 1 || nb2 == 1;
+    const int64_t a_bs = nb1 == 1 ? a_bs2 : a_bs1, b_bs = nb1 == 1 ? b_bs2 : b_bs1;
+    const int64_t n_all = (int64_t)N * nbatch;
+    if (nbatch > 1 && one_dim && M == 288 && a_bs == 0 && b_bs == N && a_rs == 1 && a_cs >= 288 && b_cs == 1 &&
+        b_rs >= n_all && alpha == 1.f && !b_colsum && !bias && !residual && N % 32 == 0 && n_all >= 768 && n_all <= 8192 &&
+        K % 32 == 0 && K >= 16384 && m4(a_cs) && m4(b_rs) && al16(A) && al16(B) && !getenv("PDN_GEMM_NO_OUTRES")) {
+      int nw = 8, kps = K;
+      const int splits = pdn_gemm_outres_tn_plan((int)n_all, K, &nw, &kps);
+      if (splits > 1 && (int64_t)splits * M * n_all <= ws_cap && nbatch * splits <= 65535) {
+        bool prof;
+        ProfRec rec;
+        {
+          std::lock_guard<std::mutex> lk(g_prof_mu);
+          prof = g_prof_on;
+        }
+        if (prof) {
+          PDN_HIP(hipEventCreate(&rec.e0));
+          PDN_HIP(hipEventCreate(&rec.e1));
+          rec.flops = 2.0 * M * (double)n_all * (double)K;
+          rec.family = 3;
+          PDN_HIP(hipEventRecord(rec.e0, st));
+        }
+        if (getenv("PDN_GEMM_DEBUG"))
+          fprintf(stderr, "pdn_gemm_f32 M=%d N=%lld K=%d -> output-resident TN (%d blocks, splits %d)\n", M,
+                  (long long)n_all, K, nbatch, splits);
+        int rc = pdn_gemm_outres_tn_blocks_launch(A, B, (float*)workspace, (int)n_all, K, a_cs, b_rs, N, nw, kps, stream);
+        if (rc) return rc;
+        p.splits = splits;
+        const int64_t total = (int64_t)M * n_all;
+        const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        const int rvec = (ldc % 4 == 0) && al16(C) && m4(c_bs1) && m4(c_bs2) && al16(workspace);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, nbatch, rvec);
+        PDN_LAUNCH_CHECK();
+        if (prof) {
+          PDN_HIP(hipEventRecord(rec.e1, st));
+          std::lock_guard<std::mutex> lk(g_prof_mu);
+          g_prof.push_back(rec);
+        }
+        return PDN_OK;
+      }
     }
   }
   // ---- weight-gradient form (small output, long K): wave-streaming kernel --------------------

@@ -325,6 +325,10 @@ struct OutResTnParams {
   const float* gdev;
   float gscale;
   float* colsum;
+  // output in column blocks of `nb_cols` (x^T against dq | dk | dv: one weight gradient per block): block b of split s
+  // at C + b * blk_stride + s * slab, rows of `ldc` floats; nb_cols = N for a single matrix
+  int nb_cols;
+  int64_t blk_stride;
 };
 
 template <int NW, bool CE = false>
@@ -471,7 +475,8 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
     if (lh == 0) p.colsum[(int64_t)blockIdx.y * p.N + n0 + li] = csum;
   }
   // accumulator register r of tile i = row 32 i + (r & 3) + 8 (r >> 2) + 4 h, column n0 + lane
-  float* __restrict__ Cw = p.C + (int64_t)blockIdx.y * p.slab + n0 + li;
+  const int blk = n0 / p.nb_cols;                   // (a wave's 32 columns never straddle two blocks: nb_cols % 32 == 0)
+  float* __restrict__ Cw = p.C + blk * p.blk_stride + (int64_t)blockIdx.y * p.slab + (n0 - blk * p.nb_cols) + li;
   const unsigned ldc = (unsigned)p.ldc;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -527,7 +532,17 @@ static int outres_tn_launch(OutResTnParams& p, int nw, bool ce, void* stream) {
 // C slabs: slab s (rows of `ldc` floats) at C + s * slab receives the partial product of split s
 int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
                               int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream) {
-  OutResTnParams p{X, G, C, N, K, ldx, ldg, ldc, slab, k_per_split, nullptr, nullptr, nullptr, 0.f, nullptr};
+  OutResTnParams p{X, G, C, N, K, ldx, ldg, ldc, slab, k_per_split, nullptr, nullptr, nullptr, 0.f, nullptr, N, 0};
+  return outres_tn_launch(p, nw, false, stream);
+}
+
+// G (K x N) as `N / nb_cols` column blocks whose products go to separate outputs: slab s of block b at
+// C + (b * splits + s) * 288 * nb_cols, rows of nb_cols floats (the batched layout of gemm_splitk_reduce_kernel)
+int pdn_gemm_outres_tn_blocks_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
+                                     int nb_cols, int nw, int k_per_split, void* stream) {
+  const int splits = (K + k_per_split - 1) / k_per_split;
+  OutResTnParams p{X, G, C, N, K, ldx, ldg, nb_cols, (int64_t)288 * nb_cols, k_per_split, nullptr, nullptr, nullptr, 0.f,
+                   nullptr, nb_cols, (int64_t)splits * 288 * nb_cols};
   return outres_tn_launch(p, nw, false, stream);
 }
 
@@ -535,6 +550,6 @@ int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, i
 int pdn_outres_ce_dw_launch(const float* X, const float* logits, float* C, int N, int K, int64_t ldx, int64_t ldg,
                             int64_t ldc, int64_t slab, int nw, int k_per_split, const float* lse,
                             const int64_t* targets, float gscale, const float* gdev, float* colsum, void* stream) {
-  OutResTnParams p{X, logits, C, N, K, ldx, ldg, ldc, slab, k_per_split, lse, targets, gdev, gscale, colsum};
+  OutResTnParams p{X, logits, C, N, K, ldx, ldg, ldc, slab, k_per_split, lse, targets, gdev, gscale, colsum, N, 0};
   return outres_tn_launch(p, nw, true, stream);
 }

@@ -769,3 +769,24 @@ def test_gemm_weight_gradient_output_resident(hip, N, K, beta):
     hip.gemm(X.T, G, C, beta=beta)
     ref = x.T.astype(np.float64) @ g.astype(np.float64) + beta * c0
     assert rel_err(C.get(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("nblk,Nb", [(3, 288), (2, 768)])
+def test_gemm_packed_weight_gradients_output_resident(hip, nblk, Nb):
+    # x^T against the column blocks of one packed (K, nblk * Nb) gradient buffer, one (288, Nb) weight gradient per
+    # block accumulated in place (beta = 1): the batch that the fused QKV / gate|up nodes issue; output-resident TN
+    # kernel with K split over the grid, slabs in the batched layout of the split-K reduce
+    K = 16384
+    rng = np.random.default_rng(nblk)
+    x = rng.standard_normal((K, 288), dtype=np.float32)
+    g = rng.standard_normal((K, nblk * Nb), dtype=np.float32)
+    w0 = rng.standard_normal((nblk, 288, Nb), dtype=np.float32)
+    X, G = hip.from_numpy(x), hip.from_numpy(g)
+    flat = hip.from_numpy(w0.reshape(-1).copy())
+    views = [flat[(nblk - 1 - i) * 288 * Nb:(nblk - i) * 288 * Nb].reshape(288, Nb) for i in range(nblk)]   # descending
+    stack = hip.stacked_view(views)
+    blocks = hip.ndarray(G._buf, G._ptr, (nblk, K, Nb), (Nb, nblk * Nb, 1), G.dtype)
+    hip.gemm(X.T, blocks, stack, beta=1.0)
+    for i in range(nblk):
+        ref = w0[nblk - 1 - i] + x.T.astype(np.float64) @ g[:, i * Nb:(i + 1) * Nb].astype(np.float64)
+        assert rel_err(views[i].get(), ref) < 2e-5
