@@ -231,7 +231,7 @@ template <int HD> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_
 template <int HD> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void attention_bwd_dkv2_kernel(const float*, const float*, const float*, const float*, const float*,
                                                             const float*, float*, float*, int, int, int64_t, int64_t, int64_t,
                                                             int64_t, float, int, const float*, const float*);
-extern "C" int64_t pdn_attention_chunk_lds_bytes(int head_dim);
+static int64_t pdn_attention_chunk_lds_bytes(int head_dim);
 // opt-in (PDN_ATTN_CHUNKED=1, read per call): the chunked kernels measured the SAME times as the whole-head ones
 static inline bool att_use_chunked() { return getenv("PDN_ATTN_CHUNKED") != nullptr; }
 
@@ -670,7 +670,7 @@ __device__ __forceinline__ void att_pair_of_wave(int w, int bh, int ntile, int& 
   else if (a == b) b = -1;
 }
 
-extern "C" int64_t pdn_attention_chunk_lds_bytes(int head_dim) {
+static int64_t pdn_attention_chunk_lds_bytes(int head_dim) {
   return ((int64_t)2 * ATT_CH + 4 * 32) * ATT_LD(head_dim) * 4 + 2 * ATT_CH * 4;
 }
 
