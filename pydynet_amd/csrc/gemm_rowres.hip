@@ -152,7 +152,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   // (I clamped: a repeated instruction is harmless)
   // STAGE 1: the wave's share of the next piece on its way to LDS, in two halves (fetched in the first / second
   // half of the current piece and parked in its middle / at its end): half the staging registers
-  constexpr int RBN = STAGE ? (NQ + 1) / 2 : 1;
+  constexpr int NPH = BT ? 2 : 3;                  // staging phases per piece (NN: three, to fit the register budget)
+  constexpr int WIN = 12 / NPH;                    // slots (k-groups) per phase
+  constexpr int RBN = STAGE ? (NQ + NPH - 1) / NPH : 1;
   float4 rb[RBN];
   auto issue_one = [&](int buf, int c, const float* cb, int kc, int q) {
     const bool tail = c == c_tail;
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   if (nloc > 0) {
     if (STAGE) {
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < NPH; ++h) {
 #pragma unroll
         for (int e = 0; e < RBN; ++e)
           if (h * RBN + e < NQ) issue_one(0, chunk_of(0), chunk_base(chunk_of(0)), 0, h * RBN + e);
@@ -273,33 +275,46 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       constexpr int PER = NW == 4 ? 2 : 1;
 #define RR_SLOT(T)                                                                   \
   if (STAGE) {                                                                       \
-    if ((T) < 6) { if ((T) < RBN) issue_one(nb, nc, ncb, nk, (T)); }                  \
-    else if ((T) - 6 < NQ - RBN) issue_one(nb, nc, ncb, nk, RBN + (T) - 6);           \
-    if ((T) == 5) park(nb, 0);                                                       \
+    if ((T) % WIN < RBN && ((T) / WIN) * RBN + (T) % WIN < NQ) issue_one(nb, nc, ncb, nk, ((T) / WIN) * RBN + (T) % WIN); \
+    if ((T) % WIN == WIN - 1 && (T) / WIN < NPH - 1) park(nb, (T) / WIN);            \
   } else if (!(ABLATE & 34) || (more && !(ABLATE & 32))) {                           \
     _Pragma("unroll") for (int e = 0; e < PER; ++e)                                  \
       if (PER * (T) + e < NQ) issue_one(nb, nc, ncb, nk, PER * (T) + e);             \
   }
-      RR_LOADB(b0, 0)
+      if (STAGE && !BT) {
+        // (NN, register-staged: one fragment set -- the partner wave of the SIMD covers the LDS latency; the second
+        //  set is what the staging registers are paid with)
 #pragma unroll
-      for (int g = 0; g < 12; g += 2) {
-        RR_LOADB(b1, g + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        RR_MFMA(b0, g)
-        __builtin_amdgcn_sched_barrier(0);
-        RR_SLOT(g)
-        __builtin_amdgcn_sched_barrier(0);
-        if (g + 2 < 12) { RR_LOADB(b0, g + 2) }
-        __builtin_amdgcn_sched_barrier(0);
-        RR_MFMA(b1, g + 1)
-        __builtin_amdgcn_sched_barrier(0);
-        RR_SLOT(g + 1)
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < 12; ++g) {
+          RR_LOADB(b0, g)
+          __builtin_amdgcn_sched_barrier(0);
+          RR_MFMA(b0, g)
+          __builtin_amdgcn_sched_barrier(0);
+          RR_SLOT(g)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+        RR_LOADB(b0, 0)
+#pragma unroll
+        for (int g = 0; g < 12; g += 2) {
+          RR_LOADB(b1, g + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          RR_MFMA(b0, g)
+          __builtin_amdgcn_sched_barrier(0);
+          RR_SLOT(g)
+          __builtin_amdgcn_sched_barrier(0);
+          if (g + 2 < 12) { RR_LOADB(b0, g + 2) }
+          __builtin_amdgcn_sched_barrier(0);
+          RR_MFMA(b1, g + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          RR_SLOT(g + 1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #undef RR_LOADB
 #undef RR_SLOT
 #undef RR_MFMA
-      if (STAGE) park(nb, 1);                       // every wave is past this piece's barrier: that buffer is idle
+      if (STAGE) park(nb, NPH - 1);                 // every wave is past this piece's barrier: that buffer is idle
     }
     // ---- store the finished 32 x 96 block of this wave -------------------------------------
     rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
@@ -335,11 +350,12 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
   static const int nw_env = getenv("PDN_ROWRES_NW") ? atoi(getenv("PDN_ROWRES_NW")) : 0;
   static const int stage_env = getenv("PDN_ROWRES_STAGE") ? atoi(getenv("PDN_ROWRES_STAGE")) : -1;
-  // NT: register-staged B (8-wave workgroups: 72.9 vs 68.6 % at N = 768, 87.9 vs 75.8 % at N = 32000); NN keeps the
-  // LDS-DMA -- its ds_read_b32 fragment addressing leaves no registers for the staging (the staged form spills)
+  // register-staged B in 8-wave workgroups: NT 72.9 vs 68.6 % at N = 768, 87.9 vs 75.8 % at N = 32000; NN (staged in
+  // three phases with a single fragment set, which is what fits in 256 registers) 85.7 vs 84.5 % at N = 32000, 76.1 vs
+  // 74.8 % at 1536, 73.3 vs 71.7 % at 864.  The 4-wave form (fewer rows than fill the chip) keeps the LDS-DMA.
   // one 8-wave workgroup per CU (half the fetch instructions per wave) as long as that fills the chip
   const int nw = nw_env ? nw_env : ((M + 255) / 256 >= 192) ? 8 : 4;
-  const int stage = stage_env >= 0 ? stage_env : (b_trans && nw == 8 ? 1 : 0);
+  const int stage = stage_env >= 0 ? stage_env : (nw == 8 ? 1 : 0);
   const int row_blocks = (M + 32 * nw - 1) / (32 * nw), target = nw == 4 ? 512 : 256;
   // fill every CU (two 4-wave or one 8-wave workgroup each): split the chunks over grid.y
   int nsplit = 1;
