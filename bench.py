@@ -93,8 +93,23 @@ def parity_gate(model, dev, pdn):
     model.train(True)
     for p in model.parameters():
         p.zero_grad()
-    loss = model.loss(ids, tgt)
-    loss.backward()
+    # the gate must take the nodes the timed steps take: at 256 tokens the model would otherwise use the separate
+    # lm_head / cross-entropy nodes (the fused one starts at 32768 tokens, where its kernels fill the chip)
+    from pydynet_amd.core import fused
+    calls = {"n": 0}
+    orig_init, min_rows = fused.linear_cross_entropy.__init__, fused.linear_cross_entropy.min_rows
+
+    def counting_init(self, *a, **k):
+        calls["n"] += 1
+        orig_init(self, *a, **k)
+    fused.linear_cross_entropy.__init__, fused.linear_cross_entropy.min_rows = counting_init, 32
+    try:
+        loss = model.loss(ids, tgt)
+        loss.backward()
+    finally:
+        fused.linear_cross_entropy.__init__, fused.linear_cross_entropy.min_rows = orig_init, min_rows
+    if calls["n"] != 1:
+        raise SystemExit("bench.py parity gate FAILED: the step did not take the fused lm_head + cross-entropy node")
     got = float(loss.item())
     if not abs(got - GATE_LOSS) <= GATE_RTOL * GATE_LOSS:
         raise SystemExit(f"bench.py parity gate FAILED: loss {got!r} != reference {GATE_LOSS!r} (rtol {GATE_RTOL}); "
@@ -113,7 +128,7 @@ def parity_gate(model, dev, pdn):
         p.zero_grad()
     return {"loss": got, "reference_loss": GATE_LOSS, "rel_err": abs(got - GATE_LOSS) / GATE_LOSS,
             "grad_norms_checked": sum(v is not None for v in norms.values()), "worst_grad_norm_rel_err": worst,
-            "rtol": GATE_RTOL}
+            "rtol": GATE_RTOL, "fused_nodes_taken": ["qkv_attention", "gate_up_swiglu", "linear_cross_entropy"]}
 
 
 def pmc_traffic():
