@@ -790,3 +790,25 @@ def test_gemm_packed_weight_gradients_output_resident(hip, nblk, Nb):
     for i in range(nblk):
         ref = w0[nblk - 1 - i] + x.T.astype(np.float64) @ g[:, i * Nb:(i + 1) * Nb].astype(np.float64)
         assert rel_err(views[i].get(), ref) < 2e-5
+
+
+def test_gemm_resident_kernels_strided_operands(hip):
+    # A as a column block of a wider packed buffer (row stride 864 > K), C as a column block of a wider output:
+    # the row-resident and output-resident kernels take leading dimensions, not just contiguous matrices
+    M = 57344
+    rng = np.random.default_rng(21)
+    packed = rng.standard_normal((M, 864), dtype=np.float32)
+    P = hip.from_numpy(packed)
+    a_view = P[:, 288:576]                                     # (M, 288), row stride 864
+    w1 = 0.1 * rng.standard_normal((288, 768), dtype=np.float32)
+    out = hip.empty((M, 1536), np.float32)
+    c_view = out[:, 768:]                                      # (M, 768), row stride 1536
+    hip.gemm(a_view, hip.from_numpy(w1), c_view)               # row-resident (K = 288, N = 768)
+    ref = packed[:256, 288:576].astype(np.float64) @ w1.astype(np.float64)
+    assert rel_err(out.get()[:256, 768:], ref) < 1e-5
+    a2 = P[:, :768]                                            # (M, 768), row stride 864
+    w2 = 0.1 * rng.standard_normal((768, 288), dtype=np.float32)
+    out2 = hip.empty((M, 576), np.float32)
+    hip.gemm(a2, hip.from_numpy(w2), out2[:, 288:])            # output-resident (N = 288, K = 768)
+    ref2 = packed[-256:, :768].astype(np.float64) @ w2.astype(np.float64)
+    assert rel_err(out2.get()[-256:, 288:], ref2) < 1e-5
