@@ -12,7 +12,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpdnhip.so")
+LIB_PATH = os.environ.get("PDN_LIB") or os.path.join(_HERE, "libpdnhip.so")     # PDN_LIB: another build, for same-box A/B runs
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "pdn_hip.h")
 
 _CTYPE = {

@@ -156,35 +156,42 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
         }
       }
     }
-    // ---- scale, mask, softmax over keys (per lane = per query) ------------------------------
+    // ---- mask, softmax over keys (per lane = per query) ---------------------------------------
+    // The 1/sqrt(hd) scale rides inside the exponential: p = exp2(s * c1 - max(s) * c1), c1 = log2(e) / sqrt(hd)
+    // (the row maximum is taken on the unscaled scores; the scale is positive), and only the diagonal key tile
+    // needs the causal compare -- four VALU operations per score instead of eight, in kernels whose waves are
+    // bound by their own instruction stream.
     const int qpos = qt * 32 + li;
+    const float c1 = inv_sqrt * 1.4426950408889634f;
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
       if (kt < nk && !(ABLATE & 4)) {
+        if (causal && kt == qt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float v = s[kt][r] * inv_sqrt;   // (x * (1/sqrt(hd)): within 1 ulp of the reference division)
-          if (causal && kt * 32 + att_krow(r, lh) > qpos) v = -INFINITY;
-          s[kt][r] = v;
-          m = fmaxf(m, v);
+          for (int r = 0; r < 16; ++r)
+            if (kt * 32 + att_krow(r, lh) > qpos) s[kt][r] = -INFINITY;
         }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(s[kt][r], s[kt][r + 1]));      // v_max3_f32
       }
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
+    const float c2 = -m * c1;
     float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
       if (kt < nk && !(ABLATE & 4)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = __expf(s[kt][r] - m);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, c2));
           s[kt][r] = p;
           l += p;
         }
       }
     }
     l += __shfl_xor(l, 32, 64);
+    m *= inv_sqrt;                                  // the maximum of the SCALED scores (for the log-sum-exp)
     // ---- O^T = V^T P^T  (two 32-row tiles over the head dim, the second half empty for hd=48)
     f32x16 o0, o1;
 #pragma unroll
@@ -388,6 +395,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   }
   const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
   const float lse_q = LSE[(int64_t)bh * L + qpos];
+  const float c1 = inv_sqrt * 1.4426950408889634f, c2q = -lse_q * 1.4426950408889634f;
   if (lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
   f32x16 dq0, dq1;
 #pragma unroll
@@ -411,12 +419,17 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
     }
-    // dS^T[key][q] = P^T o (dP^T - delta_q) / sqrt(hd)   (lane = q)
+    // dS^T[key][q] = P^T o (dP^T - delta_q) / sqrt(hd)   (lane = q);  P = exp2(s * c1 - lse * log2(e)), the causal
+    // compare only on the diagonal tile
+    if (causal && kt == qt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kt * 32 + att_krow(r, lh) > qpos) s[r] = -INFINITY;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const bool masked = causal && (kt * 32 + att_krow(r, lh) > qpos);
-      const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_q);
-      s[r] = p * (dp[r] - delta_q) * inv_sqrt;
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, c2q));
+      s[r] = p * (dp[r] - delta_q);                 // (the 1/sqrt(hd) of dS is applied once, when dQ is stored)
     }
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     }
   }
   att_store_tile_T<HD>(slots + wave * (32 * LD), dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride,
-                       row_stride, li, lh, lane, 1.f, RC, RS, qt * 32);
+                       row_stride, li, lh, lane, inv_sqrt, RC, RS, qt * 32);
 }
 
 template <int HD>
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + (int64_t)b * o_batch_stride + (int64_t)h * HD, L, row_stride,
                          o_row_stride, tid, RC, RS, true, false);
   for (int q = tid; q < L; q += 512) {
-    lse_s[q] = LSE[(int64_t)bh * L + q];
+    lse_s[q] = LSE[(int64_t)bh * L + q] * 1.4426950408889634f;
     delta_s[q] = Delta[(int64_t)bh * L + q];
   }
   __syncthreads();
@@ -468,6 +481,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const int kt = att_tile_of_wave(wave);
   if (kt >= ntile) return;
   const float inv_sqrt = 1.f / sqrt_hd;
+  const float c1 = inv_sqrt * 1.4426950408889634f;
   const bool hi_ok = (32 + li) < HD;
   const int kpos = kt * 32 + li;
   float4 kf[NT8], vf[NT8];
@@ -504,14 +518,19 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[t].w, s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.w, vf[t].w, dp, 0, 0, 0);
     }
-    // lane = key, registers = queries
+    // lane = key, registers = queries;  P = exp2(s * c1 - lse * log2(e)) (lse_s holds lse * log2(e)), the causal
+    // compare only on the diagonal tile
+    if (causal && qt == kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (kpos > qt * 32 + att_krow(r, lh)) s[r] = -INFINITY;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int q = qt * 32 + att_krow(r, lh);
-      const bool masked = causal && (kpos > q);
-      const float p = masked ? 0.f : __expf(s[r] * inv_sqrt - lse_s[q]);
+      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, -lse_s[q]));
       s[r] = p;                                          // P[q][key]
-      dp[r] = p * (dp[r] - delta_s[q]) * inv_sqrt;       // dS[q][key]
+      dp[r] = p * (dp[r] - delta_s[q]);                  // dS[q][key] * sqrt(hd): the scale is applied when dK is stored
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -526,7 +545,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     }
   }
   float* slot = slots + wave * (32 * LD);
-  att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f,
+  att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, inv_sqrt,
                        RC, RS, kt * 32);
   att_store_tile_T<HD>(slot, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
 }
