@@ -94,6 +94,46 @@ __device__ __forceinline__ void att_stage_two(float* __restrict__ s0, float* __r
   }
 }
 
+// Forward staging: K as [L][HD+4]; V as [L][64] with column HD = 1 and columns HD+1 .. 63 = 0.  The second 32-row
+// tile of O^T = V^T P^T then needs no per-lane select for the rows beyond HD, and its row HD accumulates the
+// softmax denominator (the row sums of P) for free -- the padded tile is multiplied anyway.
+#define ATT_LDV 64
+template <int HD, int NT>
+__device__ __forceinline__ void att_stage_kv(float* __restrict__ ks, float* __restrict__ vs,
+                                             const float* __restrict__ gk, const float* __restrict__ gv,
+                                             int L, int64_t row_stride, int tid,
+                                             const float* __restrict__ cs, const float* __restrict__ sn) {
+  constexpr int LD = ATT_LD(HD), F4 = HD / 4;
+  constexpr int NP = (ATT_MAX_TILES * 32 * F4 + NT - 1) / NT;
+  float4 r0[NP], r1[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < L * F4) {
+      const int row = u / F4, c4 = u % F4;
+      float4 a = *reinterpret_cast<const float4*>(gk + (int64_t)row * row_stride + 4 * c4);
+      const float4 c = *reinterpret_cast<const float4*>(gv + (int64_t)row * row_stride + 4 * c4);
+      if (cs) a = att_rot(a, cs, sn, row, 2 * c4, HD / 2, 1.f);
+      r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
+      r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < L * F4) {
+      const int row = u / F4, c4 = u % F4;
+      *reinterpret_cast<float4*>(ks + row * LD + 4 * c4) = r0[j];
+      *reinterpret_cast<float4*>(vs + row * ATT_LDV + 4 * c4) = r1[j];
+    }
+  }
+  constexpr int PF4 = (ATT_LDV - HD) / 4;                 // pad units per row
+  for (int u = tid; u < L * PF4; u += NT) {
+    const int row = u / PF4, pc = u % PF4;
+    *reinterpret_cast<float4*>(vs + row * ATT_LDV + HD + 4 * pc) = make_float4(pc == 0 ? 1.f : 0.f, 0.f, 0.f, 0.f);
+  }
+}
+
 // ABLATE (tools/micro/attn_ablate.hip only; 0 in the library): 1 = no K/V staging, 2 = no S^T MFMAs,
 // 4 = no softmax arithmetic, 8 = no PV MFMAs, 16 = no output store -- timing experiments, wrong results.
 template <int HD, int ABLATE = 0>
@@ -107,8 +147,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   constexpr int F4 = HD / 4;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* Ks = lds;                               // [L][LD]
-  float* Vs = lds + (size_t)L * LD;              // [L][LD]
-  float* Os = Vs + (size_t)L * LD;               // 8 waves x [32][LD] output staging
+  float* Vs = lds + (size_t)L * LD;              // [L][64]: V | 1 | 0 ...
 
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -118,14 +157,13 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   const float* Qb = Q + base;
   float* Ob = O + (int64_t)b * o_batch_stride + (int64_t)h * HD;
 
-  if (!(ABLATE & 1)) att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, row_stride, tid, RC, RS, true, false);
+  if (!(ABLATE & 1)) att_stage_kv<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, tid, RC, RS);
   __syncthreads();
 
   const int ntile = L / 32;
   const int qt = att_tile_of_wave(wave);
   if (qt >= ntile) return;                       // no workgroup barrier below this point
   const float inv_sqrt = 1.f / sqrt_hd;
-  float* Ow = Os + wave * (32 * LD);
   {
     const int nk = causal ? qt + 1 : ntile;       // key tiles that can be unmasked
     // Q fragments: lane (li, lh) holds Q[q = qt*32+li][8t + 4lh .. +3]
@@ -178,53 +216,48 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     const float c2 = -m * c1;
-    float l = 0.f;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
       if (kt < nk && !(ABLATE & 4)) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, c2));
-          s[kt][r] = p;
-          l += p;
-        }
+        for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c1, c2));
       }
     }
-    l += __shfl_xor(l, 32, 64);
     m *= inv_sqrt;                                  // the maximum of the SCALED scores (for the log-sum-exp)
     // ---- O^T = V^T P^T  (two 32-row tiles over the head dim, the second half empty for hd=48)
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    const bool hi_ok = (32 + li) < HD;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
       if (kt < nk && !(ABLATE & 8)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float* vrow = Vs + (kt * 32 + att_krow(r, lh)) * LD;
+          const float* vrow = Vs + (kt * 32 + att_krow(r, lh)) * ATT_LDV;
           const float a0 = vrow[li];
-          const float a1 = hi_ok ? vrow[32 + li] : 0.f;
+          const float a1 = vrow[32 + li];            // columns HD.. of the padded row: 1, 0, 0, ...
           o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[kt][r], o0, 0, 0, 0);
           o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[kt][r], o1, 0, 0, 0);
         }
       }
     }
-    // ---- normalise, stage [q][d] in LDS, store rows coalesced -------------------------------
+    // ---- row HD of O^T (register 4 (HD - 32) / 8 of the lower half-wave's second tile) is the softmax denominator
+    static_assert((HD - 32) % 8 == 0 && HD > 32 && HD < 64, "the ones column must land in the lower half-wave");
+    float l = o1[(HD - 32) / 2];
+    l = __shfl(l, li, 64);
+    // ---- normalise and store: a lane holds 4 consecutive head-dim values of its query row per register group ----
     const float inv_l = 1.f / l;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int d = att_krow(r, lh);
-      Ow[li * LD + d] = o0[r] * inv_l;
-      if (32 + d < HD) Ow[li * LD + 32 + d] = o1[r] * inv_l;
-    }
     if (lh == 0) LSE[(int64_t)bh * L + qpos] = m + logf(l);
-    __builtin_amdgcn_s_waitcnt(0xc07f);
-    __builtin_amdgcn_wave_barrier();
-    for (int u = lane; u < 32 * F4 && !(ABLATE & 16); u += 64) {
-      const int row = u / F4, c4 = u % F4;
-      *reinterpret_cast<float4*>(Ob + (int64_t)(qt * 32 + row) * o_row_stride + 4 * c4) =
-          *reinterpret_cast<const float4*>(Ow + row * LD + 4 * c4);
+    if (!(ABLATE & 16)) {
+      float* orow = Ob + (int64_t)qpos * o_row_stride + 4 * lh;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(orow + 8 * g) =
+            make_float4(o0[4 * g] * inv_l, o0[4 * g + 1] * inv_l, o0[4 * g + 2] * inv_l, o0[4 * g + 3] * inv_l);
+#pragma unroll
+      for (int g = 0; g < (HD - 32) / 8; ++g)
+        *reinterpret_cast<float4*>(orow + 32 + 8 * g) =
+            make_float4(o1[4 * g] * inv_l, o1[4 * g + 1] * inv_l, o1[4 * g + 2] * inv_l, o1[4 * g + 3] * inv_l);
     }
   }
 }
@@ -245,6 +278,7 @@ static inline bool att_use_chunked() { return getenv("PDN_ATTN_CHUNKED") != null
 extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
   return ((int64_t)2 * L + 8 * 32) * ATT_LD(head_dim) * 4;
 }
+static int64_t att_fwd_lds_bytes(int L, int head_dim) { return (int64_t)L * (ATT_LD(head_dim) + ATT_LDV) * 4; }
 
 // q, k, v (and dq, dk, dv): (B, L, H, head_dim) contiguous in head_dim, `row_stride` between consecutive
 // positions, `batch_stride` between batches -- e.g. column blocks of one packed (B*L, 3*H*hd) projection;
@@ -268,7 +302,7 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
                     (o_batch_stride % 4) == 0 &&
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0),
                 "pdn_attention_fwd_f32: 16-byte alignment required");
-  const size_t shm = (size_t)pdn_attention_lds_bytes(L, head_dim);
+  const size_t shm = (size_t)att_fwd_lds_bytes(L, head_dim);
   static bool attr_set = false;
   if (!attr_set) {
     PDN_HIP(hipFuncSetAttribute((const void*)attention_fwd_kernel<48>,
