@@ -134,6 +134,71 @@ __device__ __forceinline__ void att_stage_kv(float* __restrict__ ks, float* __re
   }
 }
 
+// Backward staging: two [L][HD] matrices as [L][ATT_LDP] images whose columns HD .. 63 are ZERO, so that the second
+// 32-row MFMA tile over the head dim reads its operand rows HD .. 63 unconditionally (no per-lane select per MFMA).
+// ATT_LDP = 68: 272-byte rows keep both access patterns conflict free (ds_read_b128 fragments along the row for
+// 16 consecutive rows, ds_read_b32 across 32 consecutive columns).
+#define ATT_LDP 68
+template <int HD, int NT, bool PAD0, bool PAD1>
+__device__ __forceinline__ void att_stage_two_pad(float* __restrict__ s0, float* __restrict__ s1,
+                                                  const float* __restrict__ g0, const float* __restrict__ g1,
+                                                  int L, int64_t row_stride, int64_t row_stride1, int tid,
+                                                  const float* __restrict__ cs, const float* __restrict__ sn,
+                                                  bool rot0, bool rot1) {
+  constexpr int LD0 = PAD0 ? ATT_LDP : ATT_LD(HD), LD1 = PAD1 ? ATT_LDP : ATT_LD(HD), F4 = HD / 4;
+  constexpr int NP = (ATT_MAX_TILES * 32 * F4 + NT - 1) / NT;
+  float4 r0[NP], r1[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < L * F4) {
+      const int row = u / F4, c4 = u % F4;
+      float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)row * row_stride + 4 * c4);
+      float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride1 + 4 * c4);
+      if (cs && rot0) a = att_rot(a, cs, sn, row, 2 * c4, HD / 2, 1.f);
+      if (cs && rot1) c = att_rot(c, cs, sn, row, 2 * c4, HD / 2, 1.f);
+      r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
+      r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int u = tid + NT * j;
+    if (u < L * F4) {
+      const int row = u / F4, c4 = u % F4;
+      *reinterpret_cast<float4*>(s0 + row * LD0 + 4 * c4) = r0[j];
+      *reinterpret_cast<float4*>(s1 + row * LD1 + 4 * c4) = r1[j];
+    }
+  }
+  constexpr int PF4 = (64 - HD) / 4;
+  for (int u = tid; u < L * PF4; u += NT) {
+    const int row = u / PF4, pc = u % PF4;
+    if (PAD0) *reinterpret_cast<float4*>(s0 + row * LD0 + HD + 4 * pc) = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (PAD1) *reinterpret_cast<float4*>(s1 + row * LD1 + HD + 4 * pc) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// X^T tiles t0 / t1 (lane = row, register r = head-dim index (r & 3) + 8 (r >> 2) + 4 h) -> the lane's own row of a
+// (rows, HD) matrix: four consecutive head-dim values per register group, stored as 16-byte pieces straight from the
+// accumulators.  `rowp` = first element of the lane's row + 4 h.  cs / sn: rotate back (the gradient of RoPE).
+template <int HD>
+__device__ __forceinline__ void att_store_rows(const f32x16& t0, const f32x16& t1, float* __restrict__ rowp, int lh,
+                                               float scale, const float* __restrict__ cs = nullptr,
+                                               const float* __restrict__ sn = nullptr, int pos = 0) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float4 v = make_float4(t0[4 * g] * scale, t0[4 * g + 1] * scale, t0[4 * g + 2] * scale, t0[4 * g + 3] * scale);
+    if (cs) v = att_rot(v, cs, sn, pos, 4 * g + 2 * lh, HD / 2, -1.f);
+    *reinterpret_cast<float4*>(rowp + 8 * g) = v;
+  }
+#pragma unroll
+  for (int g = 0; g < (HD - 32) / 8; ++g) {
+    float4 v = make_float4(t1[4 * g] * scale, t1[4 * g + 1] * scale, t1[4 * g + 2] * scale, t1[4 * g + 3] * scale);
+    if (cs) v = att_rot(v, cs, sn, pos, 16 + 4 * g + 2 * lh, HD / 2, -1.f);
+    *reinterpret_cast<float4*>(rowp + 32 + 8 * g) = v;
+  }
+}
+
 // ABLATE (tools/micro/attn_ablate.hip only; 0 in the library): 1 = no K/V staging, 2 = no S^T MFMAs,
 // 4 = no softmax arithmetic, 8 = no PV MFMAs, 16 = no output store -- timing experiments, wrong results.
 template <int HD, int ABLATE = 0>
@@ -180,14 +245,14 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     f32x16 s[ATT_MAX_TILES];
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
       if (kt < nk && !(ABLATE & 2)) {
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
 #pragma unroll
         for (int t = 0; t < NT8; ++t) {
           const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t);
-          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s[kt], 0, 0, 0);
+          // (the first product of a tile takes the constant 0 as its accumulator input: no 16 v_mov per tile)
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, t == 0 ? zero16 : s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s[kt], 0, 0, 0);
@@ -389,9 +454,9 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Ks = lds;                                 // [L][LD]
-  float* Vs = Ks + (size_t)L * LD;                 // [L][LD]
-  float* slots = Vs + (size_t)L * LD;              // 8 waves x [32][LD]
+  constexpr int LDK = ATT_LDP;
+  float* Ks = lds;                                 // [L][68]: K | 0 (read along the row for S, down the columns for dQ)
+  float* Vs = Ks + (size_t)L * LDK;                // [L][LD]
 
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -402,14 +467,13 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   const float* Qb = Q + base; const float* Ob = O + obase; const float* dOb = dO + obase;
   float* dQb = dQ + base;
 
-  att_stage_two<HD, 512>(Ks, Vs, K + base, V + base, L, row_stride, row_stride, tid, RC, RS, true, false);
+  att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, row_stride, row_stride, tid, RC, RS, true, false);
   __syncthreads();
 
   const int ntile = L / 32;
   const int qt = att_tile_of_wave(wave);
   if (qt >= ntile) return;
   const float inv_sqrt = 1.f / sqrt_hd;
-  const bool hi_ok = (32 + li) < HD;
   const int nk = causal ? qt + 1 : ntile;
   const int qpos = qt * 32 + li;
   float4 qf[NT8], gf[NT8];
@@ -436,16 +500,16 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
   for (int kt = 0; kt < nk; ++kt) {
     f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    const float* krow = Ks + (kt * 32 + li) * LD + 4 * lh;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* krow = Ks + (kt * 32 + li) * LDK + 4 * lh;
     const float* vrow = Vs + (kt * 32 + li) * LD + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       const float4 kf = *reinterpret_cast<const float4*>(krow + 8 * t);
       const float4 vf = *reinterpret_cast<const float4*>(vrow + 8 * t);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, dp, 0, 0, 0);
+      // (the first product of a tile takes the constant 0 as its accumulator input: no 32 v_mov per tile pair)
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, t == 0 ? zero16 : s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, t == 0 ? zero16 : dp, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t].y, dp, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s, 0, 0, 0);
@@ -468,15 +532,14 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float* kr = Ks + (kt * 32 + att_krow(r, lh)) * LD;
+      const float* kr = Ks + (kt * 32 + att_krow(r, lh)) * LDK;
       const float a0 = kr[li];
-      const float a1 = hi_ok ? kr[32 + li] : 0.f;
+      const float a1 = kr[32 + li];                    // columns HD .. 63 of the padded row are zero
       dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], dq0, 0, 0, 0);
       dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], dq1, 0, 0, 0);
     }
   }
-  att_store_tile_T<HD>(slots + wave * (32 * LD), dq0, dq1, dQb + (int64_t)(qt * 32) * row_stride,
-                       row_stride, li, lh, lane, inv_sqrt, RC, RS, qt * 32);
+  att_store_rows<HD>(dq0, dq1, dQb + (int64_t)qpos * row_stride + 4 * lh, lh, inv_sqrt, RC, RS, qpos);
 }
 
 template <int HD>
@@ -489,10 +552,10 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Qs = lds;                                 // [L][LD]
-  float* Gs = Qs + (size_t)L * LD;                 // [L][LD]   dO
-  float* slots = Gs + (size_t)L * LD;              // 8 waves x [32][LD]
-  float* lse_s = slots + 8 * 32 * LD;              // [L]
+  constexpr int LDP = ATT_LDP;
+  float* Qs = lds;                                 // [L][68]: Q | 0
+  float* Gs = Qs + (size_t)L * LDP;                // [L][68]: dO | 0
+  float* lse_s = Gs + (size_t)L * LDP;             // [L]
   float* delta_s = lse_s + L;                      // [L]
 
   const int bh = blockIdx.x, b = bh / H, h = bh % H;
@@ -503,8 +566,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const float* Kb = K + base; const float* Vb = V + base;
   float* dKb = dK + base; float* dVb = dV + base;
 
-  att_stage_two<HD, 512>(Qs, Gs, Q + base, dO + (int64_t)b * o_batch_stride + (int64_t)h * HD, L, row_stride,
-                         o_row_stride, tid, RC, RS, true, false);
+  att_stage_two_pad<HD, 512, true, true>(Qs, Gs, Q + base, dO + (int64_t)b * o_batch_stride + (int64_t)h * HD, L,
+                                         row_stride, o_row_stride, tid, RC, RS, true, false);
   for (int q = tid; q < L; q += 512) {
     lse_s[q] = LSE[(int64_t)bh * L + q] * 1.4426950408889634f;
     delta_s[q] = Delta[(int64_t)bh * L + q];
@@ -516,7 +579,6 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   if (kt >= ntile) return;
   const float inv_sqrt = 1.f / sqrt_hd;
   const float c1 = inv_sqrt * 1.4426950408889634f;
-  const bool hi_ok = (32 + li) < HD;
   const int kpos = kt * 32 + li;
   float4 kf[NT8], vf[NT8];
   {
@@ -535,16 +597,16 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const int q_first = causal ? kt : 0;
   for (int qt = q_first; qt < ntile; ++qt) {
     f32x16 s, dp;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-    const float* qrow = Qs + (qt * 32 + li) * LD + 4 * lh;
-    const float* grow = Gs + (qt * 32 + li) * LD + 4 * lh;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* qrow = Qs + (qt * 32 + li) * LDP + 4 * lh;
+    const float* grow = Gs + (qt * 32 + li) * LDP + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       const float4 q4 = *reinterpret_cast<const float4*>(qrow + 8 * t);
       const float4 g4 = *reinterpret_cast<const float4*>(grow + 8 * t);
-      s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t].x, s, 0, 0, 0);    // S[q][key]
-      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t].x, dp, 0, 0, 0);  // dP[q][key]
+      // (the first product of a tile takes the constant 0 as its accumulator input: no 32 v_mov per tile pair)
+      s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t].x, t == 0 ? zero16 : s, 0, 0, 0);    // S[q][key]
+      dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t].x, t == 0 ? zero16 : dp, 0, 0, 0);  // dP[q][key]
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[t].y, s, 0, 0, 0);
       dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.y, vf[t].y, dp, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.z, kf[t].z, s, 0, 0, 0);
@@ -560,33 +622,39 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
         if (kpos > qt * 32 + att_krow(r, lh)) s[r] = -INFINITY;
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int q = qt * 32 + att_krow(r, lh);
-      const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, -lse_s[q]));
-      s[r] = p;                                          // P[q][key]
-      dp[r] = p * (dp[r] - delta_s[q]);                  // dS[q][key] * sqrt(hd): the scale is applied when dK is stored
+    for (int g4 = 0; g4 < 4; ++g4) {                      // registers 4 g4 .. 4 g4 + 3 are four consecutive queries
+      const int q0 = qt * 32 + 8 * g4 + 4 * lh;
+      const float4 ls = *reinterpret_cast<const float4*>(lse_s + q0);
+      const float4 ds = *reinterpret_cast<const float4*>(delta_s + q0);
+      const float lq[4] = {ls.x, ls.y, ls.z, ls.w}, dq4[4] = {ds.x, ds.y, ds.z, ds.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g4 + e;
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, -lq[e]));
+        s[r] = p;                                        // P[q][key]
+        dp[r] = p * (dp[r] - dq4[e]);                    // dS[q][key] * sqrt(hd): the scale is applied when dK is stored
+      }
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int qr = qt * 32 + att_krow(r, lh);
-      const float g0 = Gs[qr * LD + li], q0 = Qs[qr * LD + li];
-      const float g1 = hi_ok ? Gs[qr * LD + 32 + li] : 0.f;
-      const float q1 = hi_ok ? Qs[qr * LD + 32 + li] : 0.f;
+      const float g0 = Gs[qr * LDP + li], q0 = Qs[qr * LDP + li];
+      const float g1 = Gs[qr * LDP + 32 + li], q1 = Qs[qr * LDP + 32 + li];     // zero beyond the head dim
       dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, s[r], dv0, 0, 0, 0);     // dV^T += dO^T P
       dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, dp[r], dk0, 0, 0, 0);    // dK^T += Q^T dS
       dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, s[r], dv1, 0, 0, 0);
       dk1 = __builtin_amdgcn_mfma_f32_32x32x2f32(q1, dp[r], dk1, 0, 0, 0);
     }
   }
-  float* slot = slots + wave * (32 * LD);
-  att_store_tile_T<HD>(slot, dk0, dk1, dKb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, inv_sqrt,
-                       RC, RS, kt * 32);
-  att_store_tile_T<HD>(slot, dv0, dv1, dVb + (int64_t)(kt * 32) * row_stride, row_stride, li, lh, lane, 1.f);
+  att_store_rows<HD>(dk0, dk1, dKb + (int64_t)kpos * row_stride + 4 * lh, lh, inv_sqrt, RC, RS, kpos);
+  att_store_rows<HD>(dv0, dv1, dVb + (int64_t)kpos * row_stride + 4 * lh, lh, 1.f);
 }
 
 extern "C" int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim) {
-  return ((int64_t)2 * L + 8 * 32) * ATT_LD(head_dim) * 4 + (int64_t)2 * L * 4;
+  (void)head_dim;
+  return (int64_t)2 * L * ATT_LDP * 4 + (int64_t)2 * L * 4;          // Q | 0 and dO | 0 images + lse, delta
 }
+static int64_t att_dq_lds_bytes(int L, int head_dim) { return (int64_t)L * (ATT_LDP + ATT_LD(head_dim)) * 4; }
 
 // delta[b, h, q] = sum_d dO * O is produced by the dQ kernel and consumed by the dK/dV kernel
 extern "C" int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L) {
@@ -645,7 +713,7 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
                        rope_cos, rope_sin);
   else
     hipLaunchKernelGGL((attention_bwd_dq_kernel<48>), dim3(B * H), dim3(512),
-                       (size_t)pdn_attention_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
+                       (size_t)att_dq_lds_bytes(L, head_dim), (hipStream_t)stream, q, k, v, o, d_o,
                        lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,
                        rope_cos, rope_sin);
   PDN_LAUNCH_CHECK();
