@@ -5,14 +5,14 @@
 
 template <int AB>
 static void run(const char* name, const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L) {
-  const size_t shm = (size_t)pdn_attention_lds_bytes(L, 48);
+  const size_t shm = (size_t)att_fwd_lds_bytes(L, 48);
   hipFuncSetAttribute((const void*)attention_fwd_kernel<48, AB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int w = 0; w < 2; ++w) {
     hipEventRecord(e0);
     for (int it = 0; it < 10; ++it)
       hipLaunchKernelGGL((attention_fwd_kernel<48, AB>), dim3(B * H), dim3(512), shm, 0, q, k, v, o, lse, H, L,
-                         (int64_t)H * 48, (int64_t)L * H * 48, sqrtf(48.f), 1, (const float*)nullptr, (const float*)nullptr);
+                         (int64_t)H * 48, (int64_t)L * H * 48, (int64_t)H * 48, (int64_t)L * H * 48, sqrtf(48.f), 1, (const float*)nullptr, (const float*)nullptr);
     hipEventRecord(e1); hipEventSynchronize(e1);
   }
   float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -20,7 +20,7 @@ static void run(const char* name, const float* q, const float* k, const float* v
 }
 
 int main() {
-  const int B = 128, H = 6, L = 256;
+  const int B = 256, H = 6, L = 256;
   const size_t n = (size_t)B * L * H * 48;
   float *q, *k, *v, *o, *lse;
   hipMalloc(&q, n * 4); hipMalloc(&k, n * 4); hipMalloc(&v, n * 4); hipMalloc(&o, n * 4); hipMalloc(&lse, (size_t)B * H * L * 4);
