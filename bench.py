@@ -271,7 +271,7 @@ def main():
 
     roof = None
     if not args.no_gemm_prof:
-        ms2, fl2, n2 = (ctypes.c_double * 4)(), (ctypes.c_double * 4)(), (ctypes.c_int64 * 4)()
+        ms2, fl2, n2 = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
         lib.call("pdn_gemm_prof_enable", 0)
         lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
         tf = lambda f, m: f / (m * 1e-3) / 1e12 if m > 0 else 0.0
@@ -282,10 +282,11 @@ def main():
             return {"achieved": tf(fl2[i], ms2[i]), "frac": tf(fl2[i], ms2[i]) / peak, "launches": n2[i],
                     "avg_launch_us": 1e3 * ms2[i] / max(n2[i], 1), "time_share_of_step": ms2[i] * 1e-3 / dt,
                     "algorithmic_flop_per_launch": fl2[i] / max(n2[i], 1), "traffic": traffic.get(name)}
-        # four GEMM kernels share the step; the roofline block is that of the one with the largest time share
+        # five GEMM kernels share the step; the roofline block is that of the one with the largest time share
         # (`achieved` = algorithmic 2MNK of ITS launches / HIP-event time around them, on the launch stream),
         # the others are reported beside it
-        names = ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel")
+        names = ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel",
+                 "gemm_outres_tn_kernel")
         fams = {n: family(i, n) for i, n in enumerate(names)}
         dom = max(names, key=lambda n: fams[n]["time_share_of_step"])
         f0 = fams[dom]

@@ -143,8 +143,10 @@ int pdn_gemm_prof_enable(int on);
 int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);
 /* the same split by kernel family: [0] gemm_f32_mfma_kernel (tiled, incl. its split-K reduce),
  * [1] gemm_tn_stream_*_kernel (weight gradients), [2] gemm_rowres_kernel (projections, contraction 288),
- * [3] gemm_outres_kernel (products ending in the model width); each argument points to FOUR values */
-int pdn_gemm_prof_collect_families(double* ms4, double* flops4, int64_t* launches4);
+ * [3] gemm_outres_kernel (products ending in the model width, incl. the fused lm_head input gradient),
+ * [4] gemm_outres_tn_kernel (weight gradients out of the model width, incl. the fused lm_head one);
+ * each argument points to FIVE values */
+int pdn_gemm_prof_collect_families(double* ms5, double* flops5, int64_t* launches5);
 
 /* ---- broadcasting elementwise: + - * / ** maximum minimum, comparisons
  * (tensor.py:548,564,591,612,634,811,820; 289-316).  mode 0: a op b, 1: a op scalar,

@@ -1041,7 +1041,7 @@ static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel, 3: output-resident kernel
+struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel, 3: output-resident kernel, 4: its weight-gradient (TN) form
 static std::vector<ProfRec> g_prof;
 
 extern "C" int pdn_gemm_prof_enable(int on) {
@@ -1051,10 +1051,10 @@ extern "C" int pdn_gemm_prof_enable(int on) {
 }
 
 // per kernel family: [0] gemm_f32_mfma_kernel (+ its split-K reduce), [1] gemm_tn_stream_*_kernel,
-// [2] gemm_rowres_kernel (csrc/gemm_rowres.hip), [3] gemm_outres_kernel (csrc/gemm_outres.hip); the three
-// output arrays have FOUR entries each
-#define PDN_GEMM_FAMILIES 4
-extern "C" int pdn_gemm_prof_collect_families(double* ms4, double* flops4, int64_t* launches4) {
+// [2] gemm_rowres_kernel (csrc/gemm_rowres.hip), [3] gemm_outres_kernel, [4] gemm_outres_tn_kernel (csrc/gemm_outres.hip);
+// the three output arrays have FIVE entries each
+#define PDN_GEMM_FAMILIES 5
+extern "C" int pdn_gemm_prof_collect_families(double* ms5, double* flops5, int64_t* launches5) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   double ms[PDN_GEMM_FAMILIES] = {0}, fl[PDN_GEMM_FAMILIES] = {0};
   int64_t n[PDN_GEMM_FAMILIES] = {0};
@@ -1068,9 +1068,9 @@ extern "C" int pdn_gemm_prof_collect_families(double* ms4, double* flops4, int64
     (void)hipEventDestroy(r.e1);
   }
   for (int f = 0; f < PDN_GEMM_FAMILIES; ++f) {
-    if (ms4) ms4[f] = ms[f];
-    if (flops4) flops4[f] = fl[f];
-    if (launches4) launches4[f] = n[f];
+    if (ms5) ms5[f] = ms[f];
+    if (flops5) flops5[f] = fl[f];
+    if (launches5) launches5[f] = n[f];
   }
   g_prof.clear();
   return PDN_OK;
@@ -1271,7 +1271,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
         PDN_HIP(hipEventCreate(&rec.e0));
         PDN_HIP(hipEventCreate(&rec.e1));
         rec.flops = 2.0 * M * (double)N * (double)K;
-        rec.family = 3;
+        rec.family = 4;
         PDN_HIP(hipEventRecord(rec.e0, st));
       }
       if (getenv("PDN_GEMM_DEBUG"))
@@ -1320,7 +1320,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
           PDN_HIP(hipEventCreate(&rec.e0));
           PDN_HIP(hipEventCreate(&rec.e1));
           rec.flops = 2.0 * M * (double)n_all * (double)K;
-          rec.family = 3;
+          rec.family = 4;
           PDN_HIP(hipEventRecord(rec.e0, st));
         }
         if (getenv("PDN_GEMM_DEBUG"))
@@ -1585,7 +1585,7 @@ extern "C" int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const flo
     prof_end(rec);
   }
   ProfRec rec_w;
-  if (dW || dbias) prof_begin(rec_w);
+  if (dW || dbias) { prof_begin(rec_w); rec_w.family = 4; }
   if (dW || dbias) {
     int nw, kps;
     const int splits = pdn_gemm_outres_tn_plan(V, (int)rows, &nw, &kps);
