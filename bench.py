@@ -1,7 +1,9 @@
 """Headline benchmark: training-step samples/s of the 6-layer Llama3 (seq 256) on N MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python bench.py --gpus N --steps K --warmup W            (any N: with WORLD_SIZE unset the script starts
+                                                              its own N ranks, one process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+                                                             (an external launcher's RANK / WORLD_SIZE are honoured)
 
 One step = zero_grad -> forward -> cross entropy -> backward -> (bucketed RCCL all-reduce,
 overlapped) -> Adam, on synthetic token ids resident in HBM, random-init weights, fp32.
@@ -131,6 +133,125 @@ def parity_gate(model, dev, pdn):
             "rtol": GATE_RTOL, "fused_nodes_taken": ["qkv_attention", "gate_up_swiglu", "linear_cross_entropy"]}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, timeout=None):
+    """`python bench.py --gpus N` with no launcher: start N copies of this script, one per GPU, each with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (127.0.0.1: the container hostname may not
+    resolve), rank 0 on this process's stdout -- its ONE JSON line is the output -- the others' stdout folded into
+    stderr.  Returns the worst exit code; if a rank dies the others are terminated (an RCCL peer would hang)."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"), MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = None if timeout is None else time.monotonic() + timeout
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = rc or code
+            if code != 0:                                   # one rank failed: do not leave its peers in a collective
+                for q in live:
+                    q.terminate()
+        if deadline is not None and time.monotonic() > deadline:
+            for q in live:
+                q.kill()
+            return rc or 124
+        time.sleep(0.05)
+    return rc
+
+
+def batch_gate(model, ids_np, tgt_np, dev, pdn, lib, rtol=1e-4, want_families=(2, 3, 4)):
+    """Parity of the TIMED batch.  The single-sequence step is pinned to the real reference (parity_gate above,
+    tests/test_llama_golden.py), but at 256 tokens `pdn_gemm_f32` never reaches the resident-operand kernels the
+    timed step spends most of its time in.  Samples are independent and the loss is a mean over tokens
+    (llm/llama/model.py:226-252), so one step on B sequences must equal the mean of the B single-sequence steps:
+    loss and EVERY gradient tensor are compared (max |diff| <= rtol x the tensor's largest entry).  The embedding
+    gradient is a scatter-ASSIGN (tensor.py:937-940: the last occurrence of a token id in the flattened batch
+    wins), restated here from the per-sequence gradients in batch order.  Also asserts -- through the library's
+    own per-family counters -- that the batched step really ran on the row-resident / output-resident kernels."""
+    import ctypes
+    from pydynet_amd import hipnp as hp
+    from pydynet_amd.core import fused
+    B = ids_np.shape[0]
+    tgt_np = np.asarray(tgt_np).reshape(B, -1)
+    params = dict(model.named_parameters())
+    emb_name = "tok_embedding.weight"
+    model.train(True)
+
+    def zero():
+        for p in params.values():
+            p.zero_grad()
+
+    zero()
+    lib.call("pdn_gemm_prof_enable", 1)
+    lossB = model.loss(ids_np, tgt_np.reshape(-1))
+    lossB.backward()
+    ms2, fl2, n2 = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+    lib.call("pdn_gemm_prof_enable", 0)
+    lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
+    taken = [int(n2[i]) for i in range(5)]
+    missing = [i for i in want_families if taken[i] == 0]
+    if missing:
+        raise SystemExit(f"bench.py batch gate FAILED: GEMM kernel families {missing} were not launched at batch {B} "
+                         f"(launches per family {taken})")
+    lossB = float(lossB.item())
+    with model.lm_head.weight.device:
+        gB = {n: p.grad.copy() for n, p in params.items()}
+        zero()
+        V, D = params[emb_name].shape
+        acc_emb = hp.zeros((V, D), np.float32)
+        min_rows = fused.linear_cross_entropy.min_rows
+        fused.linear_cross_entropy.min_rows = 32            # the node the reference-pinned B = 1 step is pinned with
+        losses = []
+        try:
+            for b in range(B):
+                lb = model.loss(ids_np[b:b + 1], tgt_np[b])
+                lb.backward()
+                losses.append(lb)
+                rows = hp.from_numpy(np.unique(ids_np[b]).astype(np.int64))
+                eg = params[emb_name].grad
+                acc_emb[rows] = eg[rows]                    # later sequences overwrite: last occurrence wins
+                eg[rows] = 0.0
+        finally:
+            fused.linear_cross_entropy.min_rows = min_rows
+        loss1 = float(np.mean([float(l.item()) for l in losses]))
+        worst, worst_name = 0.0, None
+        for n, p in params.items():
+            ref = acc_emb if n == emb_name else p.grad
+            ref = ref * np.float32(1.0 / B)
+            scale = float(abs(ref).max().item())
+            err = float(abs(gB[n] - ref).max().item()) / max(scale, 1e-30)
+            if err > worst:
+                worst, worst_name = err, n
+        zero()
+    if not abs(lossB - loss1) <= rtol * abs(loss1):
+        raise SystemExit(f"bench.py batch gate FAILED: loss at batch {B} = {lossB!r}, mean of the single-sequence "
+                         f"losses = {loss1!r}")
+    if worst > rtol:
+        raise SystemExit(f"bench.py batch gate FAILED: gradient {worst_name} at batch {B} differs from the mean of the "
+                         f"single-sequence gradients by {worst:.2e} of its largest entry (rtol {rtol})")
+    return {"batch": B, "loss": lossB, "mean_single_sequence_loss": loss1, "loss_rel_err": abs(lossB - loss1) / abs(loss1),
+            "grad_tensors_checked": len(params), "worst_grad_rel_err": worst, "worst_grad": worst_name, "rtol": rtol,
+            "gemm_family_launches": dict(zip(("tiled", "tn_stream", "rowres", "outres", "outres_tn"), taken))}
+
+
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command (FETCH_SIZE x 2 -- the
     gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, separate --pmc passes; tools/pmc_cmd.sh writes it).
@@ -193,7 +314,23 @@ def main():
     ap.add_argument("--no-parity-gate", action="store_true",
                     help="profiling runs only (keeps the batch-1 gate step out of per-kernel counter averages); "
                          "the JSON line then carries parity_gate = null")
+    ap.add_argument("--no-batch-gate", action="store_true",
+                    help="skip the parity check of the timed batch against the single-sequence path")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes one (the ranks re-enter main() with RANK / WORLD_SIZE set)
+        if os.environ.get("PDN_BENCH_SPAWN_PROBE") != "1":
+            from pydynet_amd import cuda as _cuda
+            have = _cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible")
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if os.environ.get("PDN_BENCH_SPAWN_PROBE") == "1":
+        # launcher self-test (tests/test_bench_contract_cpu.py): report what this rank was given, touch no GPU
+        rec = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        print(json.dumps({"probe": rec, "argv": sys.argv[1:]}), flush=True)
+        return
 
     import ctypes
     from pydynet_amd import hipnp, _lib
@@ -221,13 +358,19 @@ def main():
     model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     model.to(dev)
     gate = None if args.no_parity_gate else parity_gate(model, dev, pdn)    # refuses to go on if the path is wrong
+    rng = np.random.default_rng(1000 + rank)                # each rank owns its shard of the global batch
+    ids_np, tgt_np = rng.integers(0, V, (B, L)), rng.integers(0, V, (B * L,))
+    bgate = None
+    if not (args.no_parity_gate or args.no_batch_gate) and rank == 0:
+        # the kernels of the TIMED batch, against the reference-pinned single-sequence path, on the timed inputs
+        bgate = batch_gate(model, ids_np, tgt_np, dev, pdn, lib,
+                           want_families=(2, 3, 4) if B * L >= 57344 else ())
     opt = Adam(model.parameters(), lr=1e-4)
     dp = DataParallel(model, opt, always_reduce=force_dp) if (world > 1 or force_dp) else None
     if dp is None:
         opt.flatten_grads()                                 # one flat gradient buffer: zero_grad is a single fill
-    rng = np.random.default_rng(1000 + rank)                # each rank owns its shard of the global batch
-    ids = pdn.Tensor(rng.integers(0, V, (B, L)), dtype=np.int64, device=dev)
-    tgt = pdn.Tensor(rng.integers(0, V, (B * L,)), dtype=np.int64, device=dev)
+    ids = pdn.Tensor(ids_np, dtype=np.int64, device=dev)
+    tgt = pdn.Tensor(tgt_np, dtype=np.int64, device=dev)
     model.train(True)
 
     comm_events = []
@@ -255,6 +398,9 @@ def main():
     for _ in range(args.warmup):
         prev = step()
     fence()
+    for a, b in comm_events:                                # warm-up steps are not part of the exposed-time average
+        lib.call("pdn_event_destroy", a)
+        lib.call("pdn_event_destroy", b)
     comm_events.clear()
     if not args.no_gemm_prof:
         lib.call("pdn_gemm_prof_enable", 1)
@@ -300,7 +446,14 @@ def main():
                              "time_share_of_step": sum(ms2) * 1e-3 / dt},
                 "traffic_source": traffic.get("_source")}
         roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic) if rank == 0 else None
+    per_rank = [B * args.steps / dt]
     if world > 1:
+        mine = np.zeros((world,), np.float32)
+        mine[rank] = dt
+        every = hipnp.from_numpy(mine)
+        group.all_reduce(every, pdist.SUM)                       # every rank's own wall time, one slot each
+        group.wait()
+        per_rank = [B * args.steps / float(t) for t in every.get()]
         dt = group.all_reduce_scalar(dt, pdist.MAX)              # slowest rank's wall time
     value = world * B * args.steps / dt
     out = {
@@ -310,8 +463,10 @@ def main():
         "config": {"workload": "llm/llama 6-layer Llama3 (dim 288, 6 heads, ffn 768, vocab 32000) fwd+bwd+Adam, random init",
                    "seq_len": L, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "model_flops_frac_of_fp32_mfma_peak": FLOP_PER_SAMPLE * value / world / PEAK_FP32_MFMA,
+        "per_rank_samples_per_s": per_rank,
         "final_loss": losses[-1],
         "parity_gate": gate,
+        "batch_gate": bgate,
         "roofline": roof,
     }
     if dp is not None:
@@ -320,9 +475,16 @@ def main():
             ms_ = ctypes.c_float()
             lib.call("pdn_event_elapsed_ms", a, b, ctypes.byref(ms_))
             exposed += ms_.value / max(len(comm_events), 1)
+            lib.call("pdn_event_destroy", a)
+            lib.call("pdn_event_destroy", b)
+        comm_events.clear()
+        if world > 1:
+            exposed = group.all_reduce_scalar(exposed, pdist.MAX)
         out["comm"] = {"collective": "all-reduce(sum) of flat fp32 gradient buckets, RCCL", "buckets": len(dp.buckets),
+                       "bucket_MB": [round((hi - lo) * 4 / 1e6, 2) for lo, hi, _, _ in dp.buckets],
                        "payload_MB_per_step": dp.flat.size * 4 / 1e6, "exposed_ms_per_step": exposed,
-                       "note": "exposed = compute-stream time blocked in DataParallel.finish(); the rest overlaps backward"}
+                       "note": "exposed = compute-stream time blocked in DataParallel.finish() (max over ranks); "
+                               "the rest overlaps backward"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     # RCCL writes a version banner through C stdio (block-buffered when piped): every rank pushes its

@@ -305,7 +305,10 @@ def _accumulate(t, add_grad, xp):
     fresh = add_grad.shape != tuple(t.shape)
     if fresh:
         add_grad = _unbroadcast(add_grad, t.shape)
-    if not t.last and t.grad is not None:          # leaf: always in place into its own buffer
+    if not t.last and t.grad is not None and t._grad_owned:
+        # a true leaf accumulates in place into its own buffer.  (A stale op node that is a leaf of THIS graph
+        # adopted its first contribution below and may alias another node's gradient: `_grad_owned` is False
+        # then and the sum is formed out of place.)
         t.grad += add_grad
     elif t.grad is None:
         # first contribution to an op node: adopt, no copy.  (Also an op node whose own graph was

@@ -22,8 +22,8 @@ Design for MI355X (8 GPUs fully connected, 7 xGMI links x ~153 GB/s each):
   * the embedding gradient keeps the reference's scatter-ASSIGN semantics across ranks: an
     all-reduce(MAX) over a (V,) "owner" vector picks, for every token id, the highest rank that saw
     it (= the last occurrence in the concatenated batch) and only that rank contributes the row.
-Collectives: RCCL through the C ABI (`pdn_comm_*`, include/pdn_hip.h) for HIP devices -- no
-PyTorch involved; `torch.distributed` gloo carries NumPy buffers for the "cpu" device (CPU tests).
+Collectives: RCCL through the C ABI (`pdn_comm_*`, include/pdn_hip.h) -- no PyTorch involved.  (The GPU-less
+tests plug a host communicator in through `register_backend`; it lives under tests/.)
 """
 from __future__ import annotations
 
@@ -144,76 +144,33 @@ class RcclComm:
             self._comm = None
 
 
-class GlooComm:
-    """torch.distributed (gloo) moving NumPy buffers: the communicator of the "cpu" device.  It exists
-    so that the N > 1 logic runs in GPU-less tests; it is never used with HIP arrays."""
+_backends = {}      # name -> factory(rank, world): communicators registered from outside the product
 
-    backend = "gloo"
 
-    def __init__(self, rank: int, world: int):
-        import torch.distributed as dist
-        self._dist = dist
-        if not dist.is_initialized():
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self._works = []
-
-    def _tensor(self, arr):
-        import torch
-        assert isinstance(arr, np.ndarray) and arr.flags.c_contiguous
-        return torch.from_numpy(arr)
-
-    def all_reduce(self, arr, op=SUM):
-        dist = self._dist
-        self._works.append(dist.all_reduce(self._tensor(arr), async_op=True,
-                                           op=dist.ReduceOp.SUM if op == SUM else dist.ReduceOp.MAX))
-
-    def broadcast(self, arr, root=0):
-        self._works.append(self._dist.broadcast(self._tensor(arr), src=root, async_op=True))
-
-    def all_gather(self, send, recv):
-        import torch
-        parts = list(torch.from_numpy(recv.reshape(self.world, -1)).unbind(0))
-        self._works.append(self._dist.all_gather(parts, self._tensor(send).reshape(-1), async_op=True))
-
-    def wait(self):
-        for w in self._works:
-            w.wait()
-        self._works = []
-
-    def barrier(self):
-        self.wait()
-        self._dist.barrier()
-
-    def all_reduce_scalar(self, value: float, op=MAX) -> float:
-        a = np.array([value], np.float64)
-        self.all_reduce(a, op)
-        self.wait()
-        return float(a[0])
-
-    def destroy(self):
-        self.wait()
-        if self._dist.is_initialized():
-            self._dist.destroy_process_group()
+def register_backend(name: str, factory):
+    """Make `init_process_group(name)` build its communicator with `factory(rank, world)`.  The product ships ONE
+    communicator (RCCL through the C ABI); the GPU-less tests register a host one that moves NumPy buffers
+    (tests/gloo_comm.py) so that the N > 1 logic of DataParallel runs without a GPU."""
+    _backends[name] = factory
 
 
 def init_process_group(backend=None, device_index=None):
     """Create the process-wide communicator from the launcher's environment (RANK, WORLD_SIZE,
-    MASTER_ADDR, MASTER_PORT).  backend: "rccl" (alias "nccl") for HIP devices, "gloo" for the cpu
-    device; default: rccl when a GPU is visible.  Returns (rank, world)."""
+    MASTER_ADDR, MASTER_PORT).  backend: "rccl" (alias "nccl"), or a name given to `register_backend`.
+    Returns (rank, world)."""
     global _group
     rank, world = rendezvous.env_rank_world()
     if _group is None:
         if backend is None:
-            from . import cuda
-            backend = "rccl" if cuda.is_available() else "gloo"
+            backend = "rccl"
         if backend in ("rccl", "nccl"):
             local = int(os.environ.get("LOCAL_RANK", rank)) if device_index is None else device_index
             _group = RcclComm(rank, world, local)
-        elif backend == "gloo":
-            _group = GlooComm(rank, world)
+        elif backend in _backends:
+            _group = _backends[backend](rank, world)
         else:
-            raise ValueError(f"unknown backend {backend!r} (rccl | nccl | gloo)")
+            raise ValueError(f"unknown backend {backend!r} (rccl | nccl" +
+                             "".join(f" | {b}" for b in _backends) + ")")
     return _group.rank, _group.world
 
 

@@ -190,6 +190,14 @@ class Graph:
 
     def __init__(self):
         self._exec, self._pool, self.nodes, self._hooks, self._keep = None, None, 0, [], None
+        self._ws, self._pinned = {}, []          # scratch buffers / side tables the captured launches point into
+
+    def pin(self, obj):
+        """Keep `obj` (an array whose raw pointer a captured launch holds: a scratch workspace, an optimizer's
+        chunk table) alive until destroy(): a replay writes through the pointers baked in at capture time, so
+        nothing they address may go back to the allocator while the graph can still be launched."""
+        self._pinned.append(obj)
+        return obj
 
     def on_replay(self, fn):
         """Host bookkeeping to run at every replay (e.g. an optimizer's step counter)."""
@@ -248,10 +256,11 @@ class Graph:
             L.call("pdn_stream_synchronize", stream())
             L.call("pdn_graph_destroy", self._exec)
             self._exec = None
+        self._keep = None
+        self._ws, self._pinned = {}, []
         if self._pool:
             L.call("pdn_pool_destroy", self._pool)
             self._pool = None
-        self._keep = None
 
 
 def memory_stats(device=None):
@@ -299,6 +308,17 @@ def workspace(nbytes: int):
     if nbytes <= 0:
         return 0, 0
     key = (_state["device"], _state["stream"])
+    g = _capture["graph"]
+    if g is not None:
+        # a step being captured gets scratch of its OWN (from the graph's private pool, alive as long as the
+        # graph): the process-wide buffer below may be replaced by a bigger one by any later eager op, and the
+        # old block -- whose address the replayed launches still write to -- would be handed to another tensor
+        buf = g._ws.get(key)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None and not g.warming:
+                g._pinned.append(buf)            # launches captured so far still point into it
+            g._ws[key] = buf = _Buffer(_bi.max(nbytes, 1 << 20))
+        return buf.ptr, buf.nbytes
     buf = _ws.get(key)
     if buf is None or buf.nbytes < nbytes:
         _ws[key] = buf = _Buffer(_bi.max(nbytes, 1 << 20))
@@ -394,10 +414,20 @@ class ndarray:
     # ---- host transfer --------------------------------------------------------------
     def get(self) -> np.ndarray:
         """Device -> host copy (synchronises); the counterpart of cupy's `.get()`."""
-        a = self if self.is_contiguous() else self.copy()
-        host = np.empty(a.shape, dtype=self.dtype)
-        if host.size:
-            _lib.lib().call("pdn_memcpy_d2h", host.ctypes.data, a._ptr, host.nbytes, stream())
+        # on the stream of the device that OWNS the buffer (its producing kernels were enqueued there), not on
+        # whatever device happens to be current: `Device.__exit__` restores the previous GPU after every op
+        prev = _state["device"]
+        own = self._buf.device if self._buf is not None else prev
+        if own != prev:
+            set_device(own)
+        try:
+            a = self if self.is_contiguous() else self.copy()
+            host = np.empty(a.shape, dtype=self.dtype)
+            if host.size:
+                _lib.lib().call("pdn_memcpy_d2h", host.ctypes.data, a._ptr, host.nbytes, stream())
+        finally:
+            if own != prev:
+                set_device(prev)
         return host
 
     def item(self):

@@ -152,6 +152,7 @@ class Adam(Optimizer):
                 table = self._chunk_table(fast)
                 graph = hipnp.capturing()
                 if graph is not None:
+                    graph.pin(table)                     # the captured launch holds the table's address
                     # replayed steps cannot take a host scalar: {t, lr} live on the device, a one-thread
                     # kernel forms lr * a_t there and advances t (the host counter follows at every replay)
                     if len(fast) != len(self.params):

@@ -3,11 +3,14 @@ other rank before `pdn_comm_init`.  The reference has nothing of the kind (no mu
 SURVEY 2a); launchers (`python -m torch.distributed.run`, mpirun-style scripts) only provide
 RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment.  MASTER_PORT itself belongs to
 the launcher's own store, so rank 0 serves the payload on the first free port ABOVE it and the other
-ranks probe that short range; a handshake (magic, world size, sequence number) rejects anything
-else that may be listening there.  Plain sockets, no third-party dependency, one node or many.
+ranks probe that short range; a handshake (magic, world size, sequence number, and a job token hashed from
+MASTER_ADDR:MASTER_PORT plus PDN_JOB_ID / TORCHELASTIC_RUN_ID when set) rejects anything else that may be
+listening there -- including another job of the same world size on an adjacent MASTER_PORT -- and rank 0
+binds MASTER_ADDR itself when that address is local instead of every interface.  Plain sockets, no third-party dependency, one node or many.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import socket
 import struct
@@ -24,6 +27,12 @@ def env_rank_world():
 
 def _endpoint():
     return os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
+
+
+def _job_token() -> bytes:
+    addr, port = _endpoint()
+    ident = f"{addr}:{port}:{os.environ.get('PDN_JOB_ID', '')}:{os.environ.get('TORCHELASTIC_RUN_ID', '')}"
+    return hashlib.sha256(ident.encode()).digest()[:8]
 
 
 def _recv_exact(conn, n):
@@ -44,7 +53,7 @@ def broadcast_bytes(payload: bytes | None, rank: int, world: int, timeout: float
     if world == 1:
         return payload
     addr, base = _endpoint()
-    hello = _MAGIC + struct.pack("<ii", world, seq)
+    hello = _MAGIC + _job_token() + struct.pack("<ii", world, seq)
     deadline = time.monotonic() + timeout
     if rank == 0:
         assert payload is not None
@@ -53,7 +62,13 @@ def broadcast_bytes(payload: bytes | None, rank: int, world: int, timeout: float
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind(("", base + off))
+                try:
+                    s.bind((addr, base + off))          # MASTER_ADDR when it is one of this host's addresses
+                except OSError as e:
+                    import errno
+                    if e.errno != errno.EADDRNOTAVAIL and not isinstance(e, socket.gaierror):
+                        raise
+                    s.bind(("", base + off))
                 s.listen(world + 8)
                 srv = s
                 break
@@ -79,6 +94,9 @@ def broadcast_bytes(payload: bytes | None, rank: int, world: int, timeout: float
                             conn.sendall(b"NO")
                             continue
                         peer = struct.unpack("<i", msg[len(hello):])[0]
+                        if not 0 < peer < world:
+                            conn.sendall(b"NO")
+                            continue
                         conn.sendall(b"OK" + struct.pack("<i", len(payload)) + payload)
                         served.add(peer)
                     except (OSError, ConnectionError):

@@ -50,3 +50,46 @@ def test_command_line_defaults_and_json_keys():
                 '"roofline"', '"cpu_baseline"', '"bound"', '"achieved"', '"peak"', '"frac"', '"traffic"',
                 '"parity_gate"'):
         assert key in src, key
+
+
+def test_gpus_n_without_a_launcher_starts_n_ranks():
+    """`python bench.py --gpus N` with WORLD_SIZE unset must start its own N ranks (one per GPU), each with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; only rank 0 owns stdout.  The probe switch makes
+    every rank report its environment instead of touching a GPU."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["PDN_BENCH_SPAWN_PROBE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    out = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    err = [json.loads(l) for l in r.stderr.splitlines() if l.startswith("{")]
+    assert len(out) == 1 and out[0]["probe"]["RANK"] == "0"                  # rank 0's line is THE output
+    ranks = sorted(int(x["probe"]["RANK"]) for x in out + err)
+    assert ranks == [0, 1, 2, 3]
+    for x in out + err:
+        pr = x["probe"]
+        assert pr["WORLD_SIZE"] == "4" and pr["LOCAL_RANK"] == pr["RANK"] and pr["MASTER_ADDR"] == "127.0.0.1"
+        assert pr["MASTER_PORT"] == out[0]["probe"]["MASTER_PORT"]
+        assert x["argv"] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+
+
+def test_launcher_propagates_a_failing_rank():
+    import bench
+    import subprocess
+    # a rank that exits non-zero makes the whole launch fail (and the surviving ranks are terminated)
+    code = ("import os, sys, time\n"
+            "sys.exit(3) if os.environ['RANK'] == '1' else time.sleep(30)\n")
+    path = os.path.join(ROOT, "tests", "_rank_probe_tmp.py")
+    open(path, "w").write(code)
+    real = bench.__file__
+    try:
+        bench.__file__ = path
+        import time
+        t0 = time.monotonic()
+        rc = bench.launch_ranks(2, [], timeout=60)
+        assert rc == 3 and time.monotonic() - t0 < 20
+    finally:
+        bench.__file__ = real
+        os.remove(path)

@@ -47,6 +47,8 @@ def _worker(rank, world, port, out_dir, bucket_mb, dups=False):
     from pydynet_amd.optim import Adam
     from pydynet_amd import distributed as pdist
     from pydynet_amd.distributed import DataParallel, init_process_group, shard_batch
+    from tests import gloo_comm
+    gloo_comm.install()
     init_process_group("gloo")
     m = _build(seed=1234 + 7 * rank)          # ranks start DIFFERENT: the wrapper must broadcast rank 0's weights
     opt = Adam(m.parameters(), lr=1e-3)

@@ -115,3 +115,58 @@ def test_replayed_llama_steps_equal_eager_steps(hip):
     assert np.allclose(l0, l1, rtol=1e-6), (l0, l1)
     for n in p0:
         assert np.allclose(p0[n], p1[n], rtol=1e-4, atol=2e-6), n     # (device-side double a_t vs the host scalar)
+
+
+def test_replay_survives_a_later_eager_op_that_grows_the_workspace(hip):
+    """A captured step holds raw scratch addresses (split-K slabs, reductions, the embedding scatter's
+    last-occurrence vector, Adam's chunk table).  The process-wide scratch buffer is replaced whenever an eager op
+    needs a bigger one; the block the graph still writes into must not go back to the allocator.  Run eagerly,
+    capture, run eager ops with a much bigger scratch need and allocate arrays that would receive the freed block,
+    replay, compare with an eager run of the same steps."""
+    import pydynet_amd as pdn
+    import pydynet_amd.nn.functional as F
+    from pydynet_amd.optim import Adam
+    from pydynet_amd.core.tensor import Graph
+    rng = np.random.default_rng(0)
+    X = rng.random((64, 1, 28, 28), dtype=np.float32)
+    y = rng.integers(0, 10, 64)
+    results = []
+    for use_graph in (False, True):
+        Graph.clear()
+        np.random.seed(3)
+        net = _mlp()().to("hip:0")
+        opt = Adam(net.parameters(), lr=1e-3)
+        Xd = pdn.Tensor(X, dtype=np.float32, device="hip:0")
+        yd = pdn.Tensor(y, dtype=np.int64, device="hip:0")
+
+        def step():
+            loss = F.cross_entropy_loss(net(Xd), yd)
+            opt.zero_grad(); loss.backward(); opt.step()
+            return loss
+        step()                                              # eager first: the process-wide scratch exists
+        if use_graph:
+            g = hip.Graph()
+            loss = g.capture(step)
+        else:
+            step(); loss = step()
+        # a later eager op with a far bigger scratch need (split-K weight gradient), then arrays that take
+        # whatever block was released, filled with a pattern a stray scratch write would destroy
+        a = hip.from_numpy(rng.standard_normal((65536, 96), dtype=np.float32))
+        b = hip.from_numpy(rng.standard_normal((65536, 288), dtype=np.float32))
+        big = hip.matmul(a.T, b)
+        canaries = [hip.zeros((1 << 18,), np.float32) + 7.0 for _ in range(8)]
+        hip.synchronize()
+        if use_graph:
+            g.replay(); g.replay()
+        else:
+            step(); loss = step()
+        results.append((loss.item(), {n: p.numpy() for n, p in net.named_parameters()}))
+        for c in canaries:
+            assert np.all(c.get() == 7.0)
+        assert np.isfinite(big.get()).all()
+        if use_graph:
+            g.destroy()
+    (l0, p0), (l1, p1) = results
+    assert np.allclose(l0, l1, rtol=1e-6)
+    for n in p0:
+        assert np.allclose(p0[n], p1[n], rtol=1e-4, atol=2e-6), n

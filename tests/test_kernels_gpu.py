@@ -702,6 +702,79 @@ def test_gemm_row_resident_dispatch_matches_tiled_kernel(hip):
         assert rel_err(got[:, i * K:(i + 1) * K], x.astype(np.float64) @ ws[2 - i].astype(np.float64)) < 1e-5
 
 
+def test_gemm_row_resident_packed_gate_up_blocks(hip):
+    # the FFN's gate | up projections: two (288 x 768) weights, equally spaced, ONE launch on the `blocks` entry
+    # of the row-resident kernel, results side by side in a packed (M, 1536) buffer (fused.gate_up_swiglu)
+    K, M, F = 288, 8192 + 32, 768
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    ws = 0.1 * rng.standard_normal((2, K, F), dtype=np.float32)
+    X = hip.from_numpy(x)
+    buf = hip.from_numpy(ws)
+    stack = hip.stacked_view([buf[0], buf[1]])
+    assert stack is not None
+    packed = hip.empty((M, 2 * F), np.float32)
+    blocks = hip.ndarray(packed._buf, packed._ptr, (2, M, F), (F, 2 * F, 1), packed.dtype)
+    from pydynet_amd import _lib
+    L = _lib.lib()
+    import ctypes
+    L.call("pdn_gemm_prof_enable", 1)
+    hip.gemm(X, stack, blocks)
+    ms, fl, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+    L.call("pdn_gemm_prof_enable", 0)
+    L.call("pdn_gemm_prof_collect_families", ms, fl, n)
+    if type(L).__name__ != "EmulatedLib":                 # (the CPU emulation of the ABI has no kernel families)
+        assert n[2] == 1 and sum(n) == 1                  # one launch, on the row-resident kernel
+    got = packed.get()
+    for i in range(2):
+        assert rel_err(got[:, i * F:(i + 1) * F], x.astype(np.float64) @ ws[i].astype(np.float64)) < 1e-5
+    # bit-identical to the tiled kernel on the same packing
+    os.environ["PDN_GEMM_NO_ROWRES"] = "1"
+    try:
+        packed0 = hip.empty((M, 2 * F), np.float32)
+        blocks0 = hip.ndarray(packed0._buf, packed0._ptr, (2, M, F), (F, 2 * F, 1), packed0.dtype)
+        hip.gemm(X, stack, blocks0)
+    finally:
+        del os.environ["PDN_GEMM_NO_ROWRES"]
+    assert np.array_equal(packed0.get(), got)
+
+
+def test_lm_head_forward_row_resident_with_bias_full_vocab(hip):
+    # lm_head forward of the benchmark: (tokens, 288) @ (288, 32000) + bias on the row-resident kernel
+    # (32000 = 333 * 96 + 32: the last column chunk is partial), sampled rows / columns against float64
+    from pydynet_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    M, K, N = 8192, 288, 32000
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = 0.05 * rng.standard_normal((K, N), dtype=np.float32)
+    b = rng.standard_normal(N, dtype=np.float32)
+    X, W, Bv = hip.from_numpy(x), hip.from_numpy(w), hip.from_numpy(b)
+    Y = hip.empty((M, N), np.float32)
+    L.call("pdn_gemm_prof_enable", 1)
+    hip.gemm(X, W, Y, bias=Bv)
+    ms, fl, n = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
+    L.call("pdn_gemm_prof_enable", 0)
+    L.call("pdn_gemm_prof_collect_families", ms, fl, n)
+    if type(L).__name__ != "EmulatedLib":
+        assert n[2] == 1 and sum(n) == 1
+    y = Y.get()
+    rows = np.concatenate([rng.integers(0, M, 24), [0, M - 1]])
+    ref = x[rows].astype(np.float64) @ w.astype(np.float64) + b
+    assert rel_err(y[rows], ref) < 1e-5
+    cols = np.concatenate([rng.integers(0, N, 24), [0, 31967, 31968, N - 1]])      # both sides of the partial chunk
+    refc = x.astype(np.float64) @ w[:, cols].astype(np.float64) + b[cols]
+    assert rel_err(y[:, cols], refc) < 1e-5
+    os.environ["PDN_GEMM_NO_ROWRES"] = "1"
+    try:
+        Y0 = hip.empty((M, N), np.float32)
+        hip.gemm(X, W, Y0, bias=Bv)
+    finally:
+        del os.environ["PDN_GEMM_NO_ROWRES"]
+    assert np.array_equal(Y0.get(), y)
+
+
 # ---------------------------------------------------------------------------------------
 # output-resident GEMM (csrc/gemm_outres.hip): 32 x 288 outputs per wave in accumulators, A straight into
 # MFMA operand registers, B through LDS
