@@ -308,7 +308,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "256")), help="per-GPU batch")
+    ap.add_argument("--config", choices=("llama", "mlp", "lenet", "gru", "decode"), default="llama",
+                    help="llama = the headline line (BASELINE.json configs 4 / 5); mlp / lenet = configs 2 / 3; gru = "
+                         "examples/pydynet/ts_prediction.py; decode = KV-cache greedy generation (bench_other.py)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "0")),
+                    help="per-GPU batch (default: 256 for llama / mlp / lenet, 1568 for gru, 1 for decode)")
+    ap.add_argument("--no-graph", action="store_true", help="mlp / lenet: time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-prof", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true",
@@ -318,6 +323,10 @@ def main():
                     help="skip the parity check of the timed batch against the single-sequence path")
     args = ap.parse_args()
 
+    if args.config != "llama":
+        import bench_other
+        return bench_other.run(args)
+    args.batch = args.batch or 256
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes one (the ranks re-enter main() with RANK / WORLD_SIZE set)
         if os.environ.get("PDN_BENCH_SPAWN_PROBE") != "1":

@@ -250,6 +250,39 @@ int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = row
  * positions [0, T) of the KV cache (max_batch, max_len, H, head_dim); no mask. */
 int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* v_cache, float* o, int B,
                              int H, int T, int head_dim, int64_t cache_batch_stride, void* stream);
+/* Greedy decode step as a replayable graph (csrc/decode.hip): the loop of llm/llama/model.py:254-269 /
+ * infer.py:46-63.  Nothing in these kernels depends on a host value that changes from token to token: the position
+ * lives in device memory (`pos`, int32) and is advanced by pdn_decode_argmax_tick_f32, the last kernel of a step.
+ *   pdn_decode_gemv_f32      y (B, N) = f(x) (B, K) @ W + bias + residual, B <= 8.  f = RMSNorm(norm_w, eps)
+ *                            (norm.py:245-248) when norm_w != NULL; act = 1: x rows are packed [gate | up] of width
+ *                            2 K and f = silu(gate) * up (functional.py:39-40).  W = N / blk_cols equally spaced
+ *                            (K, blk_cols) row-major blocks (fused q | k | v, gate | up; one matrix: blk_cols = N).
+ *                            y must not alias x; residual may alias y.
+ *                            blk_max / blk_arg (optional, B x pdn_decode_gemv_blocks(N)): per row and workgroup the
+ *                            first maximum of the workgroup's columns + its column: first half of a greedy pick.
+ *                            act = 2: x rows are the partials of pdn_decode_attention_f32 (act_ns key ranges,
+ *                            heads of act_hd) and f is their softmax-weighted merge.
+ *   pdn_decode_attention_f32 qkv (B, 3 D) rows [q | k | v] of the new token: q, k rotated by the angle of position
+ *                            *pos (model.py:23-44), k / v appended to cache row *pos (model.py:105-110), then the
+ *                            query attends to cache positions [0, *pos] (model.py:112-121, L = 1: no mask), the keys
+ *                            cut into n_splits ranges: partials (B, n_splits, H, 4 + hd)
+ *                            = [max, sum of exp, -, - | sum of exp(s - max) v] per range, merged by the output
+ *                            projection's loads (act = 2).
+ *   pdn_decode_pick_tick_f32 next_ids[b] = column of the first maximum over the candidates (model.py:262-268:
+ *                            argmax(-1)); *pos += 1.  pdn_decode_argmax_tick_f32: the same from full logit rows. */
+int pdn_decode_gemv_blocks(int N);
+int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const float* norm_w, float eps, const float* W,
+                        int64_t w_row_stride, int blk_cols, int64_t w_block_stride, const float* bias,
+                        const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
+                        int B, int K, int N, int act, int act_ns, int act_hd, float* blk_max, int* blk_arg,
+                        void* stream);
+int pdn_decode_attention_f32(const float* qkv, int64_t qkv_row_stride, const float* cos_table, const float* sin_table,
+                             float* k_cache, float* v_cache, float* partials, int B, int H, int head_dim, int n_splits,
+                             int64_t cache_batch_stride, const int* pos, int max_len, void* stream);
+int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, int n_blocks, int64_t* next_ids, int* pos,
+                             void* stream);
+int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_stride, int B, int V, int64_t* next_ids, int* pos,
+                               void* stream);
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
 

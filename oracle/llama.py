@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure): the north-star workload restated on `oracle.tape`.
 
 Follows /root/reference/llm/llama/model.py op for op (same node order, same parameter names
-`layers.{i}.attention.Q.weight` ...), training branch only (KV cache is eval-only, model.py:105-110).
+`layers.{i}.attention.Q.weight` ...): the training branch on the tape, and the eval-only KV-cache branch
+(model.py:105-110) with greedy `generate` (model.py:254-269) in plain NumPy (`decode_logits`, `generate`).
 Also the two smaller workloads of BASELINE.json: the MNIST-shaped MLP and the LeNet of
 examples/pydynet/mnist.py:65-98 (shape-adapted to 3x32x32 as SURVEY 8(d) states).
 """
@@ -107,6 +108,67 @@ class Llama:
         loss.backward()
         opt.step()
         return loss.item()
+
+
+    # ---- eval branch: KV cache + greedy decoding (no tape: the reference runs it with autograd off) ----
+    def reset_cache(self, max_batch, max_seq):                 # model.py:84-91: zero (max_batch, max_seq, H, hd) caches
+        dt = self.params["norm.weight"].value.dtype
+        self.cache = [(np.zeros((max_batch, max_seq, self.heads, self.hd), dt),
+                       np.zeros((max_batch, max_seq, self.heads, self.hd), dt)) for _ in range(self.n_layers)]
+
+    def decode_logits(self, ids, start_pos):                   # model.py:95-121, 192-211, 254-256 (eval mode)
+        """Logits of the LAST position of `ids` (B, L) placed at positions [start_pos, start_pos + L)."""
+        P, H, hd = {k: v.value for k, v in self.params.items()}, self.heads, self.hd
+        ids = np.asarray(ids)
+        B, L = ids.shape
+        cos, sin = self.cos.value[start_pos:start_pos + L], self.sin.value[start_pos:start_pos + L]
+
+        def rms(x, w):                                         # norm.py:245-248, eps 1e-6
+            return x / np.sqrt((x * x).mean(-1, keepdims=True) + 1e-6) * w
+
+        def rot(x):                                            # model.py:23-44 on interleaved pairs
+            xr = x.reshape(*x.shape[:-1], -1, 2)
+            r, i = xr[..., 0], xr[..., 1]
+            c, s_ = cos[None, :, None, :], sin[None, :, None, :]
+            return np.stack([r * c - i * s_, r * s_ + i * c], axis=-1).reshape(x.shape)
+
+        h = P["tok_embedding.weight"][ids]
+        mask = None
+        if L > 1:                                              # model.py:199-203
+            mask = np.concatenate([np.zeros((L, start_pos)), np.triu(np.full((L, L), float("-inf")), k=1)], axis=1)
+            mask = mask.astype(h.dtype)
+        for i in range(self.n_layers):
+            pre = f"layers.{i}."
+            x = rms(h, P[pre + "input_norm.weight"])
+            q = (x @ P[pre + "attention.Q.weight"]).reshape(B, L, H, hd)
+            k = (x @ P[pre + "attention.K.weight"]).reshape(B, L, H, hd)
+            v = (x @ P[pre + "attention.V.weight"]).reshape(B, L, H, hd)
+            q, k = rot(q), rot(k)
+            ck, cv = self.cache[i]
+            ck[:B, start_pos:start_pos + L] = k                # model.py:105-110
+            cv[:B, start_pos:start_pos + L] = v
+            k, v = ck[:B, :start_pos + L], cv[:B, :start_pos + L]
+            att = q.transpose(0, 2, 1, 3) @ k.transpose(0, 2, 3, 1) / math.sqrt(hd)
+            if mask is not None:
+                att = att + mask
+            att = np.exp(att - att.max(-1, keepdims=True))     # functional.py:43-49
+            att = att / att.sum(-1, keepdims=True)
+            o = (att @ v.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3).reshape(B, L, -1)
+            z = h + o @ P[pre + "attention.O.weight"]
+            y = rms(z, P[pre + "post_attn_norm.weight"])
+            g = y @ P[pre + "ffn.gate.weight"]
+            h = z + (g / (1 + np.exp(-g)) * (y @ P[pre + "ffn.up.weight"])) @ P[pre + "ffn.down.weight"]
+        h = rms(h, P["norm.weight"])[:, [-1], :]               # model.py:254-256: only the last position
+        return h @ P["lm_head.weight"] + P["lm_head.bias"]
+
+    def generate(self, ids, max_new_tokens):                   # model.py:258-269
+        ids = np.asarray(ids)
+        B, L = ids.shape
+        next_id = None
+        for i, pos in enumerate(range(L, max_new_tokens)):
+            logits = self.decode_logits(ids, 0) if i == 0 else self.decode_logits(next_id, pos)
+            next_id = logits[:, -1, :].argmax(-1, keepdims=True)
+            yield next_id, logits
 
 
 class MLP:

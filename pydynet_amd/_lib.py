@@ -47,7 +47,11 @@ def parse_header(path: str = HEADER_PATH):
 
 
 class HipLibraryError(RuntimeError):
-    pass
+    """A `pdn_*` entry point returned non-zero; `code` is that status (negative PDN_E*, positive hipError_t)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 class _Lib:
@@ -74,7 +78,7 @@ class _Lib:
         rc = self.fn[name](*args)
         if rc != 0:
             msg = self._last_error()
-            raise HipLibraryError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}")
+            raise HipLibraryError(f"{name} failed (code {rc}): {msg.decode() if msg else ''}", rc)
 
     def query(self, name, *args):
         """For functions that return a value (workspace sizes, counts) rather than a status."""

@@ -12,6 +12,7 @@ fused attention kernels do not cover and for the KV-cache path, whose per-token 
 tape altogether (`_decode_step_hip`).
 """
 import math
+import os
 
 import numpy as np
 
@@ -227,24 +228,144 @@ class Llama(nn.Module):
             yield next_id
 
     # -- decode fast path -----------------------------------------------------------
-    def _decode_step_hip(self, ids, pos: int):
-        """One greedy decode step (one new token per sequence) without building tape nodes: the same
-        kernels as the module path (RMSNorm, projections as skinny GEMMs writing k / v straight into
-        their cache slots, RoPE in place, decode attention over the cache, SwiGLU), ~77 launches from
-        preallocated buffers.  ids: (B, 1) int64 device array; returns the next ids, (B, 1) int64."""
+    graph_decode = True     # class switch: False issues the step's launches one by one instead of replaying a hipGraph
+
+    def _decode_plan(self, B):
+        """Buffers and weight views of the graph-replayable decode step (csrc/decode.hip), or None when the
+        model's shapes / layout are outside what those kernels take (then the generic launches below run)."""
         from .. import hipnp as hp, _lib
-        L, st = _lib.lib(), hp.stream()
         D, H, F, V = self.embed_dim, self.n_heads, self.ffn_dim, self.vocab_size
-        hd, half = D // H, D // H // 2
+        st = getattr(self, "_decode_st", None)
+        a0 = self.layers[0].attention
+        key = (B, hp._state["device"], self.lm_head.weight.data._ptr, self.tok_embedding.weight.data._ptr,
+               a0.Q.weight.data._ptr, a0.cache_k.data._ptr)       # a captured step holds these addresses
+        if st is not None and st["key"] == key:
+            return st if st["ok"] else None
+        if st is not None and st.get("graph"):
+            st["graph"].destroy()
+        ok = (B <= 8 and B * max(D, F) <= 16384 and D % 4 == 0 and F % 4 == 0 and V % 4 == 0 and (D // H) % 4 == 0
+              and self.layers[0].attention.cache_k.shape[1] * 4 <= 60 * 1024 and D // H <= 256)
+        packs = []
+        if ok:
+            for layer in self.layers:
+                a, f = layer.attention, layer.ffn
+                qkv = hp.stacked_view([a.Q.weight.data, a.K.weight.data, a.V.weight.data])
+                gu = hp.stacked_view([f.gate.weight.data, f.up.weight.data])
+                mats = (a.O.weight.data, f.down.weight.data)
+                if qkv is None or gu is None or not all(m.is_contiguous() for m in mats):    # (block strides may be < 0)
+                    ok = False
+                    break
+                packs.append((qkv, gu))
+            ok = ok and self.lm_head.weight.data.is_contiguous() and self.tok_embedding.weight.data.is_contiguous()
+        st = {"B": B, "key": key, "ok": ok}
+        if ok:
+            nblk = _lib.lib().query("pdn_decode_gemv_blocks", V)
+            # key ranges per head in the decode attention: one CU pulls ~11 B/clk, so long caches are cut up
+            ns = int(os.environ.get("PDN_DECODE_SPLITS", "0")) or (1 if self.layers[0].attention.cache_k.shape[1] <= 256 else 4)
+            st.update(packs=packs, graph=None, host_pos=None, ns=ns,
+                      ids=hp.zeros((B, 1), np.int64), pos=hp.zeros((1,), np.int32),
+                      cand_v=hp.empty((B, nblk), np.float32), cand_i=hp.empty((B, nblk), np.int32),
+                      **{n: hp.empty((B, w), np.float32) for n, w in
+                         (("x", D), ("qkv", 3 * D), ("att", ns * H * (4 + D // H)), ("gu", 2 * F), ("logits", V))})
+            self._decode_ws = {"logits": st["logits"], "x": st["x"]}
+        self._decode_st = st
+        return st if ok else None
+
+    def _decode_launches(self, st):
+        """The 33 launches of one decode step (6 layers); every argument is fixed for the lifetime of `st` (the position
+        and the token ids are read from device memory), so the sequence can be captured once and replayed."""
+        from .. import hipnp as hp, _lib
+        L, s = _lib.lib(), hp.stream()
+        D, H, F, V, B = self.embed_dim, self.n_heads, self.ffn_dim, self.vocab_size, st["B"]
+        hd = D // H
+        x, qkv, att, gu, logits = (st[n]._ptr for n in ("x", "qkv", "att", "gu", "logits"))
+        pos = st["pos"]._ptr
+        emb = self.tok_embedding.weight.data
+        L.call("pdn_embedding_gather_f32", emb._ptr, V, D, emb._strides[0], st["ids"]._ptr, B, x, hp.err_flag_ptr(), s)
+        cos, sin = self.freqs_cos.data._ptr, self.freqs_sin.data._ptr
+        for layer, (wqkv, wgu) in zip(self.layers, st["packs"]):
+            a, f = layer.attention, layer.ffn
+            ck, cv = a.cache_k.data, a.cache_v.data
+            cbs = ck._strides[0]
+            # h = RMSNorm(x); [q | k | v] = h @ [Wq | Wk | Wv]
+            L.call("pdn_decode_gemv_f32", x, D, layer.input_norm.weight.data._ptr, layer.input_norm.eps, wqkv._ptr, D, D,
+                   wqkv._strides[0], None, None, 0, qkv, 3 * D, B, D, 3 * D, 0, 0, 0, None, None, s)
+            # RoPE of q / k, cache append, attention over positions [0, pos]
+            L.call("pdn_decode_attention_f32", qkv, 3 * D, cos, sin, ck._ptr, cv._ptr, att, B, H, hd, st["ns"], cbs, pos,
+                   ck.shape[1], s)
+            wo, wd = a.O.weight.data, f.down.weight.data
+            # x += merge(att partials) @ Wo: the key-range partials are merged while the row is staged
+            L.call("pdn_decode_gemv_f32", att, st["att"].shape[1], None, 0.0, wo._ptr, D, D, 0, None, x, D, x, D, B, D, D,
+                   2, st["ns"], hd, None, None, s)
+            L.call("pdn_decode_gemv_f32", x, D, layer.post_attn_norm.weight.data._ptr, layer.post_attn_norm.eps, wgu._ptr,
+                   F, F, wgu._strides[0], None, None, 0, gu, 2 * F, B, D, 2 * F, 0, 0, 0, None, None, s)
+            # x += (silu(gate) * up) @ Wdown: SwiGLU in the loads
+            L.call("pdn_decode_gemv_f32", gu, 2 * F, None, 0.0, wd._ptr, D, D, 0, None, x, D, x, D, B, F, D, 1, 0, 0,
+                   None, None, s)
+        head = self.lm_head
+        bias = head.bias.data._ptr if getattr(head, "bias", None) is not None else None
+        # vocabulary projection; every workgroup also leaves the first maximum of its columns, the pick kernel
+        # finishes the argmax over those candidates (model.py:262-268) and advances the position
+        L.call("pdn_decode_gemv_f32", x, D, self.norm.weight.data._ptr, self.norm.eps, head.weight.data._ptr, V, V, 0,
+               bias, None, 0, logits, V, B, D, V, 0, 0, 0, st["cand_v"]._ptr, st["cand_i"]._ptr, s)
+        L.call("pdn_decode_pick_tick_f32", st["cand_v"]._ptr, st["cand_i"]._ptr, B, st["cand_v"].shape[1],
+               st["ids"]._ptr, pos, s)
+
+    def _decode_step_hip(self, ids, pos: int):
+        """One greedy decode step (one new token per sequence) without building tape nodes.  ids: (B, 1) int64
+        device array; returns the next ids, (B, 1) int64.  The step is ONE hipGraph replay: norm + projection,
+        RoPE + cache append, decode attention, SwiGLU + down projection and the greedy pick all read the position
+        from device memory (csrc/decode.hip), so nothing changes between replays but the data."""
+        from .. import hipnp as hp, _lib
         B = ids.shape[0]
         cache = self.layers[0].attention.cache_k
-        # raw pointers are formed from `pos` below: refuse what the module path would also refuse
+        # raw pointers / device-side offsets are formed from `pos`: refuse what the module path would also refuse
         # (the reference fails with a NumPy broadcast error, model.py:105-110)
         if pos < 0 or pos >= cache.shape[1] or pos >= self.freqs_cos.shape[0]:
             raise ValueError(f"decode position {pos} is outside the KV cache / RoPE table "
                              f"(max_seq_len {cache.shape[1]}, {self.freqs_cos.shape[0]} RoPE rows)")
         if B > cache.shape[0]:
             raise ValueError(f"batch {B} exceeds the KV cache's max_batch_size {cache.shape[0]}")
+        st = self._decode_plan(B)
+        if st is None:
+            return self._decode_step_generic(ids, pos)
+        if st["host_pos"] != pos:
+            st["pos"][...] = np.int32(pos)                       # (later steps: the device advances it itself)
+        if ids is not st["ids"] and ids is not st.get("last_out"):
+            st["ids"][...] = ids                                 # (not the array the previous step returned: its
+                                                                 # value is already where the gather reads it)
+        g = st["graph"]
+        if g is None and Llama.graph_decode and pos + 2 < min(cache.shape[1], self.freqs_cos.shape[0]):
+            # capture once: hipnp.Graph runs the step twice for real (pool warm-up + first replay), which writes the
+            # cache rows of positions pos and pos + 1 with exactly what the real steps will write there; the
+            # position and the ids are then put back and the real step replayed
+            keep = st["ids"].copy()
+            try:
+                g = hp.Graph()
+                g.capture(lambda: self._decode_launches(st))
+                st["graph"] = g
+            except _lib.HipLibraryError as e:
+                if e.code != -2:                                 # PDN_EUNSUPPORTED: no graph support (the emulated
+                    raise                                        # ABI) -> plain launches; anything else is a bug
+                st["graph"] = g = False
+            st["pos"][...] = np.int32(pos)
+            st["ids"][...] = keep
+        if g:
+            g.replay()
+        else:
+            self._decode_launches(st)
+        st["host_pos"] = pos + 1
+        out = st["last_out"] = st["ids"].copy()                  # the caller's own array: the next replay rewrites `ids`
+        return out
+
+    def _decode_step_generic(self, ids, pos: int):
+        """The same step from the library's generic entry points (skinny `pdn_gemm_f32`, RMSNorm, RoPE, decode
+        attention, SwiGLU), ~77 launches from preallocated buffers: for shapes / layouts the graph path does not take."""
+        from .. import hipnp as hp, _lib
+        L, st = _lib.lib(), hp.stream()
+        D, H, F, V = self.embed_dim, self.n_heads, self.ffn_dim, self.vocab_size
+        hd, half = D // H, D // H // 2
+        B = ids.shape[0]
         ws = getattr(self, "_decode_ws", None)
         if ws is None or ws["x"].device_index != hp._state["device"] or ws["x"].shape[0] != B:
             ws = {n: hp.empty((B, w), np.float32) for n, w in

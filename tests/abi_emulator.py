@@ -52,7 +52,7 @@ class EmulatedLib:
         self.calls.append(name)
         rc = getattr(self, name)(*args)
         if rc:
-            raise _lib.HipLibraryError(f"{name} failed (emulated, code {rc})")
+            raise _lib.HipLibraryError(f"{name} failed (emulated, code {rc})", rc)
 
     def query(self, name, *args):
         assert name in self.protos and len(args) == len(self.protos[name][1]), name
@@ -600,6 +600,103 @@ class EmulatedLib:
         e = np.exp(s - s.max(-1, keepdims=True))
         pr = e / e.sum(-1, keepdims=True)
         flat(o, B * D).reshape(B, H, hd)[...] = np.einsum("bht,bthd->bhd", pr, V)
+        return 0
+
+    # -- graph-replayable decode step (csrc/decode.hip) -----------------------------------------------
+    def pdn_decode_gemv_f32(self, x, x_rs, norm_w, eps, W, w_rs, blk_cols, w_bs, bias, residual, r_rs, y, y_rs,
+                            B, K, N, act, act_ns, act_hd, blk_max, blk_arg, stream):
+        if B > 8 or B * K > 16384 or N % blk_cols or blk_cols % 4:
+            return -1
+        if act == 2:
+            H = K // act_hd
+            R = np.array(view(x, (B, act_ns, H, 4 + act_hd), (x_rs, H * (4 + act_hd), 4 + act_hd, 1), np.float32))
+            m, l, o = R[..., 0], R[..., 1], R[..., 4:]
+            m = np.where(l > 0, m, -np.inf)
+            w = np.where(l > 0, np.exp(m - m.max(1, keepdims=True)), 0).astype(np.float32)
+            a = ((w[..., None] * o).sum(1) / (w * l).sum(1)[..., None]).reshape(B, K)
+            X = None
+        else:
+            X = np.array(view(x, (B, 2 * K if act else K), (x_rs, 1), np.float32))
+        if act == 2:
+            pass
+        elif act:
+            g, u = X[:, :K], X[:, K:]
+            a = g / (np.float32(1) + np.exp(-g)) * u
+        elif norm_w:
+            a = X / np.sqrt((X * X).mean(-1, keepdims=True) + np.float32(eps)) * flat(norm_w, K)
+        else:
+            a = X
+        nb = N // blk_cols
+        Wv = view(W, (nb, K, blk_cols), (w_bs, w_rs, 1), np.float32)
+        out = np.concatenate([a @ Wv[j] for j in range(nb)], axis=1).astype(np.float32)
+        if bias:
+            out = out + flat(bias, N)
+        if residual:
+            out = out + view(residual, (B, N), (r_rs, 1), np.float32)
+        view(y, (B, N), (y_rs, 1), np.float32)[...] = out
+        if blk_max:
+            nb_ = self.pdn_decode_gemv_blocks(N)
+            tn = -(-N // nb_)
+            tn = 16 if N <= 4096 else (32 if N <= 16384 else 64)
+            bm, ba = flat(blk_max, B * nb_).reshape(B, nb_), flat(blk_arg, B * nb_, np.int32).reshape(B, nb_)
+            for j in range(nb_):
+                seg = out[:, j * tn:(j + 1) * tn]
+                bm[:, j] = seg.max(-1)
+                ba[:, j] = j * tn + seg.argmax(-1)
+        return 0
+
+    def pdn_decode_gemv_blocks(self, N):
+        return (N + 15) // 16 if N <= 4096 else ((N + 31) // 32 if N <= 16384 else (N + 63) // 64)
+
+    def pdn_decode_attention_f32(self, qkv, rs, cos, sin, kc, vc, parts, B, H, hd, NS, cbs, pos, max_len, stream):
+        D, half = H * hd, hd // 2
+        p = int(flat(pos, 1, np.int32)[0])
+        assert 0 <= p < max_len
+        rows = view(qkv, (B, 3 * D), (rs, 1), np.float32)
+        c, s_ = flat(cos + 4 * p * half, half), flat(sin + 4 * p * half, half)
+
+        def rot(v):
+            a = np.array(v).reshape(H, half, 2)
+            out = np.empty_like(a)
+            out[..., 0] = a[..., 0] * c - a[..., 1] * s_
+            out[..., 1] = a[..., 0] * s_ + a[..., 1] * c
+            return out.reshape(D)
+        Q = np.stack([rot(rows[b, :D]) for b in range(B)]).reshape(B, H, hd)
+        for b in range(B):
+            view(kc + 4 * (b * cbs + p * D), (D,), (1,), np.float32)[...] = rot(rows[b, D:2 * D])
+            view(vc + 4 * (b * cbs + p * D), (D,), (1,), np.float32)[...] = rows[b, 2 * D:]
+        T = p + 1
+        K = view(kc, (B, T, H, hd), (cbs, D, hd, 1), np.float32)
+        V = view(vc, (B, T, H, hd), (cbs, D, hd, 1), np.float32)
+        s = np.einsum("bhd,bthd->bht", Q, K) / np.float32(math.sqrt(hd))
+        out = flat(parts, B * NS * H * (4 + hd)).reshape(B, NS, H, 4 + hd)
+        chunk = -(-T // NS)
+        for sp in range(NS):
+            t0, t1 = sp * chunk, min(T, (sp + 1) * chunk)
+            if t0 >= t1:
+                out[:, sp, :, 0], out[:, sp, :, 1] = -np.inf, 0.0
+                continue
+            ss = s[:, :, t0:t1]
+            m = ss.max(-1)
+            e = np.exp(ss - m[..., None])
+            out[:, sp, :, 0], out[:, sp, :, 1] = m, e.sum(-1)
+            out[:, sp, :, 4:] = np.einsum("bht,bthd->bhd", e, V[:, t0:t1])
+        return 0
+
+    def pdn_decode_pick_tick_f32(self, vals, args, B, n, ids, pos, stream):
+        v = np.array(flat(vals, B * n).reshape(B, n))
+        a = np.array(flat(args, B * n, np.int32).reshape(B, n))
+        for b in range(B):
+            best = v[b].max()
+            flat(ids, B, np.int64)[b] = a[b][v[b] == best].min()
+        if pos:
+            flat(pos, 1, np.int32)[0] += 1
+        return 0
+
+    def pdn_decode_argmax_tick_f32(self, logits, rs, B, V, ids, pos, stream):
+        flat(ids, B, np.int64)[...] = view(logits, (B, V), (rs, 1), np.float32).argmax(-1)
+        if pos:
+            flat(pos, 1, np.int32)[0] += 1
         return 0
 
     def pdn_cross_entropy_colsum_workspace_bytes(self, rows, V):

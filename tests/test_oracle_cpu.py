@@ -299,3 +299,25 @@ def test_full_size_llama_scalars():
         if p.requires_grad:
             g = float(np.linalg.norm(p.grad.astype(np.float64)))
             assert abs(g - ref["grad1_norm"][n]) <= 1e-4 * ref["grad1_norm"][n] + 1e-12, n
+
+
+def test_oracle_kv_cache_generate_matches_reference_vectors():
+    """oracle.llama.Llama.generate (KV cache, greedy) against the reference's `generate` (generate.npz, made by
+    tools/gen_golden_r2.py importing the real reference): token ids equal, per-step logits to fp32 round-off."""
+    import os
+    from oracle import llama as ollama
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "generate.npz"))
+    V, D, H, F_, layers, cfg_max = (int(v) for v in d["cfg"])
+    for tag, B in (("b1", 1), ("b2", 2), ("long", 1)):
+        max_seq = int(d[f"{tag}/max_seq"])
+        m = ollama.Llama(V, D, H, F_, max_seq, B, layers, np.float32)
+        for k in d.files:
+            if k.startswith("init/") and k[5:] in m.params:
+                m.params[k[5:]].value[...] = d[k]
+        m.reset_cache(B, max_seq)
+        toks, logits = [], []
+        for t, lg in m.generate(d[f"{tag}/prompt"], int(d[f"{tag}/total"])):
+            toks.append(t); logits.append(lg)
+        assert np.array_equal(np.concatenate(toks, 1), d[f"{tag}/tokens"]), tag
+        got, want = np.concatenate(logits, 1), d[f"{tag}/logits"]
+        assert np.abs(got - want).max() <= 1e-5 * max(np.abs(want).max(), 1.0), tag
