@@ -405,6 +405,24 @@ int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float*
                               int C, int H, int W, int O, int k, int stride, int pad, void* workspace,
                               int64_t workspace_bytes, void* stream);
 int64_t pdn_conv2d_bwd_weight_workspace_bytes(int N, int C, int H, int W, int O, int k, int stride, int pad);
+/* conv -> relu -> max_pool(2, 2) as ONE node (the chain of examples/pydynet/mnist.py:92-95; functional.py:31-32,
+ * 254-339): the full-resolution conv output and its gradient never exist in HBM.  Forward writes the pooled map and
+ * a hit map of one BIT per conv output position, (N, O, OH * OW / 32) 32-bit words, bit (p & 31) of word p >> 5 for
+ * position p = oy * OW + ox -- set when the position receives the pooled gradient: relu(y) equals the window maximum
+ * (ties all pass, tensor.py:808-815) AND y >= 0 (relu'(0) = 1, the reference's maximum(0., x) quirk).  The backward forms expand the pooled gradient through the mask while it is staged into LDS.
+ * pdn_conv2d_relu_pool_supported -> bitmask 1 forward | 2 data gradient | 4 weight gradient;
+ * pdn_pool_mask_expand_f32 materialises the expanded gradient (rows, OH, OW) for shapes only the plain kernels take.
+ * Workspace of the weight gradient: pdn_conv2d_bwd_weight_workspace_bytes. */
+int pdn_conv2d_relu_pool_supported(int C, int H, int W, int O, int k, int stride, int pad);
+int pdn_conv2d_relu_pool_fwd_f32(const float* x, const float* w, const float* bias, float* pooled, unsigned* mask,
+                                 int N, int C, int H, int W, int O, int k, int stride, int pad, void* stream);
+int pdn_conv2d_relu_pool_bwd_data_f32(const float* dpooled, const unsigned* mask, const float* w, float* dx, int N,
+                                      int C, int H, int W, int O, int k, int stride, int pad, void* stream);
+int pdn_conv2d_relu_pool_bwd_weight_f32(const float* x, const float* dpooled, const unsigned* mask, float* dw,
+                                        float* db, int accumulate, int N, int C, int H, int W, int O, int k, int stride,
+                                        int pad, void* workspace, int64_t workspace_bytes, void* stream);
+int pdn_pool_mask_expand_f32(const float* dpooled, const unsigned* mask, float* dy, int64_t rows, int OH, int OW,
+                             void* stream);
 int pdn_pool2d_fwd_f32(const float* x, int N, int C, int H, int W, int k, int stride, int pad,
                        int mode, float* y, void* stream);
 int pdn_pool2d_bwd_f32(const float* x, const float* y, const float* dy, int N, int C, int H, int W,

@@ -23,7 +23,8 @@ import os
 
 import numpy as np
 
-from .tensor import Tensor, _Operator, _as_operand
+from ..autograd import is_grad_enable
+from .tensor import Graph, Tensor, _Operator, _as_operand
 
 
 def _hip():
@@ -89,6 +90,55 @@ def _is_leaf_f32(t):
 
 
 # ---------------------------------------------------------------------------------------
+class _Deferred:
+    """Mixin for a node whose array is produced at FIRST USE instead of at construction.
+
+    The reference composes `max_pool2d(relu(conv2d(x)), 2, 2)` from three tape nodes (mnist.py:92-95), each a full pass
+    over HBM.  A conv2d node whose shape the fused kernel takes is created without running anything; `relu` of such a
+    node is deferred too; `max_pool2d(., 2, 2)` of that then launches ONE kernel (conv + bias + relu + pool in the
+    epilogue, `conv2d_relu_pool`) and the two intermediate nodes are simply dropped.  Any other consumer reads `.data`,
+    which runs the node's own kernel then -- from that moment it is an ordinary node.  Metadata (`shape`, `dtype`,
+    ...) is answered without materialising.  (As with any lazy value: inputs modified in place between construction
+    and first use are seen in their modified state.)"""
+
+    _pending = None
+
+    def _init_deferred(self, inputs, shape, dtype):
+        self._pending, self._shape, self._dtype = tuple(inputs), tuple(int(v) for v in shape), np.dtype(dtype)
+        self.__dict__["_data"] = None
+        self.device = inputs[0].device
+        self.copy = None
+        self.grad = None
+        self.requires_grad = bool(is_grad_enable() and any(t.requires_grad for t in inputs))
+        self.last = list(inputs) if self.requires_grad else []
+        if self.requires_grad:
+            Graph._add_node(self)
+
+    @property
+    def data(self):
+        d = self.__dict__.get("_data")
+        if d is None and self._pending is not None:
+            inputs, self._pending = self._pending, None
+            with self.device:
+                d = self.forward_(*inputs)
+            self.__dict__["_data"] = d
+        return d
+
+    @data.setter
+    def data(self, value):
+        self.__dict__["_data"] = value
+        self._pending = None
+
+    @property
+    def shape(self): return self._shape if self._pending is not None else self.data.shape
+    @property
+    def dtype(self): return self._dtype if self._pending is not None else self.data.dtype
+    @property
+    def ndim(self): return len(self.shape)
+    @property
+    def size(self): return int(np.prod(self.shape, dtype=np.int64))
+
+
 class linear(_Operator):
     """y = x @ W (+ b) (+ residual) over the last axis of x; W is (in, out).
 
@@ -366,8 +416,15 @@ class silu(_Operator):
         return [dx]
 
 
-class relu(_Operator):
-    """maximum(0., x); the gradient passes where out == x, i.e. also at x == 0 (reference quirk)."""
+class relu(_Deferred, _Operator):
+    """maximum(0., x); the gradient passes where out == x, i.e. also at x == 0 (reference quirk).
+    relu of a still-deferred conv2d node is deferred as well (see _Deferred)."""
+
+    def __init__(self, x):
+        if isinstance(x, conv2d) and x._pending is not None:
+            self._init_deferred((x,), x.shape, x.dtype)
+        else:
+            super().__init__(x)
 
     def forward_(self, x):
         return self.xp.maximum(np.array(0., dtype=x.dtype) if self.xp is np else 0.0, x.data)
@@ -829,7 +886,7 @@ class linear_cross_entropy(_Operator):
         return grads
 
 
-class conv2d(_Operator):
+class conv2d(_Deferred, _Operator):
     """Square-kernel 2-D convolution (nn/functional.py:254-281).
 
     HIP device, LeNet-class shapes (the padded image and the weights fit in LDS): direct
@@ -842,11 +899,26 @@ class conv2d(_Operator):
     `node._col` is the reference-layout im2col buffer (formed on demand on the direct path)."""
 
     use_direct = True       # class switch: False forces the im2col + GEMM path (tests, A/B)
+    defer = True            # class switch: False runs the kernel at construction (no conv + relu + pool fusion)
 
     def __init__(self, x, kernel, bias=None, padding=0, stride=1):
         self.padding, self.stride = int(padding), int(stride)
         self.has_bias = bias is not None
-        super().__init__(*((x, kernel, bias) if self.has_bias else (x, kernel)))
+        inputs = (x, kernel, bias) if self.has_bias else (x, kernel)
+        if conv2d.defer and type(self) is conv2d and self._fusable(x, kernel, bias):
+            N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+            self._init_deferred(inputs, (N, O, oh, ow), np.float32)
+        else:
+            super().__init__(*inputs)
+
+    def _fusable(self, x, kernel, bias):
+        """A shape / device the fused conv + relu + 2x2 max-pool kernel takes (then the node is deferred)."""
+        if not (conv2d.use_direct and x.device.is_hip and hip_f32(x, kernel, bias)) or x.ndim != 4 or kernel.ndim != 4:
+            return False
+        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        if kernel.shape[1] != C or kernel.shape[3] != k or (bias is not None and bias.size != O):
+            return False
+        return bool(_L().query("pdn_conv2d_relu_pool_supported", C, H, W, O, k, self.stride, self.padding) & 1)
 
     def _dims(self, x, kernel):
         N, C, H, W = x.shape
@@ -924,6 +996,7 @@ class conv2d(_Operator):
     @property
     def _col(self):
         """The im2col buffer in the reference layout (N, C, kh, kw, oh, ow) (a view on the HIP path)."""
+        self.data                                        # (a deferred node runs its kernel now)
         if self.xp is np:
             return self._col_np
         N, C, H, W = self._xd.shape                      # (the node's edges are gone after backward)
@@ -998,6 +1071,79 @@ class conv2d(_Operator):
                 hp.gemm(wp.T, gc.reshape(N, O, M), dcol)                       # (Kp,O) @ (O,M) per image
                 L.call("pdn_col2im2d_f32", dcol._ptr, N, C, H, W, k, self.stride, self.padding, dx._ptr, Kp,
                        hp.stream())
+            grads[0] = dx
+        return grads
+
+
+class conv2d_relu_pool(conv2d):
+    """max_pool2d(relu(conv2d(x, w) + b), 2, 2) as ONE node (mnist.py:92-95; functional.py:31-32, 254-339).
+
+    Forward: the direct convolution with bias, ReLU and the 2x2 / stride-2 max-pool applied to the accumulators
+    (`pdn_conv2d_relu_pool_fwd_f32`): only the pooled map and a hit map of one bit per position reach HBM.
+    Backward: the pooled gradient is expanded through that mask -- every window position that equals the maximum
+    and passes relu'(y) = [y >= 0] receives it, exactly what the reference's maximum / max grad_fns produce
+    (tensor.py:808-815) -- while the data-gradient and weight-gradient kernels stage it into LDS; the
+    full-resolution conv output, its relu, and both of their gradients never exist."""
+
+    def __init__(self, x, kernel, bias=None, padding=0, stride=1):
+        self.padding, self.stride = int(padding), int(stride)
+        self.has_bias = bias is not None
+        _Operator.__init__(self, *((x, kernel, bias) if self.has_bias else (x, kernel)))
+
+    def forward_(self, x, kernel, bias=None):
+        hp, L = _hip(), _L()
+        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        self._xd = _contig(x.data)
+        self._k_shape = tuple(kernel.shape)
+        self._kernel_data = kernel.data
+        self._bias_data = bias.data if bias is not None else None
+        self._colp = self._wp = None
+        self._direct = L.query("pdn_conv2d_direct_supported", C, H, W, O, k, self.stride, self.padding)
+        self._fused = L.query("pdn_conv2d_relu_pool_supported", C, H, W, O, k, self.stride, self.padding)
+        out = hp.empty((N, O, oh // 2, ow // 2), np.float32)
+        self._mask = hp.empty((N, O, oh * ow // 32), np.int32)              # hit map: one BIT per conv output position
+        L.call("pdn_conv2d_relu_pool_fwd_f32", self._xd._ptr, _contig(kernel.data)._ptr,
+               _contig(bias.data)._ptr if bias is not None else None, out._ptr, self._mask._ptr, N, C, H, W, O, k,
+               self.stride, self.padding, hp.stream())
+        return out
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, kernel = self.last[0], self.last[1]
+        bias = self.last[2] if self.has_bias else None
+        N, C, H, W, O, k, oh, ow = self._dims(x, kernel)
+        gp = _contig(g)
+        need_dw = kernel.requires_grad
+        need_db = bias is not None and bias.requires_grad
+        need_dx = x.requires_grad
+        fused_w = bool(self._fused & 4) or not (need_dw or need_db)
+        fused_x = bool(self._fused & 2) or not need_dx
+        if not (fused_w and fused_x):
+            # a direction the expanding loads do not take: materialise the expanded gradient once, plain kernels
+            dy = hp.empty((N, O, oh, ow), np.float32)
+            L.call("pdn_pool_mask_expand_f32", gp._ptr, self._mask._ptr, dy._ptr, N * O, oh, ow, hp.stream())
+            return conv2d.backward_all(self, dy)
+        grads = [None] * len(self.last)
+        if need_dw or need_db:
+            direct_w = need_dw and _is_leaf_f32(kernel)
+            direct_b = need_db and _is_leaf_f32(bias)
+            if need_dw and need_db and direct_w != direct_b:
+                direct_w = direct_b = False
+            dw = (kernel.grad if direct_w else hp.empty(kernel.shape, np.float32)) if need_dw else None
+            db = (bias.grad if direct_b else hp.empty((O,), np.float32)) if need_db else None
+            ws, wsb = hp.workspace(L.query("pdn_conv2d_bwd_weight_workspace_bytes", N, C, H, W, O, k,
+                                           self.stride, self.padding))
+            L.call("pdn_conv2d_relu_pool_bwd_weight_f32", self._xd._ptr, gp._ptr, self._mask._ptr,
+                   dw._ptr if dw is not None else None, db._ptr if db is not None else None,
+                   1 if (direct_w or direct_b) else 0, N, C, H, W, O, k, self.stride, self.padding, ws, wsb, hp.stream())
+            if need_dw and not direct_w:
+                grads[1] = dw
+            if need_db and not direct_b:
+                grads[2] = db.reshape(bias.shape)
+        if need_dx:
+            dx = hp.empty((N, C, H, W), np.float32)
+            L.call("pdn_conv2d_relu_pool_bwd_data_f32", gp._ptr, self._mask._ptr, _contig(kernel.data)._ptr, dx._ptr,
+                   N, C, H, W, O, k, self.stride, self.padding, hp.stream())
             grads[0] = dx
         return grads
 

@@ -19,11 +19,19 @@
 //
 //   conv_direct_kernel<OT, CH>   forward (mode 0) and data gradient (mode 1: input = dy, weights
 //                                read flipped and with in/out channels swapped, pad = k-1-pad)
+//                                EP = 1: bias + ReLU + 2x2 / stride-2 max-pool in the epilogue (the conv ->
+//                                relu -> max_pool chain of examples/pydynet/mnist.py:92-95): only the pooled map
+//                                and a 4-bit mask per pooled element (which window positions receive the
+//                                gradient) are written; SRC = 1: the input image is the EXPANSION of a pooled
+//                                gradient through such a mask, formed while it is staged into LDS -- the
+//                                full-resolution conv output and its gradient never exist in HBM
 //   conv_wgrad_kernel<WT, PS>    dW[o][c][kh][kw] (+ db[o]) partial sums per workgroup over its
 //                                images: A = dy[o][pos] from LDS, B = image gather with a per-lane
 //                                column offset; contraction over positions; deterministic two-stage
 //                                reduction (partials in a workspace, fixed combine order)
 #include "common.h"
+#include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -94,15 +102,60 @@ struct TilePrefetch {
   }
 };
 
+// The same block read through a 2x2 max-pool hit map: element (c, y, x) of the (C, H, W) block is
+//   dp[c][y / 2][x / 2]  if bit ((y * W + x) & 31) of hit[c][(y * W + x) >> 5] is set, else 0
+// (reference semantics of relu -> max_pool backward, tensor.py:808-815 + functional.py:284-339: every position
+// that equals the window maximum AND passes relu'(y) = [y >= 0] receives the pooled gradient; one bit per conv
+// output position, 32 positions per word = one ballot of the forward epilogue).  A float4 piece = two pooled
+// elements: one float2 + one hit word per piece are what travels from HBM.
+__device__ __forceinline__ float4 expand_pooled(const float2& v, unsigned bits) {
+  return make_float4((bits & 1u) ? v.x : 0.f, (bits & 2u) ? v.x : 0.f, (bits & 4u) ? v.y : 0.f, (bits & 8u) ? v.y : 0.f);
+}
+
+template <int NV>
+struct PooledPrefetch {
+  float2 v[NV > 0 ? NV : 1];
+  unsigned m[NV > 0 ? NV : 1];
+  // dp of ONE image: (C, H / 2, W / 2); hit words of one image: (C, H * W / 32); piece e covers (c, y, x .. x + 3)
+  __device__ __forceinline__ void issue(const float* __restrict__ dp, const unsigned* __restrict__ hit, int total,
+                                        int H, int W) {
+    const int plane = H * W, hw = W >> 1;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (threadIdx.x + i * 256) * 4;
+      if (e < total) {
+        const int c = e / plane, rem = e - c * plane;
+        const int y = rem / W, x = rem - y * W;
+        v[i] = *reinterpret_cast<const float2*>(dp + (c * (H >> 1) + (y >> 1)) * hw + (x >> 1));
+        m[i] = hit[e >> 5];
+      }
+    }
+  }
+  __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
+                                               int pad) {
+    const int plane = H * W;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int e = (threadIdx.x + i * 256) * 4;
+      if (e < total) {
+        const int c = e / plane, rem = e - c * plane;
+        const int y = rem / W, x = rem - y * W;
+        lds_store4(frame + (c * PH + y + pad) * PW + x + pad, expand_pooled(v[i], (m[i] >> (e & 31)) & 15u));
+      }
+    }
+  }
+};
+
 // KS = compile-time tap extent (1, 3, 5) or 0 for a runtime extent.  With KS known the taps*(OT+CH)
 // LDS reads of one channel pair are issued as a block ahead of the MFMAs that consume them, and the
 // block of the NEXT channel pair is in flight while the current one is multiplied (one wave per SIMD
 // has no partner to hide the ~100-cycle ds_read latency behind, so the prefetch is explicit).
-template <int OT, int CH, int KS, int NV>
+template <int OT, int CH, int KS, int NV, int EP = 0, int SRC = 0>
 __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ bias,
-                                                           float* __restrict__ y, ConvGeom g) {
+                                                           float* __restrict__ y, ConvGeom g,
+                                                           unsigned* __restrict__ pmask) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int taps = g.k * g.k;
   float* wt = lds;                                   // [taps][Cp][OPAD]
@@ -124,28 +177,34 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
   for (int e = threadIdx.x; e < img_elems; e += blockDim.x) img[e] = 0.f;   // halo + padded channel stay 0
   __syncthreads();
 
-  float breg[OT][16];
-  unsigned rowmask[OT];
+  float breg[EP == 1 ? 1 : OT][EP == 1 ? 1 : 16];      // (the fused epilogue re-reads the bias from LDS: its
+  unsigned rowmask[OT];                                //  registers are needed for the pooling)
 #pragma unroll
   for (int o = 0; o < OT; ++o) {
     rowmask[o] = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int oc = o * 32 + acc_row(r, half);
-      breg[o][r] = bs[oc];
+      if constexpr (EP != 1) breg[o][r] = bs[oc];
       rowmask[o] |= (oc < g.Cout ? 1u : 0u) << r;
     }
   }
   const int chunks = (M + 31) / 32, per_pass = 4 * CH, passes = (chunks + per_pass - 1) / per_pass;
   const int plane = g.PH * g.PW, npair = g.Cp / 2, wstep = 2 * g.OPAD, tapw = g.Cp * g.OPAD;
   const int in_elems = g.Cin * g.Hin * g.Win;
-  TilePrefetch<NV> pf;
-  if (NV > 0 && blockIdx.x < g.N) pf.issue(x + (int64_t)blockIdx.x * in_elems, in_elems);
+  typename std::conditional<SRC == 1, PooledPrefetch<NV>, TilePrefetch<NV>>::type pf;
+  auto pf_issue = [&](int n) {
+    if constexpr (SRC == 1)
+      pf.issue(x + (int64_t)n * (in_elems >> 2), pmask + (int64_t)n * (in_elems >> 5), in_elems, g.Hin, g.Win);
+    else
+      pf.issue(x + (int64_t)n * in_elems, in_elems);
+  };
+  if (NV > 0 && blockIdx.x < g.N) pf_issue(blockIdx.x);
   for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
     if (NV > 0) {
       pf.commit_image(img, in_elems, g.Hin, g.Win, g.PH, g.PW, g.pad);
       __syncthreads();
-      if (n + (int)gridDim.x < g.N) pf.issue(x + (int64_t)(n + gridDim.x) * in_elems, in_elems);
+      if (n + (int)gridDim.x < g.N) pf_issue(n + gridDim.x);
     } else {
       stage_image(x + (int64_t)n * in_elems, img, g, g.pad);
       __syncthreads();
@@ -228,6 +287,68 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
       }
       // epilogue: rows of this lane's accumulator registers are fixed -> bias and row validity come
       // from registers set up once per kernel (no LDS read, no branch per store)
+      if constexpr (EP == 1) {
+        // bias + relu + 2x2 / stride-2 max-pool on the accumulators (lane = output position, register = channel):
+        // the window's other column is lane ^ 1, its other row is the wave's next chunk (OW = 32: a chunk is one
+        // output row, CH is even) or lane ^ OW (OW = 8 / 16: a chunk holds 32 / OW rows).  Written: the pooled
+        // value and the HIT MAP, one bit per conv output position = "this position receives the pooled gradient"
+        // = relu(v) == window max  AND  v >= 0  (ties all pass; relu'(0) = 1: the reference's maximum(0., x)
+        // quirk).  A chunk is 32 positions, so the map of (channel, chunk) is one half of a wave-wide ballot:
+        // one v_cmp and ONE dword store by lane 0 of the half-wave per accumulator register.
+        const int OW = g.OW, HW = OW >> 1, PM = (g.OH >> 1) * HW, MW = M >> 5;
+        float* pn = y + (int64_t)n * g.Cout * PM;
+        unsigned* mn = pmask + (int64_t)n * g.Cout * MW;
+        // (the 16 hit words of a tile -- one per accumulator register = per channel -- are uniform values; lane r
+        //  of each half-wave keeps the word of register r, so they leave in ONE store instruction per tile)
+        const int myrow = acc_row(l31 & 15, half);
+        if (OW == 32) {
+#pragma unroll
+          for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int c = 0; c + 1 < CH; c += 2) {
+              const bool live = pos[c] < M;
+              const int chunk = pos[c] >> 5;
+              const int pidx = (chunk >> 1) * HW + (l31 >> 1);
+              unsigned w0 = 0, w1 = 0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float bb = bs[o * 32 + acc_row(r, half)];
+                const float v0 = acc[o][c][r] + bb, v1 = acc[o][c + 1][r] + bb;
+                const float r0 = fmaxf(v0, 0.f), r1 = fmaxf(v1, 0.f);
+                const float mv = fmaxf(r0, r1);
+                const float m = fmaxf(mv, __shfl_xor(mv, 1, 64));
+                const unsigned long long h0 = __ballot(r0 == m && v0 >= 0.f), h1 = __ballot(r1 == m && v1 >= 0.f);
+                if ((l31 & 15) == r) { w0 = (unsigned)(h0 >> (32 * half)); w1 = (unsigned)(h1 >> (32 * half)); }
+                if (live && !(l31 & 1) && (rowmask[o] >> r & 1)) pn[(int64_t)(o * 32 + acc_row(r, half)) * PM + pidx] = m;
+              }
+              if (live && l31 < 16 && o * 32 + myrow < g.Cout)
+                *reinterpret_cast<uint2*>(mn + (int64_t)(o * 32 + myrow) * MW + chunk) = make_uint2(w0, w1);
+            }
+        } else {
+#pragma unroll
+          for (int o = 0; o < OT; ++o)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+              const bool live = pos[c] < M;
+              const int oy = pos[c] / OW, ox = pos[c] - oy * OW;
+              const int pidx = (oy >> 1) * HW + (ox >> 1);
+              unsigned w0 = 0;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float v = acc[o][c][r] + bs[o * 32 + acc_row(r, half)];
+                const float rr = fmaxf(v, 0.f);
+                const float up = OW == 16 ? __shfl_xor(rr, 16, 64) : __shfl_xor(rr, 8, 64);
+                const float m1 = fmaxf(rr, up);
+                const float m = fmaxf(m1, __shfl_xor(m1, 1, 64));
+                const unsigned long long h = __ballot(rr == m && v >= 0.f);
+                if ((l31 & 15) == r) w0 = (unsigned)(h >> (32 * half));
+                if (live && !(l31 & 1) && !(l31 & OW) && (rowmask[o] >> r & 1))
+                  pn[(int64_t)(o * 32 + acc_row(r, half)) * PM + pidx] = m;
+              }
+              if (live && l31 < 16 && o * 32 + myrow < g.Cout) mn[(int64_t)(o * 32 + myrow) * MW + (pos[c] >> 5)] = w0;
+            }
+        }
+      } else {
 #pragma unroll
       for (int o = 0; o < OT; ++o)
 #pragma unroll
@@ -238,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
           for (int r = 0; r < 16; ++r)
             if (rowmask[o] >> r & 1) yp[(int64_t)(o * 32 + acc_row(r, half)) * M] = acc[o][c][r] + breg[o][r];
         }
+      }
     }
     __syncthreads();                                  // everyone is done with this image
   }
@@ -253,10 +375,13 @@ struct WgradGeom {
 
 // WT = tiles per wave; PS = 1: waves share all tiles and split the positions, 0: waves split tiles.
 // The dy tile holds O + 1 rows (row O stays zero and serves the padded output channels).
-template <int WT, int PS, int NVX, int NVD>
+// SRC = 1: `dy` is a POOLED gradient (O, OH / 2, OW / 2) expanded through `dmask` while it is staged (see
+// PooledPrefetch): the relu -> max_pool backward of the fused forward epilogue.
+template <int WT, int PS, int NVX, int NVD, int SRC = 0>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ dy,
-                                                          float* __restrict__ partial, WgradGeom g) {
+                                                          float* __restrict__ partial, WgradGeom g,
+                                                          const unsigned* __restrict__ dmask) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* img = lds;                                   // [C][PH][PW]
   float* dyl = img + g.C * g.PH * g.PW;               // [O + 1][DYS]
@@ -291,18 +416,27 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   const int pstep = PS ? 4 : 1;                       // pairs between this wave's consecutive iterations
   const int nblk = (M + g.MB - 1) / g.MB, items = (n1 - n0) * nblk, x_elems = g.C * g.H * g.W;
   TilePrefetch<NVX> px;
-  float4 dv[NVD > 0 ? NVD : 1];
+  float4 dv[(NVD > 0 && SRC == 0) ? NVD : 1];
+  float2 dpv[(NVD > 0 && SRC == 1) ? NVD : 1];
+  unsigned dpm[(NVD > 0 && SRC == 1) ? NVD : 1];
   // dy[:, m0 : m0 + mb] of image n as float4 pieces: piece e -> row e / q, columns 4 * (e % q)
   auto issue = [&](int it) {
     const int n = n0 + it / nblk, m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
     if (m0 == 0) px.issue(x + (int64_t)n * x_elems, x_elems);
-    const float* dyn = dy + (int64_t)n * g.O * M + m0;
+    const float* dyn = dy + (int64_t)n * g.O * (SRC == 1 ? (M >> 2) : M) + (SRC == 1 ? 0 : m0);
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
       const int e = threadIdx.x + i * 256;
       if (e < g.O * q) {
         const int o = e / q, p = (e - o * q) * 4;
-        dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)o * M + p);
+        if constexpr (SRC == 1) {
+          const int gp = m0 + p, oy = gp / g.OW, ox = gp - oy * g.OW;
+          const int pi = (o * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
+          dpv[i] = *reinterpret_cast<const float2*>(dyn + pi);
+          dpm[i] = dmask[((int64_t)(n * g.O + o) * M + gp) >> 5];
+        } else {
+          dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)o * M + p);
+        }
       }
     }
   };
@@ -314,7 +448,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
       const int e = threadIdx.x + i * 256;
       if (e < g.O * q) {
         const int o = e / q, p = (e - o * q) * 4;
-        lds_store4(dyl + o * g.DYS + p, dv[i]);
+        if constexpr (SRC == 1)
+          lds_store4(dyl + o * g.DYS + p, expand_pooled(dpv[i], (dpm[i] >> ((m0 + p) & 31)) & 15u));
+        else
+          lds_store4(dyl + o * g.DYS + p, dv[i]);
       }
     }
   };
@@ -450,6 +587,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
   }
 }
 
+__global__ __launch_bounds__(256) void pool_mask_expand_kernel(const float* __restrict__ dp,
+                                                               const unsigned* __restrict__ hit,
+                                                               float* __restrict__ dy, int64_t n, int PH, int PW) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // pooled element
+  if (i >= n) return;
+  const int px = (int)(i % PW);
+  const int64_t t = i / PW;
+  const int py = (int)(t % PH);
+  const int64_t row = t / PH;
+  const float v = dp[i];
+  const int64_t p0 = (row * (2 * PH) + 2 * py) * (int64_t)(2 * PW) + 2 * px, p1 = p0 + 2 * PW;   // flat positions
+  const unsigned b0 = (hit[p0 >> 5] >> (p0 & 31)) & 3u, b1 = (hit[p1 >> 5] >> (p1 & 31)) & 3u;
+  *reinterpret_cast<float2*>(dy + p0) = make_float2((b0 & 1u) ? v : 0.f, (b0 & 2u) ? v : 0.f);
+  *reinterpret_cast<float2*>(dy + p1) = make_float2((b1 & 1u) ? v : 0.f, (b1 & 2u) ? v : 0.f);
+}
+
 namespace {
 const int kMaxLds = 150 * 1024;
 
@@ -469,7 +622,10 @@ int64_t fwd_lds(const ConvGeom& g) {
 }
 bool fwd_ok(const ConvGeom& g) { return g.OPAD <= 64 && g.pad >= 0 && fwd_lds(g) <= kMaxLds; }
 
-int launch_direct(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g, hipStream_t st) {
+// ep = 1: fused bias + relu + 2x2 max-pool epilogue (y = pooled map, pmask = its 4-bit masks);
+// src = 1: x is a pooled gradient expanded through pmask while staged.
+int launch_direct(const float* x, const float* w, const float* bias, float* y, const ConvGeom& g, hipStream_t st,
+                  int ep = 0, int src = 0, unsigned* pmask = nullptr) {
   const int64_t lds = fwd_lds(g);
   const int per_cu = (int)(kMaxLds / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int grid = 256 * (per_cu > 4 ? 4 : per_cu);
@@ -478,20 +634,28 @@ int launch_direct(const float* x, const float* w, const float* bias, float* y, c
   // float4 per thread that hold one input image in registers (0: rows not float4-aligned / too large)
   const int in_elems = g.Cin * g.Hin * g.Win;
   int nv = ((g.Win & 3) == 0 && in_elems <= 16 * 1024) ? (in_elems / 4 + 255) / 256 : 0;
-#define PDN_CONV_LAUNCH_KN(OT, CH, KS, NV)                                                             \
+#define PDN_CONV_LAUNCH_KNE(OT, CH, KS, NV, EP, SRC)                                                   \
   do {                                                                                                 \
-    auto kern = conv_direct_kernel<OT, CH, KS, NV>;                                                    \
+    auto kern = conv_direct_kernel<OT, CH, KS, NV, EP, SRC>;                                           \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                        (int)lds);                                                      \
     if (e != hipSuccess) { pdn_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, w, bias, y, g);                        \
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, x, w, bias, y, g, pmask);                 \
+  } while (0)
+#define PDN_CONV_LAUNCH_KN(OT, CH, KS, NV) PDN_CONV_LAUNCH_KNE(OT, CH, KS, NV, 0, 0)
+  /* the fused forms exist for 3x3 kernels on the register-prefetch path (what fused_ok() admits) */
+#define PDN_CONV_LAUNCH_KF(OT, CH, NV)                                                                 \
+  do {                                                                                                 \
+    if (ep) PDN_CONV_LAUNCH_KNE(OT, CH, 3, NV, 1, 0);                                                  \
+    else if (src) PDN_CONV_LAUNCH_KNE(OT, CH, 3, NV, 0, 1);                                            \
+    else PDN_CONV_LAUNCH_KNE(OT, CH, 3, NV, 0, 0);                                                     \
   } while (0)
 #define PDN_CONV_LAUNCH_K(OT, CH, KS)                                                                  \
   do {                                                                                                 \
     if (nv == 0 || KS != 3) PDN_CONV_LAUNCH_KN(OT, CH, KS, 0);                                         \
-    else if (nv <= 4) PDN_CONV_LAUNCH_KN(OT, CH, 3, 4);                                                \
-    else if (nv <= 8) PDN_CONV_LAUNCH_KN(OT, CH, 3, 8);                                                \
-    else PDN_CONV_LAUNCH_KN(OT, CH, 3, 16);                                                            \
+    else if (nv <= 4) PDN_CONV_LAUNCH_KF(OT, CH, 4);                                                   \
+    else if (nv <= 8) PDN_CONV_LAUNCH_KF(OT, CH, 8);                                                   \
+    else PDN_CONV_LAUNCH_KF(OT, CH, 16);                                                               \
   } while (0)
 #define PDN_CONV_LAUNCH(OT, CH)                                                                        \
   do {                                                                                                 \
@@ -501,13 +665,16 @@ int launch_direct(const float* x, const float* w, const float* bias, float* y, c
     else PDN_CONV_LAUNCH_K(OT, CH, 0);                                                                 \
   } while (0)
   if (g.OPAD == 64) {
+    // (measured equal with the fused epilogue: four accumulator tiles with a few spilled registers vs two tiles)
     if (chunks >= 8) PDN_CONV_LAUNCH(2, 2); else PDN_CONV_LAUNCH(2, 1);
   } else {
     if (chunks >= 16) PDN_CONV_LAUNCH(1, 4); else if (chunks >= 8) PDN_CONV_LAUNCH(1, 2); else PDN_CONV_LAUNCH(1, 1);
   }
 #undef PDN_CONV_LAUNCH
 #undef PDN_CONV_LAUNCH_K
+#undef PDN_CONV_LAUNCH_KF
 #undef PDN_CONV_LAUNCH_KN
+#undef PDN_CONV_LAUNCH_KNE
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -534,6 +701,11 @@ int64_t wgrad_lds(const WgradGeom& g) {
   return b > red ? b : red;
 }
 int wgrad_tiles(const WgradGeom& g) { return (g.OPAD / 32) * (g.KCOLS / 32); }
+bool wgrad_prefetch(const WgradGeom& g) {     // operands of one item fit the register prefetch (float4-aligned rows)
+  const int M = g.OH * g.OW;
+  return (g.W & 3) == 0 && (M & 3) == 0 && (g.MB & 3) == 0 && g.C * g.H * g.W <= 8 * 1024 &&
+         g.O * (g.MB < M ? g.MB : M) <= 16 * 1024;
+}
 bool wgrad_ok(const WgradGeom& g) { return wgrad_tiles(g) <= 16 && wgrad_lds(g) <= kMaxLds; }
 int wgrad_blocks(const WgradGeom& g) {
   const int64_t lds = wgrad_lds(g);
@@ -598,15 +770,15 @@ int64_t pdn_conv2d_bwd_weight_workspace_bytes(int N, int C, int H, int W, int O,
   return 4ll * wgrad_blocks(g) * g.OPAD * g.KCOLS;
 }
 
-/* dw (O, C, k, k) and db (O) [either may be NULL]; accumulate != 0 adds into them */
-int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float* db, int accumulate, int N,
-                              int C, int H, int W, int O, int k, int stride, int pad, void* workspace,
-                              int64_t workspace_bytes, void* stream) {
-  if (N == 0) return PDN_OK;
-  PDN_CHECK_ARG(x && dy && (dw || db), "pdn_conv2d_bwd_weight_f32: null operand");
+}  // extern "C"
+
+namespace {
+int launch_wgrad(const float* x, const float* dy, const unsigned* dmask, float* dw, float* db, int accumulate, int N,
+                 int C, int H, int W, int O, int k, int stride, int pad, void* workspace, int64_t workspace_bytes,
+                 void* stream, const char* who) {
   WgradGeom g;
   if (!wgrad_geom(g, N, C, H, W, O, k, stride, pad) || !wgrad_ok(g)) {
-    pdn_set_error("pdn_conv2d_bwd_weight_f32: shape outside the direct kernel (use the GEMM path)");
+    pdn_set_error("%s: shape outside the direct kernel (use the GEMM path)", who);
     return PDN_EUNSUPPORTED;
   }
   const int blocks = wgrad_blocks(g);
@@ -616,26 +788,30 @@ int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float*
   const int ps = T < 4 ? 1 : 0;
   const int slabs = used;
   if (!workspace || workspace_bytes < 4ll * slabs * g.OPAD * g.KCOLS) {
-    pdn_set_error("pdn_conv2d_bwd_weight_f32: workspace too small");
+    pdn_set_error("%s: workspace too small", who);
     return PDN_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
   const int64_t lds = wgrad_lds(g);
   float* partial = (float*)workspace;
-  const int M = g.OH * g.OW;
-  const bool pre = (W & 3) == 0 && (M & 3) == 0 && (g.MB & 3) == 0 && C * H * W <= 8 * 1024 &&
-                   O * (g.MB < M ? g.MB : M) <= 16 * 1024;
+  const bool pre = wgrad_prefetch(g);
+  if (dmask && !(pre && (g.OW & 3) == 0 && (g.OH & 1) == 0 && ((g.OH * g.OW) & 31) == 0)) {
+    pdn_set_error("%s: pooled source outside the prefetching kernel", who);
+    return PDN_EUNSUPPORTED;
+  }
 #define PDN_WGRAD_LAUNCH(WT, PS)                                                                       \
   do {                                                                                                 \
-    if (pre) PDN_WGRAD_LAUNCH_N(WT, PS, 8, 16); else PDN_WGRAD_LAUNCH_N(WT, PS, 0, 0);                 \
+    if (dmask) PDN_WGRAD_LAUNCH_N(WT, PS, 8, 16, 1);                                                   \
+    else if (pre) PDN_WGRAD_LAUNCH_N(WT, PS, 8, 16, 0);                                                \
+    else PDN_WGRAD_LAUNCH_N(WT, PS, 0, 0, 0);                                                          \
   } while (0)
-#define PDN_WGRAD_LAUNCH_N(WT, PS, NVX, NVD)                                                           \
+#define PDN_WGRAD_LAUNCH_N(WT, PS, NVX, NVD, SRC)                                                      \
   do {                                                                                                 \
-    auto kern = conv_wgrad_kernel<WT, PS, NVX, NVD>;                                                   \
+    auto kern = conv_wgrad_kernel<WT, PS, NVX, NVD, SRC>;                                              \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,  \
                                        (int)lds);                                                      \
     if (e != hipSuccess) { pdn_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
-    hipLaunchKernelGGL(kern, dim3(used), dim3(256), lds, st, x, dy, partial, g);                       \
+    hipLaunchKernelGGL(kern, dim3(used), dim3(256), lds, st, x, dy, partial, g, dmask);                \
   } while (0)
   if (ps) {
     if (T == 1) PDN_WGRAD_LAUNCH(1, 1); else if (T == 2) PDN_WGRAD_LAUNCH(2, 1); else PDN_WGRAD_LAUNCH(3, 1);
@@ -650,6 +826,99 @@ int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float*
   const int total = O * g.K1;
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, partial, slabs,
                      g.OPAD, g.KCOLS, O, g.K1 - 1, dw, db, accumulate);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+// geometry of the fused conv -> relu -> 2x2 max-pool forms: what the epilogue / the expanding loads can take
+bool fused_fwd_ok(const ConvGeom& g) {
+  const int M = g.OH * g.OW, in_elems = g.Cin * g.Hin * g.Win;
+  if (!fwd_ok(g) || g.k != 3 || (g.Win & 3) || in_elems > 16 * 1024) return false;
+  if (!(g.OW == 8 || g.OW == 16 || g.OW == 32) || (g.OH & 1) || (M & 31)) return false;
+  return g.OW != 32 || M / 32 >= 8;                  // (OW = 32 pairs two chunks of one wave: CH must be even)
+}
+}  // namespace
+
+extern "C" {
+
+/* dw (O, C, k, k) and db (O) [either may be NULL]; accumulate != 0 adds into them */
+int pdn_conv2d_bwd_weight_f32(const float* x, const float* dy, float* dw, float* db, int accumulate, int N,
+                              int C, int H, int W, int O, int k, int stride, int pad, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && dy && (dw || db), "pdn_conv2d_bwd_weight_f32: null operand");
+  return launch_wgrad(x, dy, nullptr, dw, db, accumulate, N, C, H, W, O, k, stride, pad, workspace, workspace_bytes, stream,
+                      "pdn_conv2d_bwd_weight_f32");
+}
+
+/* ---- conv -> relu -> max_pool(2, 2) as ONE node (examples/pydynet/mnist.py:92-95) ------------------------------
+ * bitmask: 1 forward, 2 data gradient, 4 weight gradient from the pooled gradient (2 / 4 only with 1). */
+int pdn_conv2d_relu_pool_supported(int C, int H, int W, int O, int k, int stride, int pad) {
+  if (C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0 || H + 2 * pad < k || W + 2 * pad < k) return 0;
+  ConvGeom f;
+  if (!fwd_geom(f, 1, C, H, W, O, k, stride, pad, 0, C, O) || !fused_fwd_ok(f)) return 0;
+  int mask = 1;
+  if (stride == 1 && k - 1 - pad >= 0) {
+    ConvGeom d;
+    if (fwd_geom(d, 1, O, f.OH, f.OW, C, k, 1, k - 1 - pad, 1, C, O) && fwd_ok(d) && d.OH == H && d.OW == W &&
+        (f.OW & 3) == 0 && O * f.OH * f.OW <= 16 * 1024)
+      mask |= 2;
+  }
+  WgradGeom g;
+  if (wgrad_geom(g, 1, C, H, W, O, k, stride, pad) && wgrad_ok(g) && wgrad_prefetch(g) && (g.OW & 3) == 0) mask |= 4;
+  return mask;
+}
+
+/* pooled (N, O, OH / 2, OW / 2) = max_pool2x2(relu(conv(x, w) + bias)); mask (N, O, OH * OW / 32) words: bit
+ * (p & 31) of word p >> 5 set when conv output position p = oy * OW + ox receives the pooled gradient (its relu equals
+ * the window maximum and y >= 0) */
+int pdn_conv2d_relu_pool_fwd_f32(const float* x, const float* w, const float* bias, float* pooled, unsigned* mask,
+                                 int N, int C, int H, int W, int O, int k, int stride, int pad, void* stream) {
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && w && pooled && mask, "pdn_conv2d_relu_pool_fwd_f32: null operand");
+  ConvGeom g;
+  if (!fwd_geom(g, N, C, H, W, O, k, stride, pad, 0, C, O) || !fused_fwd_ok(g)) {
+    pdn_set_error("pdn_conv2d_relu_pool_fwd_f32: shape outside the fused kernel");
+    return PDN_EUNSUPPORTED;
+  }
+  return launch_direct(x, w, bias, pooled, g, (hipStream_t)stream, 1, 0, mask);
+}
+
+/* dx = conv_transpose(expand(dpooled, mask), w) */
+int pdn_conv2d_relu_pool_bwd_data_f32(const float* dpooled, const unsigned* mask, const float* w, float* dx, int N,
+                                      int C, int H, int W, int O, int k, int stride, int pad, void* stream) {
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(dpooled && mask && w && dx, "pdn_conv2d_relu_pool_bwd_data_f32: null operand");
+  if (!(pdn_conv2d_relu_pool_supported(C, H, W, O, k, stride, pad) & 2)) {
+    pdn_set_error("pdn_conv2d_relu_pool_bwd_data_f32: shape outside the fused kernel");
+    return PDN_EUNSUPPORTED;
+  }
+  const int OH = H + 2 * pad - k + 1, OW = W + 2 * pad - k + 1;
+  ConvGeom g;
+  fwd_geom(g, N, O, OH, OW, C, k, 1, k - 1 - pad, 1, C, O);
+  return launch_direct(dpooled, w, nullptr, dx, g, (hipStream_t)stream, 0, 1, const_cast<unsigned*>(mask));
+}
+
+/* dw, db from x and expand(dpooled, mask); workspace as pdn_conv2d_bwd_weight_workspace_bytes */
+int pdn_conv2d_relu_pool_bwd_weight_f32(const float* x, const float* dpooled, const unsigned* mask, float* dw,
+                                        float* db, int accumulate, int N, int C, int H, int W, int O, int k, int stride,
+                                        int pad, void* workspace, int64_t workspace_bytes, void* stream) {
+  if (N == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && dpooled && mask && (dw || db), "pdn_conv2d_relu_pool_bwd_weight_f32: null operand");
+  return launch_wgrad(x, dpooled, mask, dw, db, accumulate, N, C, H, W, O, k, stride, pad, workspace, workspace_bytes,
+                      stream, "pdn_conv2d_relu_pool_bwd_weight_f32");
+}
+
+/* dy (rows, OH, OW) = expand(dpooled (rows, OH / 2, OW / 2), mask): the generic fallback when a fused backward form
+ * does not take the shape (then the plain conv kernels run on dy) */
+int pdn_pool_mask_expand_f32(const float* dpooled, const unsigned* mask, float* dy, int64_t rows, int OH, int OW,
+                             void* stream) {
+  if (rows == 0) return PDN_OK;
+  PDN_CHECK_ARG(dpooled && mask && dy && OH > 0 && OW > 0 && !(OH & 1) && !(OW & 1) && ((rows * OH * OW) & 31) == 0,
+                "pdn_pool_mask_expand_f32: bad arguments (even extents, rows * OH * OW a multiple of 32)");
+  const int64_t n = rows * (OH / 2) * (OW / 2);
+  hipLaunchKernelGGL(pool_mask_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     dpooled, mask, dy, n, OH / 2, OW / 2);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -66,6 +66,12 @@ def conv2d(x, kernel, padding: int = 0, stride: int = 1, bias=None):
 
 
 def _pool2d(x, kernel_size, stride, padding, mode):
+    if (mode == "max" and kernel_size == 2 and stride == 2 and padding == 0 and type(x) is fused.relu
+            and x._pending is not None and x._pending[0]._pending is not None):
+        # max_pool2d(relu(conv2d(...)), 2, 2) with both producers still deferred: ONE kernel (fused._Deferred)
+        conv = x._pending[0]
+        ins = conv._pending
+        return fused.conv2d_relu_pool(ins[0], ins[1], ins[2] if conv.has_bias else None, conv.padding, conv.stride)
     if not fused.hip_f32(x):
         raise TypeError(f"{mode}_pool2d on a HIP device is float32-only: got {x.dtype}")
     return fused.pool2d(x, kernel_size, stride, padding, mode)

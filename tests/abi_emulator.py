@@ -997,6 +997,80 @@ class EmulatedLib:
             d[...] = d + v if acc else v
         return 0
 
+    # -- conv -> relu -> max_pool(2, 2) as one node ------------------------------------------------------
+    def pdn_conv2d_relu_pool_supported(self, C, H, W, O, k, s, p):
+        d = self.pdn_conv2d_direct_supported(C, H, W, O, k, s, p)
+        if not d & 1 or k != 3 or W % 4 or C * H * W > 16 * 1024:
+            return 0
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        if ow not in (8, 16, 32) or oh % 2 or (oh * ow) % 32 or (ow == 32 and oh * ow // 32 < 8):
+            return 0
+        mask = 1
+        if d & 2 and ow % 4 == 0 and O * oh * ow <= 16 * 1024:
+            mask |= 2
+        M = oh * ow
+        mb = 512 if (4 * C * (H + 2 * p) * (W + 2 * p) + 4 * (O + 1) * (M | 1) > 78 * 1024 and M > 512) else M
+        if d & 4 and W % 4 == 0 and M % 4 == 0 and mb % 4 == 0 and C * H * W <= 8 * 1024 and O * min(mb, M) <= 16 * 1024 \
+                and ow % 4 == 0:
+            mask |= 4
+        return mask
+
+    @staticmethod
+    def _pool_hits(y):
+        """pooled, hit words of relu -> 2x2 max-pool on y (..., OH, OW): bit p & 31 of word p >> 5 (p = flat position
+        within the (OH, OW) plane) = relu(y) == window max and y >= 0."""
+        r = np.maximum(y, 0)
+        sh = y.shape[:-2] + (y.shape[-2] // 2, 2, y.shape[-1] // 2, 2)
+        rw, yw = r.reshape(sh), y.reshape(sh)
+        m = rw.max((-3, -1))
+        hit = ((rw == m[..., :, None, :, None]) & (yw >= 0)).reshape(y.shape[:-2] + (-1, 32))
+        words = (hit.astype(np.uint64) << np.arange(32, dtype=np.uint64)).sum(-1).astype(np.uint32)
+        return m.astype(np.float32), words
+
+    @staticmethod
+    def _expand(dp, words, OH, OW):
+        bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(dp.shape[:-2] + (OH, OW)).astype(bool)
+        up = np.repeat(np.repeat(dp, 2, -2), 2, -1)
+        return np.where(bits, up, 0).astype(np.float32)
+
+    def pdn_conv2d_relu_pool_fwd_f32(self, x, w, bias, pooled, mask, N, C, H, W, O, k, s, p, stream):
+        if not self.pdn_conv2d_relu_pool_supported(C, H, W, O, k, s, p) & 1:
+            return -2
+        col, oh, ow = self._conv_cols(x, N, C, H, W, k, s, p)
+        out = np.matmul(flat(w, O * C * k * k).reshape(O, -1), col)
+        if bias:
+            out = out + flat(bias, O).reshape(1, O, 1)
+        m, words = self._pool_hits(out.reshape(N, O, oh, ow).astype(np.float32))
+        flat(pooled, m.size).reshape(m.shape)[...] = m
+        flat(mask, words.size, np.uint32).reshape(words.shape)[...] = words
+        return 0
+
+    def _expanded(self, dp, mask, N, O, oh, ow):
+        d = np.array(flat(dp, N * O * oh * ow // 4).reshape(N, O, oh // 2, ow // 2))
+        m = np.array(flat(mask, N * O * oh * ow // 32, np.uint32).reshape(N, O, oh * ow // 32))
+        return np.ascontiguousarray(self._expand(d, m, oh, ow))
+
+    def pdn_conv2d_relu_pool_bwd_data_f32(self, dp, mask, w, dx, N, C, H, W, O, k, s, p, stream):
+        if not self.pdn_conv2d_relu_pool_supported(C, H, W, O, k, s, p) & 2:
+            return -2
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = self._expanded(dp, mask, N, O, oh, ow)
+        return self.pdn_conv2d_bwd_data_f32(dy.ctypes.data, w, dx, N, C, H, W, O, k, s, p, stream)
+
+    def pdn_conv2d_relu_pool_bwd_weight_f32(self, x, dp, mask, dw, db, acc, N, C, H, W, O, k, s, p, ws, wsb, stream):
+        if not self.pdn_conv2d_relu_pool_supported(C, H, W, O, k, s, p) & 4:
+            return -2
+        oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        dy = self._expanded(dp, mask, N, O, oh, ow)
+        return self.pdn_conv2d_bwd_weight_f32(x, dy.ctypes.data, dw, db, acc, N, C, H, W, O, k, s, p, ws, wsb, stream)
+
+    def pdn_pool_mask_expand_f32(self, dp, mask, dy, rows, OH, OW, stream):
+        d = np.array(flat(dp, rows * OH * OW // 4).reshape(rows, OH // 2, OW // 2))
+        m = np.array(flat(mask, rows * OH * OW // 32, np.uint32))
+        bits = ((m[:, None] >> np.arange(32, dtype=np.uint32)) & 1).reshape(rows, OH, OW).astype(bool)
+        flat(dy, rows * OH * OW).reshape(rows, OH, OW)[...] = np.where(bits, np.repeat(np.repeat(d, 2, 1), 2, 2), 0)
+        return 0
+
     def pdn_col2im2d_f32(self, dcol, N, C, H, W, k, s, p, dx, rows, stream):
         dxp = np.zeros((N, C, H + 2 * p, W + 2 * p), np.float32)
         oh, ow, shape, strides = self._windows(dxp, k, s)

@@ -101,6 +101,7 @@ def test_conv2d_node_direct_path_equals_im2col_path(hip):
             w = pdn.Tensor(w_np, dtype=np.float32, device="hip:0", requires_grad=True)
             b = pdn.Tensor(b_np, dtype=np.float32, device="hip:0", requires_grad=True)
             node = fused.conv2d(x * 1.0, w, b, 1, 1)
+            node.data                                       # (a deferred node runs its kernel at first use)
             assert bool(node._direct) == direct
             (node * node).sum().backward()
             col = node._col.get()
