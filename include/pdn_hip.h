@@ -138,6 +138,15 @@ int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_r
 int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
+/* K split over the grid for short M (fewer row workgroups than fill the chip): pdn_gemm_outres_plan -> number of
+ * K ranges (1 = none; *nw waves per workgroup, *kps 32-row pieces per range); with a workspace of
+ * pdn_gemm_outres_workspace_bytes(M, K) bytes pdn_gemm_outres_ws_f32 writes one (M x 288) slab per range and adds
+ * them (+ bias + residual) in a fixed order; without it the product runs unsplit. */
+int pdn_gemm_outres_plan(int M, int K, int* nw, int* kps);
+int64_t pdn_gemm_outres_workspace_bytes(int M, int K);
+int pdn_gemm_outres_ws_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                           int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* workspace,
+                           int64_t workspace_bytes, void* stream);
 /* per-launch HIP-event timing of the GEMM kernel for bench.py's roofline block */
 int pdn_gemm_prof_enable(int on);
 int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launches);

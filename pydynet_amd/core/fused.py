@@ -809,7 +809,7 @@ class linear_cross_entropy(_Operator):
 
     folds_existing = True
     enabled = True
-    min_rows = 32768
+    min_rows = int(os.environ.get("PDN_LINCE_MIN_ROWS", "16384"))
 
     @staticmethod
     def applicable(x, w, b, targets, reduction="mean"):
@@ -820,8 +820,9 @@ class linear_cross_entropy(_Operator):
         for d in x.shape[:-1]:
             rows *= d
         t = targets.data if isinstance(targets, Tensor) else targets
-        # (below `min_rows` tokens the output-resident input-gradient kernel cannot fill the chip -- 128 rows per
-        #  workgroup -- and the separate nodes on the tiled kernels are faster: 3156 vs 3600 samples/s at batch 64)
+        # (below 28672 tokens the row workgroups of the output-resident input-gradient kernel no longer fill the chip:
+        #  it then cuts K = vocabulary into ranges over the grid, pdn_gemm_outres_plan; below `min_rows` the separate
+        #  nodes on the tiled kernels are left in place)
         return (x.shape[-1] == w.shape[0] and getattr(t, "ndim", 0) == 1 and t.shape[0] == rows
                 and rows >= linear_cross_entropy.min_rows
                 and bool(_L().query("pdn_linear_ce_supported", rows, w.shape[1], w.shape[0])))

@@ -1095,6 +1095,11 @@ int pdn_gemm_outres_tn_launch(const float* X, const float* G, float* C, int N, i
                               int64_t ldc, int64_t slab, int nw, int k_per_split, void* stream);
 int pdn_gemm_outres_tn_blocks_launch(const float* X, const float* G, float* C, int N, int K, int64_t ldx, int64_t ldg,
                                      int nb_cols, int nw, int k_per_split, void* stream);
+extern "C" int64_t pdn_gemm_outres_workspace_bytes(int M, int K);
+extern "C" int pdn_gemm_outres_plan(int M, int K, int* nw, int* kps);
+extern "C" int pdn_gemm_outres_ws_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
+                                      int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans,
+                                      void* workspace, int64_t workspace_bytes, void* stream);
 extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias,
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -1183,7 +1188,12 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     const int bt = (b_rs == 1 && b_cs != 1) ? 1 : 0;
     const int64_t ldb = bt ? b_cs : b_rs;
     const bool big = (M + 255) / 256 >= 224, mid = (M + 127) / 128 >= 224 && K >= 1536;
-    if ((big || mid) && (bt || b_cs == 1) && pdn_gemm_outres_supported(M, N, K, a_rs, ldb, ldc, bt)) {
+    // fewer rows than that: K cut into ranges over grid.y (slabs in the workspace), when K is long enough
+    int pl_nw, pl_kps;
+    const int64_t or_ws = (workspace && workspace_bytes > 0) ? workspace_bytes : 0;
+    const bool cut = !big && !mid && M >= 8192 && K >= 1536 && pdn_gemm_outres_plan(M, K, &pl_nw, &pl_kps) > 1 &&
+                     or_ws >= pdn_gemm_outres_workspace_bytes(M, K);
+    if ((big || mid || cut) && (bt || b_cs == 1) && pdn_gemm_outres_supported(M, N, K, a_rs, ldb, ldc, bt)) {
       bool prof;
       ProfRec rec;
       {
@@ -1199,7 +1209,8 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       }
       if (getenv("PDN_GEMM_DEBUG"))
         fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> output-resident (%s)\n", M, N, K, bt ? "NT" : "NN");
-      const int rc = pdn_gemm_outres_f32(A, B, C, bias, residual, M, N, K, a_rs, ldb, ldc, bt, stream);
+      const int rc = cut ? pdn_gemm_outres_ws_f32(A, B, C, bias, residual, M, N, K, a_rs, ldb, ldc, bt, workspace, or_ws, stream)
+                         : pdn_gemm_outres_f32(A, B, C, bias, residual, M, N, K, a_rs, ldb, ldc, bt, stream);
       if (rc) return rc;
       if (prof) {
         PDN_HIP(hipEventRecord(rec.e1, st));
@@ -1524,7 +1535,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
 // ======================================================================================
 int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, const int64_t* targets, float gscale,
                             const float* gdev, const float* W, int64_t ldw, float* dx, int64_t ldc,
-                            const float* residual, int M, int V, void* stream);
+                            const float* residual, int M, int V, void* workspace, int64_t workspace_bytes, void* stream);
 int pdn_outres_ce_dw_launch(const float* X, const float* logits, float* C, int N, int K, int64_t ldx, int64_t ldg,
                             int64_t ldc, int64_t slab, int nw, int k_per_split, const float* lse,
                             const int64_t* targets, float gscale, const float* gdev, float* colsum, void* stream);
@@ -1538,7 +1549,8 @@ extern "C" int64_t pdn_linear_ce_workspace_bytes(int64_t rows, int V, int in_fea
   if (!pdn_linear_ce_supported(rows, V, in_features)) return 0;
   int nw, kps;
   const int splits = pdn_gemm_outres_tn_plan(V, (int)rows, &nw, &kps);
-  return (int64_t)splits * (in_features + 1) * V * 4;
+  // [weight-gradient slabs | column-sum slabs | input-gradient slabs (K split over the grid when rows are few)]
+  return (int64_t)splits * (in_features + 1) * V * 4 + pdn_gemm_outres_workspace_bytes((int)rows, V);
 }
 
 extern "C" int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const float* logits, const float* lse,
@@ -1579,8 +1591,12 @@ extern "C" int pdn_linear_ce_backward_f32(const float* x, int64_t ldx, const flo
   if (dx) {
     ProfRec rec;
     prof_begin(rec);
+    int nw_, kps_;
+    const int64_t dw_bytes = (int64_t)pdn_gemm_outres_tn_plan(V, (int)rows, &nw_, &kps_) * (in_features + 1) * V * 4;
+    const int64_t dx_bytes = pdn_gemm_outres_workspace_bytes((int)rows, V);
+    void* dx_ws = (workspace && workspace_bytes >= dw_bytes + dx_bytes && dx_bytes > 0) ? (char*)workspace + dw_bytes : nullptr;
     int rc = pdn_outres_ce_dx_launch(logits, V, lse, targets, gscale, upstream, W, V, dx, in_features, dx_residual,
-                                     (int)rows, V, stream);
+                                     (int)rows, V, dx_ws, dx_ws ? dx_bytes : 0, stream);
     if (rc) return rc;
     prof_end(rec);
   }

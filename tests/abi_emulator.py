@@ -210,6 +210,12 @@ class EmulatedLib:
         return int(N == 288 and K >= 32 and K % 32 == 0 and M >= 1 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K
                    and ldb >= (K if b_trans else N) and ldc >= N and 288 * ldb < (1 << 30) and 32 * ldc < (1 << 30))
 
+    def pdn_gemm_outres_plan(self, M, K, nw, kps): return 1
+    def pdn_gemm_outres_workspace_bytes(self, M, K): return 0
+
+    def pdn_gemm_outres_ws_f32(self, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, b_trans, ws, wsb, stream):
+        return self.pdn_gemm_outres_f32(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, b_trans, stream)
+
     def pdn_gemm_outres_f32(self, A, B, C, bias, residual, M, N, K, lda, ldb, ldc, b_trans, stream):
         if M == 0 or N == 0:
             return 0

@@ -779,7 +779,7 @@ def test_lm_head_forward_row_resident_with_bias_full_vocab(hip):
 # output-resident GEMM (csrc/gemm_outres.hip): 32 x 288 outputs per wave in accumulators, A straight into
 # MFMA operand registers, B through LDS
 @pytest.mark.parametrize("M,K,trans,extras", [(512, 768, 0, 0), (300, 864, 1, 2), (8192 + 40, 1536, 1, 3),
-                                              (256, 32, 0, 1), (1024, 3200, 1, 0)])
+                                              (256, 32, 0, 1), (1024, 3200, 1, 0), (16384 + 40, 864, 1, 3)])
 def test_gemm_output_resident_entry_point(hip, M, K, trans, extras):
     # extras: 1 = bias, 2 = residual, 3 = both; odd M values leave partial 32-row blocks and partial workgroups
     from pydynet_amd import _lib
@@ -802,6 +802,45 @@ def test_gemm_output_resident_entry_point(hip, M, K, trans, extras):
     assert rel_err(Y.get(), ref) < 1e-5
     assert not L.query("pdn_gemm_outres_supported", M, 256, K, K, w.shape[1], 256, trans)     # N = 288 only
     assert not L.query("pdn_gemm_outres_supported", M, N, K + 8, K + 8, w.shape[1] + 8, N, trans)
+
+
+@pytest.mark.parametrize("M,K,trans,extras", [(16384, 3200, 1, 3), (16384, 1536, 0, 2), (8192 + 40, 4096, 1, 1)])
+def test_gemm_output_resident_split_k(hip, M, K, trans, extras):
+    # fewer than ~224 row workgroups: K is cut into ranges over grid.y, one (M x 288) slab per range in the workspace,
+    # added up (+ bias + residual) in a fixed order.  Against float64 on sampled rows and against the unsplit launch.
+    from pydynet_amd import _lib
+    import ctypes
+    L = _lib.lib()
+    N = 288
+    rng = np.random.default_rng(M + K + trans)
+    x = rng.standard_normal((M, K), dtype=np.float32)
+    w = 0.1 * rng.standard_normal((N, K) if trans else (K, N), dtype=np.float32)
+    bias = rng.standard_normal(N, dtype=np.float32) if extras & 1 else None
+    res = rng.standard_normal((M, N), dtype=np.float32) if extras & 2 else None
+    X, W = hip.from_numpy(x), hip.from_numpy(w)
+    Bv = hip.from_numpy(bias) if bias is not None else None
+    Rv = hip.from_numpy(res) if res is not None else None
+    nw, kps = ctypes.c_int(), ctypes.c_int()
+    splits = L.query("pdn_gemm_outres_plan", M, K, ctypes.byref(nw), ctypes.byref(kps))
+    if type(L).__name__ != "EmulatedLib":
+        assert splits >= 2 and kps.value >= 24 and nw.value == 4
+    wsb = L.query("pdn_gemm_outres_workspace_bytes", M, K)
+    ws, got_b = hip.workspace(max(wsb, 4))
+    Y, Y1 = hip.empty((M, N), np.float32), hip.empty((M, N), np.float32)
+    args = (Bv._ptr if Bv is not None else None, Rv._ptr if Rv is not None else None, M, N, K, K, w.shape[1], N, trans)
+    L.call("pdn_gemm_outres_ws_f32", X._ptr, W._ptr, Y._ptr, *args, ws, got_b, hip.stream())
+    L.call("pdn_gemm_outres_f32", X._ptr, W._ptr, Y1._ptr, *args, hip.stream())
+    y, y1 = Y.get(), Y1.get()
+    assert rel_err(y, y1.astype(np.float64)) < 1e-5                        # same products, another summation order
+    rows = np.concatenate([rng.integers(0, M, 48), [0, M - 1]])
+    ref = x[rows].astype(np.float64) @ (w.T if trans else w).astype(np.float64)
+    if bias is not None: ref = ref + bias
+    if res is not None: ref = ref + res[rows]
+    assert rel_err(y[rows], ref) < 1e-5
+    # the same through pdn_gemm_f32's dispatch (hipnp.gemm hands it a workspace)
+    Y2 = hip.empty((M, N), np.float32)
+    hip.gemm(X, W.T if trans else W, Y2, bias=Bv, residual=Rv)
+    assert rel_err(Y2.get()[rows], ref) < 1e-5
 
 
 def test_gemm_output_resident_dispatch_matches_tiled_kernel(hip):

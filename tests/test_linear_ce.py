@@ -4,6 +4,7 @@ cross-entropy nodes, the (rows, V) gradient of the logits in memory -- and (b) a
 llm/llama/model.py:179 + nn/functional.py:364-381.  Tolerance: 1e-4 relative (north_star), gradients against
 their own largest entry.  Runs on the emulated C ABI and (``-m gpu``) on a real MI355X."""
 import numpy as np
+import pytest
 
 import pydynet_amd as pdn
 from pydynet_amd import nn
@@ -80,6 +81,12 @@ def check_linear_ce_many_rows_two_k_splits(dev):
     _case(dev, 4096, 256, "mean", 1.0, 2)
 
 
+def check_linear_ce_few_rows_input_gradient_split_over_the_vocabulary(dev):
+    # 16384 tokens = per-GPU batch 64: 128 row workgroups would leave half the chip idle, so the input-gradient
+    # product cuts K = vocabulary into ranges over grid.y (pdn_gemm_outres_plan) and adds the slabs in a fixed order
+    _case(dev, 16384, 3072, "mean", 1.0, 3)
+
+
 def check_linear_ce_not_applicable_falls_back(dev):
     Graph.clear()
     head = nn.Linear(96, 64, dtype=np.float32)
@@ -97,3 +104,10 @@ def check_linear_ce_not_applicable_falls_back(dev):
 for _f in (check_linear_ce_mean, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
            check_linear_ce_not_applicable_falls_back):
     device_variants(globals(), _f)
+
+
+@pytest.mark.gpu
+def test_linear_ce_few_rows_input_gradient_split_over_the_vocabulary_gpu(hip):
+    # (real kernels only: the emulated ABI has no K split to exercise, and the float64 statement is slow on CPU)
+    Graph.clear()
+    check_linear_ce_few_rows_input_gradient_split_over_the_vocabulary("hip:0")
