@@ -292,6 +292,9 @@ int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, in
                              void* stream);
 int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_stride, int B, int V, int64_t* next_ids, int* pos,
                                void* stream);
+/* shapes the resident (K / V of a head chunk-wise in LDS) kernels above take: head_dim 48 or 64, L a multiple of 32 up
+ * to 1024 -- sequences beyond 256 pass through LDS in 256-row chunks (forward: one online rescale per chunk) */
+int pdn_attention_supported(int L, int head_dim);
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
 

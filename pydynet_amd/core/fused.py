@@ -527,14 +527,14 @@ def _attn_mask_args(mask, B, H, Lq, Lk):
 
 
 def _attn_kernel(B, H, hd, Lq, Lk, start_pos, has_mask, layouts):
-    """'resident' (K/V of a head held in LDS: hd 48, L <= 256, the benchmark shape), 'stream' (general
-    kernels) or None (GEMM + softmax composition)."""
+    """'resident' (K/V of a head held in LDS 256 rows at a time: hd 48 / 64, L <= 1024 -- the benchmark shape is
+    one chunk), 'stream' (general kernels) or None (GEMM + softmax composition)."""
     if not attention.use_flash or any(l is None for l in layouts):
         return None
     ql, kl, vl = layouts
     dense = (H * hd, Lq * H * hd if B > 1 else 0)
-    if (Lq == Lk and start_pos == 0 and hd == 48 and Lq % 32 == 0 and Lq <= 256 and not has_mask
-            and attention.use_resident and ql == kl == vl == dense):
+    if (Lq == Lk and start_pos == 0 and not has_mask and attention.use_resident and ql == kl == vl == dense
+            and _L().query("pdn_attention_supported", Lq, hd)):
         return "resident"
     if _L().query("pdn_attention_stream_supported", hd) and kl == vl:
         return "stream"
@@ -1407,7 +1407,7 @@ class qkv_attention(_Operator):
 
     @staticmethod
     def _resident(L, hd):
-        return attention.use_resident and hd == 48 and L % 32 == 0 and L <= 256
+        return bool(attention.use_resident and _L().query("pdn_attention_supported", L, hd))
 
     @staticmethod
     def applicable(x, L, hd):

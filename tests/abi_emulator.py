@@ -503,8 +503,9 @@ class EmulatedLib:
         l = e.sum(-1, keepdims=True)
         return e / l, (m + np.log(l))[..., 0]
 
-    def pdn_attention_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4
-    def pdn_attention_bwd_lds_bytes(self, L, hd): return (2 * L + 256) * (hd + 4) * 4 + 8 * L
+    def pdn_attention_supported(self, L, hd): return 1 if (hd in (48, 64) and L % 32 == 0 and 32 <= L <= 1024) else 0
+    def pdn_attention_lds_bytes(self, L, hd): return min(L, 256) * (hd + 4 + 64) * 4
+    def pdn_attention_bwd_lds_bytes(self, L, hd): return min(L, 256) * (2 * 68 + 2) * 4
 
     @staticmethod
     def _rot(a, cos, sin, L, hd, sign):
@@ -519,7 +520,7 @@ class EmulatedLib:
         return out
 
     def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn, stream):
-        if hd != 48 or L % 32 or L > 256:
+        if not self.pdn_attention_supported(L, hd):
             return -2
         Q, K, V = self._att_views([q, k, v], B, H, L, hd, rs, bs)
         O, = self._att_views([o], B, H, L, hd, ors, obs)
@@ -533,7 +534,7 @@ class EmulatedLib:
 
     def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn,
                               ws, wsb, stream):
-        if hd != 48 or L % 32 or L > 256:
+        if not self.pdn_attention_supported(L, hd):
             return -2
         Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
         O, DO = [np.array(a) for a in self._att_views([o, do], B, H, L, hd, ors, obs)]

@@ -9,6 +9,11 @@ import math
 import numpy as np
 import pytest
 
+
+def rel_err(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
 pytestmark = pytest.mark.gpu
 
 
@@ -164,37 +169,49 @@ def test_attention_node_on_strided_views_and_cache_prefill(hip):
 
 
 @pytest.mark.gpu
-def test_chunked_resident_attention_matches_whole_head_kernels(hip):
-    """PDN_ATTN_CHUNKED=1: four waves per head, K,V / Q,dO through LDS in 128-row chunks, two workgroups per CU
-    (csrc/attention.hip) -- same results as the whole-head kernels up to the one online rescale (1e-5)."""
-    import os
+@pytest.mark.parametrize("L,hd", [(256, 48), (512, 48), (640, 64)])
+def test_resident_attention_rope_in_the_loads_packed_projection(hip, L, hd):
+    """The resident kernels as fused.qkv_attention drives them: q | k | v are column blocks of ONE packed projection
+    buffer (row stride 3 D), RoPE (llm/llama/model.py:23-44) is applied to q and k as they are loaded -- at the
+    positions of the 256-row chunk being staged when L > 256 -- and dq, dk are rotated back as they are stored.
+    Against float64 on explicitly rotated operands."""
+    import math
     from pydynet_amd import _lib
     Lb = _lib.lib()
-    B, H, L, hd = 3, 6, 256, 48
+    B, H = 2, 3
     D = H * hd
-    rng = np.random.default_rng(11)
-    qkv = hip.from_numpy(rng.standard_normal((B * L, 3 * D), dtype=np.float32))
-    do = hip.from_numpy(rng.standard_normal((B, L, H, hd), dtype=np.float32))
+    rng = np.random.default_rng(L + hd)
+    qkv = rng.standard_normal((B * L, 3 * D), dtype=np.float32)
+    do = rng.standard_normal((B, L, H, hd), dtype=np.float32)
     inv = 1.0 / (10000 ** (np.arange(0, hd, 2) / hd))
     fr = np.outer(np.arange(L), inv).astype(np.float32)
-    C, S = hip.from_numpy(np.cos(fr)), hip.from_numpy(np.sin(fr))
-    q, k, v = qkv._ptr, qkv._ptr + 4 * D, qkv._ptr + 8 * D
+    cos, sin = np.cos(fr), np.sin(fr)
+    QKV, DO, C, S = hip.from_numpy(qkv), hip.from_numpy(do), hip.from_numpy(cos), hip.from_numpy(sin)
+    q, k, v = QKV._ptr, QKV._ptr + 4 * D, QKV._ptr + 8 * D
+    o, lse, dqkv = hip.empty((B, L, H, hd)), hip.empty((B, H, L)), hip.empty((B * L, 3 * D))
     ws, wsb = hip.workspace(4 * B * H * L)
-    out = {}
-    for chunked in (False, True):
-        if chunked:
-            os.environ["PDN_ATTN_CHUNKED"] = "1"
-        try:
-            o, lse = hip.empty((B, L, H, hd)), hip.empty((B, H, L))
-            dqkv = hip.empty((B * L, 3 * D))
-            dq, dk, dv = dqkv._ptr, dqkv._ptr + 4 * D, dqkv._ptr + 8 * D
-            Lb.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1,
-                    C._ptr, S._ptr, hip.stream())
-            Lb.call("pdn_attention_bwd_f32", q, k, v, o._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, L, hd, 3 * D,
-                    L * 3 * D, D, L * D, 1, C._ptr, S._ptr, ws, wsb, hip.stream())
-            out[chunked] = (o.get(), lse.get(), dqkv.get())
-        finally:
-            os.environ.pop("PDN_ATTN_CHUNKED", None)
-    for a, b, what in zip(out[True], out[False], ("o", "lse", "dqkv")):
-        err = np.abs(a - b).max() / np.abs(b).max()
-        assert err < 1e-5, (what, err)
+    Lb.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1,
+            C._ptr, S._ptr, hip.stream())
+    Lb.call("pdn_attention_bwd_f32", q, k, v, o._ptr, DO._ptr, lse._ptr, dqkv._ptr, dqkv._ptr + 4 * D, dqkv._ptr + 8 * D,
+            B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1, C._ptr, S._ptr, ws, wsb, hip.stream())
+
+    def rot(a, sign):                                       # (B, L, H, hd) float64
+        c, s = cos[None, :, None, :].astype(np.float64), sign * sin[None, :, None, :].astype(np.float64)
+        out = np.empty_like(a)
+        out[..., 0::2] = a[..., 0::2] * c - a[..., 1::2] * s
+        out[..., 1::2] = a[..., 0::2] * s + a[..., 1::2] * c
+        return out
+    x = qkv.astype(np.float64).reshape(B, L, 3, H, hd)
+    q64, k64, v64 = rot(x[:, :, 0], 1.0), rot(x[:, :, 1], 1.0), x[:, :, 2]
+    qh, kh, vh, gh = (a.transpose(0, 2, 1, 3) for a in (q64, k64, v64, do.astype(np.float64)))
+    s = qh @ kh.swapaxes(-1, -2) / math.sqrt(hd) + np.triu(np.full((L, L), -np.inf), 1)
+    e = np.exp(s - s.max(-1, keepdims=True))
+    p = e / e.sum(-1, keepdims=True)
+    assert rel_err(o.get(), (p @ vh).transpose(0, 2, 1, 3)) < 2e-5
+    dp = gh @ vh.swapaxes(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / math.sqrt(hd)
+    want = np.stack([rot((ds @ kh).transpose(0, 2, 1, 3), -1.0), rot((ds.swapaxes(-1, -2) @ qh).transpose(0, 2, 1, 3), -1.0),
+                     (p.swapaxes(-1, -2) @ gh).transpose(0, 2, 1, 3)], axis=2).reshape(B * L, 3 * D)
+    got = dqkv.get()
+    for j, name in enumerate(("dq", "dk", "dv")):
+        assert rel_err(got[:, j * D:(j + 1) * D], want[:, j * D:(j + 1) * D]) < 5e-5, name

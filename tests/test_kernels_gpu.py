@@ -445,12 +445,16 @@ def test_cross_entropy_one_pass_forward_backward(hip):
     hip.check_index_errors()
 
 
-@pytest.mark.parametrize("B,H,L,causal", [(2, 6, 256, 1), (3, 2, 64, 1), (1, 6, 128, 0), (2, 3, 32, 1)])
-def test_fused_attention_forward_backward(hip, B, H, L, causal):
+@pytest.mark.parametrize("B,H,L,causal,hd", [(2, 6, 256, 1, 48), (3, 2, 64, 1, 48), (1, 6, 128, 0, 48), (2, 3, 32, 1, 48),
+                                             (2, 2, 512, 1, 48),      # two 256-key chunks, one online rescale
+                                             (1, 2, 1024, 1, 48),     # max_seq_len of llm/llama/finetune.py:44
+                                             (1, 2, 512, 0, 48),      # not causal: every query group visits every chunk
+                                             (1, 3, 736, 1, 48),      # ragged last chunk (23 tiles: 8 + 8 + 7)
+                                             (2, 4, 256, 1, 64), (1, 2, 96, 0, 64), (1, 2, 640, 1, 64)])   # head dim 64
+def test_fused_attention_forward_backward(hip, B, H, L, causal, hd):
     """Fused attention vs a float64 statement of llm/llama/model.py:112-121 and its gradients."""
     from pydynet_amd import _lib
     Lb = _lib.lib()
-    hd = 48
     rng = np.random.default_rng(100 + L)
     q, k, v, do = (rng.standard_normal((B, L, H, hd), dtype=np.float32) for _ in range(4))
     k[0, L // 2, 0] *= 6.0                       # a spiky key: large scores exercise the max shift
