@@ -254,13 +254,29 @@ def batch_gate(model, ids_np, tgt_np, dev, pdn, lib, rtol=1e-4, want_families=(2
 
 def pmc_traffic():
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command (FETCH_SIZE x 2 -- the
-    gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, separate --pmc passes; tools/pmc_cmd.sh writes it).
-    Counters cannot be read from inside the timed run, so `traffic` is null when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_bench_b256.json")
-    if not os.path.exists(path):
+    gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, separate --pmc passes; tools/round_evidence.sh
+    regenerates it with tools/pmc_cmd.sh + tools/stamp_pmc.py).  Counters cannot be read from inside the timed run,
+    so `traffic` is null when no summary is there.  The newest round's file is taken; `_sha12` identifies it and
+    `_stale` says whether the kernel sources have changed since it was collected."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_b256.json")))
+    if not files:
         return {}
-    rows = json.load(open(path))
-    out = {"_source": "profiles/r02_pmc_bench_b256.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)"}
+    path = files[-1]
+    raw = open(path, "rb").read()
+    rows = json.loads(raw)
+    meta = rows.pop("_meta", {})
+    rel = os.path.relpath(path, ROOT)
+    out = {"_source": f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
+           "_sha12": hashlib.sha256(raw).hexdigest()[:12], "_stale": None}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import stamp_pmc
+        if meta.get("kernel_sources_sha16"):
+            out["_stale"] = meta["kernel_sources_sha16"] != stamp_pmc.sources_sha()
+    except Exception:
+        pass
     for fam in ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel",
                 "gemm_outres_tn_kernel", "ce_fwd_bwd_reg_kernel", "adam_multi_kernel", "swiglu_rows_bwd_kernel",
                 "rmsnorm_bwd_kernel"):
@@ -290,6 +306,8 @@ def hbm_kernels(lib, hp, B, traffic):
         # nothing of their size is written (the gradient is formed inside the two backward products)
         lib.call("pdn_cross_entropy_fwd_f32", x._ptr, tgt._ptr, T, V, 1, row._ptr, lse._ptr, loss._ptr,
                  hp.err_flag_ptr(), hp.stream())
+    # (the statistics pass IS an instantiation of ce_fwd_bwd_reg_kernel -- <false, false>: no gradient store -- so the
+    #  counter rows of that kernel name in the PMC summary are its own)
     for name, fn, nbytes in (("ce_fwd_bwd_reg_kernel", ce, 4.0 * T * V),):
         fn(); hp.synchronize()
         with hp.Timer() as t:
@@ -453,7 +471,8 @@ def main():
                 "other_gemm_families": {n: fams[n] for n in names if n != dom},
                 "all_gemm": {"achieved": tf(sum(fl2), sum(ms2)), "frac": tf(sum(fl2), sum(ms2)) / peak,
                              "time_share_of_step": sum(ms2) * 1e-3 / dt},
-                "traffic_source": traffic.get("_source")}
+                "traffic_source": traffic.get("_source"), "traffic_source_sha12": traffic.get("_sha12"),
+                "traffic_stale": traffic.get("_stale")}
         roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic) if rank == 0 else None
     per_rank = [B * args.steps / dt]
     if world > 1:

@@ -444,7 +444,8 @@ def run_decode(args):
             "whole_step": {"algorithmic_weight_bytes_per_token": wbytes, "achieved_GBps": wbytes * value / B / 1e9,
                            "frac_of_hbm_peak": wbytes * value / B / PEAK_HBM,
                            "note": "the 97 MB of weights sit in the 256 MiB Infinity Cache after the first token; a "
-                                   "token is ~40 dependent launches replayed as one hipGraph + one 8-byte read-back"}}
+                                   "token is 33 dependent launches replayed as one hipGraph (~5.8 us each: launch + two dependent memory "
+                                   "round trips), the next step queued while the 8-byte token travels to the host"}}
     out = {"metric": "greedy decode tokens/sec (6L Llama3, KV cache, batch 1)", "value": value, "unit": "tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / produced,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -70,6 +70,11 @@ int pdn_memset(void* dst, int byte_value, int64_t bytes, void* stream);
 /* streams (non-blocking: no implicit sync with the null stream) and events; the compute stream of
  * the current device is created on first use and is what the front end passes to every kernel */
 int pdn_compute_stream(void** stream);
+/* pinned host memory and a device -> host copy that returns at once (order it with events; the destination must come
+ * from pdn_host_alloc): lets a small read-back ride on its own stream while the compute stream goes on */
+int pdn_host_alloc(void** out, int64_t bytes);
+int pdn_host_free(void* ptr);
+int pdn_memcpy_d2h_async(void* dst_pinned_host, const void* src, int64_t bytes, void* stream);
 int pdn_stream_create(void** stream, int high_priority);
 int pdn_stream_destroy(void* stream);
 int pdn_stream_wait_event(void* stream, void* event);
@@ -278,7 +283,10 @@ int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* 
  *                            = [max, sum of exp, -, - | sum of exp(s - max) v] per range, merged by the output
  *                            projection's loads (act = 2).
  *   pdn_decode_pick_tick_f32 next_ids[b] = column of the first maximum over the candidates (model.py:262-268:
- *                            argmax(-1)); *pos += 1.  pdn_decode_argmax_tick_f32: the same from full logit rows. */
+ *                            argmax(-1)), also stored at (*history)[*pos * B + b] when a history (a device-resident
+ *                            pointer to a (max_len, B) int64 buffer) is given -- a per-position slot the host fetches
+ *                            while later steps run; then *pos += 1.  pdn_decode_argmax_tick_f32: the same pick from
+ *                            full logit rows. */
 int pdn_decode_gemv_blocks(int N);
 int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const float* norm_w, float eps, const float* W,
                         int64_t w_row_stride, int blk_cols, int64_t w_block_stride, const float* bias,
@@ -289,7 +297,7 @@ int pdn_decode_attention_f32(const float* qkv, int64_t qkv_row_stride, const flo
                              float* k_cache, float* v_cache, float* partials, int B, int H, int head_dim, int n_splits,
                              int64_t cache_batch_stride, const int* pos, int max_len, void* stream);
 int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, int n_blocks, int64_t* next_ids, int* pos,
-                             void* stream);
+                             int64_t* const* history, void* stream);
 int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_stride, int B, int V, int64_t* next_ids, int* pos,
                                void* stream);
 /* shapes the resident (K / V of a head chunk-wise in LDS) kernels above take: head_dim 48 or 64, L a multiple of 32 up

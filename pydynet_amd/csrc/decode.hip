@@ -438,40 +438,52 @@ extern "C" int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_strid
 }
 
 // ---- second half of the greedy pick over per-workgroup candidates (see pdn_decode_gemv_f32) + position tick -----
+// ONE workgroup walks the B rows (B <= 8), so that "read *pos, then advance it" is race free.  Token b goes to ids[b]
+// (where the next step's gather reads it) and, when a history is given, to (*hist)[*pos * B + b]: a per-position slot
+// the host can fetch -- and hand to the caller as that token's own array -- while later steps already run.
 __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __restrict__ vals, const int* __restrict__ args,
-                                                               int n, int64_t* __restrict__ ids, int* __restrict__ pos) {
+                                                               int B, int n, int64_t* __restrict__ ids, int* __restrict__ pos,
+                                                               int64_t* const* __restrict__ hist) {
   __shared__ float bv[4];
   __shared__ int bi[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float best = -INFINITY;
-  int idx = 0x7fffffff;
-  for (int i = tid; i < n; i += 256) {
-    const float v = vals[(int64_t)b * n + i];
-    const int a = args[(int64_t)b * n + i];
-    if (v > best || (v == best && a < idx)) { best = v; idx = a; }
-  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int p = pos ? *pos : 0;
+  int64_t* hrow = hist ? *hist + (int64_t)p * B : nullptr;
+  for (int b = 0; b < B; ++b) {
+    float best = -INFINITY;
+    int idx = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+      const float v = vals[(int64_t)b * n + i];
+      const int a = args[(int64_t)b * n + i];
+      if (v > best || (v == best && a < idx)) { best = v; idx = a; }
+    }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(best, o, 64);
-    const int oi = __shfl_xor(idx, o, 64);
-    if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(idx, o, 64);
+      if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
+    }
+    if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < 4; ++w)
+        if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
+      const int64_t tok = idx == 0x7fffffff ? 0 : idx;
+      ids[b] = tok;
+      if (hrow) hrow[b] = tok;
+    }
+    __syncthreads();
   }
-  if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
-  __syncthreads();
-  if (tid == 0) {
-    for (int w = 1; w < 4; ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
-    ids[b] = idx == 0x7fffffff ? 0 : idx;
-    if (b == 0 && pos) *pos += 1;
-  }
+  if (tid == 0 && pos) *pos = p + 1;
 }
 
 extern "C" int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, int n_blocks, int64_t* next_ids,
-                                        int* pos, void* stream) {
+                                        int* pos, int64_t* const* history, void* stream) {
   if (B == 0) return PDN_OK;
   PDN_CHECK_ARG(blk_max && blk_arg && next_ids && n_blocks > 0, "pdn_decode_pick_tick_f32: bad arguments");
-  hipLaunchKernelGGL(decode_pick_tick_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, blk_max, blk_arg, n_blocks,
-                     next_ids, pos);
+  PDN_CHECK_ARG(!history || pos, "pdn_decode_pick_tick_f32: a history needs the position");
+  hipLaunchKernelGGL(decode_pick_tick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, blk_max, blk_arg, B, n_blocks,
+                     next_ids, pos, history);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -345,6 +345,27 @@ int pdn_memcpy_d2h(void* dst_host, const void* src, int64_t bytes, void* stream)
   return 0;
 }
 
+// Pinned host memory + a device -> host copy that does NOT synchronise: the read-back of a small result (the token of a
+// decode step) can be queued on its own stream behind an event while the compute stream already runs the next step;
+// the host waits on the copy's event only (pdn_event_synchronize).
+int pdn_host_alloc(void** out, int64_t bytes) {
+  PDN_CHECK_ARG(out && bytes > 0, "pdn_host_alloc: bad arguments");
+  PDN_HIP(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+  return 0;
+}
+
+int pdn_host_free(void* ptr) {
+  if (ptr) PDN_HIP(hipHostFree(ptr));
+  return 0;
+}
+
+int pdn_memcpy_d2h_async(void* dst_pinned_host, const void* src, int64_t bytes, void* stream) {
+  if (bytes == 0) return 0;
+  PDN_CHECK_ARG(dst_pinned_host && src && bytes > 0, "pdn_memcpy_d2h_async: bad arguments");
+  PDN_HIP(hipMemcpyAsync(dst_pinned_host, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return 0;
+}
+
 int pdn_memcpy_d2d(void* dst, const void* src, int64_t bytes, void* stream) {
   if (bytes == 0) return 0;
   PDN_CHECK_ARG(dst && src && bytes > 0, "pdn_memcpy_d2d: bad arguments");

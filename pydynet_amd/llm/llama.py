@@ -221,14 +221,16 @@ class Llama(nn.Module):
                 next_id = logits[:, -1, :].argmax(-1, True)
             elif (Llama.fast_decode and next_id.device.is_hip and not self._train
                   and self.lm_head.weight.dtype == np.float32 and (self.embed_dim // self.n_heads) % 4 == 0):
-                next_id = Tensor(self._decode_step_hip(next_id.data, pos), dtype=np.int64, device=next_id.device,
-                                 copy=False)
+                # (`more`: another token will be asked for -- the step after this one may be queued ahead)
+                next_id = Tensor(self._decode_step_hip(next_id.data, pos, more=pos + 1 < max_new_tokens), dtype=np.int64,
+                                 device=next_id.device, copy=False)
             else:
                 next_id = self(next_id, pos)[:, -1, :].argmax(-1, True)
             yield next_id
 
     # -- decode fast path -----------------------------------------------------------
     graph_decode = True     # class switch: False issues the step's launches one by one instead of replaying a hipGraph
+    decode_ahead = True     # class switch: False never queues the next step before the caller asked for it
 
     def _decode_plan(self, B):
         """Buffers and weight views of the graph-replayable decode step (csrc/decode.hip), or None when the
@@ -265,6 +267,10 @@ class Llama(nn.Module):
             st.update(packs=packs, graph=None, host_pos=None, ns=ns,
                       ids=hp.zeros((B, 1), np.int64), pos=hp.zeros((1,), np.int32),
                       cand_v=hp.empty((B, nblk), np.float32), cand_i=hp.empty((B, nblk), np.int32),
+                      # tokens by position: (*hist_ptr)[pos] is what the step at `pos` picked -- the array handed to
+                      # the caller; a fresh history per generation (the pointer lives on the device, the graph holds
+                      # only ITS address), so arrays returned earlier are never rewritten
+                      hist_ptr=hp.zeros((1,), np.int64), hist=None,
                       **{n: hp.empty((B, w), np.float32) for n, w in
                          (("x", D), ("qkv", 3 * D), ("att", ns * H * (4 + D // H)), ("gu", 2 * F), ("logits", V))})
             self._decode_ws = {"logits": st["logits"], "x": st["x"]}
@@ -309,9 +315,9 @@ class Llama(nn.Module):
         L.call("pdn_decode_gemv_f32", x, D, self.norm.weight.data._ptr, self.norm.eps, head.weight.data._ptr, V, V, 0,
                bias, None, 0, logits, V, B, D, V, 0, 0, 0, st["cand_v"]._ptr, st["cand_i"]._ptr, s)
         L.call("pdn_decode_pick_tick_f32", st["cand_v"]._ptr, st["cand_i"]._ptr, B, st["cand_v"].shape[1],
-               st["ids"]._ptr, pos, s)
+               st["ids"]._ptr, pos, st["hist_ptr"]._ptr, s)
 
-    def _decode_step_hip(self, ids, pos: int):
+    def _decode_step_hip(self, ids, pos: int, more: bool = False):
         """One greedy decode step (one new token per sequence) without building tape nodes.  ids: (B, 1) int64
         device array; returns the next ids, (B, 1) int64.  The step is ONE hipGraph replay: norm + projection,
         RoPE + cache append, decode attention, SwiGLU + down projection and the greedy pick all read the position
@@ -329,8 +335,19 @@ class Llama(nn.Module):
         st = self._decode_plan(B)
         if st is None:
             return self._decode_step_generic(ids, pos)
+        ahead, st["ahead"] = st.get("ahead"), None
+        if ahead is not None:
+            if ahead[0] == pos and ahead[1] is ids:              # the step queued ahead is exactly this one
+                out = st["last_out"] = ahead[2]
+                if more and Llama.decode_ahead and pos + 1 < min(cache.shape[1], self.freqs_cos.shape[0]):
+                    self._decode_ahead(st, pos + 1)
+                return out
+            hp.synchronize()                                     # a different request: the queued step is void
+            st["host_pos"] = st["last_out"] = None               # (position and ids are uploaded again below)
         if st["host_pos"] != pos:
             st["pos"][...] = np.int32(pos)                       # (later steps: the device advances it itself)
+            st["hist"] = hp.zeros((cache.shape[1], B, 1), np.int64)          # a new generation: its own history
+            st["hist_ptr"][...] = np.int64(st["hist"]._ptr)
         if ids is not st["ids"] and ids is not st.get("last_out"):
             st["ids"][...] = ids                                 # (not the array the previous step returned: its
                                                                  # value is already where the gather reads it)
@@ -355,8 +372,28 @@ class Llama(nn.Module):
         else:
             self._decode_launches(st)
         st["host_pos"] = pos + 1
-        out = st["last_out"] = st["ids"].copy()                  # the caller's own array: the next replay rewrites `ids`
+        # the caller's own array = this position's slot of the history; its host value is fetched right behind the step:
+        # reading the token waits for THIS step only, while the compute stream may already run the next one
+        if st.get("readback") is None:
+            st["readback"] = hp.Readback(8 * B)
+        out = st["last_out"] = st["readback"].issue(st["hist"][pos])
+        if (more and Llama.decode_ahead and st["graph"] is not None
+                and pos + 1 < min(cache.shape[1], self.freqs_cos.shape[0])):
+            self._decode_ahead(st, pos + 1)
         return out
+
+    def _decode_ahead(self, st, pos):
+        """Queue the step of position `pos` right behind the one just issued -- its input ids are already where the
+        gather reads them -- so the GPU does not idle while the host hands the previous token to the caller.  The
+        result is kept for the next `_decode_step_hip(last_out, pos)` call; any other call discards it."""
+        g = st["graph"]
+        if g:
+            g.replay()
+        else:
+            self._decode_launches(st)
+        st["host_pos"] = pos + 1
+        prev = st["last_out"]
+        st["ahead"] = (pos, prev, st["readback"].issue(st["hist"][pos]))
 
     def _decode_step_generic(self, ids, pos: int):
         """The same step from the library's generic entry points (skinny `pdn_gemm_f32`, RMSNorm, RoPE, decode

@@ -95,6 +95,10 @@ class EmulatedLib:
     def pdn_memcpy_d2h(self, dst, src, n, stream): return self._copy(dst, src, n)
     def pdn_memcpy_d2d(self, dst, src, n, stream): return self._copy(dst, src, n)
 
+    def pdn_host_alloc(self, out, nbytes): return self.pdn_malloc(out, nbytes)
+    def pdn_host_free(self, ptr): return self.free(ptr)
+    def pdn_memcpy_d2h_async(self, dst, src, n, stream): return self._copy(dst, src, n)
+
     def pdn_memset(self, dst, value, n, stream):
         ctypes.memset(int(dst), int(value), int(n))
         return 0
@@ -690,12 +694,16 @@ class EmulatedLib:
             out[:, sp, :, 4:] = np.einsum("bht,bthd->bhd", e, V[:, t0:t1])
         return 0
 
-    def pdn_decode_pick_tick_f32(self, vals, args, B, n, ids, pos, stream):
+    def pdn_decode_pick_tick_f32(self, vals, args, B, n, ids, pos, hist, stream):
         v = np.array(flat(vals, B * n).reshape(B, n))
         a = np.array(flat(args, B * n, np.int32).reshape(B, n))
+        p = int(flat(pos, 1, np.int32)[0]) if pos else 0
+        hrow = flat(int(flat(hist, 1, np.int64)[0]) + 8 * p * B, B, np.int64) if hist else None
         for b in range(B):
             best = v[b].max()
             flat(ids, B, np.int64)[b] = a[b][v[b] == best].min()
+            if hrow is not None:
+                hrow[b] = flat(ids, B, np.int64)[b]
         if pos:
             flat(pos, 1, np.int32)[0] += 1
         return 0
