@@ -61,6 +61,25 @@ __device__ __forceinline__ float4 att_rot(float4 v, const float* __restrict__ cs
   return o;
 }
 
+// (cos, sin) of the pairs a lane's fragments / output row pieces cover, at ITS row: read once, at the top of the
+// kernel -- behind the staging -- instead of right after the staging barrier and right before the final store, where
+// nothing hides the latency (round 3: RoPE cost the backward 83 us of 572, most of it these two exposed reads).
+template <int NT8>
+struct AttRowRope {
+  float2 c[NT8], s[NT8];
+  __device__ __forceinline__ void load(const float* __restrict__ cs, const float* __restrict__ sn, int pos, int lh, int half) {
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      c[t] = *reinterpret_cast<const float2*>(cs + pos * half + 4 * t + 2 * lh);
+      s[t] = *reinterpret_cast<const float2*>(sn + pos * half + 4 * t + 2 * lh);
+    }
+  }
+  __device__ __forceinline__ float4 rot(const float4& v, int t, float sign) const {
+    const float sx = s[t].x * sign, sy = s[t].y * sign;
+    return make_float4(v.x * c[t].x - v.y * sx, v.x * sx + v.y * c[t].x, v.z * c[t].y - v.w * sy, v.z * sy + v.w * c[t].y);
+  }
+};
+
 // Forward staging of `nrows` rows (positions pos0 ..): K as [nrows][HD+4]; V as [nrows][64].  For HD < 64 column HD
 // of V is 1 and columns HD+1 .. 63 are 0: the second 32-row tile of O^T = V^T P^T then needs no per-lane select for
 // the rows beyond HD, and its row HD accumulates the softmax denominator (the row sums of P) for free -- the padded
@@ -172,6 +191,22 @@ __device__ __forceinline__ void att_store_rows(const f32x16& t0, const f32x16& t
   }
 }
 
+// the same with the row's (cos, sin) already in registers (register group g of t0 = pairs of fragment t = g, of t1 = 4 + g)
+template <int HD>
+__device__ __forceinline__ void att_store_rows_pre(const f32x16& t0, const f32x16& t1, float* __restrict__ rowp, float scale,
+                                                   const AttRowRope<HD / 8>& rr) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const float4 v = make_float4(t0[4 * g] * scale, t0[4 * g + 1] * scale, t0[4 * g + 2] * scale, t0[4 * g + 3] * scale);
+    *reinterpret_cast<float4*>(rowp + 8 * g) = rr.rot(v, g, -1.f);
+  }
+#pragma unroll
+  for (int g = 0; g < (HD - 32) / 8; ++g) {
+    const float4 v = make_float4(t1[4 * g] * scale, t1[4 * g + 1] * scale, t1[4 * g + 2] * scale, t1[4 * g + 3] * scale);
+    *reinterpret_cast<float4*>(rowp + 32 + 8 * g) = rr.rot(v, 4 + g, -1.f);
+  }
+}
+
 // Workgroup -> (batch * head, row group): the groups of one head are consecutive blocks, heaviest first (a causal
 // group g visits g + 1 chunks), so the long ones do not start last.
 __device__ __forceinline__ void att_block(int G, int& bh, int& grp) {
@@ -234,6 +269,9 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
   float m = -INFINITY, lsum = 0.f;               // running row maximum (unscaled scores); lsum: HD = 64 only
   const int c_last = MULTI ? (causal ? qg : G - 1) : 0;
+  AttRowRope<NT8> rr;
+  const bool pre = !MULTI && RC != nullptr && active;
+  if (pre) rr.load(RC, RS, qt * 32 + li, lh, HD / 2);
   if (!MULTI) {
     if (!(ABLATE & 1)) att_stage_kv<HD, 512>(Ks, Vs, K + base, V + base, L, 0, row_stride, tid, RC, RS);
     __syncthreads();
@@ -259,7 +297,8 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
 #pragma unroll
       for (int t = 0; t < NT8; ++t) {
         qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
-        if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
+        if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
+        else if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
       }
     }
     // ---- S^T tiles ---------------------------------------------------------------------
@@ -469,6 +508,9 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   const int qtl = att_tile_of_wave(wave);
   const int qt = qg * ATT_MAX_TILES + qtl;
   const bool active = qt < ntile;
+  AttRowRope<NT8> rr;
+  const bool pre = !MULTI && RC != nullptr && active;       // (the chunk loops have no registers to spare for it)
+  if (pre) rr.load(RC, RS, qt * 32 + li, lh, HD / 2);
   if (!MULTI) {
     att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, 0, row_stride, row_stride, tid, RC, RS, true, false);
     __syncthreads();
@@ -485,7 +527,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
-      if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
+      if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
+      else if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
       gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
       const float4 ov = *reinterpret_cast<const float4*>(orow + 8 * t);
       dpart += (ov.x * gf[t].x + ov.y * gf[t].y) + (ov.z * gf[t].z + ov.w * gf[t].w);
@@ -552,7 +595,10 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
       }
     }
   }
-  if (active) att_store_rows<HD>(dq0, dq1, dQb + (int64_t)qpos * row_stride + 4 * lh, lh, inv_sqrt, RC, RS, qpos);
+  if (active) {
+    if (pre) att_store_rows_pre<HD>(dq0, dq1, dQb + (int64_t)qpos * row_stride + 4 * lh, inv_sqrt, rr);
+    else att_store_rows<HD>(dq0, dq1, dQb + (int64_t)qpos * row_stride + 4 * lh, lh, inv_sqrt, RC, RS, qpos);
+  }
 }
 
 template <int HD, bool MULTI>
@@ -587,6 +633,9 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const int ktl = att_tile_of_wave(wave);
   const int kt = kg * ATT_MAX_TILES + ktl;
   const bool active = kt < ntile;
+  AttRowRope<NT8> rr;
+  const bool pre = !MULTI && RC != nullptr && active;
+  if (pre) rr.load(RC, RS, kt * 32 + li, lh, HD / 2);
   if (!MULTI) {
     att_stage_two_pad<HD, 512, true, true>(Qs, Gs, Q + base, dO + obase, L, 0, row_stride, o_row_stride, tid, RC, RS, true,
                                            false);
@@ -607,7 +656,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
-      if (RC) kf[t] = att_rot(kf[t], RC, RS, kpos, 4 * t + 2 * lh, HD / 2, 1.f);
+      if (pre) kf[t] = rr.rot(kf[t], t, 1.f);
+      else if (RC) kf[t] = att_rot(kf[t], RC, RS, kpos, 4 * t + 2 * lh, HD / 2, 1.f);
       vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
     }
   }
@@ -683,7 +733,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     }
   }
   if (active) {
-    att_store_rows<HD>(dk0, dk1, dKb + (int64_t)kpos * row_stride + 4 * lh, lh, inv_sqrt, RC, RS, kpos);
+    if (pre) att_store_rows_pre<HD>(dk0, dk1, dKb + (int64_t)kpos * row_stride + 4 * lh, inv_sqrt, rr);
+    else att_store_rows<HD>(dk0, dk1, dKb + (int64_t)kpos * row_stride + 4 * lh, lh, inv_sqrt, RC, RS, kpos);
     att_store_rows<HD>(dv0, dv1, dVb + (int64_t)kpos * row_stride + 4 * lh, lh, 1.f);
   }
 }
