@@ -272,6 +272,12 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   AttRowRope<NT8> rr;
   const bool pre = !MULTI && RC != nullptr && active;
   if (pre) rr.load(RC, RS, qt * 32 + li, lh, HD / 2);
+  float4 qraw[MULTI ? 1 : NT8];                  // single chunk: the Q rows go out before the staging (see dQ kernel)
+  if (!MULTI && active) {
+    const float* qrow = Qb + (int64_t)(qt * 32 + li) * row_stride + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) qraw[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+  }
   if (!MULTI) {
     if (!(ABLATE & 1)) att_stage_kv<HD, 512>(Ks, Vs, K + base, V + base, L, 0, row_stride, tid, RC, RS);
     __syncthreads();
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
       const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
 #pragma unroll
       for (int t = 0; t < NT8; ++t) {
-        qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+        if constexpr (MULTI) qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t); else qf[t] = qraw[t];
         if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
         else if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
       }
@@ -511,14 +517,12 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   AttRowRope<NT8> rr;
   const bool pre = !MULTI && RC != nullptr && active;       // (the chunk loops have no registers to spare for it)
   if (pre) rr.load(RC, RS, qt * 32 + li, lh, HD / 2);
-  if (!MULTI) {
-    att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, 0, row_stride, row_stride, tid, RC, RS, true, false);
-    __syncthreads();
-    if (!active) return;                           // no workgroup barrier below this point
-  }
   const float inv_sqrt = 1.f / sqrt_hd;
   const int qpos = qt * 32 + li;
-  float4 qf[NT8], gf[NT8];
+  // this wave's operands (Q, dO, O rows of its tile, lse): the loads go out BEFORE the staging -- behind which their
+  // latency hides -- and are consumed after the barrier (six workgroups pass through a CU one after the other: every
+  // exposed round trip is paid six times per kernel)
+  float4 qf[NT8], gf[NT8], of_[NT8];
   float dpart = 0.f, lse_q = 0.f;
   if (active) {
     const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
@@ -527,13 +531,23 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
-      if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
-      else if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
       gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
-      const float4 ov = *reinterpret_cast<const float4*>(orow + 8 * t);
-      dpart += (ov.x * gf[t].x + ov.y * gf[t].y) + (ov.z * gf[t].z + ov.w * gf[t].w);
+      of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
     }
     lse_q = LSE[(int64_t)bh * L + qpos];
+  }
+  if (!MULTI) {
+    att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, 0, row_stride, row_stride, tid, RC, RS, true, false);
+    __syncthreads();
+    if (!active) return;                           // no workgroup barrier below this point
+  }
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
+      else if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
+      dpart += (of_[t].x * gf[t].x + of_[t].y * gf[t].y) + (of_[t].z * gf[t].z + of_[t].w * gf[t].w);
+    }
   }
   const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
   const float c1 = inv_sqrt * 1.4426950408889634f, c2q = -lse_q * 1.4426950408889634f;
@@ -636,6 +650,19 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   AttRowRope<NT8> rr;
   const bool pre = !MULTI && RC != nullptr && active;
   if (pre) rr.load(RC, RS, kt * 32 + li, lh, HD / 2);
+  const float inv_sqrt = 1.f / sqrt_hd;
+  const float c1 = inv_sqrt * 1.4426950408889634f;
+  const int kpos = kt * 32 + li;
+  float4 kf[NT8], vf[NT8];                          // (issued before the staging, consumed after the barrier: see dQ)
+  if (active) {
+    const float* krow = Kb + (int64_t)kpos * row_stride + 4 * lh;
+    const float* vrow = Vb + (int64_t)kpos * row_stride + 4 * lh;
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) {
+      kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
+      vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
+    }
+  }
   if (!MULTI) {
     att_stage_two_pad<HD, 512, true, true>(Qs, Gs, Q + base, dO + obase, L, 0, row_stride, o_row_stride, tid, RC, RS, true,
                                            false);
@@ -646,19 +673,11 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     __syncthreads();
     if (!active) return;                           // no workgroup barrier below this point
   }
-  const float inv_sqrt = 1.f / sqrt_hd;
-  const float c1 = inv_sqrt * 1.4426950408889634f;
-  const int kpos = kt * 32 + li;
-  float4 kf[NT8], vf[NT8];
   if (active) {
-    const float* krow = Kb + (int64_t)kpos * row_stride + 4 * lh;
-    const float* vrow = Vb + (int64_t)kpos * row_stride + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
-      kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
       if (pre) kf[t] = rr.rot(kf[t], t, 1.f);
       else if (RC) kf[t] = att_rot(kf[t], RC, RS, kpos, 4 * t + 2 * lh, HD / 2, 1.f);
-      vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
     }
   }
   f32x16 dk0, dk1, dv0, dv1;
