@@ -1393,6 +1393,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   // the grid is large enough (>= 4 rounds) for the dispatcher to even the load out.
   int best = -1, best_splits = 1;
   double best_cost = 1e300;
+  static const bool no_fixed = getenv("PDN_GEMM_NO_FIXED") != nullptr;      // A/B switch for the residency-round term
   for (int c = 0; c < kNumCfgs && !use_stream; ++c) {
     if (!vec && c != kScalarCfg) continue;  // scalar staging: 64x64 only
     if (c == 7 && N < 2048) continue;
@@ -1423,6 +1424,14 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
       const double wps = blocks * waves_pb / 1024.0;   // resident waves per SIMD in a round
       const double util = wps >= 1.875 ? 1.0 : (wps > 1.0 ? 0.7 + 0.3 * (wps - 1.0) / 0.875 : 0.7);
       double cost = rounds * ((double)BM * BN * (kps * bk + 64) / waves_pb * 4.0 / (kCfgs[c].eff * util));
+      // ... plus what a block costs besides its MFMAs (first tiles in, accumulators out: ~25k cycles = 10 us, fitted at
+      // 16384 x 288 x {288, 768, 864}: 38 us for 384 blocks of 128 x 96 against 46 us for 768 of 64 x 128), paid once
+      // per RESIDENCY round -- co-resident blocks overlap theirs -- which is what makes few fat blocks win on short
+      // products even when they leave CUs half loaded (round 3; the unit is 1/156 matrix-pipe cycle)
+      if (!no_fixed) {
+        const double per_cu = c == 12 ? 3.0 : 2.0;
+        cost += (double)cdiv64((int64_t)blocks, (int64_t)(256.0 * per_cu)) * 3.9e6;
+      }
       if (s > 1) cost += (double)M * N * nbatch * (s + 1) * 0.5 + 1.0e6;   // slab pass + extra launch
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = s; }
     }

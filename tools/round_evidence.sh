@@ -26,7 +26,7 @@ bash tools/prof_cmd.sh ${ROUND}_decode python tools/bench_decode.py 256 8 > $O/d
 bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 256 48 > $O/attn_pmc.txt 2>&1
 { python tools/bench_configs.py 10; python tools/bench_graph.py 30; python tools/bench_decode.py 256 8; python tools/bench_decode.py 900 8;
   for a in "256 256 48" "128 512 48" "64 1024 48" "192 256 64" "96 512 64"; do python tools/attn_compare.py $a; done;
-  python tools/gemm_shapes.py 256; python tools/gemm_shapes.py 64; bash tools/ab_small_batch.sh;
+  python tools/gemm_shapes.py 256; python tools/gemm_shapes.py 64; bash tools/ab_small_batch.sh; bash tools/ab_fixed_term.sh;
   python tools/gemm_generic.py; python tools/bench_llama_dims.py 512 8 1536; python tools/bench_llama_dims.py 768 12 2048 128;
   python tools/bench_llama_dims.py 384 6 1024; python tools/bench_llama_dims.py 288 6 768 128 512; python tools/decode_probe.py;
   python tools/dp_overhead_probe.py dp; python tools/dp_overhead_probe.py base; } > $O/all_configs.txt 2>&1
