@@ -285,7 +285,8 @@ int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* 
  *   pdn_decode_pick_tick_f32 next_ids[b] = column of the first maximum over the candidates (model.py:262-268:
  *                            argmax(-1)), also stored at (*history)[*pos * B + b] when a history (a device-resident
  *                            pointer to a (max_len, B) int64 buffer) is given -- a per-position slot the host fetches
- *                            while later steps run; then *pos += 1.  pdn_decode_argmax_tick_f32: the same pick from
+ *                            while later steps run; with an embedding table (V, D) the picked token's row is copied to
+ *                            x_next (B, D) at once, so the next step starts at its first projection; then *pos += 1.  pdn_decode_argmax_tick_f32: the same pick from
  *                            full logit rows. */
 int pdn_decode_gemv_blocks(int N);
 int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const float* norm_w, float eps, const float* W,
@@ -297,7 +298,8 @@ int pdn_decode_attention_f32(const float* qkv, int64_t qkv_row_stride, const flo
                              float* k_cache, float* v_cache, float* partials, int B, int H, int head_dim, int n_splits,
                              int64_t cache_batch_stride, const int* pos, int max_len, void* stream);
 int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, int n_blocks, int64_t* next_ids, int* pos,
-                             int64_t* const* history, void* stream);
+                             int64_t* const* history, const float* emb, int64_t emb_row_stride, int D, float* x_next,
+                             void* stream);
 int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_stride, int B, int V, int64_t* next_ids, int* pos,
                                void* stream);
 /* shapes the resident (K / V of a head chunk-wise in LDS) kernels above take: head_dim 48 or 64, L a multiple of 32 up

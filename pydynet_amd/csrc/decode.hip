@@ -441,11 +441,16 @@ extern "C" int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_strid
 // ONE workgroup walks the B rows (B <= 8), so that "read *pos, then advance it" is race free.  Token b goes to ids[b]
 // (where the next step's gather reads it) and, when a history is given, to (*hist)[*pos * B + b]: a per-position slot
 // the host can fetch -- and hand to the caller as that token's own array -- while later steps already run.
+// With an embedding table the picked token's row is copied to x_next[b] right away: the next step then starts at its
+// first projection (one launch less per token; model.py:254-256 feeds next_id straight back into the embedding).
 __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __restrict__ vals, const int* __restrict__ args,
                                                                int B, int n, int64_t* __restrict__ ids, int* __restrict__ pos,
-                                                               int64_t* const* __restrict__ hist) {
+                                                               int64_t* const* __restrict__ hist,
+                                                               const float* __restrict__ emb, int64_t emb_rs, int D,
+                                                               float* __restrict__ x_next) {
   __shared__ float bv[4];
   __shared__ int bi[4];
+  __shared__ int64_t chosen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int p = pos ? *pos : 0;
   int64_t* hrow = hist ? *hist + (int64_t)p * B : nullptr;
@@ -471,19 +476,27 @@ __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __re
       const int64_t tok = idx == 0x7fffffff ? 0 : idx;
       ids[b] = tok;
       if (hrow) hrow[b] = tok;
+      chosen = tok;
     }
     __syncthreads();
+    if (emb) {
+      const float* row = emb + chosen * emb_rs;
+      for (int d = tid; d < D; d += 256) x_next[(int64_t)b * D + d] = row[d];
+      __syncthreads();                       // `chosen` is rewritten for the next row
+    }
   }
   if (tid == 0 && pos) *pos = p + 1;
 }
 
 extern "C" int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, int n_blocks, int64_t* next_ids,
-                                        int* pos, int64_t* const* history, void* stream) {
+                                        int* pos, int64_t* const* history, const float* emb, int64_t emb_row_stride,
+                                        int D, float* x_next, void* stream) {
   if (B == 0) return PDN_OK;
   PDN_CHECK_ARG(blk_max && blk_arg && next_ids && n_blocks > 0, "pdn_decode_pick_tick_f32: bad arguments");
   PDN_CHECK_ARG(!history || pos, "pdn_decode_pick_tick_f32: a history needs the position");
+  PDN_CHECK_ARG(!emb || (x_next && D > 0), "pdn_decode_pick_tick_f32: an embedding table needs x_next and D");
   hipLaunchKernelGGL(decode_pick_tick_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, blk_max, blk_arg, B, n_blocks,
-                     next_ids, pos, history);
+                     next_ids, pos, history, emb, emb_row_stride, D, x_next);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

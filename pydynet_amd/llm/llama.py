@@ -278,7 +278,7 @@ class Llama(nn.Module):
         return st if ok else None
 
     def _decode_launches(self, st):
-        """The 33 launches of one decode step (6 layers); every argument is fixed for the lifetime of `st` (the position
+        """The 32 launches of one decode step (6 layers); every argument is fixed for the lifetime of `st` (the position
         and the token ids are read from device memory), so the sequence can be captured once and replayed."""
         from .. import hipnp as hp, _lib
         L, s = _lib.lib(), hp.stream()
@@ -286,8 +286,9 @@ class Llama(nn.Module):
         hd = D // H
         x, qkv, att, gu, logits = (st[n]._ptr for n in ("x", "qkv", "att", "gu", "logits"))
         pos = st["pos"]._ptr
+        # (x = embedding rows of the current ids: left there by the previous step's pick kernel, or by
+        #  `_decode_gather` when the ids came from outside)
         emb = self.tok_embedding.weight.data
-        L.call("pdn_embedding_gather_f32", emb._ptr, V, D, emb._strides[0], st["ids"]._ptr, B, x, hp.err_flag_ptr(), s)
         cos, sin = self.freqs_cos.data._ptr, self.freqs_sin.data._ptr
         for layer, (wqkv, wgu) in zip(self.layers, st["packs"]):
             a, f = layer.attention, layer.ffn
@@ -315,7 +316,14 @@ class Llama(nn.Module):
         L.call("pdn_decode_gemv_f32", x, D, self.norm.weight.data._ptr, self.norm.eps, head.weight.data._ptr, V, V, 0,
                bias, None, 0, logits, V, B, D, V, 0, 0, 0, st["cand_v"]._ptr, st["cand_i"]._ptr, s)
         L.call("pdn_decode_pick_tick_f32", st["cand_v"]._ptr, st["cand_i"]._ptr, B, st["cand_v"].shape[1],
-               st["ids"]._ptr, pos, st["hist_ptr"]._ptr, s)
+               st["ids"]._ptr, pos, st["hist_ptr"]._ptr, emb._ptr, emb._strides[0], D, x, s)
+
+    def _decode_gather(self, st):
+        """x = tok_embedding[ids] for ids that did not come out of the previous step's pick kernel."""
+        from .. import hipnp as hp, _lib
+        emb = self.tok_embedding.weight.data
+        _lib.lib().call("pdn_embedding_gather_f32", emb._ptr, self.vocab_size, self.embed_dim, emb._strides[0],
+                        st["ids"]._ptr, st["B"], st["x"]._ptr, hp.err_flag_ptr(), hp.stream())
 
     def _decode_step_hip(self, ids, pos: int, more: bool = False):
         """One greedy decode step (one new token per sequence) without building tape nodes.  ids: (B, 1) int64
@@ -348,9 +356,10 @@ class Llama(nn.Module):
             st["pos"][...] = np.int32(pos)                       # (later steps: the device advances it itself)
             st["hist"] = hp.zeros((cache.shape[1], B, 1), np.int64)          # a new generation: its own history
             st["hist_ptr"][...] = np.int64(st["hist"]._ptr)
-        if ids is not st["ids"] and ids is not st.get("last_out"):
-            st["ids"][...] = ids                                 # (not the array the previous step returned: its
-                                                                 # value is already where the gather reads it)
+        fresh = ids is not st["ids"] and ids is not st.get("last_out")
+        if fresh:
+            st["ids"][...] = ids                                 # (not the array the previous step returned: that
+            self._decode_gather(st)                              # one's embedding row is already in x)
         g = st["graph"]
         if g is None and Llama.graph_decode and pos + 2 < min(cache.shape[1], self.freqs_cos.shape[0]):
             # capture once: hipnp.Graph runs the step twice for real (pool warm-up + first replay), which writes the
@@ -367,6 +376,7 @@ class Llama(nn.Module):
                 st["graph"] = g = False
             st["pos"][...] = np.int32(pos)
             st["ids"][...] = keep
+            self._decode_gather(st)
         if g:
             g.replay()
         else:

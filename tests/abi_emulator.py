@@ -694,7 +694,7 @@ class EmulatedLib:
             out[:, sp, :, 4:] = np.einsum("bht,bthd->bhd", e, V[:, t0:t1])
         return 0
 
-    def pdn_decode_pick_tick_f32(self, vals, args, B, n, ids, pos, hist, stream):
+    def pdn_decode_pick_tick_f32(self, vals, args, B, n, ids, pos, hist, emb, emb_rs, D, x_next, stream):
         v = np.array(flat(vals, B * n).reshape(B, n))
         a = np.array(flat(args, B * n, np.int32).reshape(B, n))
         p = int(flat(pos, 1, np.int32)[0]) if pos else 0
@@ -704,6 +704,9 @@ class EmulatedLib:
             flat(ids, B, np.int64)[b] = a[b][v[b] == best].min()
             if hrow is not None:
                 hrow[b] = flat(ids, B, np.int64)[b]
+            if emb:
+                tok = int(flat(ids, B, np.int64)[b])
+                flat(x_next, B * D).reshape(B, D)[b] = flat(emb + 4 * tok * emb_rs, D)
         if pos:
             flat(pos, 1, np.int32)[0] += 1
         return 0

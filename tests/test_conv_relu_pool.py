@@ -145,6 +145,33 @@ def check_deferred_nodes_materialise_for_any_other_consumer(dev):
     assert type(p3).__name__ == "pool2d" and p3.shape == (2, 20, 8, 8)
 
 
+def check_fused_chain_without_bias_and_without_autograd(dev):
+    """No bias operand; and under no_grad (inference) the chain is still one kernel and builds no tape."""
+    import pydynet_amd as pdn
+    import pydynet_amd.nn.functional as F
+    from pydynet_amd.core.tensor import Graph
+    Graph.clear()
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((3, 20, 16, 16), dtype=np.float32)
+    w = (0.2 * rng.standard_normal((50, 20, 3, 3))).astype(np.float32)
+    gp = rng.standard_normal((3, 50, 8, 8), dtype=np.float32)
+    X = pdn.Tensor(x, dtype=np.float32, device=dev, requires_grad=True)
+    Wt = pdn.Tensor(w, dtype=np.float32, device=dev, requires_grad=True)
+    out = F.max_pool2d(F.relu(F.conv2d(X, Wt, 1, 1)), 2, 2)
+    assert type(out).__name__ == "conv2d_relu_pool" and len(out.last) == 2
+    (out * pdn.Tensor(gp, dtype=np.float32, device=dev)).sum().backward()
+    ref = _ref(x, w, np.zeros(50, np.float32), gp)
+    _close(out.numpy(), ref[0], "pooled (no bias)")
+    _close(X.grad.get(), ref[1], "dx (no bias)")
+    _close(Wt.grad.get(), ref[2], "dw (no bias)")
+    with pdn.no_grad():
+        n0 = Graph.size()
+        y = F.max_pool2d(F.relu(F.conv2d(pdn.Tensor(x, dtype=np.float32, device=dev), pdn.Tensor(w, dtype=np.float32, device=dev),
+                                         1, 1)), 2, 2)
+        assert type(y).__name__ == "conv2d_relu_pool" and not y.requires_grad and Graph.size() == n0
+        assert np.array_equal(y.numpy(), out.numpy())
+
+
 def check_mask_expansion_entry(dev):
     from pydynet_amd import hipnp as hp, _lib
     import pydynet_amd as pdn  # noqa: F401
@@ -165,5 +192,5 @@ def check_mask_expansion_entry(dev):
 
 
 for _fn in (check_fused_chain_matches_float64_and_unfused, check_deferred_nodes_materialise_for_any_other_consumer,
-            check_mask_expansion_entry):
+            check_fused_chain_without_bias_and_without_autograd, check_mask_expansion_entry):
     device_variants(globals(), _fn)
