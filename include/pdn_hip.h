@@ -302,6 +302,31 @@ int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, in
                              void* stream);
 int pdn_decode_argmax_tick_f32(const float* logits, int64_t row_stride, int B, int V, int64_t* next_ids, int* pos,
                                void* stream);
+/* Fused decode layer (csrc/decode_layer.hip, decode_stage.h): three launches per TransformerBlock (model.py:118-121)
+ * instead of five.  An output projection is a sum over heads / hidden units, so its producer stops one step early:
+ * every workgroup leaves the contribution of ITS head / 32 hidden units to the projected row as a record, and every
+ * workgroup of the next kernel adds the records to the residual row, in one fixed order, while staging its input.
+ *   pdn_decode_attention_oproj_f32  pdn_decode_attention_f32 + the head's rows of Wo (D, D; model.py:116):
+ *                            records (B, n_splits, H, 4 + D) = [max, sum of exp, -, - | unnormalised contribution].
+ *   pdn_decode_mlp_f32       h = base + merge(records) (written to x_out), n = RMSNorm(h), then per workgroup 32
+ *                            hidden units of silu(n @ Wg) * (n @ Wu) (model.py:56-58) times their rows of Wd:
+ *                            parts (B, pdn_decode_mlp_slices(F), D) plain partial rows of the feed-forward output.
+ *   pdn_decode_gemv_sum_f32  pdn_decode_gemv_f32 whose input rows are base + sum of n_parts partial rows (written to
+ *                            x_out), then RMSNorm: the next layer's q | k | v projection, or the vocabulary projection. */
+int pdn_decode_attention_oproj_f32(const float* qkv, int64_t qkv_row_stride, const float* cos_table,
+                                   const float* sin_table, float* k_cache, float* v_cache, const float* Wo,
+                                   int64_t wo_row_stride, float* records, int B, int H, int head_dim, int n_splits,
+                                   int64_t cache_batch_stride, const int* pos, int max_len, void* stream);
+int pdn_decode_mlp_slices(int F);
+int pdn_decode_mlp_f32(const float* base, int64_t base_row_stride, const float* records, int64_t records_row_stride,
+                       int n_splits, int H, float* x_out, int64_t x_out_row_stride, const float* norm_w, float eps,
+                       const float* Wg, const float* Wu, int64_t w_row_stride, const float* Wd, int64_t wd_row_stride,
+                       float* parts, int64_t parts_row_stride, int B, int D, int F, void* stream);
+int pdn_decode_gemv_sum_f32(const float* base, int64_t base_row_stride, const float* parts, int n_parts,
+                            int64_t parts_row_stride, float* x_out, int64_t x_out_row_stride, const float* norm_w,
+                            float eps, const float* W, int64_t w_row_stride, int blk_cols, int64_t w_block_stride,
+                            const float* bias, float* y, int64_t y_row_stride, int B, int K, int N, float* blk_max,
+                            int* blk_arg, void* stream);
 /* shapes the resident (K / V of a head chunk-wise in LDS) kernels above take: head_dim 48 or 64, L a multiple of 32 up
  * to 1024 -- sequences beyond 256 pass through LDS in 256-row chunks (forward: one online rescale per chunk) */
 int pdn_attention_supported(int L, int head_dim);

@@ -85,6 +85,37 @@ __device__ __forceinline__ T block_sum(T v, T* smem) {
   for (int i = 0; i < nw; ++i) r += smem[i];
   return r;
 }
+// Barrier for LDS traffic only.  __syncthreads() carries a fence that drains vmcnt to 0: it waits for EVERY global
+// load in flight, i.e. it ends any overlap of a prefetch with the LDS work in front of it.  Only where no thread
+// reads global memory another thread of the workgroup wrote in this kernel.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+// block_sum / block_max below with that barrier
+__device__ __forceinline__ float block_sum_lds(float v, float* smem) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (nw == 1) return v;
+  lds_barrier();
+  if (lane == 0) smem[wid] = v;
+  lds_barrier();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += smem[i];
+  return r;
+}
+__device__ __forceinline__ float block_max_lds(float v, float* smem) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  if (nw == 1) return v;
+  lds_barrier();
+  if (lane == 0) smem[wid] = v;
+  lds_barrier();
+  float r = smem[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, smem[i]);
+  return r;
+}
 __device__ __forceinline__ float block_max(float v, float* smem) {
   v = wave_max(v);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;

@@ -20,16 +20,17 @@
 // summed by wave shuffles and then across the four waves through LDS in a FIXED order (no atomics: the result
 // does not depend on timing, and greedy decoding must give the same tokens every run).
 #include "common.h"
+#include "decode_stage.h"
 
 #define DEC_MAX_B 8
 
 template <int TN, int NB, int P>
 __global__ __launch_bounds__(256) void decode_gemv_kernel(
-    const float* __restrict__ x, int64_t x_rs, const float* __restrict__ norm_w, float eps,
-    const float* __restrict__ W, int64_t w_rs, int blk_cols, int64_t w_bs,
-    const float* __restrict__ bias, const float* residual, int64_t r_rs,
-    float* y, int64_t y_rs, int B, int K, int N, int act, int act_ns, int act_hd,
-    float* __restrict__ blk_max, int* __restrict__ blk_arg) {
+    const float* __restrict__ x, int x_rs, const float* __restrict__ norm_w, float eps,
+    const float* __restrict__ W, int w_rs, int blk_cols, int64_t w_bs,
+    const float* __restrict__ bias, const float* residual, int r_rs,
+    float* y, int y_rs, int B, int K, int N, int act, int act_ns, int act_hd,
+    float* __restrict__ blk_max, int* __restrict__ blk_arg, DecSum sum) {
   extern __shared__ __attribute__((aligned(16))) float xs[];        // [B][K] staged (normalised / gated) input rows
   __shared__ float red[16];
   __shared__ float4 part[4][TN / 4][NB];
@@ -40,19 +41,25 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
   const int quad = tid % Q, slice = tid / Q;
+  DEC_T_BEGIN(TN == 64 ? 4 : 0);
   const int n = blockIdx.x * TN + 4 * quad;                         // first of this thread's four columns
   const bool live = n < N;
   const int blk = live ? n / blk_cols : 0, col = live ? n - blk * blk_cols : 0;
-  const float* wp = W + (int64_t)blk * w_bs + col;
+  const float* wp = W + (int64_t)blk * w_bs + col;                  // (threads past N read column 0: loaded, never stored)
 
-  // ---- the weights do not depend on the activation: put the first P k-steps of this thread's column quad in flight
-  //      BEFORE the input rows are staged, so the two memory latencies overlap (these kernels are latency chains:
-  //      a token is ~35 dependent launches of a few microseconds each) ----
+  // ---- the input row first (a wave's loads return in issue order and the row is what the chain waits for), then,
+  //      without waiting, the first P k-steps of this thread's column quad: the weights do not depend on the
+  //      activation, so they travel while the row is summed and normalised (these kernels are latency chains:
+  //      a token is ~20 dependent launches of a few microseconds each).  No load sits behind a branch: rows past K
+  //      re-read row `slice` and are masked where they are used (32-bit offsets, two instructions per load) ----
+  DecStage stg;
+  const bool staged = sum.base != nullptr;
+  if (staged) dec_stage_issue(sum, K, 0, norm_w, stg);
   float4 wreg[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int k = slice + i * S;
-    wreg[i] = (live && k < K) ? *reinterpret_cast<const float4*>(wp + (int64_t)k * w_rs) : make_float4(0.f, 0.f, 0.f, 0.f);
+    wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < K ? k : slice) * w_rs));
   }
   // epilogue operands of the finishing threads, likewise
   const int fq = tid % Q, fj = tid / Q, fn = blockIdx.x * TN + 4 * fq;
@@ -60,12 +67,20 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
   float4 fbias = make_float4(0.f, 0.f, 0.f, 0.f);
   if (fin && bias) fbias = *reinterpret_cast<const float4*>(bias + fn);
   float4 fres = make_float4(0.f, 0.f, 0.f, 0.f);          // (row fj of the first pass; later passes load in place)
-  if (fin && residual && fj < B) fres = *reinterpret_cast<const float4*>(residual + (int64_t)fj * r_rs + fn);
+  if (fin && residual && fj < B) fres = *reinterpret_cast<const float4*>(residual + (unsigned)(fj * r_rs + fn));
 
+  DEC_T(1);
   // ---- stage the input rows: RMSNorm (norm.py:245-248: x / sqrt(mean(x^2) + eps) * w) or SwiGLU
   //      (functional.py:39-40, model.py:56-58: g / (1 + exp(-g)) * u on packed [gate | up] rows) on the way ----
+  if (staged) {
+    // the rows arrive as base (+ records of the previous kernel's workgroups, decode_stage.h), then RMSNorm
+    for (int b = 0; b < B; ++b) {
+      if (b) dec_stage_issue(sum, K, b, norm_w, stg);
+      dec_stage_row(sum, K, b, stg, xs, xs + B * K, red, blockIdx.x == 0, norm_w != nullptr, eps);
+    }
+  } else
   for (int b = 0; b < B; ++b) {
-    const float* xr = x + (int64_t)b * x_rs;
+    const float* xr = x + (unsigned)(b * x_rs);
     if (act == 2) {
       // x row b = the NS partial results of pdn_decode_attention_f32 (key ranges of one query):
       // per (split, head) [m, l, pad, pad | o[hd]]; the row of the product is their softmax-weighted merge
@@ -73,10 +88,10 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
       // The records come in with ONE round of independent loads (into LDS), then the merge reads LDS.
       const int NS = act_ns, hd = act_hd, rec = 4 + hd, H = K / hd, tot = NS * H * rec;
       float* raw = xs + B * K;
-      __syncthreads();                     // (the previous row's merge is done with `raw`)
+      lds_barrier();                     // (the previous row's merge is done with `raw`)
       for (int i = 4 * tid; i < tot; i += 1024)
         *reinterpret_cast<float4*>(raw + i) = *reinterpret_cast<const float4*>(xr + i);
-      __syncthreads();
+      lds_barrier();
       // one thread per head turns (m, l) of its NS ranges into merge weights w_s = exp(m_s - M) / sum_s exp(m_s - M) l_s
       // (left in the record's pad slot), then every element is NS independent multiply-adds
       if (tid < H) {
@@ -95,7 +110,7 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
         const float inv = 1.f / den;
         for (int sp = 0; sp < NS; ++sp) raw[(sp * H + tid) * rec + 2] *= inv;
       }
-      __syncthreads();
+      lds_barrier();
       for (int k = tid; k < K; k += 256) {
         const int h = k / hd, d = k - h * hd;
         float num = 0.f;
@@ -122,7 +137,7 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
       } else {
         for (int k = tid; k < K; k += 256) { const float v = xr[k]; ss += v * v; }
       }
-      ss = block_sum(ss, red);
+      ss = block_sum_lds(ss, red);
       const float scale = 1.f / sqrtf(ss / (float)K + eps);
       if (small) {
         if (tid < K) xs[b * K + tid] = v0 * scale * w0;
@@ -130,34 +145,34 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
       } else {
         for (int k = tid; k < K; k += 256) xs[b * K + k] = xr[k] * scale * norm_w[k];
       }
-      __syncthreads();                     // `red` is reused by the next row
+      lds_barrier();                     // `red` is reused by the next row
     } else {
       for (int k = tid; k < K; k += 256) xs[b * K + k] = xr[k];
     }
   }
-  __syncthreads();
+  lds_barrier();
+  DEC_T(2);
 
   for (int b0 = 0; b0 < B; b0 += NB) {
     float4 acc[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (live) {
+    {
 #pragma unroll
       for (int i = 0; i < P; ++i) {
-        const int k = slice + i * S;
-        if (k < K) {
-          const float4 w = wreg[i];
+        const int k = slice + i * S, kc = k < K ? k : slice;
+        const float4 w = wreg[i];
 #pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            const float a = (b0 + j < B) ? xs[(b0 + j) * K + k] : 0.f;
-            acc[j].x = fmaf(a, w.x, acc[j].x); acc[j].y = fmaf(a, w.y, acc[j].y);
-            acc[j].z = fmaf(a, w.z, acc[j].z); acc[j].w = fmaf(a, w.w, acc[j].w);
-          }
+        for (int j = 0; j < NB; ++j) {
+          float a = xs[min(b0 + j, B - 1) * K + kc];
+          a = (k < K && b0 + j < B) ? a : 0.f;
+          acc[j].x = fmaf(a, w.x, acc[j].x); acc[j].y = fmaf(a, w.y, acc[j].y);
+          acc[j].z = fmaf(a, w.z, acc[j].z); acc[j].w = fmaf(a, w.w, acc[j].w);
         }
       }
 #pragma unroll 4
       for (int k = slice + P * S; k < K; k += S) {
-        const float4 w = *reinterpret_cast<const float4*>(wp + (int64_t)k * w_rs);
+        const float4 w = *reinterpret_cast<const float4*>(wp + (unsigned)(k * w_rs));
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           const float a = (b0 + j < B) ? xs[(b0 + j) * K + k] : 0.f;
@@ -175,12 +190,13 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
         acc[j].z += __shfl_xor(acc[j].z, o, 64); acc[j].w += __shfl_xor(acc[j].w, o, 64);
       }
     }
-    __syncthreads();
+    DEC_T(3);
+    lds_barrier();
     if (lane < Q) {
 #pragma unroll
       for (int j = 0; j < NB; ++j) part[wave][lane][j] = acc[j];
     }
-    __syncthreads();
+    lds_barrier();
     const int b = b0 + fj;
     const bool mine = fin && b < B;
     if (mine) {
@@ -192,10 +208,10 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
       }
       r.x += fbias.x; r.y += fbias.y; r.z += fbias.z; r.w += fbias.w;
       if (residual) {
-        const float4 t = b0 == 0 ? fres : *reinterpret_cast<const float4*>(residual + (int64_t)b * r_rs + fn);
+        const float4 t = b0 == 0 ? fres : *reinterpret_cast<const float4*>(residual + (unsigned)(b * r_rs + fn));
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
       }
-      *reinterpret_cast<float4*>(y + (int64_t)b * y_rs + fn) = r;
+      *reinterpret_cast<float4*>(y + (unsigned)(b * y_rs + fn)) = r;
       if (blk_max) {                       // first maximum of this thread's four columns
         float bv = r.x; int bi = fn;
         if (r.y > bv) { bv = r.y; bi = fn + 1; }
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
     }
     if (blk_max) {
       // per row: first maximum over this workgroup's columns (quads ascend with the column index)
-      __syncthreads();
+      lds_barrier();
       if (tid < NB && b0 + tid < B) {
         float bv = -INFINITY; int bi = 0x7fffffff;
         for (int q = 0; q < Q; ++q) {
@@ -219,16 +235,19 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
       }
     }
   }
+  DEC_T(4);
+  DEC_T_END();
 }
 
 template <int TN, int P>
 static int launch_gemv(int nb, dim3 grid, size_t shm, hipStream_t st, const float* x, int64_t x_rs, const float* norm_w,
                        float eps, const float* W, int64_t w_rs, int blk_cols, int64_t w_bs, const float* bias,
                        const float* residual, int64_t r_rs, float* y, int64_t y_rs, int B, int K, int N, int act,
-                       int act_ns, int act_hd, float* blk_max, int* blk_arg) {
+                       int act_ns, int act_hd, float* blk_max, int* blk_arg, const DecSum& sum) {
 #define DEC_GO(NB)                                                                                                     \
-  hipLaunchKernelGGL((decode_gemv_kernel<TN, NB, P>), grid, dim3(256), shm, st, x, x_rs, norm_w, eps, W, w_rs, blk_cols, \
-                     w_bs, bias, residual, r_rs, y, y_rs, B, K, N, act, act_ns, act_hd, blk_max, blk_arg)
+  hipLaunchKernelGGL((decode_gemv_kernel<TN, NB, P>), grid, dim3(256), shm, st, x, (int)x_rs, norm_w, eps, W, (int)w_rs, \
+                     blk_cols, w_bs, bias, residual, (int)r_rs, y, (int)y_rs, B, K, N, act, act_ns, act_hd, blk_max,     \
+                     blk_arg, sum)
   if (nb == 1) DEC_GO(1); else if (nb == 2) DEC_GO(2); else DEC_GO(4);
 #undef DEC_GO
   PDN_LAUNCH_CHECK();
@@ -244,11 +263,11 @@ static int launch_gemv(int nb, dim3 grid, size_t shm, hipStream_t st, const floa
 // pick over a wide vocabulary projection (pdn_decode_pick_tick_f32 finishes it).
 extern "C" int pdn_decode_gemv_blocks(int N) { return N <= 4096 ? (N + 15) / 16 : (N <= 16384 ? (N + 31) / 32 : (N + 63) / 64); }
 
-extern "C" int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const float* norm_w, float eps, const float* W,
-                                   int64_t w_row_stride, int blk_cols, int64_t w_block_stride, const float* bias,
-                                   const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
-                                   int B, int K, int N, int act, int act_ns, int act_hd, float* blk_max, int* blk_arg,
-                                   void* stream) {
+static int decode_gemv_impl(const float* x, int64_t x_row_stride, const float* norm_w, float eps, const float* W,
+                            int64_t w_row_stride, int blk_cols, int64_t w_block_stride, const float* bias,
+                            const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride, int B, int K,
+                            int N, int act, int act_ns, int act_hd, float* blk_max, int* blk_arg, const DecSum& sum_in,
+                            void* stream) {
   if (B == 0 || N == 0) return PDN_OK;
   PDN_CHECK_ARG((blk_max == nullptr) == (blk_arg == nullptr), "pdn_decode_gemv_f32: blk_max and blk_arg go together");
   PDN_CHECK_ARG(x && W && y && K > 0 && blk_cols > 0 && N % blk_cols == 0, "pdn_decode_gemv_f32: bad arguments");
@@ -258,9 +277,18 @@ extern "C" int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const f
                     ((((uintptr_t)W | (uintptr_t)y | (uintptr_t)bias | (uintptr_t)residual) & 15) == 0),
                 "pdn_decode_gemv_f32: columns in multiples of 4, 16-byte aligned operands");
   PDN_CHECK_ARG(act == 0 || norm_w == nullptr, "pdn_decode_gemv_f32: act and norm are exclusive");
+  const int64_t lim = (int64_t)1 << 31;  // (the kernels do their row arithmetic in 32 bits)
+  PDN_CHECK_ARG(w_row_stride >= 0 && (int64_t)K * w_row_stride < lim && (int64_t)B * (x_row_stride < 0 ? -x_row_stride : x_row_stride) * 2 < lim &&
+                    x_row_stride >= 0 && (int64_t)B * y_row_stride < lim && y_row_stride >= 0 && res_row_stride >= 0 &&
+                    (int64_t)B * res_row_stride < lim,
+                "pdn_decode_gemv_f32: strides out of the 32-bit range of the kernel");
   PDN_CHECK_ARG(act != 2 || (act_ns > 0 && act_hd > 0 && K % act_hd == 0), "pdn_decode_gemv_f32: act 2 needs splits / head_dim");
   const int nb = B == 1 ? 1 : (B == 2 ? 2 : 4);
-  const size_t shm = ((size_t)B * K + (act == 2 ? (size_t)act_ns * (K / act_hd) * (4 + act_hd) : 0)) * sizeof(float);
+  DecSum sum = sum_in;
+  if (act == 0 && !sum.base && K % 4 == 0 && K <= 1024 && x_row_stride % 4 == 0 && (((uintptr_t)x | (uintptr_t)norm_w) & 15) == 0)
+    sum.base = x, sum.base_rs = (int)x_row_stride;       // (the staged path with no records)
+  const size_t shm = ((size_t)B * K + (act == 2 ? (size_t)act_ns * (K / act_hd) * (4 + act_hd) : 0) +
+                      (sum.R > 0 ? (size_t)dec_sum_scratch(K, sum.R, sum.hdr) : 0)) * sizeof(float);
   PDN_CHECK_ARG(shm <= 64 * 1024 && (act != 2 || (x_row_stride % 4 == 0 && act_hd % 4 == 0 && ((uintptr_t)x & 15) == 0)),
                 "pdn_decode_gemv_f32: act 2 staging does not fit / is not 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
@@ -268,115 +296,253 @@ extern "C" int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const f
   // (prefetch depth P: 12 k-steps of 64 slices cover K <= 768, 18 of 16 slices cover K <= 288 -- the Llama shapes)
   if (N <= 4096)
     return launch_gemv<16, 12>(nb, dim3((N + 15) / 16), shm, st, x, x_row_stride, norm_w, eps, W, w_row_stride, blk_cols,
-                               w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg);
+                               w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg, sum);
   if (N <= 16384)
     return launch_gemv<32, 12>(nb, dim3((N + 31) / 32), shm, st, x, x_row_stride, norm_w, eps, W, w_row_stride, blk_cols,
-                               w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg);
+                               w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg, sum);
   return launch_gemv<64, 18>(nb, dim3((N + 63) / 64), shm, st, x, x_row_stride, norm_w, eps, W, w_row_stride, blk_cols,
-                             w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg);
+                             w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg, sum);
+}
+
+extern "C" int pdn_decode_gemv_f32(const float* x, int64_t x_row_stride, const float* norm_w, float eps, const float* W,
+                                   int64_t w_row_stride, int blk_cols, int64_t w_block_stride, const float* bias,
+                                   const float* residual, int64_t res_row_stride, float* y, int64_t y_row_stride,
+                                   int B, int K, int N, int act, int act_ns, int act_hd, float* blk_max, int* blk_arg,
+                                   void* stream) {
+  DecSum none{};
+  return decode_gemv_impl(x, x_row_stride, norm_w, eps, W, w_row_stride, blk_cols, w_block_stride, bias, residual,
+                          res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg, none, stream);
+}
+
+// The same product with its input rows handed over as  base + sum of `n_parts` partial rows  (decode_stage.h; the
+// records pdn_decode_mlp_f32 leaves: row b's j-th partial at parts + b * parts_row_stride + j * K), then RMSNorm.
+// x_out (optional): the summed rows, written once -- the base of the next hand-off.
+extern "C" int pdn_decode_gemv_sum_f32(const float* base, int64_t base_row_stride, const float* parts, int n_parts,
+                                       int64_t parts_row_stride, float* x_out, int64_t x_out_row_stride,
+                                       const float* norm_w, float eps, const float* W, int64_t w_row_stride, int blk_cols,
+                                       int64_t w_block_stride, const float* bias, float* y, int64_t y_row_stride, int B,
+                                       int K, int N, float* blk_max, int* blk_arg, void* stream) {
+  PDN_CHECK_ARG(base && parts && n_parts > 0 && K % 4 == 0 && K <= 1024 && base_row_stride % 4 == 0 &&
+                    parts_row_stride % 4 == 0 && x_out_row_stride % 4 == 0 &&
+                    ((((uintptr_t)base | (uintptr_t)parts | (uintptr_t)x_out | (uintptr_t)norm_w) & 15) == 0),
+                "pdn_decode_gemv_sum_f32: K %% 4 == 0, K <= 1024, 16-byte aligned rows");
+  const int64_t lim = (int64_t)1 << 31;
+  PDN_CHECK_ARG(base_row_stride >= 0 && parts_row_stride >= 0 && x_out_row_stride >= 0 && (int64_t)B * base_row_stride < lim &&
+                    (int64_t)B * parts_row_stride + (int64_t)n_parts * K < lim && (int64_t)B * x_out_row_stride < lim,
+                "pdn_decode_gemv_sum_f32: strides out of the 32-bit range of the kernel");
+  DecSum sum{base, parts, x_out, (int)base_row_stride, (int)parts_row_stride, (int)x_out_row_stride, n_parts, 0, 0, 0};
+  return decode_gemv_impl(base, base_row_stride, norm_w, eps, W, w_row_stride, blk_cols, w_block_stride, bias, nullptr, 0,
+                          y, y_row_stride, B, K, N, 0, 0, 0, blk_max, blk_arg, sum, stream);
 }
 
 // ---- RoPE of the new q / k rows + KV-cache append + decode attention (model.py:23-44, 105-121 with L = 1) ----------
 // qkv: (B, 3 D) packed [q | k | v] rows of the fused projection.  A workgroup = (batch, head, key range): one CU
 // pulls ~11 bytes per clock, and a head's K / V rows at a few hundred positions are ~100 KB, so the T = *pos + 1 keys
-// of a head are cut into NS ranges handled by NS workgroups (flash-decoding).  Each rotates its head's q by the angle
-// of position *pos (interleaved pairs (x[2i], x[2i+1])); the one whose range holds position *pos also rotates k and
-// appends k / v to cache row *pos (kept in LDS: the row this workgroup just stored is not re-read from memory).
-// Result per (split, head): [max score m, sum of exp l, -, - | sum of exp(s - m) v]; the merge over the NS ranges
-// happens in the staging phase of the output projection (pdn_decode_gemv_f32, act = 2) -- no extra launch.
+// of a head are cut into NS ranges handled by NS workgroups (flash-decoding).  A kernel of the decode step is a chain
+// of memory round trips and what a CU can pull per microsecond (~26 KB): once the scalar load of *pos is back, EVERY
+// load of the kernel is issued at once, most urgent first (a wave's loads return in issue order) -- the new q | k | v
+// pairs and cos / sin of position *pos, the range's K rows (thread = key), its V rows (thread = (row group, column
+// quad)), the head's rows of Wo -- and only rows that exist are fetched.
+// Each workgroup rotates its head's q by the angle of position *pos (interleaved pairs (x[2i], x[2i+1])); the one
+// whose range holds *pos also rotates k and appends k / v to cache row *pos (kept in LDS: the row is not re-read).
+// Result per (range, head): [max score m, sum of exp l, -, - | sum of exp(s - m) v]; the merge over the NS ranges
+// happens in the staging phase of the next kernel (pdn_decode_gemv_f32 act = 2, or decode_stage.h) -- no extra launch.
+//
+// OPROJ: the workgroup also multiplies its (unnormalised) partial result by ITS head's rows of the output projection
+// (model.py:116: self.O(output); rows h * hd ... of Wo) and leaves a record [m, l, -, - | D values]
+// (decode_stage.h): the projection's sum over heads, the merge of the key ranges and the residual add all happen in
+// the staging of the next kernel -- one launch less per layer.  Those rows are 4 hd D bytes for ONE CU, so C
+// workgroups share a (range, head): each repeats the attention (the K / V rows come out of L2) and owns D / C columns.
+// KPRE / VPRE: float4s of the thread's K row / V rows of the thread held in registers from the start (head_dim 48:
+// 12 / 13, 64: 16 / 16 -- a 256-key range completely; 0 / 0: any head_dim, loads where they are used).
+template <int KPRE, int VPRE, bool OPROJ>
 __global__ __launch_bounds__(256) void decode_attention_kernel(const float* __restrict__ qkv, int64_t qkv_rs,
                                                                const float* __restrict__ cs, const float* __restrict__ sn,
                                                                float* __restrict__ kc, float* __restrict__ vc,
-                                                               float* __restrict__ part_out, int H, int hd, int NS,
-                                                               int64_t cbs, const int* __restrict__ pos_ptr, float inv_sqrt) {
+                                                               float* __restrict__ part_out, int H, int hd, int NS, int C,
+                                                               int64_t cbs, const int* __restrict__ pos_ptr, float inv_sqrt,
+                                                               const float* __restrict__ Wo, int wo_rs) {
   extern __shared__ __attribute__((aligned(16))) float sc[];      // [chunk] scores, then [groups + 8][hd] partial sums
   __shared__ __attribute__((aligned(16))) float qs[256], ks[256], vs[256];
   __shared__ float red[16];
+  DEC_T_BEGIN(1);
   const int pos = *pos_ptr, T = pos + 1;
-  const int sp = blockIdx.x % NS, bh = blockIdx.x / NS, b = bh / H, h = bh % H, tid = threadIdx.x;
+  const int ci = blockIdx.x % C, sp = (blockIdx.x / C) % NS, bh = blockIdx.x / (C * NS), b = bh / H, h = bh % H;
+  const int tid = threadIdx.x;
   const int chunk = (T + NS - 1) / NS, t0 = sp * chunk, t1 = min(T, t0 + chunk);
-  const int D = H * hd, f4 = hd / 4, half = hd / 2, rec = 4 + hd;
+  const int D = H * hd, f4 = hd / 4, half = hd / 2, rec = 4 + (OPROJ ? D : hd);
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int Dc = D / C, nqd = Dc / 4;                              // this workgroup's columns of the projected row
   float* out = part_out + (((int64_t)b * NS + sp) * H + h) * rec;
   if (t0 >= t1) {                        // no keys in this range (uniform over the workgroup)
-    if (tid == 0) { out[0] = -INFINITY; out[1] = 0.f; }
+    if (tid == 0 && ci == 0) { out[0] = -INFINITY; out[1] = 0.f; }
+    if (OPROJ) for (int i = tid; i < nqd; i += 256) reinterpret_cast<float4*>(out + 4 + ci * Dc)[i] = z4;
     return;
   }
   float* kb = kc + (int64_t)b * cbs + (int64_t)h * hd;
   float* vb = vc + (int64_t)b * cbs + (int64_t)h * hd;
   const bool owner = pos >= t0 && pos < t1;
-  if (tid < half) {
-    const float* row = qkv + (int64_t)b * qkv_rs + (int64_t)h * hd + 2 * tid;
-    const float c = cs[(int64_t)pos * half + tid], s = sn[(int64_t)pos * half + tid];
-    const float2 q = *reinterpret_cast<const float2*>(row);
-    *reinterpret_cast<float2*>(qs + 2 * tid) = make_float2(q.x * c - q.y * s, q.x * s + q.y * c);
-    if (owner) {
-      const float2 k = *reinterpret_cast<const float2*>(row + D);
-      const float2 v = *reinterpret_cast<const float2*>(row + 2 * D);
-      const float2 kr = make_float2(k.x * c - k.y * s, k.x * s + k.y * c);
-      *reinterpret_cast<float2*>(ks + 2 * tid) = kr;
-      *reinterpret_cast<float2*>(vs + 2 * tid) = v;
-      *reinterpret_cast<float2*>(kb + (int64_t)pos * D + 2 * tid) = kr;
-      *reinterpret_cast<float2*>(vb + (int64_t)pos * D + 2 * tid) = v;
+
+  // ---- every load of the kernel, most urgent first; none behind a branch (threads without a row re-read row t0 /
+  //      row 0 and the masks are applied where the values are used) ----
+  const int hq = min(tid, half - 1);                               // the new token's q / k / v pair of thread tid < hd / 2
+  const float* row = qkv + (int64_t)b * qkv_rs + (unsigned)(h * hd + 2 * hq);
+  const float2 nq = *reinterpret_cast<const float2*>(row);
+  const float rc = cs[(unsigned)(pos * half + hq)], rs = sn[(unsigned)(pos * half + hq)];
+  const float2 nk = *reinterpret_cast<const float2*>(row + D);
+  const float2 nv = *reinterpret_cast<const float2*>(row + 2 * D);
+  float4 kreg[KPRE > 0 ? KPRE : 1];
+  const int kt = t0 + tid;                                         // the key whose score this thread computes first
+  if (KPRE > 0) {                                                  // (KPRE = hd / 4)
+    const float* kp = kb + (unsigned)(((kt < t1 && kt != pos) ? kt : t0) * D);
+#pragma unroll
+    for (int c = 0; c < KPRE; ++c) kreg[c] = *reinterpret_cast<const float4*>(kp + 4 * c);
+  }
+  const int groups = 256 / f4, vc4 = tid % f4, tg = tid / f4;
+  float4 vreg[VPRE > 0 ? VPRE : 1];
+  if (VPRE > 0) {
+#pragma unroll
+    for (int i = 0; i < VPRE; ++i) {
+      const int t = t0 + tg + i * groups;
+      vreg[i] = *reinterpret_cast<const float4*>(vb + (unsigned)(((t < t1 && t != pos) ? t : t0) * D + 4 * vc4));
     }
   }
-  __syncthreads();
+  // this head's rows of the output projection: thread = (row slice, column quad), PW rows each
+  constexpr int PW = 16;
+  const int G = OPROJ ? 256 / nqd : 1, osl = tid / nqd, oq = tid - osl * nqd;
+  float4 wo[OPROJ ? PW : 1];
+  if (OPROJ) {
+    const float* wop = Wo + (unsigned)(h * hd * wo_rs + ci * Dc + 4 * oq);
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int d = osl + i * G;
+      wo[i] = *reinterpret_cast<const float4*>(wop + (unsigned)((d < hd ? d : 0) * wo_rs));
+    }
+  }
+  DEC_T(1);
+
+  if (tid < half) {
+    *reinterpret_cast<float2*>(qs + 2 * tid) = make_float2(nq.x * rc - nq.y * rs, nq.x * rs + nq.y * rc);
+    if (owner) {
+      const float2 kr = make_float2(nk.x * rc - nk.y * rs, nk.x * rs + nk.y * rc);
+      *reinterpret_cast<float2*>(ks + 2 * tid) = kr;
+      *reinterpret_cast<float2*>(vs + 2 * tid) = nv;
+      if (ci == 0) {
+        *reinterpret_cast<float2*>(kb + (int64_t)pos * D + 2 * tid) = kr;
+        *reinterpret_cast<float2*>(vb + (int64_t)pos * D + 2 * tid) = nv;
+      }
+    }
+  }
+  lds_barrier();
+  DEC_T(2);
   const float4* q4 = reinterpret_cast<const float4*>(qs);
   float m = -INFINITY;
-  for (int t = t0 + tid; t < t1; t += 256) {
-    const float4* k4 = t == pos ? reinterpret_cast<const float4*>(ks) : reinterpret_cast<const float4*>(kb + (int64_t)t * D);
+  for (int t = kt; t < t1; t += 256) {
     float s = 0.f;
-    for (int c = 0; c < f4; ++c) {
-      const float4 a = q4[c], k = k4[c];
-      s += (a.x * k.x + a.y * k.y) + (a.z * k.z + a.w * k.w);
+    if (KPRE > 0 && t == kt && t != pos) {
+#pragma unroll
+      for (int c = 0; c < KPRE; ++c) {
+        const float4 a = q4[c], k = kreg[c];
+        s += (a.x * k.x + a.y * k.y) + (a.z * k.z + a.w * k.w);
+      }
+    } else {
+      const float4* k4 = t == pos ? reinterpret_cast<const float4*>(ks) : reinterpret_cast<const float4*>(kb + (int64_t)t * D);
+      for (int c = 0; c < f4; ++c) {
+        const float4 a = q4[c], k = k4[c];
+        s += (a.x * k.x + a.y * k.y) + (a.z * k.z + a.w * k.w);
+      }
     }
     s *= inv_sqrt;
     sc[t - t0] = s;
     m = fmaxf(m, s);
   }
-  m = block_max(m, red);
+  m = block_max_lds(m, red);
+  DEC_T(3);
   float l = 0.f;
-  for (int t = t0 + tid; t < t1; t += 256) {
+  for (int t = kt; t < t1; t += 256) {
     const float pr = expf(sc[t - t0] - m);
     sc[t - t0] = pr;
     l += pr;
   }
-  l = block_sum(l, red);                 // (its barriers also publish the probabilities)
-  const int groups = 256 / f4, c = tid % f4, tg = tid / f4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  l = block_sum_lds(l, red);                 // (its barriers also publish the probabilities)
+  DEC_T(4);
+  float4 acc = z4;
   if (tg < groups) {
-    for (int t = t0 + tg; t < t1; t += groups) {
+    if (VPRE > 0) {
+#pragma unroll
+      for (int i = 0; i < VPRE; ++i) {
+        const int t = t0 + tg + i * groups;
+        if (t < t1) {
+          const float pr = sc[t - t0];
+          const float4 v = t == pos ? reinterpret_cast<const float4*>(vs)[vc4] : vreg[i];
+          acc.x += pr * v.x; acc.y += pr * v.y; acc.z += pr * v.z; acc.w += pr * v.w;
+        }
+      }
+    }
+    for (int t = t0 + tg + VPRE * groups; t < t1; t += groups) {
       const float pr = sc[t - t0];
-      const float4 v = t == pos ? reinterpret_cast<const float4*>(vs)[c]
-                                : *reinterpret_cast<const float4*>(vb + (int64_t)t * D + 4 * c);
+      const float4 v = t == pos ? reinterpret_cast<const float4*>(vs)[vc4]
+                                : *reinterpret_cast<const float4*>(vb + (int64_t)t * D + 4 * vc4);
       acc.x += pr * v.x; acc.y += pr * v.y; acc.z += pr * v.z; acc.w += pr * v.w;
     }
   }
-  __syncthreads();                       // scores are dead: reuse the buffer for the partial sums
+  DEC_T(5);
+  lds_barrier();                       // scores are dead: reuse the buffer for the partial sums
   float4* part = reinterpret_cast<float4*>(sc);
-  if (tg < groups) part[tg * f4 + c] = acc;
-  __syncthreads();
+  if (tg < groups) part[tg * f4 + vc4] = acc;
+  lds_barrier();
   // combine in a fixed order: 8 threads per column quad add every 8th group, then one thread adds those 8
   if (tid < 8 * f4) {
     const int g0 = tid / f4;
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int g = g0; g < groups; g += 8) { const float4 t = part[g * f4 + c]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+    float4 r = z4;
+    for (int g = g0; g < groups; g += 8) { const float4 t = part[g * f4 + vc4]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
     part[groups * f4 + tid] = r;
   }
-  __syncthreads();
+  lds_barrier();
   if (tid < f4) {
     float4 r = part[groups * f4 + tid];
     for (int g = 1; g < 8; ++g) { const float4 t = part[groups * f4 + g * f4 + tid]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
-    reinterpret_cast<float4*>(out + 4)[tid] = r;
-    if (tid == 0) { out[0] = m; out[1] = l; }
+    if (OPROJ) reinterpret_cast<float4*>(qs)[tid] = r;            // (q is dead: the head's hd sums go there)
+    else reinterpret_cast<float4*>(out + 4)[tid] = r;
+    if (tid == 0 && ci == 0) { out[0] = m; out[1] = l; }
   }
+  DEC_T(6);
+  if (OPROJ) {
+    lds_barrier();
+    float4 oacc = z4;
+    if (osl < G) {
+#pragma unroll
+      for (int i = 0; i < PW; ++i) {
+        const int d = osl + i * G;
+        float a = qs[d < hd ? d : 0];
+        a = d < hd ? a : 0.f;
+        oacc.x = fmaf(a, wo[i].x, oacc.x); oacc.y = fmaf(a, wo[i].y, oacc.y);
+        oacc.z = fmaf(a, wo[i].z, oacc.z); oacc.w = fmaf(a, wo[i].w, oacc.w);
+      }
+      for (int d = osl + PW * G; d < hd; d += G) {
+        const float4 w = *reinterpret_cast<const float4*>(Wo + (unsigned)((h * hd + d) * wo_rs + ci * Dc + 4 * oq));
+        const float a = qs[d];
+        oacc.x = fmaf(a, w.x, oacc.x); oacc.y = fmaf(a, w.y, oacc.y); oacc.z = fmaf(a, w.z, oacc.z); oacc.w = fmaf(a, w.w, oacc.w);
+      }
+      part[osl * nqd + oq] = oacc;       // (the combine above is done with `part`: the barrier before this block)
+    }
+    lds_barrier();
+    if (tid < nqd) {
+      float4 r = part[tid];
+      for (int g = 1; g < G; ++g) { const float4 t = part[g * nqd + tid]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
+      reinterpret_cast<float4*>(out + 4 + ci * Dc)[tid] = r;
+    }
+  }
+  DEC_T(7);
+  DEC_T_END();
 }
 
 // qkv rows `qkv_row_stride` floats apart; partials: (B, n_splits, H, 4 + head_dim) floats; caches hold `max_len` positions per sequence, `cache_batch_stride` floats between sequences; cos / sin
 // tables (max_len, head_dim / 2).
-extern "C" int pdn_decode_attention_f32(const float* qkv, int64_t qkv_row_stride, const float* cos_table,
-                                        const float* sin_table, float* k_cache, float* v_cache, float* partials, int B,
-                                        int H, int head_dim, int n_splits, int64_t cache_batch_stride, const int* pos,
-                                        int max_len, void* stream) {
+static int decode_attention_impl(const float* qkv, int64_t qkv_row_stride, const float* cos_table, const float* sin_table,
+                                 float* k_cache, float* v_cache, float* partials, int B, int H, int head_dim, int n_splits,
+                                 int64_t cache_batch_stride, const int* pos, int max_len, const float* Wo,
+                                 int64_t wo_row_stride, bool oproj, void* stream) {
   if (B == 0 || H == 0) return PDN_OK;
   PDN_CHECK_ARG(qkv && cos_table && sin_table && k_cache && v_cache && partials && pos && max_len > 0,
                 "pdn_decode_attention_f32: bad arguments");
@@ -389,11 +555,48 @@ extern "C" int pdn_decode_attention_f32(const float* qkv, int64_t qkv_row_stride
   const size_t need = (size_t)(groups + 8) * head_dim, chunk = (size_t)(max_len + NS - 1) / NS;
   const size_t shm = sizeof(float) * (chunk > need ? chunk : need);
   PDN_CHECK_ARG(shm <= 60 * 1024, "pdn_decode_attention_f32: max_len = %d too long", max_len);
-  hipLaunchKernelGGL(decode_attention_kernel, dim3(B * H * NS), dim3(256), shm, (hipStream_t)stream, qkv, qkv_row_stride,
-                     cos_table, sin_table, k_cache, v_cache, partials, H, head_dim, NS, cache_batch_stride, pos,
-                     1.f / sqrtf((float)head_dim));
+  const float inv_sqrt = 1.f / sqrtf((float)head_dim);
+  const int D = H * head_dim;
+  int C = 1;                             // workgroups sharing a (range, head): D / C columns of the projected row each
+  if (oproj) {
+    PDN_CHECK_ARG(Wo && D <= 1024 && wo_row_stride % 4 == 0 && (((uintptr_t)Wo) & 15) == 0 && NS * H <= 256,
+                  "pdn_decode_attention_oproj_f32: D <= 1024, n_splits * H <= 256, 16-byte aligned Wo rows");
+    C = D % 16 == 0 ? 4 : (D % 12 == 0 ? 3 : (D % 8 == 0 ? 2 : 1));
+  }
+  PDN_CHECK_ARG((int64_t)max_len * D < ((int64_t)1 << 31) && wo_row_stride >= 0 && (int64_t)D * wo_row_stride < ((int64_t)1 << 31),
+                "pdn_decode_attention_f32: cache rows / Wo out of the 32-bit range of the kernel");
+  const dim3 grid(B * H * NS * C);
+  hipStream_t st = (hipStream_t)stream;
+#define ATT_GO(KP, VP, OP)                                                                                              \
+  hipLaunchKernelGGL((decode_attention_kernel<KP, VP, OP>), grid, dim3(256), shm, st, qkv, qkv_row_stride, cos_table,    \
+                     sin_table, k_cache, v_cache, partials, H, head_dim, NS, C, cache_batch_stride, pos, inv_sqrt, Wo,  \
+                     (int)wo_row_stride)
+  if (head_dim == 48) { if (oproj) ATT_GO(12, 13, true); else ATT_GO(12, 13, false); }
+  else if (head_dim == 64) { if (oproj) ATT_GO(16, 16, true); else ATT_GO(16, 16, false); }
+  else { if (oproj) ATT_GO(0, 0, true); else ATT_GO(0, 0, false); }
+#undef ATT_GO
   PDN_LAUNCH_CHECK();
   return PDN_OK;
+}
+
+extern "C" int pdn_decode_attention_f32(const float* qkv, int64_t qkv_row_stride, const float* cos_table,
+                                        const float* sin_table, float* k_cache, float* v_cache, float* partials, int B,
+                                        int H, int head_dim, int n_splits, int64_t cache_batch_stride, const int* pos,
+                                        int max_len, void* stream) {
+  return decode_attention_impl(qkv, qkv_row_stride, cos_table, sin_table, k_cache, v_cache, partials, B, H, head_dim,
+                               n_splits, cache_batch_stride, pos, max_len, nullptr, 0, false, stream);
+}
+
+// The same with the output projection applied per head: records (B, n_splits, H, 4 + D) of [m, l, -, - | the
+// head's unnormalised contribution to the projected row] for the staging of pdn_decode_mlp_f32.  Wo: (D, D) as
+// nn.Linear stores it (in, out), rows wo_row_stride floats apart.
+extern "C" int pdn_decode_attention_oproj_f32(const float* qkv, int64_t qkv_row_stride, const float* cos_table,
+                                              const float* sin_table, float* k_cache, float* v_cache, const float* Wo,
+                                              int64_t wo_row_stride, float* records, int B, int H, int head_dim,
+                                              int n_splits, int64_t cache_batch_stride, const int* pos, int max_len,
+                                              void* stream) {
+  return decode_attention_impl(qkv, qkv_row_stride, cos_table, sin_table, k_cache, v_cache, records, B, H, head_dim,
+                               n_splits, cache_batch_stride, pos, max_len, Wo, wo_row_stride, true, stream);
 }
 
 // ---- greedy pick + position tick (model.py:262-268: logits[:, -1, :].argmax(-1, keepdims=True)) ------------------
@@ -418,7 +621,7 @@ __global__ __launch_bounds__(1024) void decode_argmax_tick_kernel(const float* _
     if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
   }
   if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
-  __syncthreads();
+  lds_barrier();
   if (tid == 0) {
     for (int w = 1; w < 16; ++w)
       if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
@@ -452,6 +655,7 @@ __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __re
   __shared__ int bi[4];
   __shared__ int64_t chosen;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  DEC_T_BEGIN(2);
   const int p = pos ? *pos : 0;
   int64_t* hrow = hist ? *hist + (int64_t)p * B : nullptr;
   for (int b = 0; b < B; ++b) {
@@ -469,7 +673,7 @@ __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __re
       if (ov > best || (ov == best && oi < idx)) { best = ov; idx = oi; }
     }
     if (lane == 0) { bv[wave] = best; bi[wave] = idx; }
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
       for (int w = 1; w < 4; ++w)
         if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
@@ -478,15 +682,19 @@ __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __re
       if (hrow) hrow[b] = tok;
       chosen = tok;
     }
-    __syncthreads();
+    lds_barrier();
+    DEC_T(1);
     if (emb) {
       const float* row = emb + chosen * emb_rs;
       for (int d = tid; d < D; d += 256) x_next[(int64_t)b * D + d] = row[d];
-      __syncthreads();                       // `chosen` is rewritten for the next row
+      lds_barrier();                       // `chosen` is rewritten for the next row
     }
   }
   if (tid == 0 && pos) *pos = p + 1;
+  DEC_T(2);
+  DEC_T_END();
 }
+DEC_TRACE_DUMP(pdn_dec_trace_dump_step)
 
 extern "C" int pdn_decode_pick_tick_f32(const float* blk_max, const int* blk_arg, int B, int n_blocks, int64_t* next_ids,
                                         int* pos, int64_t* const* history, const float* emb, int64_t emb_row_stride,

@@ -231,6 +231,7 @@ class Llama(nn.Module):
     # -- decode fast path -----------------------------------------------------------
     graph_decode = True     # class switch: False issues the step's launches one by one instead of replaying a hipGraph
     decode_ahead = True     # class switch: False never queues the next step before the caller asked for it
+    fused_decode = True     # class switch: False keeps the five-launch layer (separate output / down projections)
 
     def _decode_plan(self, B):
         """Buffers and weight views of the graph-replayable decode step (csrc/decode.hip), or None when the
@@ -273,12 +274,20 @@ class Llama(nn.Module):
                       hist_ptr=hp.zeros((1,), np.int64), hist=None,
                       **{n: hp.empty((B, w), np.float32) for n, w in
                          (("x", D), ("qkv", 3 * D), ("att", ns * H * (4 + D // H)), ("gu", 2 * F), ("logits", V))})
+            # three launches per layer (csrc/decode_layer.hip): the output / down projections leave per-head /
+            # per-32-hidden-unit records that the next kernel's staging adds to the residual row
+            J = _lib.lib().query("pdn_decode_mlp_slices", F)
+            st["fused"] = bool(Llama.fused_decode and J and D <= 1024 and ns * H <= 256 and len(self.layers) > 0 and all(
+                l.ffn.gate.weight.data.is_contiguous() and l.ffn.up.weight.data.is_contiguous() for l in self.layers))
+            if st["fused"]:
+                st.update(J=J, recs=hp.empty((B, ns * H * (4 + D)), np.float32), dparts=hp.empty((B, J * D), np.float32),
+                          xa=hp.empty((B, D), np.float32), xb=hp.empty((B, D), np.float32))
             self._decode_ws = {"logits": st["logits"], "x": st["x"]}
         self._decode_st = st
         return st if ok else None
 
     def _decode_launches(self, st):
-        """The 32 launches of one decode step (6 layers); every argument is fixed for the lifetime of `st` (the position
+        """The launches of one decode step (3 per layer + 2, or 5 per layer + 2 with `fused_decode` off); every argument is fixed for the lifetime of `st` (the position
         and the token ids are read from device memory), so the sequence can be captured once and replayed."""
         from .. import hipnp as hp, _lib
         L, s = _lib.lib(), hp.stream()
@@ -290,6 +299,36 @@ class Llama(nn.Module):
         #  `_decode_gather` when the ids came from outside)
         emb = self.tok_embedding.weight.data
         cos, sin = self.freqs_cos.data._ptr, self.freqs_sin.data._ptr
+        head = self.lm_head
+        bias = head.bias.data._ptr if getattr(head, "bias", None) is not None else None
+        if st["fused"]:
+            J, ns = st["J"], st["ns"]
+            recs, dparts, xa, xb = (st[n]._ptr for n in ("recs", "dparts", "xa", "xb"))
+            rrs = st["recs"].shape[1]
+            for li, (layer, (wqkv, _)) in enumerate(zip(self.layers, st["packs"])):
+                a, f = layer.attention, layer.ffn
+                ck, cv = a.cache_k.data, a.cache_v.data
+                nrm = layer.input_norm
+                # [q | k | v] = RMSNorm(x) @ [Wq | Wk | Wv]; x = previous block's h + its feed-forward records
+                if li == 0:
+                    L.call("pdn_decode_gemv_f32", x, D, nrm.weight.data._ptr, nrm.eps, wqkv._ptr, D, D, wqkv._strides[0],
+                           None, None, 0, qkv, 3 * D, B, D, 3 * D, 0, 0, 0, None, None, s)
+                else:
+                    L.call("pdn_decode_gemv_sum_f32", xb, D, dparts, J, J * D, xa, D, nrm.weight.data._ptr, nrm.eps,
+                           wqkv._ptr, D, D, wqkv._strides[0], None, qkv, 3 * D, B, D, 3 * D, None, None, s)
+                # RoPE, cache append, attention over [0, pos], each head times its rows of Wo -> records
+                L.call("pdn_decode_attention_oproj_f32", qkv, 3 * D, cos, sin, ck._ptr, cv._ptr, a.O.weight.data._ptr, D,
+                       recs, B, H, hd, ns, ck._strides[0], pos, ck.shape[1], s)
+                # h = x + merged records (-> xb); 32 hidden units per workgroup: gate | up, SwiGLU, their rows of Wdown
+                nrm = layer.post_attn_norm
+                L.call("pdn_decode_mlp_f32", x if li == 0 else xa, D, recs, rrs, ns, H, xb, D, nrm.weight.data._ptr,
+                       nrm.eps, f.gate.weight.data._ptr, f.up.weight.data._ptr, F, f.down.weight.data._ptr, D, dparts,
+                       J * D, B, D, F, s)
+            L.call("pdn_decode_gemv_sum_f32", xb, D, dparts, J, J * D, None, 0, self.norm.weight.data._ptr, self.norm.eps,
+                   head.weight.data._ptr, V, V, 0, bias, logits, V, B, D, V, st["cand_v"]._ptr, st["cand_i"]._ptr, s)
+            L.call("pdn_decode_pick_tick_f32", st["cand_v"]._ptr, st["cand_i"]._ptr, B, st["cand_v"].shape[1],
+                   st["ids"]._ptr, pos, st["hist_ptr"]._ptr, emb._ptr, emb._strides[0], D, x, s)
+            return
         for layer, (wqkv, wgu) in zip(self.layers, st["packs"]):
             a, f = layer.attention, layer.ffn
             ck, cv = a.cache_k.data, a.cache_v.data
@@ -309,8 +348,6 @@ class Llama(nn.Module):
             # x += (silu(gate) * up) @ Wdown: SwiGLU in the loads
             L.call("pdn_decode_gemv_f32", gu, 2 * F, None, 0.0, wd._ptr, D, D, 0, None, x, D, x, D, B, F, D, 1, 0, 0,
                    None, None, s)
-        head = self.lm_head
-        bias = head.bias.data._ptr if getattr(head, "bias", None) is not None else None
         # vocabulary projection; every workgroup also leaves the first maximum of its columns, the pick kernel
         # finishes the argmax over those candidates (model.py:262-268) and advances the position
         L.call("pdn_decode_gemv_f32", x, D, self.norm.weight.data._ptr, self.norm.eps, head.weight.data._ptr, V, V, 0,

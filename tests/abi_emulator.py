@@ -694,6 +694,69 @@ class EmulatedLib:
             out[:, sp, :, 4:] = np.einsum("bht,bthd->bhd", e, V[:, t0:t1])
         return 0
 
+    def pdn_decode_attention_oproj_f32(self, qkv, rs, cos, sin, kc, vc, Wo, wo_rs, recs, B, H, hd, NS, cbs, pos,
+                                       max_len, stream):
+        D = H * hd
+        if D > 1024 or NS * H > 256:
+            return -1
+        tmp = np.zeros(B * NS * H * (4 + hd), np.float32)
+        rc = self.pdn_decode_attention_f32(qkv, rs, cos, sin, kc, vc, tmp.ctypes.data, B, H, hd, NS, cbs, pos, max_len,
+                                           stream)
+        if rc:
+            return rc
+        t = tmp.reshape(B, NS, H, 4 + hd)
+        W = view(Wo, (H, hd, D), (hd * wo_rs, wo_rs, 1), np.float32)
+        out = flat(recs, B * NS * H * (4 + D)).reshape(B, NS, H, 4 + D)
+        out[..., :2] = t[..., :2]
+        live = t[..., 1] > 0
+        out[..., 4:] = np.where(live[..., None], np.einsum("bshd,hdn->bshn", np.where(live[..., None], t[..., 4:], 0), W), 0)
+        return 0
+
+    @staticmethod
+    def _merge_records(rec, ns, H, D):
+        """(B, ns, H, 4 + D) softmax partial records -> (B, D) sum over heads of the merged contributions."""
+        m, l, o = rec[..., 0], rec[..., 1], rec[..., 4:]
+        m = np.where(l > 0, m, -np.inf)
+        w = np.where(l > 0, np.exp(m - m.max(1, keepdims=True)), 0).astype(np.float32)
+        w = w / (w * l).sum(1, keepdims=True)
+        return (w[..., None] * np.where(l[..., None] > 0, o, 0)).sum((1, 2)).astype(np.float32)
+
+    def pdn_decode_mlp_slices(self, F):
+        return F // 32 if F > 0 and F % 32 == 0 else 0
+
+    def pdn_decode_mlp_f32(self, base, base_rs, recs, recs_rs, ns, H, x_out, x_out_rs, norm_w, eps, Wg, Wu, w_rs, Wd,
+                           wd_rs, parts, parts_rs, B, D, F, stream):
+        if B > 8 or D % 4 or D > 1024 or F % 32 or (recs and ns * H > 256):
+            return -1
+        h = np.array(view(base, (B, D), (base_rs, 1), np.float32))
+        if recs:
+            h = h + self._merge_records(np.array(view(recs, (B, ns, H, 4 + D), (recs_rs, H * (4 + D), 4 + D, 1),
+                                                      np.float32)), ns, H, D)
+            if x_out:
+                view(x_out, (B, D), (x_out_rs, 1), np.float32)[...] = h
+        n = h / np.sqrt((h * h).mean(-1, keepdims=True) + np.float32(eps)) * flat(norm_w, D)
+        g = n @ view(Wg, (D, F), (w_rs, 1), np.float32)
+        u = n @ view(Wu, (D, F), (w_rs, 1), np.float32)
+        a = (g / (np.float32(1) + np.exp(-g)) * u).astype(np.float32)
+        Wdv = view(Wd, (F, D), (wd_rs, 1), np.float32)
+        J = F // 32
+        out = view(parts, (B, J, D), (parts_rs, D, 1), np.float32)
+        for j in range(J):
+            out[:, j] = a[:, 32 * j:32 * j + 32] @ Wdv[32 * j:32 * j + 32]
+        return 0
+
+    def pdn_decode_gemv_sum_f32(self, base, base_rs, parts, n_parts, parts_rs, x_out, x_out_rs, norm_w, eps, W, w_rs,
+                                blk_cols, w_bs, bias, y, y_rs, B, K, N, blk_max, blk_arg, stream):
+        if K % 4 or K > 1024 or n_parts <= 0:
+            return -1
+        x = np.array(view(base, (B, K), (base_rs, 1), np.float32))
+        x = (x + view(parts, (B, n_parts, K), (parts_rs, K, 1), np.float32).sum(1)).astype(np.float32)
+        tmp = np.ascontiguousarray(x)
+        if x_out:
+            view(x_out, (B, K), (x_out_rs, 1), np.float32)[...] = x
+        return self.pdn_decode_gemv_f32(tmp.ctypes.data, K, norm_w, eps, W, w_rs, blk_cols, w_bs, bias, None, 0, y, y_rs,
+                                        B, K, N, 0, 0, 0, blk_max, blk_arg, stream)
+
     def pdn_decode_pick_tick_f32(self, vals, args, B, n, ids, pos, hist, emb, emb_rs, D, x_next, stream):
         v = np.array(flat(vals, B * n).reshape(B, n))
         a = np.array(flat(args, B * n, np.int32).reshape(B, n))
