@@ -74,8 +74,11 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
   //      (functional.py:39-40, model.py:56-58: g / (1 + exp(-g)) * u on packed [gate | up] rows) on the way ----
   if (staged) {
     // the rows arrive as base (+ records of the previous kernel's workgroups, decode_stage.h), then RMSNorm
-    for (int b = 0; b < B; ++b) {
-      if (b) dec_stage_issue(sum, K, b, norm_w, stg);
+    // (row 0 outside the loop: merged with the later rows' re-issue, the compiler's wait for the first use of the
+    //  row would be "all but the last eight loads", i.e. nearly all the weights)
+    dec_stage_row(sum, K, 0, stg, xs, xs + B * K, red, blockIdx.x == 0, norm_w != nullptr, eps);
+    for (int b = 1; b < B; ++b) {
+      dec_stage_issue(sum, K, b, norm_w, stg);
       dec_stage_row(sum, K, b, stg, xs, xs + B * K, red, blockIdx.x == 0, norm_w != nullptr, eps);
     }
   } else
@@ -356,12 +359,13 @@ extern "C" int pdn_decode_gemv_sum_f32(const float* base, int64_t base_row_strid
 // KPRE / VPRE: float4s of the thread's K row / V rows of the thread held in registers from the start (head_dim 48:
 // 12 / 13, 64: 16 / 16 -- a 256-key range completely; 0 / 0: any head_dim, loads where they are used).
 template <int KPRE, int VPRE, bool OPROJ>
-__global__ __launch_bounds__(256) void decode_attention_kernel(const float* __restrict__ qkv, int64_t qkv_rs,
-                                                               const float* __restrict__ cs, const float* __restrict__ sn,
-                                                               float* __restrict__ kc, float* __restrict__ vc,
-                                                               float* __restrict__ part_out, int H, int hd, int NS, int C,
-                                                               int64_t cbs, const int* __restrict__ pos_ptr, float inv_sqrt,
-                                                               const float* __restrict__ Wo, int wo_rs) {
+__global__ __launch_bounds__(256) void decode_attention_kernel(const int* __restrict__ pos_ptr, int H, int hd, int NS, int C,
+                                                               const float* __restrict__ qkv, float* __restrict__ kc,
+                                                               float* __restrict__ vc, const float* __restrict__ cs,
+                                                               // ^ 14 dwords: in SGPRs at dispatch (kernarg preload)
+                                                               const float* __restrict__ sn, const float* __restrict__ Wo,
+                                                               float* __restrict__ part_out, int64_t qkv_rs, int64_t cbs,
+                                                               float inv_sqrt, int wo_rs) {
   extern __shared__ __attribute__((aligned(16))) float sc[];      // [chunk] scores, then [groups + 8][hd] partial sums
   __shared__ __attribute__((aligned(16))) float qs[256], ks[256], vs[256];
   __shared__ float red[16];
@@ -568,8 +572,8 @@ static int decode_attention_impl(const float* qkv, int64_t qkv_row_stride, const
   const dim3 grid(B * H * NS * C);
   hipStream_t st = (hipStream_t)stream;
 #define ATT_GO(KP, VP, OP)                                                                                              \
-  hipLaunchKernelGGL((decode_attention_kernel<KP, VP, OP>), grid, dim3(256), shm, st, qkv, qkv_row_stride, cos_table,    \
-                     sin_table, k_cache, v_cache, partials, H, head_dim, NS, C, cache_batch_stride, pos, inv_sqrt, Wo,  \
+  hipLaunchKernelGGL((decode_attention_kernel<KP, VP, OP>), grid, dim3(256), shm, st, pos, H, head_dim, NS, C, qkv,      \
+                     k_cache, v_cache, cos_table, sin_table, Wo, partials, qkv_row_stride, cache_batch_stride, inv_sqrt, \
                      (int)wo_row_stride)
   if (head_dim == 48) { if (oproj) ATT_GO(12, 13, true); else ATT_GO(12, 13, false); }
   else if (head_dim == 64) { if (oproj) ATT_GO(16, 16, true); else ATT_GO(16, 16, false); }

@@ -53,8 +53,9 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DecSum sum, const float
 
   // ---- h = base + records (the first workgroup leaves it in x_out), n = RMSNorm(h) ----
   float* scratch = xs + B * D;
-  for (int b = 0; b < B; ++b) {
-    if (b) dec_stage_issue(sum, D, b, norm_w, stg);
+  dec_stage_row(sum, D, 0, stg, xs, scratch, red, j == 0, true, eps);     // (row 0 outside the loop: exact load waits)
+  for (int b = 1; b < B; ++b) {
+    dec_stage_issue(sum, D, b, norm_w, stg);
     dec_stage_row(sum, D, b, stg, xs, scratch, red, j == 0, true, eps);
   }
   DEC_T(2);
