@@ -26,11 +26,14 @@
 
 template <int TN, int NB, int P>
 __global__ __launch_bounds__(256) void decode_gemv_kernel(
-    const float* __restrict__ x, int x_rs, const float* __restrict__ norm_w, float eps,
-    const float* __restrict__ W, int w_rs, int blk_cols, int64_t w_bs,
-    const float* __restrict__ bias, const float* residual, int r_rs,
-    float* y, int y_rs, int B, int K, int N, int act, int act_ns, int act_hd,
-    float* __restrict__ blk_max, int* __restrict__ blk_arg, DecSum sum) {
+    const float* __restrict__ x, const float* __restrict__ recs, int K, int R, const float* __restrict__ norm_w,
+    const float* __restrict__ W, int64_t w_bs, int w_rs, int N,
+    // ^ 14 dwords: in SGPRs at dispatch (kernarg preload)
+    int blk_cols, int x_rs, float eps, const float* __restrict__ bias, const float* residual, int r_rs,
+    float* y, int y_rs, int B, int act, int act_ns, int act_hd,
+    float* __restrict__ blk_max, int* __restrict__ blk_arg, float* x_out, int recs_rs, int x_out_rs, int staged_) {
+  // x is also the base row of the hand-off (decode_stage.h); staged_: the row goes through dec_stage_* (K % 4 == 0, K <= 1024)
+  const DecSum sum{staged_ ? x : nullptr, recs, x_out, x_rs, recs_rs, x_out_rs, R, 0, 0, 0};
   extern __shared__ __attribute__((aligned(16))) float xs[];        // [B][K] staged (normalised / gated) input rows
   __shared__ float red[16];
   __shared__ float4 part[4][TN / 4][NB];
@@ -55,11 +58,16 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
   DecStage stg;
   const bool staged = sum.base != nullptr;
   if (staged) dec_stage_issue(sum, K, 0, norm_w, stg);
+  // (a load instruction costs its 16 clocks of the CU's address path whether its lanes are useful or not -- four
+  //  waves x a few dozen loads is most of a microsecond -- so steps past K are skipped by a uniform branch; they are
+  //  the LAST loads, where the compiler's then conservative wait counts cost nothing)
+  const int nsteps = (K + S - 1) / S;
   float4 wreg[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int k = slice + i * S;
-    wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < K ? k : slice) * w_rs));
+    wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < nsteps) wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < K ? k : slice) * w_rs));
   }
   // epilogue operands of the finishing threads, likewise
   const int fq = tid % Q, fj = tid / Q, fn = blockIdx.x * TN + 4 * fq;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
 #pragma unroll
       for (int i = 0; i < P; ++i) {
         const int k = slice + i * S, kc = k < K ? k : slice;
-        const float4 w = wreg[i];
+        const float4 w = wreg[i];          // (zeros where the step was skipped)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
           float a = xs[min(b0 + j, B - 1) * K + kc];
@@ -248,9 +256,9 @@ static int launch_gemv(int nb, dim3 grid, size_t shm, hipStream_t st, const floa
                        const float* residual, int64_t r_rs, float* y, int64_t y_rs, int B, int K, int N, int act,
                        int act_ns, int act_hd, float* blk_max, int* blk_arg, const DecSum& sum) {
 #define DEC_GO(NB)                                                                                                     \
-  hipLaunchKernelGGL((decode_gemv_kernel<TN, NB, P>), grid, dim3(256), shm, st, x, (int)x_rs, norm_w, eps, W, (int)w_rs, \
-                     blk_cols, w_bs, bias, residual, (int)r_rs, y, (int)y_rs, B, K, N, act, act_ns, act_hd, blk_max,     \
-                     blk_arg, sum)
+  hipLaunchKernelGGL((decode_gemv_kernel<TN, NB, P>), grid, dim3(256), shm, st, x, sum.recs, K, sum.R, norm_w, W, w_bs,  \
+                     (int)w_rs, N, blk_cols, (int)x_rs, eps, bias, residual, (int)r_rs, y, (int)y_rs, B, act, act_ns,    \
+                     act_hd, blk_max, blk_arg, sum.x_out, sum.recs_rs, sum.x_out_rs, sum.base != nullptr ? 1 : 0)
   if (nb == 1) DEC_GO(1); else if (nb == 2) DEC_GO(2); else DEC_GO(4);
 #undef DEC_GO
   PDN_LAUNCH_CHECK();
@@ -397,30 +405,35 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const int* __rest
   const float2 nv = *reinterpret_cast<const float2*>(row + 2 * D);
   float4 kreg[KPRE > 0 ? KPRE : 1];
   const int kt = t0 + tid;                                         // the key whose score this thread computes first
-  if (KPRE > 0) {                                                  // (KPRE = hd / 4)
+  // (a load instruction costs its 16 clocks of the CU's address path whether its lanes are useful or not -- four
+  //  waves x ~45 loads is the "issue" microsecond of these kernels -- so whole-wave skips are uniform branches)
+  if (KPRE > 0 && t0 + (tid & ~63) < t1) {                         // (KPRE = hd / 4; this wave has a key)
     const float* kp = kb + (unsigned)(((kt < t1 && kt != pos) ? kt : t0) * D);
 #pragma unroll
     for (int c = 0; c < KPRE; ++c) kreg[c] = *reinterpret_cast<const float4*>(kp + 4 * c);
   }
-  const int groups = 256 / f4, vc4 = tid % f4, tg = tid / f4;
+  const int groups = dec_div(256, f4), tg = dec_div(tid, f4), vc4 = tid - tg * f4;
   float4 vreg[VPRE > 0 ? VPRE : 1];
   if (VPRE > 0) {
+    const int nv_rows = __builtin_amdgcn_readfirstlane((t1 - t0 + groups - 1) / groups);     // row steps with any key
 #pragma unroll
     for (int i = 0; i < VPRE; ++i) {
       const int t = t0 + tg + i * groups;
-      vreg[i] = *reinterpret_cast<const float4*>(vb + (unsigned)(((t < t1 && t != pos) ? t : t0) * D + 4 * vc4));
+      if (i < nv_rows)
+        vreg[i] = *reinterpret_cast<const float4*>(vb + (unsigned)(((t < t1 && t != pos) ? t : t0) * D + 4 * vc4));
     }
   }
   // this head's rows of the output projection: thread = (row slice, column quad), PW rows each
   constexpr int PW = 16;
-  const int G = OPROJ ? 256 / nqd : 1, osl = tid / nqd, oq = tid - osl * nqd;
+  const int G = OPROJ ? dec_div(256, nqd) : 1, osl = dec_div(tid, nqd), oq = tid - osl * nqd;
   float4 wo[OPROJ ? PW : 1];
   if (OPROJ) {
     const float* wop = Wo + (unsigned)(h * hd * wo_rs + ci * Dc + 4 * oq);
+    const int nw_rows = __builtin_amdgcn_readfirstlane((hd + G - 1) / G);                    // row steps with any row
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
       const int d = osl + i * G;
-      wo[i] = *reinterpret_cast<const float4*>(wop + (unsigned)((d < hd ? d : 0) * wo_rs));
+      if (i < nw_rows) wo[i] = *reinterpret_cast<const float4*>(wop + (unsigned)((d < hd ? d : 0) * wo_rs));
     }
   }
   DEC_T(1);
@@ -497,7 +510,7 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const int* __rest
   lds_barrier();
   // combine in a fixed order: 8 threads per column quad add every 8th group, then one thread adds those 8
   if (tid < 8 * f4) {
-    const int g0 = tid / f4;
+    const int g0 = dec_div(tid, f4);
     float4 r = z4;
     for (int g = g0; g < groups; g += 8) { const float4 t = part[g * f4 + vc4]; r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w; }
     part[groups * f4 + tid] = r;
@@ -518,10 +531,12 @@ __global__ __launch_bounds__(256) void decode_attention_kernel(const int* __rest
 #pragma unroll
       for (int i = 0; i < PW; ++i) {
         const int d = osl + i * G;
-        float a = qs[d < hd ? d : 0];
-        a = d < hd ? a : 0.f;
-        oacc.x = fmaf(a, wo[i].x, oacc.x); oacc.y = fmaf(a, wo[i].y, oacc.y);
-        oacc.z = fmaf(a, wo[i].z, oacc.z); oacc.w = fmaf(a, wo[i].w, oacc.w);
+        if (i < (hd + G - 1) / G) {        // (uniform: the same row steps that were loaded)
+          float a = qs[d < hd ? d : 0];
+          a = d < hd ? a : 0.f;
+          oacc.x = fmaf(a, wo[i].x, oacc.x); oacc.y = fmaf(a, wo[i].y, oacc.y);
+          oacc.z = fmaf(a, wo[i].z, oacc.z); oacc.w = fmaf(a, wo[i].w, oacc.w);
+        }
       }
       for (int d = osl + PW * G; d < hd; d += G) {
         const float4 w = *reinterpret_cast<const float4*>(Wo + (unsigned)((h * hd + d) * wo_rs + ci * Dc + 4 * oq));

@@ -16,10 +16,15 @@
 #define MLP_SL 32                          // hidden units per workgroup (32 columns = one 128-byte line per matrix row)
 
 template <int NB>
-__global__ __launch_bounds__(256) void decode_mlp_kernel(DecSum sum, const float* __restrict__ norm_w, float eps,
+__global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict__ base, const float* __restrict__ recs, int D,
+                                                         int R, const float* __restrict__ norm_w,
                                                          const float* __restrict__ Wg, const float* __restrict__ Wu,
-                                                         int w_rs, const float* __restrict__ Wd, int wd_rs,
-                                                         float* __restrict__ parts, int parts_rs, int B, int D) {
+                                                         const float* __restrict__ Wd,
+                                                         // ^ 14 dwords: in SGPRs at dispatch (kernarg preload)
+                                                         int w_rs, int wd_rs, int ns, int H, float eps, float* x_out,
+                                                         float* __restrict__ parts, int base_rs, int recs_rs, int x_out_rs,
+                                                         int parts_rs, int B) {
+  const DecSum sum{base, recs, x_out, base_rs, recs_rs, x_out_rs, R, R > 0 ? 4 : 0, ns, H};
   extern __shared__ __attribute__((aligned(16))) float xs[];        // [B][D] staged rows, then scratch
   __shared__ float red[16];
   __shared__ float4 part[4][16][NB];
@@ -35,19 +40,25 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DecSum sum, const float
   DecStage stg;
   dec_stage_issue(sum, D, 0, norm_w, stg);
   const float* wp = (quad < 8 ? Wg : Wu) + (unsigned)(j * MLP_SL + 4 * (quad & 7));
+  // (a load instruction costs its 16 clocks of the CU's address path whether its lanes are useful or not, so steps
+  //  past the end are skipped by uniform branches; they are the LAST loads of their group)
+  const int nsteps = (D + S - 1) / S;
   float4 wreg[P];
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int k = slice + i * S;
-    wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < D ? k : slice) * w_rs));
+    wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < nsteps) wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < D ? k : slice) * w_rs));
   }
-  const int nq = D >> 2, G = 256 / nq, dsl = tid / nq, dq = tid - dsl * nq;
+  const int nq = D >> 2, G = dec_div(256, nq), dsl = dec_div(tid, nq), dq = tid - dsl * nq;
   const float* wdp = Wd + (unsigned)(j * MLP_SL * wd_rs + 4 * dq);
+  const int ndsteps = __builtin_amdgcn_readfirstlane((MLP_SL + G - 1) / G);
   float4 wd[PD];
 #pragma unroll
   for (int i = 0; i < PD; ++i) {
     const int r = dsl + i * G;
-    wd[i] = *reinterpret_cast<const float4*>(wdp + (unsigned)((r < MLP_SL ? r : 0) * wd_rs));
+    wd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < ndsteps) wd[i] = *reinterpret_cast<const float4*>(wdp + (unsigned)((r < MLP_SL ? r : 0) * wd_rs));
   }
   DEC_T(1);
 
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DecSum sum, const float
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int k = slice + i * S, kc = k < D ? k : slice;
-      const float4 w = wreg[i];
+      const float4 w = wreg[i];            // (zeros where the step was skipped)
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         float a = xs[min(b0 + r, B - 1) * D + kc];
@@ -127,7 +138,7 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(DecSum sum, const float
       for (int i = 0; i < PD; ++i) {
         const int r = dsl + i * G;
         float a = hb[b][r < MLP_SL ? r : 0];
-        a = r < MLP_SL ? a : 0.f;
+        a = r < MLP_SL ? a : 0.f;            // (wd: zeros where the step was skipped)
         acc.x = fmaf(a, wd[i].x, acc.x); acc.y = fmaf(a, wd[i].y, acc.y);
         acc.z = fmaf(a, wd[i].z, acc.z); acc.w = fmaf(a, wd[i].w, acc.w);
       }
@@ -181,16 +192,16 @@ extern "C" int pdn_decode_mlp_f32(const float* base, int64_t base_row_stride, co
                     (int64_t)D * w_row_stride < lim && (int64_t)F * wd_row_stride < lim &&
                     (int64_t)B * parts_row_stride + (int64_t)F / MLP_SL * D < lim,
                 "pdn_decode_mlp_f32: strides out of the 32-bit range of the kernel");
-  DecSum sum{base, records, x_out, (int)base_row_stride, (int)records_row_stride, (int)x_out_row_stride, R, records ? 4 : 0,
-             n_splits, H};
+
   const int scratch = records ? dec_sum_scratch(D, R, 4) : 0;
   const size_t shm = sizeof(float) * ((size_t)B * D + (scratch > G * D ? scratch : G * D));
   PDN_CHECK_ARG(shm <= 64 * 1024, "pdn_decode_mlp_f32: rows do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(F / MLP_SL);
 #define MLP_GO(NB)                                                                                                     \
-  hipLaunchKernelGGL((decode_mlp_kernel<NB>), grid, dim3(256), shm, st, sum, norm_w, eps, Wg, Wu, (int)w_row_stride, Wd, \
-                     (int)wd_row_stride, parts, (int)parts_row_stride, B, D)
+  hipLaunchKernelGGL((decode_mlp_kernel<NB>), grid, dim3(256), shm, st, base, records, D, R, norm_w, Wg, Wu, Wd,         \
+                     (int)w_row_stride, (int)wd_row_stride, n_splits, H, eps, x_out, parts, (int)base_row_stride,       \
+                     (int)records_row_stride, (int)x_out_row_stride, (int)parts_row_stride, B)
   if (B == 1) MLP_GO(1); else if (B == 2) MLP_GO(2); else MLP_GO(4);
 #undef MLP_GO
   PDN_LAUNCH_CHECK();

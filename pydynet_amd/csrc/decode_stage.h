@@ -35,6 +35,11 @@ static __device__ unsigned dec_trace_cnt;
 #define DEC_TRACE_DUMP(name)
 #endif
 
+// a / d for 0 <= a <= 256, 1 <= d <= 256, exact: (a + 0.5) / d is at least 0.5 / d away from an integer, far more than
+// the error of the reciprocal (4 instructions instead of the ~20 of an integer division; these kernels are short
+// chains at one wave per SIMD, where every instruction in front of the first load is latency)
+__device__ __forceinline__ int dec_div(int a, int d) { return (int)(((float)a + 0.5f) * __frcp_rn((float)d)); }
+
 struct DecSum {
   const float* base; const float* recs; float* x_out;   // (B, K) rows; per row R records of hdr + K floats (R = 0: none)
   int base_rs, recs_rs, x_out_rs;                       // row strides in floats (32-bit: the hot loop is address math)
@@ -63,7 +68,7 @@ struct DecStage {
 // Branch-free: every thread loads from a valid (clamped) address and the masks are applied where the values are used
 // -- a conditional load costs ~20 instructions of control flow, and the waitcnt pass can only count loads it is sure of.
 __device__ __forceinline__ void dec_stage_issue(const DecSum& s, int K, int b, const float* __restrict__ norm_w, DecStage& r) {
-  const int tid = threadIdx.x, nq = K >> 2, G = 256 / nq, g = tid / nq, q = tid - g * nq;
+  const int tid = threadIdx.x, nq = K >> 2, G = dec_div(256, nq), g = dec_div(tid, nq), q = tid - g * nq;
   const int rec = s.hdr + K;
   r.bs = *reinterpret_cast<const float4*>(s.base + (unsigned)(b * s.base_rs + 4 * q));
   if (b == 0) r.nw = norm_w ? *reinterpret_cast<const float4*>(norm_w + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -81,7 +86,7 @@ __device__ __forceinline__ void dec_stage_issue(const DecSum& s, int K, int b, c
 // RMSNorm(row) (norm.py:245-248); x_out always receives the un-normalised sum.
 __device__ __forceinline__ void dec_stage_row(const DecSum& s, int K, int b, DecStage& r, float* xs, float* scratch,
                                               float* red, bool writer, bool norm, float eps) {
-  const int tid = threadIdx.x, nq = K >> 2, G = 256 / nq, g = tid / nq, q = tid - g * nq;
+  const int tid = threadIdx.x, nq = K >> 2, G = dec_div(256, nq), g = dec_div(tid, nq), q = tid - g * nq;
   const bool on = g < G;
   const int rec = s.hdr + K;
   float* wts = scratch + G * K;            // [R] weights, then [R] m, [R] l
