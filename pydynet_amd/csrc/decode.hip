@@ -680,7 +680,17 @@ __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __re
   for (int b = 0; b < B; ++b) {
     float best = -INFINITY;
     int idx = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
+    // the first four candidates of the thread with ONE round of loads (n <= 1024: all of them), the rest in a loop
+    float cv[4]; int ca[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = min(tid + 256 * u, n - 1);
+      cv[u] = vals[(unsigned)(b * n + i)]; ca[u] = args[(unsigned)(b * n + i)];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (tid + 256 * u < n && (cv[u] > best || (cv[u] == best && ca[u] < idx))) { best = cv[u]; idx = ca[u]; }
+    for (int i = tid + 1024; i < n; i += 256) {
       const float v = vals[(int64_t)b * n + i];
       const int a = args[(int64_t)b * n + i];
       if (v > best || (v == best && a < idx)) { best = v; idx = a; }

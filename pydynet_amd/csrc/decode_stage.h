@@ -95,20 +95,46 @@ __device__ __forceinline__ void dec_stage_row(const DecSum& s, int K, int b, Dec
       if (tid < s.R) { wts[s.R + tid] = r.ml.x; wts[2 * s.R + tid] = r.ml.y; }
       lds_barrier();
       if (tid < s.H) {
-        float M = -INFINITY;
-        for (int sp = 0; sp < s.ns; ++sp) {
-          const int rr = sp * s.H + tid;
-          if (wts[2 * s.R + rr] > 0.f) M = fmaxf(M, wts[s.R + rr]);
+        // the head's (m, l) pairs go to registers with ONE round of independent LDS reads: done through LDS value by
+        // value, this merge is ~60 dependent LDS round trips (> 1 us on the chain of every feed-forward kernel)
+        constexpr int NSM = 8;
+        if (s.ns <= NSM) {
+          float mm[NSM], ll[NSM];
+#pragma unroll
+          for (int sp = 0; sp < NSM; ++sp) {
+            const int rr = min(sp, s.ns - 1) * s.H + tid;
+            mm[sp] = wts[s.R + rr]; ll[sp] = wts[2 * s.R + rr];
+          }
+          float M = -INFINITY;
+#pragma unroll
+          for (int sp = 0; sp < NSM; ++sp)
+            if (sp < s.ns && ll[sp] > 0.f) M = fmaxf(M, mm[sp]);
+          float den = 0.f;
+#pragma unroll
+          for (int sp = 0; sp < NSM; ++sp) {
+            mm[sp] = (sp < s.ns && ll[sp] > 0.f) ? expf(mm[sp] - M) : 0.f;
+            den += mm[sp] * ll[sp];
+          }
+          const float inv = 1.f / den;
+#pragma unroll
+          for (int sp = 0; sp < NSM; ++sp)
+            if (sp < s.ns) wts[sp * s.H + tid] = mm[sp] * inv;
+        } else {
+          float M = -INFINITY;
+          for (int sp = 0; sp < s.ns; ++sp) {
+            const int rr = sp * s.H + tid;
+            if (wts[2 * s.R + rr] > 0.f) M = fmaxf(M, wts[s.R + rr]);
+          }
+          float den = 0.f;
+          for (int sp = 0; sp < s.ns; ++sp) {
+            const int rr = sp * s.H + tid;
+            const float w = wts[2 * s.R + rr] > 0.f ? expf(wts[s.R + rr] - M) : 0.f;
+            wts[rr] = w;
+            den += w * wts[2 * s.R + rr];
+          }
+          const float inv = 1.f / den;
+          for (int sp = 0; sp < s.ns; ++sp) wts[sp * s.H + tid] *= inv;
         }
-        float den = 0.f;
-        for (int sp = 0; sp < s.ns; ++sp) {
-          const int rr = sp * s.H + tid;
-          const float w = wts[2 * s.R + rr] > 0.f ? expf(wts[s.R + rr] - M) : 0.f;
-          wts[rr] = w;
-          den += w * wts[2 * s.R + rr];
-        }
-        const float inv = 1.f / den;
-        for (int sp = 0; sp < s.ns; ++sp) wts[sp * s.H + tid] *= inv;
       }
       lds_barrier();
     }
