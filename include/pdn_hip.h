@@ -322,6 +322,20 @@ int pdn_decode_mlp_f32(const float* base, int64_t base_row_stride, const float* 
                        int n_splits, int H, float* x_out, int64_t x_out_row_stride, const float* norm_w, float eps,
                        const float* Wg, const float* Wu, int64_t w_row_stride, const float* Wd, int64_t wd_row_stride,
                        float* parts, int64_t parts_row_stride, int B, int D, int F, void* stream);
+/* Two launches per TransformerBlock (csrc/decode_block.hip): the q | k | v projection is done where it is used.
+ *   pdn_decode_block_f32     x = base + sum of n_parts plain records (written to x_out), n = RMSNorm(x),
+ *                            q | k | v = n @ Wqkv (three (D, D) blocks), RoPE at *pos, cache[*pos] = k, v, attention
+ *                            over [0, *pos]: per head n_ranges workgroups for the cached keys (ceil(*pos / n_ranges)
+ *                            each) + one for the new key, each times its columns of the head's rows of Wo:
+ *                            records (B, n_ranges + 1, H, 4 + D) for pdn_decode_mlp_f32 (n_splits = n_ranges + 1).
+ *                            head_dim 48 / 64 (pdn_decode_block_supported), else PDN_EUNSUPPORTED. */
+int pdn_decode_block_supported(int D, int H, int head_dim, int n_ranges);
+int pdn_decode_block_f32(const float* base, int64_t base_row_stride, const float* parts, int n_parts,
+                         int64_t parts_row_stride, float* x_out, int64_t x_out_row_stride, const float* norm_w, float eps,
+                         const float* Wqkv, int64_t w_row_stride, int64_t w_block_stride, const float* cos_table,
+                         const float* sin_table, float* k_cache, float* v_cache, int64_t cache_batch_stride, const int* pos,
+                         int max_len, const float* Wo, int64_t wo_row_stride, float* records, int B, int H, int head_dim,
+                         int n_ranges, void* stream);
 int pdn_decode_gemv_sum_f32(const float* base, int64_t base_row_stride, const float* parts, int n_parts,
                             int64_t parts_row_stride, float* x_out, int64_t x_out_row_stride, const float* norm_w,
                             float eps, const float* W, int64_t w_row_stride, int blk_cols, int64_t w_block_stride,

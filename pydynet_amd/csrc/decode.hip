@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
   const DecSum sum{staged_ ? x : nullptr, recs, x_out, x_rs, recs_rs, x_out_rs, R, 0, 0, 0};
   extern __shared__ __attribute__((aligned(16))) float xs[];        // [B][K] staged (normalised / gated) input rows
   __shared__ float red[16];
+  __shared__ float ssq[4 * DEC_MAX_B];
   __shared__ float4 part[4][TN / 4][NB];
   __shared__ float cand_v[NB][TN / 4];
   __shared__ int cand_i[NB][TN / 4];
@@ -84,10 +85,10 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
     // the rows arrive as base (+ records of the previous kernel's workgroups, decode_stage.h), then RMSNorm
     // (row 0 outside the loop: merged with the later rows' re-issue, the compiler's wait for the first use of the
     //  row would be "all but the last eight loads", i.e. nearly all the weights)
-    dec_stage_row(sum, K, 0, stg, xs, xs + B * K, red, blockIdx.x == 0, norm_w != nullptr, eps);
+    dec_stage_row(sum, K, 0, stg, xs, xs + B * K, ssq, blockIdx.x == 0, norm_w != nullptr);
     for (int b = 1; b < B; ++b) {
       dec_stage_issue(sum, K, b, norm_w, stg);
-      dec_stage_row(sum, K, b, stg, xs, xs + B * K, red, blockIdx.x == 0, norm_w != nullptr, eps);
+      dec_stage_row(sum, K, b, stg, xs, xs + B * K, ssq, blockIdx.x == 0, norm_w != nullptr);
     }
   } else
   for (int b = 0; b < B; ++b) {
@@ -216,6 +217,10 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
       for (int wv = 1; wv < 4; ++wv) {
         const float4 t = part[wv][fq][fj];
         r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      if (staged && norm_w) {              // (the row was staged without RMSNorm's scalar: decode_stage.h)
+        const float sc_ = dec_norm_scale(ssq, b, K, eps);
+        r.x *= sc_; r.y *= sc_; r.z *= sc_; r.w *= sc_;
       }
       r.x += fbias.x; r.y += fbias.y; r.z += fbias.z; r.w += fbias.w;
       if (residual) {

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict
                                                          int parts_rs, int B) {
   const DecSum sum{base, recs, x_out, base_rs, recs_rs, x_out_rs, R, R > 0 ? 4 : 0, ns, H};
   extern __shared__ __attribute__((aligned(16))) float xs[];        // [B][D] staged rows, then scratch
-  __shared__ float red[16];
+  __shared__ float ssq[4 * DEC_MAX_B];
   __shared__ float4 part[4][16][NB];
   __shared__ float hb[DEC_MAX_B][MLP_SL];
   constexpr int Q = 16, S = 16, P = 18, PD = 16;
@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict
 
   // ---- h = base + records (the first workgroup leaves it in x_out), n = RMSNorm(h) ----
   float* scratch = xs + B * D;
-  dec_stage_row(sum, D, 0, stg, xs, scratch, red, j == 0, true, eps);     // (row 0 outside the loop: exact load waits)
+  dec_stage_row(sum, D, 0, stg, xs, scratch, ssq, j == 0, true);          // (row 0 outside the loop: exact load waits)
   for (int b = 1; b < B; ++b) {
     dec_stage_issue(sum, D, b, norm_w, stg);
-    dec_stage_row(sum, D, b, stg, xs, scratch, red, j == 0, true, eps);
+    dec_stage_row(sum, D, b, stg, xs, scratch, ssq, j == 0, true);
   }
   DEC_T(2);
   DEC_T(3);
@@ -122,6 +122,8 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict
           g += reinterpret_cast<const float*>(&part[wv][i >> 2][r])[i & 3];
           u += reinterpret_cast<const float*>(&part[wv][8 + (i >> 2)][r])[i & 3];
         }
+        const float sc_ = dec_norm_scale(ssq, b, D, eps);           // (RMSNorm's scalar, applied to the products)
+        g *= sc_; u *= sc_;
         hb[b][i] = g / (1.f + expf(-g)) * u;
       }
     }

@@ -82,10 +82,17 @@ __device__ __forceinline__ void dec_stage_issue(const DecSum& s, int K, int b, c
   }
 }
 
-// `scratch`: dec_sum_scratch(K, R, hdr) floats of LDS; `red`: 16 floats.  With norm (r.nw loaded) the row left in xs is
-// RMSNorm(row) (norm.py:245-248); x_out always receives the un-normalised sum.
+// `scratch`: dec_sum_scratch(K, R, hdr) floats of LDS.  With norm (r.nw loaded) the row left in xs is x * w of
+// RMSNorm(x) = x / sqrt(mean(x^2) + eps) * w (norm.py:245-248) WITHOUT the scalar 1 / sqrt(...): a product of the row
+// with a matrix is linear in it, so the consumer multiplies its few outputs by dec_norm_scale() instead -- the sum of
+// squares then needs no barriers of its own (each wave leaves its part in ssq[4 b + wave], published by the barrier
+// that publishes xs).  x_out always receives the un-normalised sum.  ssq: 4 floats per row.
+__device__ __forceinline__ float dec_norm_scale(const float* ssq, int b, int K, float eps) {
+  const float ss = (ssq[4 * b] + ssq[4 * b + 1]) + (ssq[4 * b + 2] + ssq[4 * b + 3]);
+  return 1.f / sqrtf(ss / (float)K + eps);
+}
 __device__ __forceinline__ void dec_stage_row(const DecSum& s, int K, int b, DecStage& r, float* xs, float* scratch,
-                                              float* red, bool writer, bool norm, float eps) {
+                                              float* ssq, bool writer, bool norm) {
   const int tid = threadIdx.x, nq = K >> 2, G = dec_div(256, nq), g = dec_div(tid, nq), q = tid - g * nq;
   const bool on = g < G;
   const int rec = s.hdr + K;
@@ -178,9 +185,9 @@ __device__ __forceinline__ void dec_stage_row(const DecSum& s, int K, int b, Dec
     ss = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   if (norm) {
-    ss = block_sum_lds(ss, red);
-    const float scale = 1.f / sqrtf(ss / (float)K + eps);
-    v.x = v.x * scale * r.nw.x; v.y = v.y * scale * r.nw.y; v.z = v.z * scale * r.nw.z; v.w = v.w * scale * r.nw.w;
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) ssq[4 * b + (tid >> 6)] = ss;
+    v.x *= r.nw.x; v.y *= r.nw.y; v.z *= r.nw.z; v.w *= r.nw.w;
   }
   if (tid < nq) *reinterpret_cast<float4*>(xs + b * K + 4 * q) = v;
   lds_barrier();                         // (xs is read next; scratch / weights / red may be rewritten)

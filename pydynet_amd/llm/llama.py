@@ -231,7 +231,7 @@ class Llama(nn.Module):
     # -- decode fast path -----------------------------------------------------------
     graph_decode = True     # class switch: False issues the step's launches one by one instead of replaying a hipGraph
     decode_ahead = True     # class switch: False never queues the next step before the caller asked for it
-    fused_decode = True     # class switch: False keeps the five-launch layer (separate output / down projections)
+    fused_decode = 2        # class switch: launches per layer = 2 (q|k|v inside the attention kernel), 1 -> 3, 0 / False -> 5
 
     def _decode_plan(self, B):
         """Buffers and weight views of the graph-replayable decode step (csrc/decode.hip), or None when the
@@ -279,15 +279,19 @@ class Llama(nn.Module):
             J = _lib.lib().query("pdn_decode_mlp_slices", F)
             st["fused"] = bool(Llama.fused_decode and J and D <= 1024 and ns * H <= 256 and len(self.layers) > 0 and all(
                 l.ffn.gate.weight.data.is_contiguous() and l.ffn.up.weight.data.is_contiguous() for l in self.layers))
+            # two launches per layer (csrc/decode_block.hip): the q | k | v projection inside the attention kernel, one
+            # more record per head for the new key
+            st["block"] = bool(st["fused"] and int(Llama.fused_decode) >= 2 and
+                               _lib.lib().query("pdn_decode_block_supported", D, H, D // H, ns))
             if st["fused"]:
-                st.update(J=J, recs=hp.empty((B, ns * H * (4 + D)), np.float32), dparts=hp.empty((B, J * D), np.float32),
+                st.update(J=J, recs=hp.empty((B, (ns + 1) * H * (4 + D)), np.float32), dparts=hp.empty((B, J * D), np.float32),
                           xa=hp.empty((B, D), np.float32), xb=hp.empty((B, D), np.float32))
             self._decode_ws = {"logits": st["logits"], "x": st["x"]}
         self._decode_st = st
         return st if ok else None
 
     def _decode_launches(self, st):
-        """The launches of one decode step (3 per layer + 2, or 5 per layer + 2 with `fused_decode` off); every argument is fixed for the lifetime of `st` (the position
+        """The launches of one decode step (2 per layer + 2; 3 or 5 per layer at lower `fused_decode` levels); every argument is fixed for the lifetime of `st` (the position
         and the token ids are read from device memory), so the sequence can be captured once and replayed."""
         from .. import hipnp as hp, _lib
         L, s = _lib.lib(), hp.stream()
@@ -304,11 +308,22 @@ class Llama(nn.Module):
         if st["fused"]:
             J, ns = st["J"], st["ns"]
             recs, dparts, xa, xb = (st[n]._ptr for n in ("recs", "dparts", "xa", "xb"))
-            rrs = st["recs"].shape[1]
+            rrs = ns * H * (4 + D)
             for li, (layer, (wqkv, _)) in enumerate(zip(self.layers, st["packs"])):
                 a, f = layer.attention, layer.ffn
                 ck, cv = a.cache_k.data, a.cache_v.data
                 nrm = layer.input_norm
+                if st["block"]:
+                    # x = previous block's h + its feed-forward records (-> xa); q | k | v, RoPE, cache append, attention
+                    # and each head's rows of Wo in one launch: records of ns key ranges + the new key
+                    L.call("pdn_decode_block_f32", x if li == 0 else xb, D, None if li == 0 else dparts, 0 if li == 0 else J,
+                           J * D, xa, D, nrm.weight.data._ptr, nrm.eps, wqkv._ptr, D, wqkv._strides[0], cos, sin, ck._ptr,
+                           cv._ptr, ck._strides[0], pos, ck.shape[1], a.O.weight.data._ptr, D, recs, B, H, hd, ns, s)
+                    nrm = layer.post_attn_norm
+                    L.call("pdn_decode_mlp_f32", xa, D, recs, (ns + 1) * H * (4 + D), ns + 1, H, xb, D,
+                           nrm.weight.data._ptr, nrm.eps, f.gate.weight.data._ptr, f.up.weight.data._ptr, F,
+                           f.down.weight.data._ptr, D, dparts, J * D, B, D, F, s)
+                    continue
                 # [q | k | v] = RMSNorm(x) @ [Wq | Wk | Wv]; x = previous block's h + its feed-forward records
                 if li == 0:
                     L.call("pdn_decode_gemv_f32", x, D, nrm.weight.data._ptr, nrm.eps, wqkv._ptr, D, D, wqkv._strides[0],

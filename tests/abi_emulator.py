@@ -712,6 +712,59 @@ class EmulatedLib:
         out[..., 4:] = np.where(live[..., None], np.einsum("bshd,hdn->bshn", np.where(live[..., None], t[..., 4:], 0), W), 0)
         return 0
 
+    def pdn_decode_block_supported(self, D, H, hd, ns):
+        return int(hd in (48, 64) and H > 0 and D == H * hd and D <= 1024 and 1 <= ns <= 7 and (ns + 1) * H <= 256)
+
+    def pdn_decode_block_f32(self, base, base_rs, parts, n_parts, parts_rs, x_out, x_out_rs, norm_w, eps, Wqkv, w_rs, w_bs,
+                             cos, sin, kc, vc, cbs, pos, max_len, Wo, wo_rs, recs, B, H, hd, NS, stream):
+        D, half = H * hd, hd // 2
+        if not self.pdn_decode_block_supported(D, H, hd, NS):
+            return -2
+        if B > 8:
+            return -1
+        x = np.array(view(base, (B, D), (base_rs, 1), np.float32))
+        if n_parts:
+            x = (x + view(parts, (B, n_parts, D), (parts_rs, D, 1), np.float32).sum(1)).astype(np.float32)
+        view(x_out, (B, D), (x_out_rs, 1), np.float32)[...] = x
+        n = (x / np.sqrt((x * x).mean(-1, keepdims=True) + np.float32(eps)) * flat(norm_w, D)).astype(np.float32)
+        W = view(Wqkv, (3, D, D), (w_bs, w_rs, 1), np.float32)
+        q, k, v = (n @ W[j] for j in range(3))
+        p = int(flat(pos, 1, np.int32)[0])
+        assert 0 <= p < max_len
+        c, s_ = flat(cos + 4 * p * half, half), flat(sin + 4 * p * half, half)
+
+        def rot(t):
+            a = np.array(t).reshape(B, H, half, 2)
+            out = np.empty_like(a)
+            out[..., 0] = a[..., 0] * c - a[..., 1] * s_
+            out[..., 1] = a[..., 0] * s_ + a[..., 1] * c
+            return out.reshape(B, H, hd)
+        Q, Kn, Vn = rot(q), rot(k), np.array(v).reshape(B, H, hd)
+        for b in range(B):
+            view(kc + 4 * (b * cbs + p * D), (D,), (1,), np.float32)[...] = Kn[b].reshape(D)
+            view(vc + 4 * (b * cbs + p * D), (D,), (1,), np.float32)[...] = Vn[b].reshape(D)
+        Wov = view(Wo, (H, hd, D), (hd * wo_rs, wo_rs, 1), np.float32)
+        out = flat(recs, B * (NS + 1) * H * (4 + D)).reshape(B, NS + 1, H, 4 + D)
+        out[...] = 0
+        Kc = view(kc, (B, max(p, 1), H, hd), (cbs, D, hd, 1), np.float32)
+        Vc = view(vc, (B, max(p, 1), H, hd), (cbs, D, hd, 1), np.float32)
+        sc = np.float32(1 / math.sqrt(hd))
+        chunk = -(-p // NS)
+        for sp in range(NS):
+            t0, t1 = sp * chunk, min(p, (sp + 1) * chunk)
+            if t0 >= t1:
+                out[:, sp, :, 0] = -np.inf
+                continue
+            ss = np.einsum("bhd,bthd->bht", Q, Kc[:, t0:t1]) * sc
+            m = ss.max(-1)
+            e = np.exp(ss - m[..., None])
+            out[:, sp, :, 0], out[:, sp, :, 1] = m, e.sum(-1)
+            out[:, sp, :, 4:] = np.einsum("bhd,hdn->bhn", np.einsum("bht,bthd->bhd", e, Vc[:, t0:t1]), Wov)
+        out[:, NS, :, 0] = (Q * Kn).sum(-1) * sc
+        out[:, NS, :, 1] = 1.0
+        out[:, NS, :, 4:] = np.einsum("bhd,hdn->bhn", Vn, Wov)
+        return 0
+
     @staticmethod
     def _merge_records(rec, ns, H, D):
         """(B, ns, H, 4 + D) softmax partial records -> (B, D) sum over heads of the merged contributions."""

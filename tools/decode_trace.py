@@ -11,12 +11,13 @@ from pydynet_amd import hipnp as hp, _lib
 import pydynet_amd as pdn
 from pydynet_amd.llm.llama import Llama
 
-KIND = {0: "gemv q|k|v", 1: "attention+oproj", 2: "pick", 3: "mlp", 4: "gemv lm_head"}
+KIND = {0: "gemv q|k|v", 1: "attention+oproj", 2: "pick", 3: "mlp", 4: "gemv lm_head", 5: "block (range 0)"}
 PHASES = {0: ["issue prefetch", "stage+norm", "fma+shuffle", "reduce+store"],
           4: ["issue prefetch", "stage+norm", "fma+shuffle", "reduce+store"],
           1: ["pos + issue Wo", "rope/append", "scores+max", "exp+sum", "p.v", "combine", "oproj"],
           2: ["candidates", "emb row"],
-          3: ["issue prefetch", "stage sum", "norm", "gate|up fma", "swiglu", "down+store"]}
+          3: ["issue prefetch", "stage sum", "norm", "gate|up fma", "swiglu", "down+store"],
+          5: ["issue", "stage+norm", "q|k|v", "rope", "scores+max", "exp, p.v, combine", "oproj"]}
 
 np.random.seed(0)
 model = Llama(32000, 288, 6, 768, 1024, 1, 6, np.float32)
@@ -39,11 +40,11 @@ with pdn.no_grad():
     for _ in model.generate(ids, 60):          # warm-up, capture
         pass
     hp.synchronize()
-    dump("pdn_dec_trace_dump_step"); dump("pdn_dec_trace_dump_layer")
+    dump("pdn_dec_trace_dump_step"); dump("pdn_dec_trace_dump_layer"); dump("pdn_dec_trace_dump_block")
     for _ in model.generate(ids, 200):
         pass
     hp.synchronize()
-rows = np.concatenate([dump("pdn_dec_trace_dump_step"), dump("pdn_dec_trace_dump_layer")])
+rows = np.concatenate([dump("pdn_dec_trace_dump_step"), dump("pdn_dec_trace_dump_layer"), dump("pdn_dec_trace_dump_block")])
 rows = rows[np.argsort(rows[:, 0])]
 rows = rows[len(rows) // 4:]                   # the prompt pass / first tokens are not graph replays
 kinds = rows[:, 9].astype(int)

@@ -9,7 +9,7 @@ if [ ! -f $T ] || [ "$1" = build ]; then
   B=$(mktemp -d)
   for f in $R/pydynet_amd/csrc/*.hip; do
     n=$(basename $f .hip)
-    case $n in decode|decode_layer) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDEC_TRACE -mllvm -amdgpu-kernarg-preload-count=16 -I$R/pydynet_amd/csrc -c $f -o $B/$n.o ;;
+    case $n in decode|decode_layer|decode_block) /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DDEC_TRACE -mllvm -amdgpu-kernarg-preload-count=16 -I$R/pydynet_amd/csrc -c $f -o $B/$n.o ;;
       *) cp $R/pydynet_amd/csrc/build/$n.o $B/$n.o ;; esac
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/*.o -o $T
