@@ -73,6 +73,9 @@ int pdn_compute_stream(void** stream);
 /* pinned host memory and a device -> host copy that returns at once (order it with events; the destination must come
  * from pdn_host_alloc): lets a small read-back ride on its own stream while the compute stream goes on */
 int pdn_host_alloc(void** out, int64_t bytes);
+/* coherent pinned host memory mapped into the device: a kernel's system-scope store is seen by a polling host thread
+ * without any copy command or event (the token of a decode step); free with pdn_host_free(*host_ptr) */
+int pdn_host_alloc_mapped(void** host_ptr, void** device_ptr, int64_t bytes);
 int pdn_host_free(void* ptr);
 int pdn_memcpy_d2h_async(void* dst_pinned_host, const void* src, int64_t bytes, void* stream);
 int pdn_stream_create(void** stream, int high_priority);
@@ -283,9 +286,9 @@ int pdn_attention_decode_f32(const float* q, const float* k_cache, const float* 
  *                            = [max, sum of exp, -, - | sum of exp(s - max) v] per range, merged by the output
  *                            projection's loads (act = 2).
  *   pdn_decode_pick_tick_f32 next_ids[b] = column of the first maximum over the candidates (model.py:262-268:
- *                            argmax(-1)), also stored at (*history)[*pos * B + b] when a history (a device-resident
- *                            pointer to a (max_len, B) int64 buffer) is given -- a per-position slot the host fetches
- *                            while later steps run; with an embedding table (V, D) the picked token's row is copied to
+ *                            argmax(-1)), also stored (system scope) at (*history)[*pos * B + b] when a history (a
+ *                            device-resident pointer to a (max_len, B) int64 buffer, possibly mapped host memory:
+ *                            pdn_host_alloc_mapped) is given -- a per-position slot the host reads while later steps run; with an embedding table (V, D) the picked token's row is copied to
  *                            x_next (B, D) at once, so the next step starts at its first projection; then *pos += 1.  pdn_decode_argmax_tick_f32: the same pick from
  *                            full logit rows. */
 int pdn_decode_gemv_blocks(int N);

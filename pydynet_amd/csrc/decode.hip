@@ -713,7 +713,7 @@ __global__ __launch_bounds__(256) void decode_pick_tick_kernel(const float* __re
         if (bv[w] > best || (bv[w] == best && bi[w] < idx)) { best = bv[w]; idx = bi[w]; }
       const int64_t tok = idx == 0x7fffffff ? 0 : idx;
       ids[b] = tok;
-      if (hrow) hrow[b] = tok;
+      if (hrow) __hip_atomic_store(hrow + b, tok, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (may be host memory)
       chosen = tok;
     }
     lds_barrier();

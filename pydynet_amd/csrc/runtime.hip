@@ -354,6 +354,16 @@ int pdn_host_alloc(void** out, int64_t bytes) {
   return 0;
 }
 
+// Coherent pinned host memory the GPU can write directly: *host_ptr for the CPU, *device_ptr for kernels.  A kernel
+// that leaves a few bytes there (system-scope store) hands them to the host with no copy command and no event: the
+// host polls the location (the token of a decode step, llm/llama.py).  Freed with pdn_host_free(host_ptr).
+int pdn_host_alloc_mapped(void** host_ptr, void** device_ptr, int64_t bytes) {
+  PDN_CHECK_ARG(host_ptr && device_ptr && bytes > 0, "pdn_host_alloc_mapped: bad arguments");
+  PDN_HIP(hipHostMalloc(host_ptr, (size_t)bytes, hipHostMallocCoherent | hipHostMallocMapped));
+  PDN_HIP(hipHostGetDevicePointer(device_ptr, *host_ptr, 0));
+  return 0;
+}
+
 int pdn_host_free(void* ptr) {
   if (ptr) PDN_HIP(hipHostFree(ptr));
   return 0;

@@ -718,6 +718,67 @@ class _Pending:
         arr._host = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape).copy()
 
 
+class _MappedHost:
+    """Owner of a block of coherent pinned host memory mapped into the device (pdn_host_alloc_mapped)."""
+
+    __slots__ = ("host", "ptr", "nbytes", "device", "__weakref__")
+
+    def __init__(self, nbytes):
+        h, d = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.lib().call("pdn_host_alloc_mapped", ctypes.byref(h), ctypes.byref(d), int(nbytes))
+        self.host, self.ptr, self.nbytes, self.device = h.value, d.value, int(nbytes), _state["device"]
+
+    def __del__(self):
+        h, self.host = self.host, 0
+        if h:
+            try:
+                _lib.lib().call("pdn_host_free", h)
+            except Exception:                      # interpreter shutdown
+                pass
+
+
+class Mailbox:
+    """(n, *shape) int64 slots in host memory the GPU writes directly: a kernel stores slot i (system scope), the host
+    reads it by polling -- no copy command, no event, nothing queued between two graph replays.  Slots start at -1
+    (the kernels store non-negative values: token ids); `slot(i)` is slot i as a device array (its address is the
+    mapped one: kernels may read it) whose `get()` / `item()` wait until the GPU has filled it."""
+
+    def __init__(self, n, shape):
+        self.shape = tuple(int(s) for s in shape)
+        self.n, self.per = int(n), int(math.prod(self.shape))
+        self._mem = _MappedHost(8 * self.n * self.per)
+        buf = (ctypes.c_char * self._mem.nbytes).from_address(self._mem.host)
+        self.host = np.frombuffer(buf, dtype=np.int64).reshape((self.n,) + self.shape)
+        self.host[...] = -1
+        self._ptr = self._mem.ptr
+
+    def slot(self, i):
+        strides, acc = [], 1
+        for d in reversed(self.shape):
+            strides.append(acc); acc *= d
+        out = readback_array(self._mem, self._ptr + 8 * self.per * int(i), self.shape, tuple(reversed(strides)), np.int64)
+        out._host = None
+        out._rb = _Polled(self.host[int(i)])
+        return out
+
+
+class _Polled:
+    __slots__ = ("view",)
+
+    def __init__(self, view):
+        self.view = view
+
+    def _finish(self, arr):
+        v, spins = self.view, 0
+        while (v < 0).any():                       # the GPU's store has not landed yet
+            spins += 1
+            if spins == 200000:                    # far beyond any decode step: make sure the stream is still alive
+                synchronize()
+            elif spins > 400000:
+                raise RuntimeError("Mailbox slot was never written by the GPU")
+        arr._host = v.copy()
+
+
 def stacked_view(arrays):
     """A (n, *shape) view over `arrays` when they are contiguous, alike and equally spaced in memory
     (e.g. consecutive parameters of a flat buffer), else None.  Lets n GEMMs that share an operand

@@ -244,8 +244,9 @@ class Llama(nn.Module):
                a0.Q.weight.data._ptr, a0.cache_k.data._ptr)       # a captured step holds these addresses
         if st is not None and st["key"] == key:
             return st if st["ok"] else None
-        if st is not None and st.get("graph"):
-            st["graph"].destroy()
+        if st is not None:
+            for g in st.get("graphs", {}).values():
+                g.destroy()
         ok = (B <= 8 and B * max(D, F) <= 16384 and D % 4 == 0 and F % 4 == 0 and V % 4 == 0 and (D // H) % 4 == 0
               and self.layers[0].attention.cache_k.shape[1] * 4 <= 60 * 1024 and D // H <= 256)
         packs = []
@@ -265,7 +266,7 @@ class Llama(nn.Module):
             nblk = _lib.lib().query("pdn_decode_gemv_blocks", V)
             # key ranges per head in the decode attention: one CU pulls ~11 B/clk, so long caches are cut up
             ns = int(os.environ.get("PDN_DECODE_SPLITS", "0")) or (1 if self.layers[0].attention.cache_k.shape[1] <= 256 else 4)
-            st.update(packs=packs, graph=None, host_pos=None, ns=ns,
+            st.update(packs=packs, graphs={}, nograph=False, host_pos=None, ns=ns,
                       ids=hp.zeros((B, 1), np.int64), pos=hp.zeros((1,), np.int32),
                       cand_v=hp.empty((B, nblk), np.float32), cand_i=hp.empty((B, nblk), np.int32),
                       # tokens by position: (*hist_ptr)[pos] is what the step at `pos` picked -- the array handed to
@@ -283,14 +284,26 @@ class Llama(nn.Module):
             # more record per head for the new key
             st["block"] = bool(st["fused"] and int(Llama.fused_decode) >= 2 and
                                _lib.lib().query("pdn_decode_block_supported", D, H, D // H, ns))
+            # (block path: the number of key ranges follows the position -- 256 cached keys per range, one captured
+            #  step per count -- unless PDN_DECODE_SPLITS pins it)
+            cache_len = self.layers[0].attention.cache_k.shape[1]
+            st["ns_max"] = ns if os.environ.get("PDN_DECODE_SPLITS") else min(7, max(1, -(-(cache_len - 1) // 256)))
+            if st["block"] and not _lib.lib().query("pdn_decode_block_supported", D, H, D // H, st["ns_max"]):
+                st["ns_max"] = ns
             if st["fused"]:
-                st.update(J=J, recs=hp.empty((B, (ns + 1) * H * (4 + D)), np.float32), dparts=hp.empty((B, J * D), np.float32),
+                st.update(J=J, recs=hp.empty((B, (max(ns, st["ns_max"]) + 1) * H * (4 + D)), np.float32), dparts=hp.empty((B, J * D), np.float32),
                           xa=hp.empty((B, D), np.float32), xb=hp.empty((B, D), np.float32))
             self._decode_ws = {"logits": st["logits"], "x": st["x"]}
         self._decode_st = st
         return st if ok else None
 
-    def _decode_launches(self, st):
+    def _decode_ns(self, st, pos):
+        """Key ranges per head for the step at position `pos`."""
+        if not st.get("block") or os.environ.get("PDN_DECODE_SPLITS"):
+            return st["ns"]
+        return min(st["ns_max"], max(1, -(-pos // 256)))
+
+    def _decode_launches(self, st, ns=None):
         """The launches of one decode step (2 per layer + 2; 3 or 5 per layer at lower `fused_decode` levels); every argument is fixed for the lifetime of `st` (the position
         and the token ids are read from device memory), so the sequence can be captured once and replayed."""
         from .. import hipnp as hp, _lib
@@ -306,7 +319,7 @@ class Llama(nn.Module):
         head = self.lm_head
         bias = head.bias.data._ptr if getattr(head, "bias", None) is not None else None
         if st["fused"]:
-            J, ns = st["J"], st["ns"]
+            J, ns = st["J"], (st["ns"] if ns is None else ns)
             recs, dparts, xa, xb = (st[n]._ptr for n in ("recs", "dparts", "xa", "xb"))
             rrs = ns * H * (4 + D)
             for li, (layer, (wqkv, _)) in enumerate(zip(self.layers, st["packs"])):
@@ -406,13 +419,15 @@ class Llama(nn.Module):
             st["host_pos"] = st["last_out"] = None               # (position and ids are uploaded again below)
         if st["host_pos"] != pos:
             st["pos"][...] = np.int32(pos)                       # (later steps: the device advances it itself)
-            st["hist"] = hp.zeros((cache.shape[1], B, 1), np.int64)          # a new generation: its own history
+            # a new generation: its own history -- slots in mapped host memory the pick kernel stores into directly
+            st["hist"] = hp.Mailbox(cache.shape[1], (B, 1))
             st["hist_ptr"][...] = np.int64(st["hist"]._ptr)
         fresh = ids is not st["ids"] and ids is not st.get("last_out")
         if fresh:
             st["ids"][...] = ids                                 # (not the array the previous step returned: that
             self._decode_gather(st)                              # one's embedding row is already in x)
-        g = st["graph"]
+        ns = self._decode_ns(st, pos)
+        g = False if st["nograph"] else st["graphs"].get(ns)
         if g is None and Llama.graph_decode and pos + 2 < min(cache.shape[1], self.freqs_cos.shape[0]):
             # capture once: hipnp.Graph runs the step twice for real (pool warm-up + first replay), which writes the
             # cache rows of positions pos and pos + 1 with exactly what the real steps will write there; the
@@ -420,26 +435,24 @@ class Llama(nn.Module):
             keep = st["ids"].copy()
             try:
                 g = hp.Graph()
-                g.capture(lambda: self._decode_launches(st))
-                st["graph"] = g
+                g.capture(lambda: self._decode_launches(st, ns))
+                st["graphs"][ns] = g
             except _lib.HipLibraryError as e:
                 if e.code != -2:                                 # PDN_EUNSUPPORTED: no graph support (the emulated
                     raise                                        # ABI) -> plain launches; anything else is a bug
-                st["graph"] = g = False
+                st["nograph"], g = True, False
             st["pos"][...] = np.int32(pos)
             st["ids"][...] = keep
             self._decode_gather(st)
         if g:
             g.replay()
         else:
-            self._decode_launches(st)
+            self._decode_launches(st, ns)
         st["host_pos"] = pos + 1
-        # the caller's own array = this position's slot of the history; its host value is fetched right behind the step:
-        # reading the token waits for THIS step only, while the compute stream may already run the next one
-        if st.get("readback") is None:
-            st["readback"] = hp.Readback(8 * B)
-        out = st["last_out"] = st["readback"].issue(st["hist"][pos])
-        if (more and Llama.decode_ahead and st["graph"] is not None
+        # the caller's own array = this position's slot of the history (host memory the GPU writes): reading the token
+        # polls THAT slot only -- no copy command, no event -- while the compute stream may already run the next step
+        out = st["last_out"] = st["hist"].slot(pos)
+        if (more and Llama.decode_ahead and (st["graphs"] or st["nograph"])
                 and pos + 1 < min(cache.shape[1], self.freqs_cos.shape[0])):
             self._decode_ahead(st, pos + 1)
         return out
@@ -448,14 +461,17 @@ class Llama(nn.Module):
         """Queue the step of position `pos` right behind the one just issued -- its input ids are already where the
         gather reads them -- so the GPU does not idle while the host hands the previous token to the caller.  The
         result is kept for the next `_decode_step_hip(last_out, pos)` call; any other call discards it."""
-        g = st["graph"]
+        ns = self._decode_ns(st, pos)
+        g = False if st["nograph"] else st["graphs"].get(ns)
+        if g is None:
+            return                                               # (a new range count: its step is captured by the next call)
         if g:
             g.replay()
         else:
-            self._decode_launches(st)
+            self._decode_launches(st, ns)
         st["host_pos"] = pos + 1
         prev = st["last_out"]
-        st["ahead"] = (pos, prev, st["readback"].issue(st["hist"][pos]))
+        st["ahead"] = (pos, prev, st["hist"].slot(pos))
 
     def _decode_step_generic(self, ids, pos: int):
         """The same step from the library's generic entry points (skinny `pdn_gemm_f32`, RMSNorm, RoPE, decode

@@ -97,6 +97,11 @@ class EmulatedLib:
 
     def pdn_host_alloc(self, out, nbytes): return self.pdn_malloc(out, nbytes)
     def pdn_host_free(self, ptr): return self.free(ptr)
+
+    def pdn_host_alloc_mapped(self, host_out, dev_out, nbytes):
+        rc = self.pdn_malloc(host_out, nbytes)
+        ctypes.cast(dev_out, ctypes.POINTER(ctypes.c_void_p))[0] = ctypes.cast(host_out, ctypes.POINTER(ctypes.c_void_p))[0]
+        return rc
     def pdn_memcpy_d2h_async(self, dst, src, n, stream): return self._copy(dst, src, n)
 
     def pdn_memset(self, dst, value, n, stream):

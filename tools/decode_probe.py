@@ -33,17 +33,11 @@ with pdn.no_grad():
         for view in (False, True):
             print(f"generate ahead={ahead} read_view={view}: {run(ahead, view):7.0f} tok/s", flush=True)
     st = model._decode_st
-    g = st["graph"]
+    g = st["graphs"][1]
     st["pos"][...] = np.int32(20)
     hp.synchronize(); t0 = time.perf_counter()
     for _ in range(200):
         g.replay()
     hp.synchronize()
     print(f"back-to-back replays: {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per token ({g.nodes} nodes)")
-    st["pos"][...] = np.int32(20)
-    hp.synchronize(); t0 = time.perf_counter()
-    for _ in range(200):
-        g.replay(); o = st["readback"].issue(st["hist"][20])
-    hp.synchronize()
-    print(f"replay + readback issue (no host wait): {(time.perf_counter() - t0) / 200 * 1e6:.1f} us per token")
     st["host_pos"] = None
