@@ -24,7 +24,7 @@
 
 #define DEC_MAX_B 8
 
-template <int TN, int NB, int P>
+template <int TN, int NB, int P, bool EXACT>
 __global__ __launch_bounds__(256) void decode_gemv_kernel(
     const float* __restrict__ x, const float* __restrict__ recs, int K, int R, const float* __restrict__ norm_w,
     const float* __restrict__ W, int64_t w_bs, int w_rs, int N,
@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void decode_gemv_kernel(
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int k = slice + i * S;
-    wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < nsteps) wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < K ? k : slice) * w_rs));
+    if (!EXACT) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);        // (EXACT: K needs exactly P k-steps)
+    if (EXACT || i < nsteps) wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < K ? k : slice) * w_rs));
   }
   // epilogue operands of the finishing threads, likewise
   const int fq = tid % Q, fj = tid / Q, fn = blockIdx.x * TN + 4 * fq;
@@ -260,11 +260,14 @@ static int launch_gemv(int nb, dim3 grid, size_t shm, hipStream_t st, const floa
                        float eps, const float* W, int64_t w_rs, int blk_cols, int64_t w_bs, const float* bias,
                        const float* residual, int64_t r_rs, float* y, int64_t y_rs, int B, int K, int N, int act,
                        int act_ns, int act_hd, float* blk_max, int* blk_arg, const DecSum& sum) {
-#define DEC_GO(NB)                                                                                                     \
-  hipLaunchKernelGGL((decode_gemv_kernel<TN, NB, P>), grid, dim3(256), shm, st, x, sum.recs, K, sum.R, norm_w, W, w_bs,  \
-                     (int)w_rs, N, blk_cols, (int)x_rs, eps, bias, residual, (int)r_rs, y, (int)y_rs, B, act, act_ns,    \
-                     act_hd, blk_max, blk_arg, sum.x_out, sum.recs_rs, sum.x_out_rs, sum.base != nullptr ? 1 : 0)
-  if (nb == 1) DEC_GO(1); else if (nb == 2) DEC_GO(2); else DEC_GO(4);
+  constexpr int S = 256 / (TN / 4);
+  const bool exact = (K + S - 1) / S == P;     // (no conditional weight loads: see decode_block.hip)
+#define DEC_GO(NB, EX)                                                                                                 \
+  hipLaunchKernelGGL((decode_gemv_kernel<TN, NB, P, EX>), grid, dim3(256), shm, st, x, sum.recs, K, sum.R, norm_w, W,    \
+                     w_bs, (int)w_rs, N, blk_cols, (int)x_rs, eps, bias, residual, (int)r_rs, y, (int)y_rs, B, act,     \
+                     act_ns, act_hd, blk_max, blk_arg, sum.x_out, sum.recs_rs, sum.x_out_rs, sum.base != nullptr ? 1 : 0)
+  if (exact) { if (nb == 1) DEC_GO(1, true); else if (nb == 2) DEC_GO(2, true); else DEC_GO(4, true); }
+  else { if (nb == 1) DEC_GO(1, false); else if (nb == 2) DEC_GO(2, false); else DEC_GO(4, false); }
 #undef DEC_GO
   PDN_LAUNCH_CHECK();
   return PDN_OK;
@@ -310,6 +313,9 @@ static int decode_gemv_impl(const float* x, int64_t x_row_stride, const float* n
   hipStream_t st = (hipStream_t)stream;
   // narrow column tiles while N is small: a workgroup streams K * TN * 4 bytes, the chip has 256 CUs
   // (prefetch depth P: 12 k-steps of 64 slices cover K <= 768, 18 of 16 slices cover K <= 288 -- the Llama shapes)
+  if (N <= 4096 && K <= 320)             // (five k-steps of 64 slices: the 288-wide Llama)
+    return launch_gemv<16, 5>(nb, dim3((N + 15) / 16), shm, st, x, x_row_stride, norm_w, eps, W, w_row_stride, blk_cols,
+                              w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg, sum);
   if (N <= 4096)
     return launch_gemv<16, 12>(nb, dim3((N + 15) / 16), shm, st, x, x_row_stride, norm_w, eps, W, w_row_stride, blk_cols,
                                w_block_stride, bias, residual, res_row_stride, y, y_row_stride, B, K, N, act, act_ns, act_hd, blk_max, blk_arg, sum);

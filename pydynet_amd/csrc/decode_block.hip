@@ -21,8 +21,11 @@
 #define DEC_MAX_B 8
 
 // F4 = head_dim / 4 (12 or 16), VPRE = V rows per thread held in registers (a 256-key range), QP = k-steps of the
-// q | k | v products held in registers (D <= QP * (256 / F4): 288 at hd 48), PW = rows of Wo per thread.
-template <int F4, int VPRE, int QP, int PW>
+// q | k | v products held in registers (14 at hd 48: D <= 294, i.e. 288; later steps load in place; QP >= F4, VPRE: the
+// same registers hold the K / V rows of a range role), PW = rows of Wo per thread.  EXACT: the shape needs exactly QP
+// steps and PW rows -- every weight load is unconditional (a zero-initialised register overwritten by a conditional
+// load costs a copy that WAITS for the load: the compiler's phi).
+template <int F4, int VPRE, int QP, int PW, bool EXACT>
 __global__ __launch_bounds__(256) void decode_block_kernel(
     const int* __restrict__ pos_ptr, const float* __restrict__ base, const float* __restrict__ parts, int D, int R,
     const float* __restrict__ norm_w, const float* __restrict__ Wqkv, int64_t w_bs,
@@ -37,6 +40,9 @@ __global__ __launch_bounds__(256) void decode_block_kernel(
   __shared__ float ssq[4];
   const int tid = threadIdx.x;
   DEC_T_BEGIN(5);
+  // (the position: requested FIRST and as a vector load -- a scalar load would be sunk to its first use by the
+  //  compiler and cost a whole round trip in the middle of the issue phase; everything about the keys waits for it)
+  const int pos_v = __hip_atomic_load(pos_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int ci = blockIdx.x % C, role = (blockIdx.x / C) % (NS + 1), bh = blockIdx.x / (C * (NS + 1)), b = bh / H, h = bh % H;
   const bool isnew = role == NS;           // (uniform)
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -54,14 +60,16 @@ __global__ __launch_bounds__(256) void decode_block_kernel(
   const bool live = slice < SL;
   const int nsteps = (D + SL - 1) / SL;
   const float* wq = Wqkv + (unsigned)(h * HD + 4 * quad);
+  // (row base per thread + a uniform step offset: two instructions per load; only the last step can run past D)
+  const float* wq_t = wq + (unsigned)((live ? slice : 0) * w_rs);
   float4 wa[QP], wb[QP], wc[QP];
 #pragma unroll
   for (int i = 0; i < QP; ++i) {
     const int k = slice + i * SL;
-    wa[i] = z4;
-    if (i < nsteps) wa[i] = *reinterpret_cast<const float4*>(wq + (unsigned)(((live && k < D) ? k : 0) * w_rs));
+    if (!EXACT) wa[i] = z4;
+    if (EXACT || i < nsteps) wa[i] = *reinterpret_cast<const float4*>(wq_t + ((i < nsteps - 1 || k < D) ? (unsigned)(i * SL * w_rs) : 0u));
   }
-  const int pos = *pos_ptr;
+  const int pos = __builtin_amdgcn_readfirstlane(pos_v);           // (first use: by now the load is back)
   const int chunk = (pos + NS - 1) / NS, t0 = isnew ? 0 : role * chunk, t1 = isnew ? 0 : min(pos, t0 + chunk);
   float* kb = kc + (int64_t)b * cbs + (unsigned)(h * HD);
   float* vb = vc + (int64_t)b * cbs + (unsigned)(h * HD);
@@ -69,14 +77,14 @@ __global__ __launch_bounds__(256) void decode_block_kernel(
   constexpr int groups = 256 / F4;         // (= SL)
   const int tg = slice, vc4 = quad;
   if (isnew) {
-    const float* wk = wq + w_bs;
+    const float* wk = wq_t + w_bs;
     const float* wv = wk + w_bs;
 #pragma unroll
     for (int i = 0; i < QP; ++i) {
       const int k = slice + i * SL;
-      wb[i] = z4; wc[i] = z4;
-      if (i < nsteps) {
-        const unsigned off = (unsigned)(((live && k < D) ? k : 0) * w_rs);
+      if (!EXACT) { wb[i] = z4; wc[i] = z4; }
+      if (EXACT || i < nsteps) {
+        const unsigned off = (i < nsteps - 1 || k < D) ? (unsigned)(i * SL * w_rs) : 0u;
         wb[i] = *reinterpret_cast<const float4*>(wk + off);
         wc[i] = *reinterpret_cast<const float4*>(wv + off);
       }
@@ -104,8 +112,8 @@ __global__ __launch_bounds__(256) void decode_block_kernel(
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
       const int d = osl + i * Go;
-      wo[i] = z4;
-      if (i < nw_rows) wo[i] = *reinterpret_cast<const float4*>(wop + (unsigned)((d < HD ? d : 0) * wo_rs));
+      if (!EXACT) wo[i] = z4;
+      if (EXACT || i < nw_rows) wo[i] = *reinterpret_cast<const float4*>(wop + (unsigned)((d < HD ? d : 0) * wo_rs));
     }
   }
 
@@ -196,7 +204,10 @@ __global__ __launch_bounds__(256) void decode_block_kernel(
     lds_barrier();
     if (tid < HD) qs[tid] = vs[tid];       // (q is dead: the hd sums go there for the projection)
   } else {
-    m = -INFINITY;
+    // scores; softmax statistics per WAVE first (its own maximum and sum, no barrier), merged by every thread after
+    // ONE barrier: m = max_w m_w, l = sum_w exp(m_w - m) l_w, and a key's probability is rescaled by its wave's factor
+    // where it is used (keys kt, kt + 256, ... of a thread belong to the same wave)
+    float mw = -INFINITY;
     for (int t = kt; t < t1; t += 256) {
       float s = 0.f;
       if (t == kt) {
@@ -214,29 +225,41 @@ __global__ __launch_bounds__(256) void decode_block_kernel(
       }
       s *= inv_sqrt;
       sc[t - t0] = s;
-      m = fmaxf(m, s);
+      mw = fmaxf(mw, s);
     }
-    m = block_max_lds(m, red);
-    DEC_T(5);
-    l = 0.f;
+    mw = wave_max(mw);
+    float lw = 0.f;
     for (int t = kt; t < t1; t += 256) {
-      const float pr = expf(sc[t - t0] - m);
+      const float pr = expf(sc[t - t0] - mw);  // (this thread's own entries: no barrier in between)
       sc[t - t0] = pr;
-      l += pr;
+      lw += pr;
     }
-    l = block_sum_lds(l, red);             // (its barriers also publish the probabilities)
+    lw = wave_sum(lw);
+    if ((tid & 63) == 0) { red[tid >> 6] = mw; red[4 + (tid >> 6)] = lw; }
+    lds_barrier();
+    DEC_T(5);
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float fw[4];
+    l = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      fw[w] = red[w] > -INFINITY ? expf(red[w] - m) : 0.f;         // (a wave without keys: m_w = -inf, l_w = 0)
+      l += fw[w] * red[4 + w];
+    }
     float4 acc = z4;
     if (live) {
 #pragma unroll
       for (int i = 0; i < VPRE; ++i) {
         const int t = t0 + tg + i * groups;
         if (t < t1) {
-          const float pr = sc[t - t0];
+          const int w = ((t - t0) >> 6) & 3;
+          const float pr = sc[t - t0] * (w == 0 ? fw[0] : (w == 1 ? fw[1] : (w == 2 ? fw[2] : fw[3])));
           acc.x += pr * wc[i].x; acc.y += pr * wc[i].y; acc.z += pr * wc[i].z; acc.w += pr * wc[i].w;
         }
       }
       for (int t = t0 + tg + VPRE * groups; t < t1; t += groups) {
-        const float pr = sc[t - t0];
+        const int w = ((t - t0) >> 6) & 3;
+        const float pr = sc[t - t0] * (w == 0 ? fw[0] : (w == 1 ? fw[1] : (w == 2 ? fw[2] : fw[3])));
         const float4 v = *reinterpret_cast<const float4*>(vb + (unsigned)(t * D + 4 * vc4));
         acc.x += pr * v.x; acc.y += pr * v.y; acc.z += pr * v.z; acc.w += pr * v.w;
       }
@@ -348,14 +371,21 @@ extern "C" int pdn_decode_block_f32(const float* base, int64_t base_row_stride, 
   const dim3 grid(B * H * (NS + 1) * C);
   hipStream_t st = (hipStream_t)stream;
   const float inv_sqrt = 1.f / sqrtf((float)head_dim);
-#define BLK_GO(F4, VP, PW)                                                                                              \
-  hipLaunchKernelGGL((decode_block_kernel<F4, VP, 16, PW>), grid, dim3(256), shm, st, pos, base, parts, D, n_parts,      \
+#define BLK_GO(F4, VP, QP, PW, EX)                                                                                      \
+  hipLaunchKernelGGL((decode_block_kernel<F4, VP, QP, PW, EX>), grid, dim3(256), shm, st, pos, base, parts, D, n_parts,  \
                      norm_w, Wqkv, w_block_stride, (int)w_row_stride, H, NS, C, eps, x_out, cos_table, sin_table,       \
                      k_cache, v_cache, cache_batch_stride, Wo, (int)wo_row_stride, records, (int)base_row_stride,       \
                      (int)parts_row_stride, (int)x_out_row_stride, inv_sqrt, scf)
-  const int pw_need = (head_dim + Go - 1) / Go;
-  if (head_dim == 48) { if (pw_need <= 4) BLK_GO(12, 13, 4); else BLK_GO(12, 13, 16); }
-  else { if (pw_need <= 4) BLK_GO(16, 16, 4); else BLK_GO(16, 16, 16); }
+  const int pw_need = (head_dim + Go - 1) / Go, nsteps = (D + SL - 1) / SL;
+  if (head_dim == 48) {
+    if (pw_need == 4 && nsteps == 14) BLK_GO(12, 13, 14, 4, true);
+    else if (pw_need <= 4) BLK_GO(12, 13, 14, 4, false);
+    else BLK_GO(12, 13, 14, 16, false);
+  } else {
+    if (pw_need == 4 && nsteps == 16) BLK_GO(16, 16, 16, 4, true);
+    else if (pw_need <= 4) BLK_GO(16, 16, 16, 4, false);
+    else BLK_GO(16, 16, 16, 16, false);
+  }
 #undef BLK_GO
   PDN_LAUNCH_CHECK();
   return PDN_OK;

@@ -15,7 +15,7 @@
 #define DEC_MAX_B 8
 #define MLP_SL 32                          // hidden units per workgroup (32 columns = one 128-byte line per matrix row)
 
-template <int NB>
+template <int NB, int PD, bool EXACT>
 __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict__ base, const float* __restrict__ recs, int D,
                                                          int R, const float* __restrict__ norm_w,
                                                          const float* __restrict__ Wg, const float* __restrict__ Wu,
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict
   __shared__ float ssq[4 * DEC_MAX_B];
   __shared__ float4 part[4][16][NB];
   __shared__ float hb[DEC_MAX_B][MLP_SL];
-  constexpr int Q = 16, S = 16, P = 18, PD = 16;
+  constexpr int Q = 16, S = 16, P = 18;    // (EXACT: D needs exactly P k-steps and PD rows of Wd per thread: no conditional loads)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = tid % Q, slice = tid / Q, j = blockIdx.x;
   DEC_T_BEGIN(3);
@@ -47,8 +47,8 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < P; ++i) {
     const int k = slice + i * S;
-    wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < nsteps) wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < D ? k : slice) * w_rs));
+    if (!EXACT) wreg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EXACT || i < nsteps) wreg[i] = *reinterpret_cast<const float4*>(wp + (unsigned)((k < D ? k : slice) * w_rs));
   }
   const int nq = D >> 2, G = dec_div(256, nq), dsl = dec_div(tid, nq), dq = tid - dsl * nq;
   const float* wdp = Wd + (unsigned)(j * MLP_SL * wd_rs + 4 * dq);
@@ -57,8 +57,8 @@ __global__ __launch_bounds__(256) void decode_mlp_kernel(const float* __restrict
 #pragma unroll
   for (int i = 0; i < PD; ++i) {
     const int r = dsl + i * G;
-    wd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < ndsteps) wd[i] = *reinterpret_cast<const float4*>(wdp + (unsigned)((r < MLP_SL ? r : 0) * wd_rs));
+    if (!EXACT) wd[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EXACT || i < ndsteps) wd[i] = *reinterpret_cast<const float4*>(wdp + (unsigned)((r < MLP_SL ? r : 0) * wd_rs));
   }
   DEC_T(1);
 
@@ -200,11 +200,13 @@ extern "C" int pdn_decode_mlp_f32(const float* base, int64_t base_row_stride, co
   PDN_CHECK_ARG(shm <= 64 * 1024, "pdn_decode_mlp_f32: rows do not fit in LDS");
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid(F / MLP_SL);
-#define MLP_GO(NB)                                                                                                     \
-  hipLaunchKernelGGL((decode_mlp_kernel<NB>), grid, dim3(256), shm, st, base, records, D, R, norm_w, Wg, Wu, Wd,         \
+#define MLP_GO(NB, PD, EX)                                                                                              \
+  hipLaunchKernelGGL((decode_mlp_kernel<NB, PD, EX>), grid, dim3(256), shm, st, base, records, D, R, norm_w, Wg, Wu, Wd, \
                      (int)w_row_stride, (int)wd_row_stride, n_splits, H, eps, x_out, parts, (int)base_row_stride,       \
                      (int)records_row_stride, (int)x_out_row_stride, (int)parts_row_stride, B)
-  if (B == 1) MLP_GO(1); else if (B == 2) MLP_GO(2); else MLP_GO(4);
+  const bool exact = (D + 15) / 16 == 18 && (MLP_SL + G - 1) / G == 11;      // (D = 288: 18 k-steps, 11 rows of Wd)
+  if (exact) { if (B == 1) MLP_GO(1, 11, true); else if (B == 2) MLP_GO(2, 11, true); else MLP_GO(4, 11, true); }
+  else { if (B == 1) MLP_GO(1, 16, false); else if (B == 2) MLP_GO(2, 16, false); else MLP_GO(4, 16, false); }
 #undef MLP_GO
   PDN_LAUNCH_CHECK();
   return PDN_OK;
