@@ -1,17 +1,18 @@
 // Greedy KV-cache decode step (llm/llama/model.py:105-121 in eval mode + `generate`, model.py:254-269;
 // the loop the reference times in llm/llama/infer.py:46-63), one new token per sequence.
 //
-// At batch 1 a step is ~40 MB of weight traffic (16 us at the attainable HBM rate; the whole model sits in the
-// 256 MiB Infinity Cache after the first token) and round 2 spent 430 us on it: ~77 launches issued from Python,
-// each a generic kernel.  These kernels are built so that ONE hipGraph holds the whole step and can be replayed
-// for every token:
+// At batch 1 a step is ~60 MB of weight traffic (the whole model sits in the 256 MiB Infinity Cache after the first
+// token) and round 2 spent 430 us on it: ~77 launches issued from Python, each a generic kernel.  These kernels are
+// built so that ONE hipGraph holds the whole step and can be replayed for every token:
 //   * nothing depends on a host value that changes between tokens -- the position is read from DEVICE memory
-//     (`pos`, advanced by the last kernel of the step), the token ids are written where the next step's embedding
-//     gather reads them;
-//   * six launches per transformer block instead of thirteen: RMSNorm is applied while the activation row is staged
-//     into LDS by the projection that consumes it (it is 288 floats: every workgroup redoes it), q | k | v and
-//     gate | up are single skinny products over equally spaced weight blocks, RoPE + the KV-cache append are one
-//     kernel, SwiGLU is applied in the loads of the down projection, residual adds ride in the epilogues.
+//     (`pos`, advanced by the last kernel of the step), the picked token's embedding row is written where the next
+//     step starts, the token itself goes to a history slot that may be mapped host memory;
+//   * few launches per transformer block: this file holds the skinny product with its fused stagings (RMSNorm /
+//     SwiGLU / merge of attention partials / sum of hand-off records, decode_stage.h), the attention over the cache with
+//     the optional per-head output projection, and the pick; decode_layer.hip the feed-forward half of a block in one
+//     launch, decode_block.hip the attention half (2 launches per block; 3 and 5 are the fallbacks).
+// What these kernels are tuned for is the latency chain, not bandwidth: DESIGN.md 4.10 lists what was measured from
+// inside them (tools/decode_trace.sh).
 //
 // Skinny product y (B x N) = a (B x K) @ W (K x N), B <= a few rows, W row-major (in, out) as the reference
 // stores it (nn/modules/linear.py:26-27).  HBM/L2-bound on W and latency-bound at these sizes, so the design
