@@ -85,6 +85,19 @@ struct AttRowRope {
 // the rows beyond HD, and its row HD accumulates the softmax denominator (the row sums of P) for free -- the padded
 // tile is multiplied anyway.  `gk` / `gv` point at row pos0.
 #define ATT_LDV 64
+// the same with the pairs' (cos, sin) already in registers
+__device__ __forceinline__ float4 att_rot_pre(float4 v, float2 c, float2 s) {
+  float4 o;
+  o.x = v.x * c.x - v.y * s.x; o.y = v.x * s.x + v.y * c.x;
+  o.z = v.z * c.y - v.w * s.y; o.w = v.z * s.y + v.w * c.y;
+  return o;
+}
+
+// Every load of the staging -- K, V and the (cos, sin) pairs -- is issued in ONE batch, unconditionally (threads past
+// the end re-read unit 0), with 32-bit offsets; rotation and LDS stores follow.  Written as one loop that loads, rotates
+// and keeps the result (round 2), every iteration sat in its own branch region and used its load at once: six
+// serialised memory round trips per workgroup and kernel, ~12 us of the 30 us a workgroup lives (six workgroups pass
+// through a CU one after the other, nothing overlaps them: 98 KB of LDS each).
 template <int HD, int NT>
 __device__ __forceinline__ void att_stage_kv(float* __restrict__ ks, float* __restrict__ vs,
                                              const float* __restrict__ gk, const float* __restrict__ gv,
@@ -92,26 +105,31 @@ __device__ __forceinline__ void att_stage_kv(float* __restrict__ ks, float* __re
                                              const float* __restrict__ cs, const float* __restrict__ sn) {
   constexpr int LD = ATT_LD(HD), F4 = HD / 4;
   constexpr int NP = (ATT_CHUNK * F4 + NT - 1) / NT;
+  const int nu = nrows * F4, rs = (int)row_stride;
   float4 r0[NP], r1[NP];
+  float2 tc[NP], ts[NP];
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    const int u = tid + NT * j;
-    if (u < nrows * F4) {
-      const int row = u / F4, c4 = u % F4;
-      // component-wise: a whole-float4 store into the array defeats SROA (scratch) on hipcc 7.2
-      float4 a = *reinterpret_cast<const float4*>(gk + (int64_t)row * row_stride + 4 * c4);
-      const float4 c = *reinterpret_cast<const float4*>(gv + (int64_t)row * row_stride + 4 * c4);
-      if (cs) a = att_rot(a, cs, sn, pos0 + row, 2 * c4, HD / 2, 1.f);
-      r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
-      r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    const int u = tid + NT * j, uc = u < nu ? u : 0;
+    const int row = uc / F4, c4 = uc - row * F4;
+    const unsigned off = (unsigned)(row * rs + 4 * c4);
+    // component-wise: a whole-float4 store into the array defeats SROA (scratch) on hipcc 7.2
+    const float4 a = *reinterpret_cast<const float4*>(gk + off);
+    const float4 c = *reinterpret_cast<const float4*>(gv + off);
+    r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
+    r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    if (cs) {                                                     // (uniform)
+      const unsigned to = (unsigned)((pos0 + row) * (HD / 2) + 2 * c4);
+      tc[j] = *reinterpret_cast<const float2*>(cs + to);
+      ts[j] = *reinterpret_cast<const float2*>(sn + to);
     }
   }
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const int u = tid + NT * j;
-    if (u < nrows * F4) {
-      const int row = u / F4, c4 = u % F4;
-      *reinterpret_cast<float4*>(ks + row * LD + 4 * c4) = r0[j];
+    if (u < nu) {
+      const int row = u / F4, c4 = u - row * F4;
+      *reinterpret_cast<float4*>(ks + row * LD + 4 * c4) = cs ? att_rot_pre(r0[j], tc[j], ts[j]) : r0[j];
       *reinterpret_cast<float4*>(vs + row * ATT_LDV + 4 * c4) = r1[j];
     }
   }
@@ -137,27 +155,32 @@ __device__ __forceinline__ void att_stage_two_pad(float* __restrict__ s0, float*
                                                   bool rot0, bool rot1) {
   constexpr int LD0 = PAD0 ? ATT_LDP : ATT_LD(HD), LD1 = PAD1 ? ATT_LDP : ATT_LD(HD), F4 = HD / 4;
   constexpr int NP = (ATT_CHUNK * F4 + NT - 1) / NT;
+  const int nu = nrows * F4, rs0 = (int)row_stride, rs1 = (int)row_stride1;
+  const bool rot = cs && (rot0 || rot1);                          // (uniform)
   float4 r0[NP], r1[NP];
+  float2 tc[NP], ts[NP];
+  // (all loads in one batch, unconditional, then rotate + store: see att_stage_kv)
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    const int u = tid + NT * j;
-    if (u < nrows * F4) {
-      const int row = u / F4, c4 = u % F4;
-      float4 a = *reinterpret_cast<const float4*>(g0 + (int64_t)row * row_stride + 4 * c4);
-      float4 c = *reinterpret_cast<const float4*>(g1 + (int64_t)row * row_stride1 + 4 * c4);
-      if (cs && rot0) a = att_rot(a, cs, sn, pos0 + row, 2 * c4, HD / 2, 1.f);
-      if (cs && rot1) c = att_rot(c, cs, sn, pos0 + row, 2 * c4, HD / 2, 1.f);
-      r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
-      r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    const int u = tid + NT * j, uc = u < nu ? u : 0;
+    const int row = uc / F4, c4 = uc - row * F4;
+    const float4 a = *reinterpret_cast<const float4*>(g0 + (unsigned)(row * rs0 + 4 * c4));
+    const float4 c = *reinterpret_cast<const float4*>(g1 + (unsigned)(row * rs1 + 4 * c4));
+    r0[j].x = a.x; r0[j].y = a.y; r0[j].z = a.z; r0[j].w = a.w;
+    r1[j].x = c.x; r1[j].y = c.y; r1[j].z = c.z; r1[j].w = c.w;
+    if (rot) {
+      const unsigned to = (unsigned)((pos0 + row) * (HD / 2) + 2 * c4);
+      tc[j] = *reinterpret_cast<const float2*>(cs + to);
+      ts[j] = *reinterpret_cast<const float2*>(sn + to);
     }
   }
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
     const int u = tid + NT * j;
-    if (u < nrows * F4) {
-      const int row = u / F4, c4 = u % F4;
-      *reinterpret_cast<float4*>(s0 + row * LD0 + 4 * c4) = r0[j];
-      *reinterpret_cast<float4*>(s1 + row * LD1 + 4 * c4) = r1[j];
+    if (u < nu) {
+      const int row = u / F4, c4 = u - row * F4;
+      *reinterpret_cast<float4*>(s0 + row * LD0 + 4 * c4) = (cs && rot0) ? att_rot_pre(r0[j], tc[j], ts[j]) : r0[j];
+      *reinterpret_cast<float4*>(s1 + row * LD1 + 4 * c4) = (cs && rot1) ? att_rot_pre(r1[j], tc[j], ts[j]) : r1[j];
     }
   }
   if constexpr (HD < 64) {
@@ -270,11 +293,16 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   float m = -INFINITY, lsum = 0.f;               // running row maximum (unscaled scores); lsum: HD = 64 only
   const int c_last = MULTI ? (causal ? qg : G - 1) : 0;
   AttRowRope<NT8> rr;
-  const bool pre = !MULTI && RC != nullptr && active;
-  if (pre) rr.load(RC, RS, qt * 32 + li, lh, HD / 2);
+  // (operand preloads are UNCONDITIONAL -- an idle wave reads tile 0: a load under `if (active)` makes the compiler
+  //  copy the loaded registers right behind it (the phi with the untaken path), i.e. wait for the load at once
+  //  instead of after the staging it was meant to hide behind)
+  const bool pre = !MULTI && RC != nullptr;
+  const int qpos_l = (active ? qt : 0) * 32 + li;
+  // (without RoPE the same loads read the first floats of Q: unconditional, never used)
+  if constexpr (!MULTI) rr.load(RC ? RC : Q, RC ? RS : Q, RC ? qpos_l : 0, lh, HD / 2);
   float4 qraw[MULTI ? 1 : NT8];                  // single chunk: the Q rows go out before the staging (see dQ kernel)
-  if (!MULTI && active) {
-    const float* qrow = Qb + (int64_t)(qt * 32 + li) * row_stride + 4 * lh;
+  if (!MULTI) {
+    const float* qrow = Qb + (int64_t)qpos_l * row_stride + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) qraw[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
   }
@@ -515,8 +543,9 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   const int qt = qg * ATT_MAX_TILES + qtl;
   const bool active = qt < ntile;
   AttRowRope<NT8> rr;
-  const bool pre = !MULTI && RC != nullptr && active;       // (the chunk loops have no registers to spare for it)
-  if (pre) rr.load(RC, RS, qt * 32 + li, lh, HD / 2);
+  const bool pre = !MULTI && RC != nullptr;                 // (the chunk loops have no registers to spare for it)
+  const int qpos_l = (active ? qt : 0) * 32 + li;           // (an idle wave preloads tile 0: unconditional loads, see forward)
+  if constexpr (!MULTI) rr.load(RC ? RC : Q, RC ? RS : Q, RC ? qpos_l : 0, lh, HD / 2);   // (no RoPE: reads Q, unused)
   const float inv_sqrt = 1.f / sqrt_hd;
   const int qpos = qt * 32 + li;
   // this wave's operands (Q, dO, O rows of its tile, lse): the loads go out BEFORE the staging -- behind which their
@@ -524,17 +553,17 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
   // exposed round trip is paid six times per kernel)
   float4 qf[NT8], gf[NT8], of_[NT8];
   float dpart = 0.f, lse_q = 0.f;
-  if (active) {
-    const float* qrow = Qb + (int64_t)qpos * row_stride + 4 * lh;
-    const float* grow = dOb + (int64_t)qpos * o_row_stride + 4 * lh;
-    const float* orow = Ob + (int64_t)qpos * o_row_stride + 4 * lh;
+  {
+    const float* qrow = Qb + (int64_t)qpos_l * row_stride + 4 * lh;
+    const float* grow = dOb + (int64_t)qpos_l * o_row_stride + 4 * lh;
+    const float* orow = Ob + (int64_t)qpos_l * o_row_stride + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
       gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
       of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
     }
-    lse_q = LSE[(int64_t)bh * L + qpos];
+    lse_q = LSE[(int64_t)bh * L + qpos_l];
   }
   if (!MULTI) {
     att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, 0, row_stride, row_stride, tid, RC, RS, true, false);
@@ -648,15 +677,16 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const int kt = kg * ATT_MAX_TILES + ktl;
   const bool active = kt < ntile;
   AttRowRope<NT8> rr;
-  const bool pre = !MULTI && RC != nullptr && active;
-  if (pre) rr.load(RC, RS, kt * 32 + li, lh, HD / 2);
+  const bool pre = !MULTI && RC != nullptr;
+  const int kpos_l = (active ? kt : 0) * 32 + li;           // (an idle wave preloads tile 0: unconditional loads, see forward)
+  if constexpr (!MULTI) rr.load(RC ? RC : K, RC ? RS : K, RC ? kpos_l : 0, lh, HD / 2);   // (no RoPE: reads K, unused)
   const float inv_sqrt = 1.f / sqrt_hd;
   const float c1 = inv_sqrt * 1.4426950408889634f;
   const int kpos = kt * 32 + li;
   float4 kf[NT8], vf[NT8];                          // (issued before the staging, consumed after the barrier: see dQ)
-  if (active) {
-    const float* krow = Kb + (int64_t)kpos * row_stride + 4 * lh;
-    const float* vrow = Vb + (int64_t)kpos * row_stride + 4 * lh;
+  {
+    const float* krow = Kb + (int64_t)kpos_l * row_stride + 4 * lh;
+    const float* vrow = Vb + (int64_t)kpos_l * row_stride + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
       kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
