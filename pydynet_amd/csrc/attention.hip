@@ -35,6 +35,31 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// -DATT_TRACE (tools/attn_trace.sh, never the shipped build): every wave of the forward kernel leaves 100 MHz
+// timestamps of its phases, its tile and the CU it ran on.
+#ifdef ATT_TRACE
+#define ATT_TRACE_SLOTS (1 << 17)
+static __device__ unsigned long long att_trace_buf[ATT_TRACE_SLOTS][10];
+static __device__ unsigned att_trace_cnt;
+#define ATT_T_BEGIN() unsigned long long tr_[8] = {}; tr_[0] = __builtin_amdgcn_s_memrealtime()
+#define ATT_T(i) tr_[i] = __builtin_amdgcn_s_memrealtime()
+#define ATT_T_END(tile) do { if ((threadIdx.x & 63) == 0) { const unsigned sl = atomicAdd(&att_trace_cnt, 1u);             \
+  if (sl < ATT_TRACE_SLOTS) { for (int i_ = 0; i_ < 8; ++i_) att_trace_buf[sl][i_] = tr_[i_];                             \
+    att_trace_buf[sl][8] = ((unsigned long long)blockIdx.x << 8) | (unsigned)(tile);                                      \
+    att_trace_buf[sl][9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 32) |                        \
+                           (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20); } } } while (0)
+extern "C" int pdn_att_trace_dump(unsigned long long* out, unsigned* n) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(att_trace_buf), sizeof(unsigned long long) * ATT_TRACE_SLOTS * 10);
+  hipMemcpyFromSymbol(n, HIP_SYMBOL(att_trace_cnt), sizeof(unsigned));
+  unsigned z = 0; hipMemcpyToSymbol(HIP_SYMBOL(att_trace_cnt), &z, sizeof(unsigned));
+  return 0;
+}
+#else
+#define ATT_T_BEGIN()
+#define ATT_T(i)
+#define ATT_T_END(tile)
+#endif
+
 #define ATT_MAX_TILES 8      // key / query tiles per LDS chunk (256 rows)
 #define ATT_CHUNK (32 * ATT_MAX_TILES)
 #define ATT_MAX_L 1024
@@ -275,6 +300,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   if (MULTI) att_block(G, bh, qg); else { bh = blockIdx.x; qg = 0; }
   const int b = bh / H, h = bh % H;
   const int tid = threadIdx.x, lane = tid & 63;
+  ATT_T_BEGIN();
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int64_t base = (int64_t)b * batch_stride + (int64_t)h * HD;
@@ -308,7 +334,9 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   }
   if (!MULTI) {
     if (!(ABLATE & 1)) att_stage_kv<HD, 512>(Ks, Vs, K + base, V + base, L, 0, row_stride, tid, RC, RS);
+    ATT_T(1);
     __syncthreads();
+    ATT_T(2);
     if (!active) return;                         // no workgroup barrier below this point
   }
   for (int c = 0; c <= c_last; ++c) {
@@ -353,6 +381,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
         }
       }
     }
+    ATT_T(3);
     // ---- mask, softmax over keys (per lane = per query) ---------------------------------------
     // The 1/sqrt(hd) scale rides inside the exponential: p = exp2(s * c1 - max(s) * c1), c1 = log2(e) / sqrt(hd)
     // (the row maximum is taken on the unscaled scores; the scale is positive), and only the diagonal key tile
@@ -394,6 +423,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
       }
     }
     if constexpr (HD >= ATT_LDV) lsum += lc + __shfl_xor(lc, 32, 64);
+    ATT_T(4);
     // ---- O^T += V^T P^T  (two 32-row tiles over the head dim, the second one partly padding for hd < 64)
     if (!MULTI) {
 #pragma unroll
@@ -413,6 +443,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
       }
     }
   }
+  ATT_T(5);
   if (!active) return;
   // ---- hd < 64: row HD of O^T (register 4 (HD - 32) / 8 of the lower half-wave's second tile) is the softmax denominator
   float l;
@@ -436,6 +467,8 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
       *reinterpret_cast<float4*>(orow + 32 + 8 * g) =
           make_float4(o1[4 * g] * inv_l, o1[4 * g + 1] * inv_l, o1[4 * g + 2] * inv_l, o1[4 * g + 3] * inv_l);
   }
+  ATT_T(6);
+  ATT_T_END(qtl);
 }
 
 static bool att_shape_ok(int L, int head_dim) {
