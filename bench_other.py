@@ -446,21 +446,22 @@ def run_decode(args):
                                              head.weight.data._ptr, V, V, 0, head.bias.data._ptr, None, 0, lg._ptr, V,
                                              B, D, V, 0, 0, 0, None, None, hp.stream()), n=50)
     hb = 4.0 * (D * V + V + B * D + B * V)
-    roof = {"bound": "hbm", "kernel": "decode_gemv_kernel<64, 1> (lm_head, decode.hip)", "achieved": hb / (us * 1e-6) / 1e9,
+    roof = {"bound": "hbm", "kernel": "decode_gemv_kernel<64, 1, 18, true> (lm_head, decode.hip)", "achieved": hb / (us * 1e-6) / 1e9,
             "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": hb / (us * 1e-6) / PEAK_HBM, "traffic": None,
             "avg_launch_us": us, "algorithmic_bytes_per_launch": hb,
             "whole_step": {"algorithmic_weight_bytes_per_token": wbytes, "achieved_GBps": wbytes * value / B / 1e9,
                            "frac_of_hbm_peak": wbytes * value / B / PEAK_HBM,
-                           "note": "the 97 MB of weights sit in the 256 MiB Infinity Cache after the first token; a "
-                                   "token is 33 dependent launches replayed as one hipGraph (~5.8 us each: launch + two dependent memory "
-                                   "round trips), the next step queued while the 8-byte token travels to the host"}}
+                           "note": "the 61 MB of weights sit in the 256 MiB Infinity Cache after the first token; a "
+                                   "token is 2 launches per block + 2 = 14 dependent launches replayed as one hipGraph "
+                                   "(latency chain: DESIGN.md 4.10, profiles/*_decode_trace.txt), the next step queued "
+                                   "while the host polls the mapped mailbox slot the pick kernel stored the token into"}}
     out = {"metric": "greedy decode tokens/sec (6L Llama3, KV cache, batch 1)", "value": value, "unit": "tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / produced,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "llm/llama 6-layer Llama3 (dim 288, 6 heads, ffn 768, vocab 32000) greedy generate with KV cache, "
                                   "random init, one token read back to the host per step (infer.py:46-63)",
                       "batch": B, "prompt_len": prompt_len, "parallelism": "dp1",
-                      "step_launch": "hipGraph replay" if getattr(model, "_decode_st", {}).get("graph") else "eager launches"},
+                      "step_launch": "hipGraph replay, 14 kernel nodes" if getattr(model, "_decode_st", {}).get("graph") else "eager launches"},
            "parity_gate": gate, "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_decode(host_w, ids, (V, D, H, F_, LAYERS))

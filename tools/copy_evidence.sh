@@ -14,5 +14,7 @@ cp $S/lenet_pmc.txt $D/${ROUND}_lenet_b4096_pmc.txt
 cp $S/decode_kernel_stats.txt $D/${ROUND}_decode_kernel_stats.txt
 cp $S/attn_pmc.txt $D/${ROUND}_attention_pmc.txt
 cp $S/all_configs.txt $D/${ROUND}_all_configs.txt
+cp $S/decode_trace.txt $D/${ROUND}_decode_trace.txt
+cp $S/attn_trace.txt $D/${ROUND}_attention_fwd_trace.txt
 { tail -3 $S/pytest_gpu.log; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt
 ls -la $D | grep ${ROUND}_

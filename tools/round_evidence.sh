@@ -29,5 +29,9 @@ bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 2
   python tools/gemm_shapes.py 256; python tools/gemm_shapes.py 64; bash tools/ab_small_batch.sh; bash tools/ab_fixed_term.sh;
   python tools/gemm_generic.py; python tools/bench_llama_dims.py 512 8 1536; python tools/bench_llama_dims.py 768 12 2048 128;
   python tools/bench_llama_dims.py 384 6 1024; python tools/bench_llama_dims.py 288 6 768 128 512; python tools/decode_probe.py;
-  python tools/dp_overhead_probe.py dp; python tools/dp_overhead_probe.py base; } > $O/all_configs.txt 2>&1
+  python tools/dp_overhead_probe.py dp; python tools/dp_overhead_probe.py base;
+  python bench.py --config decode --steps 900 --warmup 20 --no-cpu-baseline; } > $O/all_configs.txt 2>&1
+# phase timestamps from inside the decode kernels / the attention forward (traced builds made by the same scripts here)
+bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
+bash tools/attn_trace.sh > $O/attn_trace.txt 2>&1
 ls -la $O
