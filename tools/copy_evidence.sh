@@ -16,5 +16,5 @@ cp $S/attn_pmc.txt $D/${ROUND}_attention_pmc.txt
 cp $S/all_configs.txt $D/${ROUND}_all_configs.txt
 cp $S/decode_trace.txt $D/${ROUND}_decode_trace.txt
 cp $S/attn_trace.txt $D/${ROUND}_attention_fwd_trace.txt
-{ tail -3 $S/pytest_gpu.log; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt
+{ grep -E "passed|failed|error" $S/pytest_gpu.log | tail -2; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt
 ls -la $D | grep ${ROUND}_
