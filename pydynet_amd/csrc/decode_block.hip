@@ -16,7 +16,6 @@
 // order the results are needed (a wave's loads return in issue order); the staging of x overlaps the weights' flight.
 #include "common.h"
 #include "decode_stage.h"
-#include <cstdlib>
 
 #define DEC_MAX_B 8
 
@@ -355,11 +354,9 @@ extern "C" int pdn_decode_block_f32(const float* base, int64_t base_row_stride, 
   PDN_CHECK_ARG(((((uintptr_t)base | (uintptr_t)parts | (uintptr_t)x_out | (uintptr_t)norm_w | (uintptr_t)Wqkv |
                    (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)Wo | (uintptr_t)records) & 15) == 0),
                 "pdn_decode_block_f32: 16-byte aligned operands");
-  int C = D % 16 == 0 ? 4 : (D % 12 == 0 ? 3 : (D % 8 == 0 ? 2 : 1));
-  if (const char* e = getenv("PDN_DECODE_BLOCK_C")) {               // (tuning knob: copies per (role, head))
-    const int c = atoi(e);
-    if (c >= 1 && c <= 4 && D % (4 * c) == 0) C = c;
-  }
+  // copies per (role, head), each with D / C columns of Wo (measured flat between 1 and 4 at D = 288: kept at the
+  // count that keeps a workgroup's share of Wo small)
+  const int C = D % 16 == 0 ? 4 : (D % 12 == 0 ? 3 : (D % 8 == 0 ? 2 : 1));
   const int f4 = head_dim / 4, SL = 256 / f4, groups = SL, G = 256 / (D / 4), nqd = D / C / 4, Go = 256 / nqd;
   const int chunk = (max_len + NS - 1) / NS;
   int scf = chunk;                                                  // scores | partial sums | projection partials

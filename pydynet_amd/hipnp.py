@@ -617,11 +617,11 @@ def full(shape, value, dtype=None):
 def zeros_like(a, dtype=None): return zeros(a.shape, dtype or a.dtype)
 def ones_like(a, dtype=None): return ones(a.shape, dtype or a.dtype)
 class readback_array(ndarray):
-    """A device array whose HOST value arrives by itself: its producer queued a copy into pinned host memory on a
-    side stream (`Readback.issue`); `get()` / `item()` wait for THAT copy's event instead of synchronising the
-    compute stream -- which may already be running later work (the next decode step, llm/llama.py).  Basic-index
-    views (`a[0]`) keep the property.  Writing into the array drops the host value: it is an ordinary device array
-    from then on."""
+    """A device array whose HOST value arrives by itself: its producer leaves it in host-visible memory
+    (`Mailbox.slot`: a kernel stores straight into mapped host memory); `get()` / `item()` wait for THAT value only
+    instead of synchronising the compute stream -- which may already be running later work (the next decode step,
+    llm/llama.py).  Basic-index views (`a[0]`) keep the property.  Writing into the array drops the host value: it is
+    an ordinary device array from then on."""
 
     __slots__ = ("_rb", "_host")
 
@@ -661,61 +661,6 @@ class readback_array(ndarray):
     def __isub__(self, o): self._dirty(); return ndarray.__isub__(self, o)
     def __imul__(self, o): self._dirty(); return ndarray.__imul__(self, o)
     def __itruediv__(self, o): self._dirty(); return ndarray.__itruediv__(self, o)
-
-
-class Readback:
-    """Two pinned host slots: `issue(src)` -- called after the work producing the device array `src` was enqueued on
-    the compute stream -- queues a copy of it into pinned host memory right behind that work (same stream: a second
-    queue holding a barrier packet slows every kernel of the compute queue) and returns `src` as a readback_array,
-    whose `get()` waits for the copy's event only; work enqueued AFTER issue() does not delay the read."""
-
-    def __init__(self, nbytes):
-        L = _lib.lib()
-        self.nbytes = int(nbytes)
-        self._slots = []
-        for _ in range(2):
-            hp_, e1 = ctypes.c_void_p(), ctypes.c_void_p()
-            L.call("pdn_host_alloc", ctypes.byref(hp_), _bi.max(self.nbytes, 8))
-            L.call("pdn_event_create", ctypes.byref(e1), 0)
-            self._slots.append({"host": hp_.value, "done": e1.value, "owner": None})
-        self._next = 0
-
-    def issue(self, src):
-        import weakref
-        L = _lib.lib()
-        assert src.is_contiguous() and src.nbytes == self.nbytes
-        slot = self._slots[self._next]
-        self._next ^= 1
-        prev = slot["owner"]() if slot["owner"] is not None else None
-        if prev is not None:
-            prev._settle()                                   # the slot is about to be rewritten: take its value out
-        out = readback_array(src._buf, src._ptr, src.shape, src._strides, src.dtype)
-        out._host = None
-        out._rb = _Pending(self, slot, src.shape, src.dtype)
-        L.call("pdn_memcpy_d2h_async", slot["host"], src._ptr, self.nbytes, stream())
-        L.call("pdn_event_record", slot["done"], stream())
-        slot["owner"] = weakref.ref(out)
-        return out
-
-    def destroy(self):
-        L = _lib.lib()
-        synchronize()
-        for s in self._slots:
-            L.call("pdn_host_free", s["host"])
-            L.call("pdn_event_destroy", s["done"])
-        self._slots = []
-
-
-class _Pending:
-    __slots__ = ("rb", "slot", "shape", "dtype")
-
-    def __init__(self, rb, slot, shape, dtype):
-        self.rb, self.slot, self.shape, self.dtype = rb, slot, shape, dtype
-
-    def _finish(self, arr):
-        _lib.lib().call("pdn_event_synchronize", self.slot["done"])
-        buf = (ctypes.c_char * self.rb.nbytes).from_address(self.slot["host"])
-        arr._host = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape).copy()
 
 
 class _MappedHost:
