@@ -353,8 +353,12 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   // register-staged B in 8-wave workgroups: NT 72.9 vs 68.6 % at N = 768, 87.9 vs 75.8 % at N = 32000; NN (staged in
   // three phases with a single fragment set, which is what fits in 256 registers) 85.7 vs 84.5 % at N = 32000, 76.1 vs
   // 74.8 % at 1536, 73.3 vs 71.7 % at 864.  The 4-wave form (fewer rows than fill the chip) keeps the LDS-DMA.
-  // one 8-wave workgroup per CU (half the fetch instructions per wave) as long as that fills the chip
-  const int nw = nw_env ? nw_env : ((M + 255) / 256 >= 192) ? 8 : 4;
+  // one 8-wave workgroup per CU (half the fetch instructions per wave) as long as that fills the chip -- with the
+  // column chunks split over grid.y if need be (round 3: at 8192 / 16384 / 32768 rows the 8-wave form measured
+  // 74 / 83 / 85 % on the lm_head forward against 70 / 77 / 79 % for two 4-wave workgroups per CU, 1-4 points
+  // on the layer projections: the threshold of round 2, 49152 rows, only looked at the row blocks)
+  const int rb8 = (M + 255) / 256;
+  const int nw = nw_env ? nw_env : (rb8 >= 192 || (int64_t)rb8 * p.chunks >= 256) ? 8 : 4;
   const int stage = stage_env >= 0 ? stage_env : (nw == 8 ? 1 : 0);
   const int row_blocks = (M + 32 * nw - 1) / (32 * nw), target = nw == 4 ? 512 : 256;
   // fill every CU (two 4-wave or one 8-wave workgroup each): split the chunks over grid.y
