@@ -1191,7 +1191,8 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     // fewer rows than that: K cut into ranges over grid.y (slabs in the workspace), when K is long enough
     int pl_nw, pl_kps;
     const int64_t or_ws = (workspace && workspace_bytes > 0) ? workspace_bytes : 0;
-    const bool cut = !big && !mid && M >= 8192 && K >= 1536 && pdn_gemm_outres_plan(M, K, &pl_nw, &pl_kps) > 1 &&
+    // (the plan may also cut K where unsplit 4-wave workgroups would fill the chip: 8-wave ones over two ranges)
+    const bool cut = !big && M >= 8192 && K >= 1536 && pdn_gemm_outres_plan(M, K, &pl_nw, &pl_kps) > 1 &&
                      or_ws >= pdn_gemm_outres_workspace_bytes(M, K);
     if ((big || mid || cut) && (bt || b_cs == 1) && pdn_gemm_outres_supported(M, N, K, a_rs, ldb, ldc, bt)) {
       bool prof;

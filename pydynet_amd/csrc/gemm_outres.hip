@@ -284,13 +284,29 @@ extern "C" int pdn_gemm_outres_plan(int M, int K, int* nw, int* kps) {
   const int npieces = K / OR_KP, wg8 = (M + 255) / 256, wg4 = (M + 127) / 128;
   *nw = wg8 >= 224 ? 8 : 4;
   *kps = npieces;
-  if (wg4 >= 224 || getenv("PDN_OUTRES_NO_SPLIT")) return 1;
+  if (wg8 >= 224 || getenv("PDN_OUTRES_NO_SPLIT")) return 1;
+  // fewer rows than fill the chip with 8-wave workgroups: K cut into ranges over grid.y, >= 24 pieces each.
+  // 8-wave workgroups first (round 3: the lm_head input gradient at 16384 rows 86.4 % against 82.4 % for four ranges
+  // of 4-wave workgroups), 4-wave ones where the contraction is too short to make ~256 of those.
+  if (!getenv("PDN_OUTRES_NO_PLAN8")) {
+    int s8 = (256 + wg8 - 1) / wg8;
+    if (s8 > npieces / 24) s8 = npieces / 24;
+    if (s8 >= 2 && wg8 * s8 >= 224) {
+      *nw = 8;
+      *kps = (npieces + s8 - 1) / s8;
+      return (npieces + *kps - 1) / *kps;
+    }
+  }
+  if (wg4 >= 224) return 1;
   int splits = (448 + wg4 - 1) / wg4;
   if (splits > npieces / 24) splits = npieces / 24;
   if (splits < 2) return 1;     // (64-row / 2-wave workgroups for short K measured 29 % against the tiled kernel's 42 %)
   *kps = (npieces + splits - 1) / splits;
   return (npieces + *kps - 1) / *kps;
 }
+
+// workgroup size when a planned K split cannot be used (no workspace): what fills the chip without it
+static int outres_unsplit_nw(int M) { return (M + 255) / 256 >= 224 ? 8 : 4; }
 
 extern "C" int64_t pdn_gemm_outres_workspace_bytes(int M, int K) {
   int nw, kps;
@@ -337,8 +353,10 @@ static int outres_launch(const float* A, const float* B, float* C, const float* 
   int plan_nw = 8, kps = K / OR_KP;
   int splits = pdn_gemm_outres_plan(M, K, &plan_nw, &kps);
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * OR_N * 4 || (ldc & 3) ||
-                     ((uintptr_t)C & 15) || ((uintptr_t)workspace & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)))
+                     ((uintptr_t)C & 15) || ((uintptr_t)workspace & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15))) {
     splits = 1;
+    plan_nw = outres_unsplit_nw(M);
+  }
   if (splits > 1) { p.kps = kps; p.slab = (float*)workspace; }
   static const int nw_env = getenv("PDN_OUTRES_NW") ? atoi(getenv("PDN_OUTRES_NW")) : 0;
   static const int stage_env = getenv("PDN_OUTRES_STAGE") ? atoi(getenv("PDN_OUTRES_STAGE")) : -1;
@@ -374,8 +392,10 @@ int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, 
   int nw = 8, kps = V / OR_KP;
   int splits = pdn_gemm_outres_plan(M, V, &nw, &kps);
   if (splits > 1 && (!workspace || workspace_bytes < (int64_t)splits * M * OR_N * 4 || (ldc & 3) || ((uintptr_t)dx & 15) ||
-                     ((uintptr_t)workspace & 15) || ((uintptr_t)residual & 15)))
+                     ((uintptr_t)workspace & 15) || ((uintptr_t)residual & 15))) {
     splits = 1;
+    nw = outres_unsplit_nw(M);
+  }
   if (splits > 1) { p.kps = kps; p.slab = (float*)workspace; }
   const dim3 grid((M + 32 * nw - 1) / (32 * nw), splits);
   if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
