@@ -82,8 +82,11 @@ struct TilePrefetch {
   __device__ __forceinline__ void issue(const float* __restrict__ src, int total) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
+      // (unconditional: a load under `if (e < total)` is followed by a copy of its registers -- the phi with the
+      //  untaken path -- that WAITS for it, and the "prefetch" becomes NV serialised round trips; threads past the
+      //  end re-read piece 0 and never commit it)
       const int e = (threadIdx.x + i * 256) * 4;
-      if (e < total) v[i] = *reinterpret_cast<const float4*>(src + e);
+      v[i] = *reinterpret_cast<const float4*>(src + (e < total ? e : 0));
     }
   }
   // (c, y, x) of element e in a (C, H, W) block -> frame[(c * PH + y + pad) * PW + x + pad]
@@ -122,13 +125,11 @@ struct PooledPrefetch {
     const int plane = H * W, hw = W >> 1;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const int e = (threadIdx.x + i * 256) * 4;
-      if (e < total) {
-        const int c = e / plane, rem = e - c * plane;
-        const int y = rem / W, x = rem - y * W;
-        v[i] = *reinterpret_cast<const float2*>(dp + (c * (H >> 1) + (y >> 1)) * hw + (x >> 1));
-        m[i] = hit[e >> 5];
-      }
+      const int e0 = (threadIdx.x + i * 256) * 4, e = e0 < total ? e0 : 0;      // (unconditional loads: see TilePrefetch)
+      const int c = e / plane, rem = e - c * plane;
+      const int y = rem / W, x = rem - y * W;
+      v[i] = *reinterpret_cast<const float2*>(dp + (c * (H >> 1) + (y >> 1)) * hw + (x >> 1));
+      m[i] = hit[e >> 5];
     }
   }
   __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
@@ -426,17 +427,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
     const float* dyn = dy + (int64_t)n * g.O * (SRC == 1 ? (M >> 2) : M) + (SRC == 1 ? 0 : m0);
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
-      const int e = threadIdx.x + i * 256;
-      if (e < g.O * q) {
-        const int o = e / q, p = (e - o * q) * 4;
-        if constexpr (SRC == 1) {
-          const int gp = m0 + p, oy = gp / g.OW, ox = gp - oy * g.OW;
-          const int pi = (o * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
-          dpv[i] = *reinterpret_cast<const float2*>(dyn + pi);
-          dpm[i] = dmask[((int64_t)(n * g.O + o) * M + gp) >> 5];
-        } else {
-          dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)o * M + p);
-        }
+      const int e0 = threadIdx.x + i * 256, e = e0 < g.O * q ? e0 : 0;         // (unconditional loads: see TilePrefetch)
+      const int o = e / q, p = (e - o * q) * 4;
+      if constexpr (SRC == 1) {
+        const int gp = m0 + p, oy = gp / g.OW, ox = gp - oy * g.OW;
+        const int pi = (o * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
+        dpv[i] = *reinterpret_cast<const float2*>(dyn + pi);
+        dpm[i] = dmask[((int64_t)(n * g.O + o) * M + gp) >> 5];
+      } else {
+        dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)o * M + p);
       }
     }
   };
