@@ -37,10 +37,13 @@ __device__ __forceinline__ float g_tanh(float x) {              // tensor.py:101
 // accumulator-layout load / store of a (B, C) row block: lane = sequence b, register r = unit col0 + row(r, half)
 __device__ __forceinline__ void g_load(f32x16& a, const float* __restrict__ base, int64_t row_stride, int b, int col0,
                                        int half, bool ok) {
+  // (unconditional: `b` is clamped by the caller for lanes past the batch, whose values are never stored -- a load
+  //  under `if (ok)` is followed by the copy that merges it with the zero of the untaken path, and that copy WAITS for
+  //  the load: the one-step-ahead prefetch of the recurrence would be no prefetch)
+  (void)ok;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) v = *reinterpret_cast<const float4*>(base + (int64_t)b * row_stride + col0 + 8 * q + 4 * half);
+    const float4 v = *reinterpret_cast<const float4*>(base + (int64_t)b * row_stride + col0 + 8 * q + 4 * half);
     a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
   }
 }
@@ -71,6 +74,7 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_kernel(const float* __rest
   const int b = tile * 32 + li;
   if (tile * 32 >= B) return;                                   // wave-uniform
   const bool ok = b < B;
+  const int bl = ok ? b : B - 1;                                // row the loads of a lane past the batch read
   // A operands: lane (i = li, half) of MFMA r supplies W^T[out = i][k = row(r, half)] = W[k][out]
   float wz[16], wr[16], wn[16];
 #pragma unroll
@@ -81,20 +85,21 @@ __global__ __launch_bounds__(256, 1) void gru_seq_fwd_kernel(const float* __rest
     wn[r] = wh2[k * 32 + li];
   }
   f32x16 h;
-  g_load(h, h0, GH, b, 0, half, ok);
+  g_load(h, h0, GH, bl, 0, half, ok);
   // the hoisted projections of step t+1 do not depend on step t: their loads are issued one step ahead, so
   // the only latency left on the recurrence's critical path is MFMA -> gate math -> MFMA
   f32x16 nz, nr, nn;
-  g_load(nz, g1x, 64, b, 0, half, ok);
-  g_load(nr, g1x, 64, b, 32, half, ok);
-  g_load(nn, g2x, 32, b, 0, half, ok);
+  g_load(nz, g1x, 64, bl, 0, half, ok);
+  g_load(nr, g1x, 64, bl, 32, half, ok);
+  g_load(nn, g2x, 32, bl, 0, half, ok);
   for (int t = 0; t < T; ++t) {
     const int64_t off = (int64_t)t * B;
     f32x16 az = nz, ar = nr, an = nn;
-    if (t + 1 < T) {
-      g_load(nz, g1x + (off + B) * 64, 64, b, 0, half, ok);
-      g_load(nr, g1x + (off + B) * 64, 64, b, 32, half, ok);
-      g_load(nn, g2x + (off + B) * 32, 32, b, 0, half, ok);
+    {
+      const int64_t on = (int64_t)min(t + 1, T - 1) * B;        // (the last step re-reads itself: unconditional loads)
+      g_load(nz, g1x + on * 64, 64, bl, 0, half, ok);
+      g_load(nr, g1x + on * 64, 64, bl, 32, half, ok);
+      g_load(nn, g2x + on * 32, 32, bl, 0, half, ok);
     }
     g_mma(az, wz, h);
     g_mma(ar, wr, h);
@@ -147,20 +152,23 @@ __global__ __launch_bounds__(256, 1) void gru_seq_bwd_kernel(const float* __rest
 #pragma unroll
   for (int r = 0; r < 16; ++r) dh[r] = 0.f;
   f32x16 pg, pz, pr, pn, ph;                                    // operands of the step about to run
+  const int bl = ok ? b : B - 1;                                // row the loads of a lane past the batch read
   auto fetch = [&](int t) {
     const int64_t o2 = (int64_t)t * B;
-    g_load(pg, G + o2 * 32, 32, b, 0, half, ok);
-    g_load(pz, Z + o2 * 32, 32, b, 0, half, ok);
-    g_load(pr, R + o2 * 32, 32, b, 0, half, ok);
-    g_load(pn, N + o2 * 32, 32, b, 0, half, ok);
-    if (t > 0) g_load(ph, OUT + (o2 - B) * 32, 32, b, 0, half, ok);
-    else g_load(ph, h0, GH, b, 0, half, ok);
+    g_load(pg, G + o2 * 32, 32, bl, 0, half, ok);
+    g_load(pz, Z + o2 * 32, 32, bl, 0, half, ok);
+    g_load(pr, R + o2 * 32, 32, bl, 0, half, ok);
+    g_load(pn, N + o2 * 32, 32, bl, 0, half, ok);
+    // h of the step before: one address select instead of two loads under a branch (GH = row stride of h0)
+    const float* hsrc = t > 0 ? OUT + (o2 - B) * 32 : h0;
+    g_load(ph, hsrc, t > 0 ? 32 : GH, bl, 0, half, ok);
   };
   fetch(T - 1);
   for (int t = T - 1; t >= 0; --t) {
     const int64_t off = (int64_t)t * B;
     f32x16 g = pg, z = pz, rr = pr, n = pn, hp = ph;
-    if (t > 0) fetch(t - 1);                                    // saved tensors of the next step: no dependence
+    fetch(t > 0 ? t - 1 : 0);                                   // saved tensors of the next step: no dependence (step 0
+                                                                // re-reads itself: unconditional loads)
     f32x16 dg2, dgz, dgr, drh, dhp;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
