@@ -393,6 +393,16 @@ def _cpu_gru(T_, Hd, budget=10.0):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+
+def _decode_step_launch(model):
+    """How a decode step was issued, from the plan the model actually used (graphs captured per key-range count)."""
+    st = getattr(model, "_decode_st", None) or {}
+    graphs = st.get("graphs") or {}
+    if graphs and not st.get("nograph"):
+        nodes = sorted({int(g.nodes) for g in graphs.values() if g})
+        return f"hipGraph replay, {'/'.join(str(n) for n in nodes)} kernel nodes per step ({len(graphs)} captured range count{'s' if len(graphs) != 1 else ''})"
+    return "eager launches"
+
 def run_decode(args):
     """Greedy KV-cache decoding of the 6-layer Llama at batch 1 (llm/llama/infer.py:46-63 prints tokens/s this
     way; the reference's README quotes 300 tok/s): a "step" is one generated token, host read-back included."""
@@ -461,7 +471,7 @@ def run_decode(args):
            "config": {"workload": "llm/llama 6-layer Llama3 (dim 288, 6 heads, ffn 768, vocab 32000) greedy generate with KV cache, "
                                   "random init, one token read back to the host per step (infer.py:46-63)",
                       "batch": B, "prompt_len": prompt_len, "parallelism": "dp1",
-                      "step_launch": "hipGraph replay, 14 kernel nodes" if getattr(model, "_decode_st", {}).get("graph") else "eager launches"},
+                      "step_launch": _decode_step_launch(model)},
            "parity_gate": gate, "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_decode(host_w, ids, (V, D, H, F_, LAYERS))

@@ -132,6 +132,24 @@ int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
 int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
+/* Projections with the bandwidth pass next to them folded into the store of the accumulators (round 4;
+ * csrc/gemm_rowres.hip, contraction 288 only -- `*_supported` says whether a shape is taken; PDN_EUNSUPPORTED otherwise):
+ *  - gate | up projection + SwiGLU (llm/llama/model.py:56-58, nn/functional.py:39-40): gu (M x 2F) = x [Wg | Wu] and
+ *    h (M x F) = silu(gate) * up in ONE launch; Wg, Wu (K x F) row-major, `w_stride` floats apart;
+ *  - its backward half: dgu (M x 2F) = d[gate | up] from dh = dy (M x K) W_down^T, W_down (F x K) row-major, and the
+ *    saved gu -- dh itself is never written;
+ *  - q | k | v projection + RoPE on the q and k blocks (model.py:23-44, 93-104): qkv (M x 3D) = x [Wq | Wk | Wv], row m is
+ *    position m % L; `rope` is the (L x hd x 2) table pdn_rope_table_f32 expands from the reference's (L x hd/2)
+ *    cos / sin tables: (cos, sin with the sign of the column's place in its pair). */
+int pdn_gateup_swiglu_supported(int M, int F, int K);
+int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, int64_t w_stride, float* gu, float* h, int M,
+                              int F, int K, int64_t ldx, void* stream);
+int pdn_swiglu_bwd_gemm_f32(const float* dy, const float* w_down, const float* gu, float* dgu, int M, int F, int K,
+                            int64_t ldy, void* stream);
+int pdn_qkv_rope_supported(int M, int D, int K, int L, int hd);
+int pdn_qkv_rope_fwd_f32(const float* x, const float* wq, int64_t w_stride, float* qkv, const float* rope, int M,
+                         int D, int K, int L, int hd, int64_t ldx, void* stream);
+int pdn_rope_table_f32(const float* cos_t, const float* sin_t, float* out, int L, int hd, void* stream);
 /* float64 matmul (the reference's default dtype: a script that never says float32 still gets the right numbers
  * on the HIP device).  v_mfma_f64_16x16x4_f64, same stride / batch conventions, no epilogue fusions. */
 int pdn_gemm_f64(int M, int N, int K, double alpha, const double* A, int64_t a_rs, int64_t a_cs,
@@ -262,6 +280,14 @@ int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const 
                           int64_t o_row_stride, int64_t o_batch_stride,
                           int causal, const float* rope_cos, const float* rope_sin, void* workspace,
                           int64_t workspace_bytes, void* stream);
+/* the same with q and k given ALREADY ROTATED (pdn_qkv_rope_fwd_f32 applied RoPE in the projection's epilogue):
+ * nothing is rotated on the way in, dq / dk are rotated back on the way out (gradients of the un-rotated projections) */
+int pdn_attention_bwd_rotated_f32(const float* q, const float* k, const float* v, const float* o,
+                          const float* d_o, const float* lse, float* dq, float* dk, float* dv, int B,
+                          int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                          int64_t o_row_stride, int64_t o_batch_stride,
+                          int causal, const float* rope_cos, const float* rope_sin, void* workspace,
+                          int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = rowsum(dO * O) */
 /* Decode step (model.py:105-121 in eval mode, L = 1): q, o (B, H, head_dim); the new token attends to
  * positions [0, T) of the KV cache (max_batch, max_len, H, head_dim); no mask. */
@@ -333,6 +359,9 @@ int pdn_decode_mlp_f32(const float* base, int64_t base_row_stride, const float* 
  *                            records (B, n_ranges + 1, H, 4 + D) for pdn_decode_mlp_f32 (n_splits = n_ranges + 1).
  *                            head_dim 48 / 64 (pdn_decode_block_supported), else PDN_EUNSUPPORTED. */
 int pdn_decode_block_supported(int D, int H, int head_dim, int n_ranges);
+/* LDS bytes a launch with `n_ranges` key ranges over a cache of `max_len` positions needs (it runs when that is
+ * <= 64 KiB: a workgroup holds the scores of ceil(max_len / n_ranges) positions); 0 = shape not taken at all */
+int64_t pdn_decode_block_lds_bytes(int D, int H, int head_dim, int n_ranges, int max_len);
 int pdn_decode_block_f32(const float* base, int64_t base_row_stride, const float* parts, int n_parts,
                          int64_t parts_row_stride, float* x_out, int64_t x_out_row_stride, const float* norm_w, float eps,
                          const float* Wqkv, int64_t w_row_stride, int64_t w_block_stride, const float* cos_table,

@@ -1400,6 +1400,23 @@ class qkv_attention(_Operator):
 
     folds_existing = True
     enabled = True          # class switch: False sends Attention through the separate nodes (tests, A/B)
+    rope_epilogue = os.environ.get("PDN_NO_ROPE_EPILOGUE", "0") != "1"   # RoPE in the store of the q | k | v projection
+    rope_min_rows = 4096
+    _rope_tables = {}       # (cos ptr, sin ptr, L, hd) -> expanded (L, hd, 2) table for the projection's epilogue
+
+    @staticmethod
+    def _rope_table(cos, sin, Lq, hd):
+        hp, L = _hip(), _L()
+        key = (cos._ptr, sin._ptr, Lq, hd)
+        ent = qkv_attention._rope_tables.get(key)
+        if ent is None:
+            if len(qkv_attention._rope_tables) > 16:
+                qkv_attention._rope_tables.clear()
+            tab = hp.empty((Lq, hd, 2), np.float32)
+            L.call("pdn_rope_table_f32", cos._ptr, sin._ptr, tab._ptr, Lq, hd, hp.stream())
+            # (the tables are kept alive with the entry: the key is made of their addresses)
+            ent = qkv_attention._rope_tables[key] = (tab, cos, sin)
+        return ent[0]
 
     def __init__(self, x, wq, wk, wv, cos, sin, n_heads):
         self._cos, self._sin, self.H = cos, sin, int(n_heads)
@@ -1432,20 +1449,28 @@ class qkv_attention(_Operator):
         blocks = self._blocks(qkv, T, D)
         ws = [_contig(w.data) for w in (wq, wk, wv)]
         stack = hp.stacked_view(ws)
-        if stack is not None:
+        cos, sin = _contig(self._cos.data), _contig(self._sin.data)
+        resident = qkv_attention._resident(Lq, hd)
+        # RoPE in the projection's store (q, k leave rotated; the attention kernels read them as they are and only
+        # rotate dq, dk back), or -- shapes that kernel does not take -- inside the attention kernels' loads
+        self.rotated = bool(qkv_attention.rope_epilogue and resident and stack is not None
+                            and T >= qkv_attention.rope_min_rows
+                            and L.query("pdn_qkv_rope_supported", T, D, D, Lq, hd))
+        if self.rotated:
+            tab = self._rope_table(cos, sin, Lq, hd)
+            L.call("pdn_qkv_rope_fwd_f32", x2._ptr, ws[0]._ptr, (ws[1]._ptr - ws[0]._ptr) // 4, qkv._ptr, tab._ptr,
+                   T, D, D, Lq, hd, D, hp.stream())
+        elif stack is not None:
             hp.gemm(x2, stack, blocks)
         else:
             for i in range(3):
                 hp.gemm(x2, ws[i], blocks[i])
-        # RoPE rides inside the attention kernels (q, k rotated as they are loaded; dq, dk rotated
-        # back as they are stored), so `qkv` keeps the un-rotated projections
-        cos, sin = _contig(self._cos.data), _contig(self._sin.data)
         out = hp.empty((B, Lq, H, hd), np.float32)
         lse = hp.empty((B, H, Lq), np.float32)
         q, k, v = qkv._ptr, qkv._ptr + 4 * D, qkv._ptr + 8 * D
-        if qkv_attention._resident(Lq, hd):
+        if resident:
             L.call("pdn_attention_fwd_f32", q, k, v, out._ptr, lse._ptr, B, H, Lq, hd, 3 * D, Lq * 3 * D,
-                   D, Lq * D, 1, cos._ptr, sin._ptr, hp.stream())
+                   D, Lq * D, 1, None if self.rotated else cos._ptr, None if self.rotated else sin._ptr, hp.stream())
         else:                   # any length / head dim: key tiles stream through LDS, RoPE still in the loads
             if (3 * D) % 4 or D % 4:
                 raise ValueError("qkv_attention: dim must be a multiple of 4")
@@ -1470,7 +1495,8 @@ class qkv_attention(_Operator):
         dq, dk, dv = dqkv._ptr, dqkv._ptr + 4 * D, dqkv._ptr + 8 * D
         if qkv_attention._resident(Lq, hd):
             ws_, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
-            L.call("pdn_attention_bwd_f32", q, k, v, self.data._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, Lq, hd,
+            L.call("pdn_attention_bwd_rotated_f32" if self.rotated else "pdn_attention_bwd_f32", q, k, v, self.data._ptr,
+                   do._ptr, lse._ptr, dq, dk, dv, B, H, Lq, hd,
                    3 * D, Lq * 3 * D, D, Lq * D, 1, cos._ptr, sin._ptr, ws_, wsb, hp.stream())
         else:
             ws_, wsb = hp.workspace(L.query("pdn_attention_stream_bwd_workspace_bytes", B, H, Lq))
@@ -1592,6 +1618,116 @@ class gate_up_swiglu(_Operator):
             grads[0] = dx
         if side is not None:
             side.join()
+        return grads
+
+
+class ffn_swiglu(_Operator):
+    """The whole feed-forward block as ONE tape node (llm/llama/model.py:47-58):
+    y = (silu(x Wg) * (x Wu)) Wd (+ residual).  What the merge buys over `gate_up_swiglu` + `linear` is that the two
+    bandwidth passes of SwiGLU ride in GEMM epilogues (csrc/gemm_rowres.hip, round 4): forward, the packed gate | up
+    projection writes h = silu(gate) * up beside [gate | up] in the same launch; backward, dh = dy Wd^T is never
+    written -- the product's store reads the saved gate / up and leaves d[gate | up].  Shapes the epilogue kernels do
+    not take (contraction other than 288, ffn not a multiple of 96, few rows) run the same algebra with the separate
+    SwiGLU kernels.  The reference: 3 matmul + 5 elementwise nodes forward and their per-edge gradients."""
+
+    folds_existing = True
+    enabled = os.environ.get("PDN_NO_FFN_NODE", "0") != "1"            # (same-box A/B switches)
+    epilogues = os.environ.get("PDN_NO_SWIGLU_EPILOGUE", "0") != "1"
+    epilogue_min_rows = 4096         # below this the projections are launch-sized: the separate kernels are as good
+
+    @staticmethod
+    def applicable(x, wg, wu, wd):
+        return (ffn_swiglu.enabled and gate_up_swiglu.applicable(x, wg, wu) and wd.dtype == np.float32
+                and wd.shape == (wg.shape[1], wg.shape[0]))
+
+    def __init__(self, x, w_gate, w_up, w_down, residual=None):
+        self.has_res = residual is not None
+        super().__init__(*([x, w_gate, w_up, w_down] + ([residual] if self.has_res else [])))
+
+    @staticmethod
+    def _epilogue(T, F, fin, stack):
+        return bool(ffn_swiglu.epilogues and stack is not None and T >= ffn_swiglu.epilogue_min_rows
+                    and _L().query("pdn_gateup_swiglu_supported", T, F, fin))
+
+    def forward_(self, x, wg, wu, wd, r=None):
+        _require_f32(self, x, wg, wu, wd, r)
+        hp, L = _hip(), _L()
+        fin, F = wg.shape
+        x2 = _contig(x.data).reshape(-1, fin)
+        T = x2.shape[0]
+        gu = hp.empty((T, 2 * F), np.float32)
+        h = hp.empty((T, F), np.float32)
+        ws = [_contig(wg.data), _contig(wu.data)]
+        stack = hp.stacked_view(ws)
+        self.used_epilogue = self._epilogue(T, F, fin, stack)
+        if self.used_epilogue:
+            L.call("pdn_gateup_swiglu_fwd_f32", x2._ptr, ws[0]._ptr, (ws[1]._ptr - ws[0]._ptr) // 4, gu._ptr, h._ptr,
+                   T, F, fin, fin, hp.stream())
+        else:
+            halves = gate_up_swiglu._halves(gu, T, F)
+            if stack is not None:
+                hp.gemm(x2, stack, halves)
+            else:
+                hp.gemm(x2, ws[0], halves[0])
+                hp.gemm(x2, ws[1], halves[1])
+            L.call("pdn_swiglu_rows_fwd_f32", gu._ptr, h._ptr, T, F, hp.stream())
+        out = hp.empty(x.shape[:-1] + (fin,), np.float32)
+        res = _contig(r.data).reshape(-1, fin) if r is not None else None
+        hp.gemm(h, wd.data, out.reshape(-1, fin), residual=res)
+        self._saved = (x2, gu, h)
+        return out
+
+    def backward_all(self, g):
+        hp, L = _hip(), _L()
+        x, wg, wu, wd = self.last[:4]
+        fin, F = wg.shape
+        x2, gu, h = self._saved
+        T = x2.shape[0]
+        grads = [None] * len(self.last)
+        if self.has_res and self.last[4].requires_grad:
+            grads[4] = g
+        g2 = _contig(g).reshape(T, fin)
+        # down projection: dWd += h^T g
+        if wd.requires_grad:
+            if _is_leaf_f32(wd):
+                hp.gemm(h.T, g2, wd.grad, beta=1.0)
+            else:
+                grads[3] = hp.empty((F, fin), np.float32)
+                hp.gemm(h.T, g2, grads[3])
+        if not (x.requires_grad or wg.requires_grad or wu.requires_grad):
+            return grads
+        # d[gate | up] = SwiGLU'(gate, up) o (g Wd^T)
+        dgu = hp.empty((T, 2 * F), np.float32)
+        wdd = _contig(wd.data)
+        if self.used_epilogue:
+            L.call("pdn_swiglu_bwd_gemm_f32", g2._ptr, wdd._ptr, gu._ptr, dgu._ptr, T, F, fin, fin, hp.stream())
+        else:
+            dh = hp.empty((T, F), np.float32)
+            hp.gemm(g2, wdd.T, dh)
+            L.call("pdn_swiglu_rows_bwd_f32", gu._ptr, dh._ptr, dgu._ptr, T, F, hp.stream())
+        dhalves = gate_up_swiglu._halves(dgu, T, F)
+        weights = (wg, wu)
+        gstack = None
+        if all(w.requires_grad and _is_leaf_f32(w) for w in weights):
+            gstack = hp.stacked_view([w.grad for w in weights])
+        if gstack is not None:
+            hp.gemm(x2.T, dhalves, gstack, beta=1.0)
+        else:
+            for i, w in enumerate(weights):
+                if not w.requires_grad:
+                    continue
+                if _is_leaf_f32(w):
+                    hp.gemm(x2.T, dhalves[i], w.grad, beta=1.0)
+                else:
+                    grads[1 + i] = hp.empty(w.shape, np.float32)
+                    hp.gemm(x2.T, dhalves[i], grads[1 + i])
+        if x.requires_grad:
+            dx = hp.empty(x.shape, np.float32)
+            ex = _foldable(self, 0, x)
+            # (a residual that IS x hands its gradient g over separately: the engine adds it)
+            wcat = _pack_columns(hp, [wg.data, wu.data])                           # (fin, 2F)
+            hp.gemm(dgu, wcat.T, dx.reshape(T, fin), residual=ex.reshape(T, fin) if ex is not None else None)
+            grads[0] = dx
         return grads
 
 

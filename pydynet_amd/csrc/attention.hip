@@ -276,8 +276,8 @@ __device__ __attribute__((noinline)) void att_stage_kv_call(float* ks, float* vs
 template <int HD, bool PAD1>
 __device__ __attribute__((noinline)) void att_stage_pad_call(float* s0, float* s1, const float* g0, const float* g1, int nrows,
                                                              int pos0, int64_t rs0, int64_t rs1, int tid, const float* cs,
-                                                             const float* sn) {
-  att_stage_two_pad<HD, 512, true, PAD1>(s0, s1, g0, g1, nrows, pos0, rs0, rs1, tid, cs, sn, true, false);
+                                                             const float* sn, bool rot0) {
+  att_stage_two_pad<HD, 512, true, PAD1>(s0, s1, g0, g1, nrows, pos0, rs0, rs1, tid, cs, sn, rot0, false);
 }
 
 // MULTI = false: L <= 256, one chunk (the chunk loop and the rescale fold away).
@@ -471,6 +471,12 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
   ATT_T_END(qtl);
 }
 
+// csrc/attention_p.hip
+int pdn_attention_p_supported(int L, int head_dim);
+int pdn_attention_p_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L,
+                        int head_dim, int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                        int64_t o_batch_stride, int causal, void* stream);
+
 static bool att_shape_ok(int L, int head_dim) {
   return (head_dim == 48 || head_dim == 64) && L % 32 == 0 && L >= 32 && L <= ATT_MAX_L;
 }
@@ -505,6 +511,10 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
                     (o_batch_stride % 4) == 0 &&
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0),
                 "pdn_attention_fwd_f32: 16-byte alignment required");
+  // rotation-free operands at the benchmark shape class: the persistent, DMA-staged kernels (csrc/attention_p.hip)
+  if (!rope_cos && pdn_attention_p_supported(L, head_dim))
+    return pdn_attention_p_fwd(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride,
+                               causal, stream);
   const size_t shm = (size_t)pdn_attention_lds_bytes(L, head_dim);
   static bool attr_set = false;
   if (!attr_set) {
@@ -551,7 +561,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
     float* __restrict__ dQ, float* __restrict__ Delta, int H, int L, int64_t row_stride,
     int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
-    const float* __restrict__ RC, const float* __restrict__ RS) {
+    const float* __restrict__ RC, const float* __restrict__ RS, int prerot) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -599,14 +609,15 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     lse_q = LSE[(int64_t)bh * L + qpos_l];
   }
   if (!MULTI) {
-    att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, 0, row_stride, row_stride, tid, RC, RS, true, false);
+    att_stage_two_pad<HD, 512, true, false>(Ks, Vs, K + base, V + base, L, 0, row_stride, row_stride, tid, RC, RS, !prerot, false);
     __syncthreads();
     if (!active) return;                           // no workgroup barrier below this point
   }
   if (active) {
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
-      if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
+      if (prerot) {}                                // (q, k come rotated: only dq / dk are rotated back at the store)
+      else if (pre) qf[t] = rr.rot(qf[t], t, 1.f);
       else if (RC) qf[t] = att_rot(qf[t], RC, RS, qpos, 4 * t + 2 * lh, HD / 2, 1.f);
       dpart += (of_[t].x * gf[t].x + of_[t].y * gf[t].y) + (of_[t].z * gf[t].z + of_[t].w * gf[t].w);
     }
@@ -623,7 +634,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     if (MULTI) {
       if (c) __syncthreads();
       att_stage_pad_call<HD, false>(Ks, Vs, K + base + (int64_t)row0 * row_stride, V + base + (int64_t)row0 * row_stride,
-                                    nrows, row0, row_stride, row_stride, tid, RC, RS);
+                                    nrows, row0, row_stride, row_stride, tid, RC, RS, !prerot);
       __syncthreads();
       if (!active) continue;
     }
@@ -683,7 +694,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Delta,
     float* __restrict__ dK, float* __restrict__ dV, int H, int L, int64_t row_stride,
     int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
-    const float* __restrict__ RC, const float* __restrict__ RS) {
+    const float* __restrict__ RC, const float* __restrict__ RS, int prerot) {
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int LDP = ATT_LDP;
@@ -727,7 +738,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     }
   }
   if (!MULTI) {
-    att_stage_two_pad<HD, 512, true, true>(Qs, Gs, Q + base, dO + obase, L, 0, row_stride, o_row_stride, tid, RC, RS, true,
+    att_stage_two_pad<HD, 512, true, true>(Qs, Gs, Q + base, dO + obase, L, 0, row_stride, o_row_stride, tid, RC, RS, !prerot,
                                            false);
     for (int q = tid; q < L; q += 512) {
       lse_s[q] = LSE[(int64_t)bh * L + q] * 1.4426950408889634f;
@@ -739,7 +750,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   if (active) {
 #pragma unroll
     for (int t = 0; t < NT8; ++t) {
-      if (pre) kf[t] = rr.rot(kf[t], t, 1.f);
+      if (prerot) {}
+      else if (pre) kf[t] = rr.rot(kf[t], t, 1.f);
       else if (RC) kf[t] = att_rot(kf[t], RC, RS, kpos, 4 * t + 2 * lh, HD / 2, 1.f);
     }
   }
@@ -752,7 +764,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     if (MULTI) {
       if (c != c_first) __syncthreads();
       att_stage_pad_call<HD, true>(Qs, Gs, Q + base + (int64_t)row0 * row_stride, dO + obase + (int64_t)row0 * o_row_stride,
-                                   nrows, row0, row_stride, o_row_stride, tid, RC, RS);
+                                   nrows, row0, row_stride, o_row_stride, tid, RC, RS, !prerot);
       for (int q = tid; q < nrows; q += 512) {
         lse_s[q] = LSE[(int64_t)bh * L + row0 + q] * 1.4426950408889634f;
         delta_s[q] = Delta[(int64_t)bh * L + row0 + q];
@@ -833,13 +845,13 @@ extern "C" int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L) {
   return (int64_t)B * H * L * 4;
 }
 
-extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
-                                     const float* d_o, const float* lse, float* dq, float* dk,
-                                     float* dv, int B, int H, int L, int head_dim,
-                                     int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
-                                     int64_t o_batch_stride, int causal,
-                                     const float* rope_cos, const float* rope_sin, void* workspace,
-                                     int64_t workspace_bytes, void* stream) {
+static int att_bwd_impl(const float* q, const float* k, const float* v, const float* o,
+                        const float* d_o, const float* lse, float* dq, float* dk,
+                        float* dv, int B, int H, int L, int head_dim,
+                        int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                        int64_t o_batch_stride, int causal,
+                        const float* rope_cos, const float* rope_sin, void* workspace,
+                        int64_t workspace_bytes, void* stream, int prerot) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
   PDN_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) &&
                     ((((uintptr_t)rope_cos | (uintptr_t)rope_sin) & 7) == 0),
@@ -875,17 +887,41 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
 #define ATT_BWD(HD_, M_)                                                                                               \
   hipLaunchKernelGGL((attention_bwd_dq_kernel<HD_, M_>), grid, dim3(512), (size_t)att_dq_lds_bytes(L, head_dim), st, q, k, v, \
                      o, d_o, lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,    \
-                     rope_cos, rope_sin);                                                                                 \
+                     rope_cos, rope_sin, prerot);                                                                         \
   PDN_LAUNCH_CHECK();                                                                                                     \
   hipLaunchKernelGGL((attention_bwd_dkv_kernel<HD_, M_>), grid, dim3(512), (size_t)pdn_attention_bwd_lds_bytes(L, head_dim),  \
                      st, q, k, v, d_o, lse, delta, dk, dv, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride,  \
-                     sq, causal, rope_cos, rope_sin);                                                                     \
+                     sq, causal, rope_cos, rope_sin, prerot);                                                             \
   PDN_LAUNCH_CHECK();
   const bool multi = L > ATT_CHUNK;
   if (head_dim == 48) { if (multi) { ATT_BWD(48, true) } else { ATT_BWD(48, false) } }
   else { if (multi) { ATT_BWD(64, true) } else { ATT_BWD(64, false) } }
 #undef ATT_BWD
   return PDN_OK;
+}
+
+extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float* v, const float* o,
+                                     const float* d_o, const float* lse, float* dq, float* dk,
+                                     float* dv, int B, int H, int L, int head_dim,
+                                     int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                                     int64_t o_batch_stride, int causal,
+                                     const float* rope_cos, const float* rope_sin, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
+  return att_bwd_impl(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
+                      o_batch_stride, causal, rope_cos, rope_sin, workspace, workspace_bytes, stream, 0);
+}
+// q and k are given ALREADY ROTATED (the q | k | v projection applied RoPE in its epilogue, pdn_qkv_rope_fwd_f32);
+// dq and dk are still rotated back to the un-rotated projections' gradients as they are stored.
+extern "C" int pdn_attention_bwd_rotated_f32(const float* q, const float* k, const float* v, const float* o,
+                                             const float* d_o, const float* lse, float* dq, float* dk,
+                                             float* dv, int B, int H, int L, int head_dim,
+                                             int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                                             int64_t o_batch_stride, int causal,
+                                             const float* rope_cos, const float* rope_sin, void* workspace,
+                                             int64_t workspace_bytes, void* stream) {
+  PDN_CHECK_ARG(rope_cos && rope_sin, "pdn_attention_bwd_rotated_f32: the rope tables are required");
+  return att_bwd_impl(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
+                      o_batch_stride, causal, rope_cos, rope_sin, workspace, workspace_bytes, stream, 1);
 }
 
 // ======================================================================================

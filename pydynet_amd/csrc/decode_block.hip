@@ -321,6 +321,26 @@ extern "C" int pdn_decode_block_supported(int D, int H, int head_dim, int n_rang
          (n_ranges + 1) * H <= 256;
 }
 
+// LDS bytes of one decode_block workgroup: the residual row, the staging region and the scores of ONE key range
+// (ceil(max_len / n_ranges) positions) -- the range count must be high enough for the cache length, whatever the position.
+static int64_t dec_block_lds(int D, int head_dim, int NS, int max_len, int* scf_out) {
+  const int C = D % 16 == 0 ? 4 : (D % 12 == 0 ? 3 : (D % 8 == 0 ? 2 : 1));
+  const int f4 = head_dim / 4, SL = 256 / f4, groups = SL, G = 256 / (D / 4), nqd = D / C / 4, Go = 256 / nqd;
+  const int chunk = (max_len + NS - 1) / NS;
+  int scf = chunk;                                                  // scores | partial sums | projection partials
+  if ((groups + 8) * head_dim > scf) scf = (groups + 8) * head_dim;
+  if (Go * nqd * 4 > scf) scf = Go * nqd * 4;
+  const int scr = G * D > 3 * SL * head_dim ? G * D : 3 * SL * head_dim;
+  if (scf_out) *scf_out = scf;
+  return (int64_t)sizeof(float) * ((int64_t)D + scr + scf);
+}
+// 0 when the shape is not taken at all; otherwise the LDS bytes a launch with `n_ranges` key ranges over a cache of
+// `max_len` positions needs (it runs when that is <= 64 KiB)
+extern "C" int64_t pdn_decode_block_lds_bytes(int D, int H, int head_dim, int n_ranges, int max_len) {
+  if (n_ranges < 1 || max_len < 1 || !pdn_decode_block_supported(D, H, head_dim, n_ranges)) return 0;
+  return dec_block_lds(D, head_dim, n_ranges, max_len, nullptr);
+}
+
 // base (B, D) rows + parts (B, n_parts, D) plain records of the previous feed-forward (n_parts = 0: none) = x, written
 // to x_out; Wqkv: three (D, D) matrices (in, out) w_block_stride floats apart, rows w_row_stride apart; cos / sin
 // tables (max_len, head_dim / 2); caches (B, max_len, H, head_dim) with cache_batch_stride between sequences; Wo (D, D).
@@ -357,14 +377,13 @@ extern "C" int pdn_decode_block_f32(const float* base, int64_t base_row_stride, 
   // copies per (role, head), each with D / C columns of Wo (measured flat between 1 and 4 at D = 288: kept at the
   // count that keeps a workgroup's share of Wo small)
   const int C = D % 16 == 0 ? 4 : (D % 12 == 0 ? 3 : (D % 8 == 0 ? 2 : 1));
-  const int f4 = head_dim / 4, SL = 256 / f4, groups = SL, G = 256 / (D / 4), nqd = D / C / 4, Go = 256 / nqd;
-  const int chunk = (max_len + NS - 1) / NS;
-  int scf = chunk;                                                  // scores | partial sums | projection partials
-  if ((groups + 8) * head_dim > scf) scf = (groups + 8) * head_dim;
-  if (Go * nqd * 4 > scf) scf = Go * nqd * 4;
-  const int scr = G * D > 3 * SL * head_dim ? G * D : 3 * SL * head_dim;
-  const size_t shm = sizeof(float) * ((size_t)D + scr + scf);
-  PDN_CHECK_ARG(shm <= 64 * 1024, "pdn_decode_block_f32: max_len = %d too long for %d ranges", max_len, NS);
+  const int f4 = head_dim / 4, SL = 256 / f4, G = 256 / (D / 4), nqd = D / C / 4, Go = 256 / nqd;
+  int scf = 0;
+  const size_t shm = (size_t)dec_block_lds(D, head_dim, NS, max_len, &scf);
+  if (shm > 64 * 1024) {        // (a valid request this build does not take: callers fall back, pdn_decode_block_lds_bytes says so beforehand)
+    pdn_set_error("pdn_decode_block_f32: max_len = %d too long for %d ranges", max_len, NS);
+    return PDN_EUNSUPPORTED;
+  }
   const dim3 grid(B * H * (NS + 1) * C);
   hipStream_t st = (hipStream_t)stream;
   const float inv_sqrt = 1.f / sqrtf((float)head_dim);

@@ -1044,6 +1044,24 @@ static bool g_prof_on = false;
 struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel, 3: output-resident kernel, 4: its weight-gradient (TN) form
 static std::vector<ProfRec> g_prof;
 
+// for the fused-epilogue entry points of the other GEMM files: time a launch under a family when profiling is on
+// (token = index + 1 of the open record, 0 when profiling is off)
+int pdn_gemm_prof_begin(int family, double flops, void* stream) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on) return 0;
+  ProfRec rec;
+  if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return 0;
+  rec.flops = flops; rec.family = family;
+  (void)hipEventRecord(rec.e0, (hipStream_t)stream);
+  g_prof.push_back(rec);
+  return (int)g_prof.size();
+}
+void pdn_gemm_prof_end(int token, void* stream) {
+  if (!token) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (token <= (int)g_prof.size()) (void)hipEventRecord(g_prof[token - 1].e1, (hipStream_t)stream);
+}
+
 extern "C" int pdn_gemm_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   g_prof_on = on != 0;

@@ -39,6 +39,15 @@ struct RowResParams {
   int chunks, chunks_per_wg;      // 96-column chunks of N in total / per workgroup (grid.y)
   int cpb;                        // chunks per column block of B (B may come as several equally spaced
   int64_t b_bstride;              // matrices side by side: Wq | Wk | Wv); `chunks` when B is one matrix
+  // ---- fused epilogues (EPI != 0, see below) ----
+  float* H;                       // EPI 1: silu(gate) * up, (M x F), leading dimension ldh
+  const float* GU;                // EPI 2: the saved [gate | up] rows (M x 2F, leading dimension ldc) of the forward
+  const float2* rope;             // EPI 3: (L x hd) table of (cos, -+sin) per column of a head (rr_rope_table)
+  int64_t ldh;
+  int F;                          // EPI 1 / 2: FFN width (columns per half of the packed buffer)
+  int L, hd, rope_chunks;         // EPI 3: positions per sequence, head dim, chunks (of 96 columns) that are rotated
+  unsigned hd_magic;              //        2^32 / hd rounded up (x / hd = umulhi(x, magic) for x < 2^16)
+  unsigned g_off, u_off;          // EPI 1: first float of the gate / up matrix relative to B
 };
 
 __device__ __forceinline__ void rr_glds16(const float* g, float* l) {
@@ -95,19 +104,190 @@ __device__ __forceinline__ void rr_store(const RowResParams& p, f32x16 (&acc)[3]
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused epilogues (round 4): the bandwidth passes the reference composes as separate nodes next to a projection
+// ride in the store of the accumulator block instead of being a read + write of the whole activation.
+//   EPI 1  gate | up projection with SwiGLU (llm/llama/model.py:56-58, nn/functional.py:39-40): the 96-column chunks
+//          of a workgroup walk the two weight matrices in TILE pairs -- chunk 2p = (gate a, up a, gate b), chunk
+//          2p + 1 = (up b, gate c, up c) with a, b, c the three 32-column tiles 3p .. 3p + 2 of the FFN width -- so
+//          that gate and up of the same columns meet in the registers of one lane: h = silu(g) u leaves with the
+//          packed [gate | up] rows (kept for the backward); only tile `gate b` waits one chunk, parked in 4 KiB of
+//          LDS per wave.  NN form, 8-wave workgroups.
+//   EPI 2  dh = dy W_down^T with the SwiGLU gradient: the accumulator block is dh for 96 hidden units; the saved
+//          gate / up values of the same positions are read (lane = column: 128-byte row segments) and
+//          d[gate | up] is what leaves -- dh never exists in memory.  NT form.
+//   EPI 3  q | k | v projection with RoPE (model.py:23-44) on the q and k column blocks: lane = column, so the
+//          interleaved pair (2i, 2i + 1) is the neighbour lane (one DPP quad permute); (cos, -+sin) of the lane's
+//          column come from an expanded (L x hd) table.  The attention kernels then read rotated rows as they are.
+__device__ __forceinline__ float rr_sigmoid(float g) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * g));
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void rr_store_swiglu(const RowResParams& p, f32x16 (&acc)[3], int m0, int c, int li, int lh,
+                                                float* __restrict__ park) {
+  const int pr = c >> 1, odd = c & 1, F = p.F;
+  float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + 96 * pr;
+  float* __restrict__ Hw = p.H + (int64_t)m0 * p.ldh + 96 * pr;
+  const unsigned ldc = (unsigned)p.ldc, ldh = (unsigned)p.ldh;
+  unsigned o = (unsigned)(4 * lh) * ldc + li, oh = (unsigned)(4 * lh) * ldh + li;
+  asm volatile("" : "+v"(o), "+v"(oh));
+  const int mrem = p.M - m0 - 4 * lh;
+  if (!odd) {                                       // tiles: gate a | up a | gate b
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        const float g = acc[0][r], u = acc[1][r], g2 = acc[2][r];
+        park[r * 64] = g2;
+        if (!GUARD || 8 * q + e < mrem) {
+          Cw[o] = g; Cw[o + F] = u; Cw[o + 32] = g2;
+          Hw[oh] = g * rr_sigmoid(g) * u;
+        }
+        o += (e == 3) ? 5 * ldc : ldc; oh += (e == 3) ? 5 * ldh : ldh;
+      }
+    }
+  } else {                                          // tiles: up b | gate c | up c
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * q + e;
+        const float ub = acc[0][r], g = acc[1][r], u = acc[2][r];
+        const float gb = park[r * 64];
+        if (!GUARD || 8 * q + e < mrem) {
+          Cw[o + F + 32] = ub; Cw[o + 64] = g; Cw[o + F + 64] = u;
+          Hw[oh + 32] = gb * rr_sigmoid(gb) * ub;
+          Hw[oh + 64] = g * rr_sigmoid(g) * u;
+        }
+        o += (e == 3) ? 5 * ldc : ldc; oh += (e == 3) ? 5 * ldh : ldh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void rr_store_swiglu_bwd(const RowResParams& p, f32x16 (&acc)[3], int m0, int c, int li, int lh) {
+  const int F = p.F;
+  float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + c * RR_NC;
+  const float* __restrict__ Gw = p.GU + (int64_t)m0 * p.ldc + c * RR_NC;
+  const unsigned ldc = (unsigned)p.ldc;
+  const int mrem = p.M - m0 - 4 * lh;
+  // half a tile (8 rows of 32 columns) at a time: 16 loads in flight, then 16 stores -- what the registers beside
+  // the A block and the accumulators allow
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      unsigned o = (unsigned)(4 * lh + 16 * hf) * ldc + li + 32 * j;
+      asm volatile("" : "+v"(o));
+      float gv[8], uv[8];
+      {
+        unsigned oo = o;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const bool ok = !GUARD || 16 * hf + 8 * (r >> 2) + (r & 3) < mrem;
+          gv[r] = ok ? Gw[oo] : 0.f;
+          uv[r] = ok ? Gw[oo + F] : 0.f;
+          oo += ((r & 3) == 3) ? 5 * ldc : ldc;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float g = gv[r], s = rr_sigmoid(g), sl = g * s, dh = acc[j][8 * hf + r];
+        const float dsl = fmaf(sl, 1.f - s, s);       // silu'(g) = s (1 + g (1 - s))
+        if (!GUARD || 16 * hf + 8 * (r >> 2) + (r & 3) < mrem) {
+          Cw[o] = dh * uv[r] * dsl;
+          Cw[o + F] = dh * sl;
+        }
+        o += ((r & 3) == 3) ? 5 * ldc : ldc;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
+// the neighbour lane's value (lane ^ 1): DPP quad_perm [1, 0, 3, 2]
+__device__ __forceinline__ float rr_pair(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+}
+
+template <bool GUARD>
+__device__ __forceinline__ void rr_store_rope(const RowResParams& p, f32x16 (&acc)[3], int m0, int c, int li, int lh) {
+  float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + c * RR_NC;
+  const unsigned ldc = (unsigned)p.ldc, hd = (unsigned)p.hd;
+  const int mrem = p.M - m0 - 4 * lh;
+  const bool rot = c < p.rope_chunks;               // (uniform)
+  const float2* __restrict__ tab = p.rope + (int64_t)(m0 % p.L) * p.hd;      // the 32 rows of a wave lie in one sequence
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (rot) {
+      // column inside its head: (96 c + 32 j + li) mod hd with the uniform part reduced by a multiply-high (hd >= 32)
+      const unsigned x0 = (unsigned)__builtin_amdgcn_readfirstlane(c * RR_NC + 32 * j);
+      const unsigned b0 = x0 - hd * __umulhi(x0, p.hd_magic);
+      unsigned colh = b0 + (unsigned)li;
+      colh = colh >= hd ? colh - hd : colh;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {              // half a tile at a time: 8 table entries (16 registers) in flight
+        unsigned o = (unsigned)(4 * lh + 16 * hf) * ldc + li + 32 * j;
+        unsigned ot = (unsigned)(4 * lh + 16 * hf) * hd + colh;
+        asm volatile("" : "+v"(o), "+v"(ot));
+        float2 cs[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float2 t = tab[ot];
+          cs[r].x = t.x; cs[r].y = t.y;
+          ot += ((r & 3) == 3) ? 5 * hd : hd;
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const float v = acc[j][8 * hf + r];
+          const float w = fmaf(v, cs[r].x, rr_pair(v) * cs[r].y);
+          if (!GUARD || 16 * hf + 8 * (r >> 2) + (r & 3) < mrem) Cw[o] = w;
+          o += ((r & 3) == 3) ? 5 * ldc : ldc;
+        }
+      }
+    } else {
+      unsigned o = (unsigned)(4 * lh) * ldc + li + 32 * j;
+      asm volatile("" : "+v"(o));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (!GUARD || 8 * (r >> 2) + (r & 3) < mrem) Cw[o] = acc[j][r];
+        o += ((r & 3) == 3) ? 5 * ldc : ldc;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
 // KG = K / 8.  BT: B is given as the row-major (N x K) matrix whose transpose is meant.
 // ABLATE (timing experiments only, 0 in the library): 2 = no B DMA after the first two pieces,
 // 32 = the DMA of a piece issued as one burst.
 // NW: waves per workgroup (4: two workgroups per CU; 8: one -- half the DMA instructions per wave).
 // STAGE: the B piece reaches LDS by LDS-DMA (0) or through registers, global_load_dwordx4 + ds_write_b128 (1):
 // an LDS-DMA instruction holds up the issuing wave's MFMA stream for 50-170 cycles, a plain load far less.
-template <int KG, bool BT, int NW, int STAGE, int ABLATE = 0>
+// EPI: fused epilogue (0 none, 1 SwiGLU forward, 2 SwiGLU backward, 3 RoPE on the leading chunks), see above.
+template <int KG, bool BT, int NW, int STAGE, int ABLATE = 0, int EPI = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(RowResParams p) {
+  static_assert(EPI != 1 || (!BT && NW == 8), "SwiGLU forward epilogue: NN form, one 8-wave workgroup per CU");
+  static_assert(EPI != 2 || BT, "SwiGLU backward epilogue: NT form");
   constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
   constexpr int NPK = KG / 12;                    // pieces along K
   constexpr int PIECE = RR_KP * RR_NC;            // floats
   static_assert(KG % 12 == 0, "K must be a multiple of 96");
-  __shared__ __attribute__((aligned(16))) float smem[2 * PIECE];
+  __shared__ __attribute__((aligned(16))) float smem[2 * PIECE + (EPI == 1 ? NW * 1024 : 0)];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -120,6 +300,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   auto chunk_of = [&](int ci) { return c_begin + ci; };
   // first element of chunk c in B: column block c / cpb, 96-column (NN) or 96-row (NT) slice c % cpb of it
   auto chunk_base = [&](int c) -> const float* {
+    if (EPI == 1) return p.B;                       // (tile bases: see issue_one)
     const int blk = c / p.cpb, cin = c - blk * p.cpb;
     return p.B + blk * p.b_bstride + (BT ? (int64_t)(cin * RR_NC) * p.ldb : (int64_t)(cin * RR_NC));
   };
@@ -148,6 +329,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
     else cu &= cmask;
     return (unsigned)row * ldb + 4u * (unsigned)cu;
   };
+  // EPI 1: the three 32-column tiles of chunk c come from different places -- chunk 2p: gate tile 3p, up tile 3p,
+  // gate tile 3p + 1; chunk 2p + 1: up tile 3p + 1, gate tile 3p + 2, up tile 3p + 2 (up = gate + b_bstride floats)
+  auto lane_off_tiles = [&](int j, int c) -> unsigned {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int u = ln + 64 * j, row = u / 24, cu = u - 24 * row, t = cu >> 3;
+    // (gate / up offsets from p.B = the lower of the two addresses: the matrices may sit in either order)
+    const unsigned gt = p.g_off + 96u * (unsigned)(c >> 1), ut = p.u_off + 96u * (unsigned)(c >> 1);
+    const unsigned tb0 = (c & 1) ? ut + 32u : gt, tb1 = (c & 1) ? gt + 64u : ut, tb2 = (c & 1) ? ut + 64u : gt + 32u;
+    const unsigned tb = t == 0 ? tb0 : (t == 1 ? tb1 : tb2);
+    return (unsigned)row * ldb + tb + 4u * (unsigned)(cu & 7);
+  };
   // instruction q (0 .. NQ-1) of this wave's share of piece (chunk c, k-piece kc) into buffer `buf`
   // (I clamped: a repeated instruction is harmless)
   // STAGE 1: the wave's share of the next piece on its way to LDS, in two halves (fetched in the first / second
@@ -163,11 +356,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
     float* dst = smem + buf * PIECE + I * 256;
     const float* src = BT ? cb + (int64_t)(gks * 8) * p.ldb + kc * RR_KP
                           : cb + (int64_t)(kc * RR_KP + gk * 8) * p.ldb;
+    const unsigned loff = EPI == 1 ? lane_off_tiles(j, c) : lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31);
     if (STAGE) {
-      const float4 v = *reinterpret_cast<const float4*>(src + lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31));
+      const float4 v = *reinterpret_cast<const float4*>(src + loff);
       rb[q % RBN].x = v.x; rb[q % RBN].y = v.y; rb[q % RBN].z = v.z; rb[q % RBN].w = v.w;
     } else {
-      rr_glds16(src + lane_off(j, gk, tail ? 8 * nt_tail - 1 : 31), dst);
+      rr_glds16(src + loff, dst);
     }
   };
   auto park = [&](int buf, int half) {            // STAGE 1: registers -> LDS (unit 64 I + lane, linear: no conflicts)
@@ -317,7 +511,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       if (STAGE) park(nb, NPH - 1);                 // every wave is past this piece's barrier: that buffer is idle
     }
     // ---- store the finished 32 x 96 block of this wave -------------------------------------
-    rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
+    if constexpr (EPI == 1) {
+      float* park = smem + 2 * PIECE + wave * 1024 + lane;
+      if (full) rr_store_swiglu<false>(p, acc, m0, c, li, lh, park); else rr_store_swiglu<true>(p, acc, m0, c, li, lh, park);
+    } else if constexpr (EPI == 2) {
+      if (full) rr_store_swiglu_bwd<false>(p, acc, m0, c, li, lh); else rr_store_swiglu_bwd<true>(p, acc, m0, c, li, lh);
+    } else if constexpr (EPI == 3) {
+      if (full) rr_store_rope<false>(p, acc, m0, c, li, lh); else rr_store_rope<true>(p, acc, m0, c, li, lh);
+    } else {
+      rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
 }
@@ -331,9 +534,21 @@ extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64
 
 // B as `nblocks` matrices side by side (block b at B + b * b_block_stride floats; NN: each (K x N / nblocks),
 // NT: each (N / nblocks x K)); nblocks > 1 needs N / nblocks to be a multiple of 96.
+// `epi` (may be null): fused epilogue request, EPI of the kernel template + its operands.
+int pdn_gemm_prof_begin(int family, double flops, void* stream);    // csrc/gemm.hip: bench.py's per-family timing
+void pdn_gemm_prof_end(int token, void* stream);
+struct RowResEpi {
+  int kind;                 // 1 SwiGLU forward, 2 SwiGLU backward, 3 RoPE
+  float* H; int64_t ldh;    // 1
+  const float* GU;          // 2
+  int F;                    // 1, 2
+  const float* rope; int L, hd, rope_cols;   // 3
+  unsigned g_off = 0, u_off = 0;              // 1
+};
+
 static int rowres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M,
                          int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, int nblocks,
-                         int64_t b_block_stride, void* stream) {
+                         int64_t b_block_stride, void* stream, const RowResEpi* epi = nullptr) {
   if (M == 0 || N == 0) return PDN_OK;
   PDN_CHECK_ARG(A && B && C, "pdn_gemm_rowres_f32: null operand");
   const int nper = nblocks > 0 ? N / nblocks : 0;
@@ -346,6 +561,15 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_rowres_f32: 16-byte alignment required");
   RowResParams p{A, B, C, bias, residual, M, N, lda, ldb, ldc, (N + RR_NC - 1) / RR_NC, 0, 0, b_block_stride};
   p.cpb = nblocks > 1 ? nper / RR_NC : p.chunks;
+  p.H = nullptr; p.GU = nullptr; p.rope = nullptr; p.ldh = 0; p.F = 0; p.L = 1; p.hd = 1; p.rope_chunks = 0; p.hd_magic = 0; p.g_off = 0; p.u_off = 0;
+  const int kind = epi ? epi->kind : 0;
+  if (kind) {
+    p.H = epi->H; p.ldh = epi->ldh; p.GU = epi->GU; p.F = epi->F;
+    p.rope = reinterpret_cast<const float2*>(epi->rope); p.L = epi->L; p.hd = epi->hd;
+    p.rope_chunks = epi->rope_cols / RR_NC;
+    p.hd_magic = (unsigned)(((1ull << 32) + (unsigned)epi->hd - 1) / (unsigned)epi->hd);
+    p.g_off = epi->g_off; p.u_off = epi->u_off;
+  }
   hipStream_t st = (hipStream_t)stream;
   static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
   static const int nw_env = getenv("PDN_ROWRES_NW") ? atoi(getenv("PDN_ROWRES_NW")) : 0;
@@ -358,17 +582,24 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   // 74 / 83 / 85 % on the lm_head forward against 70 / 77 / 79 % for two 4-wave workgroups per CU, 1-4 points
   // on the layer projections: the threshold of round 2, 49152 rows, only looked at the row blocks)
   const int rb8 = (M + 255) / 256;
-  const int nw = nw_env ? nw_env : (rb8 >= 192 || (int64_t)rb8 * p.chunks >= 256) ? 8 : 4;
-  const int stage = stage_env >= 0 ? stage_env : (nw == 8 ? 1 : 0);
+  const int nw = kind ? 8 : nw_env ? nw_env : (rb8 >= 192 || (int64_t)rb8 * p.chunks >= 256) ? 8 : 4;
+  const int stage = kind ? 1 : stage_env >= 0 ? stage_env : (nw == 8 ? 1 : 0);
   const int row_blocks = (M + 32 * nw - 1) / (32 * nw), target = nw == 4 ? 512 : 256;
   // fill every CU (two 4-wave or one 8-wave workgroup each): split the chunks over grid.y
   int nsplit = 1;
   while (row_blocks * nsplit < target && nsplit < p.chunks) ++nsplit;
   p.chunks_per_wg = (p.chunks + nsplit - 1) / nsplit;
+  if (kind == 1) p.chunks_per_wg += p.chunks_per_wg & 1;       // gate / up tiles meet inside a PAIR of chunks
   nsplit = (p.chunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
   const dim3 grid(row_blocks, nsplit);
 #define RR_LAUNCH(BT_, NW_, AB_) if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 1, 0>), grid, dim3(NW_ * 64), 0, st, p); else hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 0, AB_>), grid, dim3(NW_ * 64), 0, st, p)
-  if (nw == 8) {
+  if (kind == 1) {
+    hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 1>), grid, dim3(512), 0, st, p);
+  } else if (kind == 2) {
+    hipLaunchKernelGGL((gemm_rowres_kernel<36, true, 8, 1, 0, 2>), grid, dim3(512), 0, st, p);
+  } else if (kind == 3) {
+    hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 3>), grid, dim3(512), 0, st, p);
+  } else if (nw == 8) {
     if (b_trans) RR_LAUNCH(true, 8, 0); else RR_LAUNCH(false, 8, 0);
   } else if (b_trans) {
     RR_LAUNCH(true, 4, 0);
@@ -380,6 +611,84 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     RR_LAUNCH(false, 4, 0);
   }
 #undef RR_LAUNCH
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+// ---- fused-epilogue entry points (include/pdn_hip.h) ------------------------------------------------------------
+// gu (M x 2F) = x (M x 288) [Wg | Wu]  and  h (M x F) = silu(gate) * up in the same launch.  Wg, Wu: (288 x F) row-major,
+// `w_stride` floats apart.  F a multiple of 96.
+extern "C" int pdn_gateup_swiglu_supported(int M, int F, int K) {
+  return (K == 288 && F % RR_NC == 0 && F >= RR_NC && M >= 1 && (int64_t)64 * F < (1ll << 29)) ? 1 : 0;
+}
+extern "C" int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, int64_t w_stride, float* gu, float* h, int M,
+                                         int F, int K, int64_t ldx, void* stream) {
+  if (M == 0 || F == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && w_gate && gu && h, "pdn_gateup_swiglu_fwd_f32: null operand");
+  const int64_t ws = w_stride < 0 ? -w_stride : w_stride;      // (the up matrix may sit below the gate matrix)
+  if (!pdn_gateup_swiglu_supported(M, F, K) || ws % 4 != 0 || ws < (int64_t)K * F || ws + (int64_t)K * F >= (1ll << 30)) {
+    pdn_set_error("pdn_gateup_swiglu_fwd_f32: unsupported shape M=%d F=%d K=%d (K 288, F a multiple of 96)", M, F, K);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{1, h, F, nullptr, F, nullptr, 1, 1, 0};
+  e.g_off = w_stride < 0 ? (unsigned)ws : 0u;
+  e.u_off = w_stride < 0 ? 0u : (unsigned)ws;
+  const float* wbase = w_stride < 0 ? w_gate + w_stride : w_gate;
+  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (2.0 * F) * K, stream);
+  const int rc = rowres_launch(x, wbase, gu, nullptr, nullptr, M, 2 * F, K, ldx, F, 2 * F, 0, 2, ws, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+// dgu (M x 2F) = SwiGLU'(gu) applied to dh = dy (M x 288) W_down^T, W_down (F x 288) row-major; dh is never written.
+extern "C" int pdn_swiglu_bwd_gemm_f32(const float* dy, const float* w_down, const float* gu, float* dgu, int M, int F, int K,
+                                       int64_t ldy, void* stream) {
+  if (M == 0 || F == 0) return PDN_OK;
+  PDN_CHECK_ARG(dy && w_down && gu && dgu, "pdn_swiglu_bwd_gemm_f32: null operand");
+  if (!pdn_gateup_swiglu_supported(M, F, K)) {
+    pdn_set_error("pdn_swiglu_bwd_gemm_f32: unsupported shape M=%d F=%d K=%d (K 288, F a multiple of 96)", M, F, K);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{2, nullptr, 0, gu, F, nullptr, 1, 1, 0};
+  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (double)F * K, stream);
+  const int rc = rowres_launch(dy, w_down, dgu, nullptr, nullptr, M, F, K, ldy, K, 2 * F, 1, 1, 0, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+// qkv (M x 3D) = x (M x 288) [Wq | Wk | Wv] with RoPE applied to the q and k column blocks: row m is position m % L,
+// `rope` the (L x hd x 2) table of pdn_rope_table_f32.  D a multiple of 96, hd even, L a multiple of 32.
+extern "C" int pdn_qkv_rope_supported(int M, int D, int K, int L, int hd) {
+  return (K == 288 && D % RR_NC == 0 && hd >= 32 && hd % 2 == 0 && D % hd == 0 && 3 * D < 65536 && L % 32 == 0 && L > 0 && M % L == 0) ? 1 : 0;
+}
+extern "C" int pdn_qkv_rope_fwd_f32(const float* x, const float* wq, int64_t w_stride, float* qkv, const float* rope, int M,
+                                    int D, int K, int L, int hd, int64_t ldx, void* stream) {
+  if (M == 0 || D == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && wq && qkv && rope && (((uintptr_t)rope & 7) == 0), "pdn_qkv_rope_fwd_f32: null / misaligned operand");
+  if (!pdn_qkv_rope_supported(M, D, K, L, hd) || w_stride % 4 != 0) {
+    pdn_set_error("pdn_qkv_rope_fwd_f32: unsupported shape M=%d D=%d K=%d L=%d hd=%d", M, D, K, L, hd);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{3, nullptr, 0, nullptr, 0, rope, L, hd, 2 * D};
+  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (3.0 * D) * K, stream);
+  const int rc = rowres_launch(x, wq, qkv, nullptr, nullptr, M, 3 * D, K, ldx, D, 3 * D, 0, 3, w_stride, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+
+// (L x hd x 2) table for the RoPE epilogue from the reference's (L x hd/2) cos / sin tables (llm/llama/model.py:13-20):
+// entry (pos, col) = (cos[pos][col / 2], col odd ? sin : -sin), so that out = v cos + pair(v) * entry.y
+__global__ void rr_rope_table_kernel(const float* __restrict__ cs, const float* __restrict__ sn, float2* __restrict__ out,
+                                     int total, int hd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int pos = i / hd, col = i - pos * hd;
+  const float c = cs[pos * (hd / 2) + (col >> 1)], s = sn[pos * (hd / 2) + (col >> 1)];
+  out[i] = make_float2(c, (col & 1) ? s : -s);
+}
+extern "C" int pdn_rope_table_f32(const float* cos_t, const float* sin_t, float* out, int L, int hd, void* stream) {
+  if (L == 0 || hd == 0) return PDN_OK;
+  PDN_CHECK_ARG(cos_t && sin_t && out && hd % 2 == 0 && (((uintptr_t)out & 7) == 0), "pdn_rope_table_f32: bad arguments");
+  hipLaunchKernelGGL(rr_rope_table_kernel, dim3((L * hd + 255) / 256), dim3(256), 0, (hipStream_t)stream, cos_t, sin_t,
+                     reinterpret_cast<float2*>(out), L * hd, hd);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -240,6 +240,12 @@ class DataParallel:
         cap = max(int(bucket_mb * (1 << 20) / 4), 1)
         self.buckets, start, first = [], 0, 0        # (elem_lo, elem_hi, param_lo, param_hi)
         for i, (off, n) in enumerate(zip(offs, sizes)):
+            # a parameter that fills a bucket by itself (the embedding table: 36.9 MB, and the LAST gradient of
+            # backward) reduces alone: what was collected before it -- layer 0's 2.6 MB -- goes out now instead of
+            # waiting for it (anything under 1/8 of a bucket rides along: not worth a message of its own)
+            if n >= cap and off - start >= cap // 8:
+                self.buckets.append((start, off, first, i))
+                start, first = off, i
             end = off + (n + 3) // 4 * 4
             if end - start >= cap or i == len(sizes) - 1:
                 self.buckets.append((start, end, first, i + 1))

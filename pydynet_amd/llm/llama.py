@@ -61,6 +61,9 @@ class FeedForward(nn.Module):
             w.data = buf[i]
 
     def forward(self, x, residual=None):
+        if fused.ffn_swiglu.applicable(x, self.gate.weight, self.up.weight, self.down.weight):
+            # the whole block as one node: SwiGLU forward / backward ride in the projections' epilogues
+            return fused.ffn_swiglu(x, self.gate.weight, self.up.weight, self.down.weight, residual)
         if fused.gate_up_swiglu.applicable(x, self.gate.weight, self.up.weight):
             h = fused.gate_up_swiglu(x, self.gate.weight, self.up.weight)
         else:
@@ -239,9 +242,19 @@ class Llama(nn.Module):
         from .. import hipnp as hp, _lib
         D, H, F, V = self.embed_dim, self.n_heads, self.ffn_dim, self.vocab_size
         st = getattr(self, "_decode_st", None)
-        a0 = self.layers[0].attention
-        key = (B, hp._state["device"], self.lm_head.weight.data._ptr, self.tok_embedding.weight.data._ptr,
-               a0.Q.weight.data._ptr, a0.cache_k.data._ptr)       # a captured step holds these addresses
+        # a captured step (and the stacked weight views) hold the address of EVERY array the launches read: the key
+        # covers them all -- rebinding `.data` of any parameter / cache re-plans -- and the switches that shape the plan
+        ptrs = [self.lm_head.weight.data._ptr, self.tok_embedding.weight.data._ptr, self.norm.weight.data._ptr,
+                self.freqs_cos.data._ptr, self.freqs_sin.data._ptr]
+        bias = getattr(self.lm_head, "bias", None)
+        ptrs.append(bias.data._ptr if bias is not None else 0)
+        for layer in self.layers:
+            a, f = layer.attention, layer.ffn
+            ptrs += [t.data._ptr for t in (a.Q.weight, a.K.weight, a.V.weight, a.O.weight, a.cache_k, a.cache_v,
+                                            f.gate.weight, f.up.weight, f.down.weight, layer.input_norm.weight,
+                                            layer.post_attn_norm.weight)]
+        key = (B, hp._state["device"], int(Llama.fused_decode or 0), os.environ.get("PDN_DECODE_SPLITS", ""),
+               self.layers[0].attention.cache_k.shape[1], hash(tuple(ptrs)))
         if st is not None and st["key"] == key:
             return st if st["ok"] else None
         if st is not None:
@@ -290,6 +303,17 @@ class Llama(nn.Module):
             st["ns_max"] = ns if os.environ.get("PDN_DECODE_SPLITS") else min(7, max(1, -(-(cache_len - 1) // 256)))
             if st["block"] and not _lib.lib().query("pdn_decode_block_supported", D, H, D // H, st["ns_max"]):
                 st["ns_max"] = ns
+            # a workgroup of the block kernel holds the scores of ceil(cache_len / ranges) positions in LDS whatever the
+            # position: `ns_min` = the fewest ranges a cache of this length allows (long caches start above one range);
+            # none up to ns_max -> the three-launch path
+            st["ns_min"] = 1
+            if st["block"]:
+                fits = [n for n in range(1, st["ns_max"] + 1)
+                        if 0 < _lib.lib().query("pdn_decode_block_lds_bytes", D, H, D // H, n, cache_len) <= 64 * 1024]
+                if fits:
+                    st["ns_min"] = fits[0]
+                else:
+                    st["block"] = False
             if st["fused"]:
                 st.update(J=J, recs=hp.empty((B, (max(ns, st["ns_max"]) + 1) * H * (4 + D)), np.float32), dparts=hp.empty((B, J * D), np.float32),
                           xa=hp.empty((B, D), np.float32), xb=hp.empty((B, D), np.float32))
@@ -299,9 +323,11 @@ class Llama(nn.Module):
 
     def _decode_ns(self, st, pos):
         """Key ranges per head for the step at position `pos`."""
-        if not st.get("block") or os.environ.get("PDN_DECODE_SPLITS"):
+        if not st.get("block"):
             return st["ns"]
-        return min(st["ns_max"], max(1, -(-pos // 256)))
+        if os.environ.get("PDN_DECODE_SPLITS"):
+            return max(st["ns"], st.get("ns_min", 1))
+        return min(st["ns_max"], max(st.get("ns_min", 1), -(-pos // 256)))
 
     def _decode_launches(self, st, ns=None):
         """The launches of one decode step (2 per layer + 2; 3 or 5 per layer at lower `fused_decode` levels); every argument is fixed for the lifetime of `st` (the position
@@ -432,7 +458,12 @@ class Llama(nn.Module):
             # capture once: hipnp.Graph runs the step twice for real (pool warm-up + first replay), which writes the
             # cache rows of positions pos and pos + 1 with exactly what the real steps will write there; the
             # position and the ids are then put back and the real step replayed
+            # The pick kernel of those two runs stores its tokens into the history: it is pointed at a SCRATCH
+            # history meanwhile, so that slots pos / pos + 1 of the real one stay "not written" (-1) until the real
+            # steps store there (a later step with other ids would otherwise read the capture's token as its own).
             keep = st["ids"].copy()
+            scratch = hp.Mailbox(cache.shape[1], (B, 1))
+            st["hist_ptr"][...] = np.int64(scratch._ptr)
             try:
                 g = hp.Graph()
                 g.capture(lambda: self._decode_launches(st, ns))
@@ -441,6 +472,8 @@ class Llama(nn.Module):
                 if e.code != -2:                                 # PDN_EUNSUPPORTED: no graph support (the emulated
                     raise                                        # ABI) -> plain launches; anything else is a bug
                 st["nograph"], g = True, False
+            hp.synchronize()                                     # the capture's runs are done with the scratch history
+            st["hist_ptr"][...] = np.int64(st["hist"]._ptr)
             st["pos"][...] = np.int32(pos)
             st["ids"][...] = keep
             self._decode_gather(st)

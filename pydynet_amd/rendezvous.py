@@ -45,6 +45,29 @@ def _recv_exact(conn, n):
     return buf
 
 
+def _bind_host(addr: str, world: int) -> str:
+    """The address rank 0 listens on: MASTER_ADDR, unless it resolves to loopback HERE while the job spans nodes.
+    (A container's /etc/hosts often maps its own hostname to 127.0.1.1: rank 0 would then listen on loopback only
+    while the other nodes resolve the same name to the real address and get `connection refused`.)  In that case --
+    and when the name does not resolve, or PDN_RDZV_BIND_ALL=1 -- all interfaces; the job-token handshake keeps
+    strangers out."""
+    if os.environ.get("PDN_RDZV_BIND_ALL") == "1":
+        return ""
+    try:
+        ips = {info[4][0] for info in socket.getaddrinfo(addr, None, socket.AF_INET)}
+    except (socket.gaierror, UnicodeError):
+        return ""
+    try:
+        local = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        nnodes = int(os.environ.get("GROUP_WORLD_SIZE", os.environ.get("NNODES", "1")))
+    except ValueError:
+        local, nnodes = world, 1
+    spans_nodes = local < world or nnodes > 1
+    if spans_nodes and ips and all(ip.startswith("127.") for ip in ips):
+        return ""
+    return addr
+
+
 def broadcast_bytes(payload: bytes | None, rank: int, world: int, timeout: float = 600.0) -> bytes:
     """Rank 0 passes `payload`; every rank returns rank 0's payload.  Blocks until all `world - 1`
     peers have fetched it (rank 0) or until it is received (others); raises TimeoutError."""
@@ -63,7 +86,7 @@ def broadcast_bytes(payload: bytes | None, rank: int, world: int, timeout: float
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
                 try:
-                    s.bind((addr, base + off))          # MASTER_ADDR when it is one of this host's addresses
+                    s.bind((_bind_host(addr, world), base + off))   # MASTER_ADDR when it is one of this host's addresses
                 except OSError as e:
                     import errno
                     if e.errno != errno.EADDRNOTAVAIL and not isinstance(e, socket.gaierror):

@@ -118,12 +118,17 @@ class EmulatedLib:
     def pdn_stream_destroy(self, s): return 0
     def pdn_stream_wait_event(self, s, e): return 0
     def pdn_event_create(self, out, timing): return self._handle(out)
-    def pdn_event_record(self, e, s): return 0
+    def pdn_event_record(self, e, s):
+        import time
+        self.__dict__.setdefault("_etimes", {})[getattr(e, "value", e)] = time.perf_counter()   # the host clock stands in
+        return 0
     def pdn_event_synchronize(self, e): return 0
     def pdn_event_destroy(self, e): return 0
 
     def pdn_event_elapsed_ms(self, a, b, out):
-        ctypes.cast(out, ctypes.POINTER(ctypes.c_float))[0] = 0.0
+        t = self.__dict__.get("_etimes", {})
+        ms = 1e3 * (t.get(getattr(b, "value", b), 0.0) - t.get(getattr(a, "value", a), 0.0))
+        ctypes.cast(out, ctypes.POINTER(ctypes.c_float))[0] = max(ms, 1e-6)
         return 0
 
     # hipGraph capture has no host counterpart: the emulated library refuses it (tests are GPU-only)
@@ -213,6 +218,69 @@ class EmulatedLib:
         if residual:
             r = r + view(residual, (M, N), (ldc, 1), np.float32)
         view(C, (M, N), (ldc, 1), np.float32)[...] = r
+        return 0
+
+    # -- projections with a fused epilogue (csrc/gemm_rowres.hip, round 4) ----------------------------------
+    def pdn_gateup_swiglu_supported(self, M, F, K):
+        return int(K == 288 and F % 96 == 0 and F >= 96 and M >= 1 and 64 * F < (1 << 29))
+
+    def pdn_gateup_swiglu_fwd_f32(self, x, wg, w_stride, gu, h, M, F, K, ldx, stream):
+        if M == 0 or F == 0:
+            return 0
+        if not self.pdn_gateup_swiglu_supported(M, F, K) or w_stride % 4 or abs(w_stride) < K * F:
+            return -2
+        a = view(x, (M, K), (ldx, 1), np.float32)
+        g = np.matmul(a, view(wg, (K, F), (F, 1), np.float32))
+        u = np.matmul(a, view(int(wg) + 4 * w_stride, (K, F), (F, 1), np.float32))      # (either order in memory)
+        out = flat(gu, M * 2 * F).reshape(M, 2 * F)
+        out[:, :F], out[:, F:] = g, u
+        flat(h, M * F).reshape(M, F)[...] = g / (1 + np.exp(-g)) * u
+        return 0
+
+    def pdn_swiglu_bwd_gemm_f32(self, dy, wd, gu, dgu, M, F, K, ldy, stream):
+        if M == 0 or F == 0:
+            return 0
+        if not self.pdn_gateup_swiglu_supported(M, F, K):
+            return -2
+        d = np.matmul(view(dy, (M, K), (ldy, 1), np.float32), flat(wd, F * K).reshape(F, K).T)
+        a = np.array(flat(gu, M * 2 * F).reshape(M, 2 * F))
+        g, u = a[:, :F], a[:, F:]
+        sg = 1 / (1 + np.exp(-g))
+        out = flat(dgu, M * 2 * F).reshape(M, 2 * F)
+        out[:, :F] = d * u * sg * (1 + g * (1 - sg))
+        out[:, F:] = d * g * sg
+        return 0
+
+    def pdn_qkv_rope_supported(self, M, D, K, L, hd):
+        return int(K == 288 and D % 96 == 0 and hd >= 32 and hd % 2 == 0 and D % hd == 0 and 3 * D < 65536
+                   and L % 32 == 0 and L > 0 and M % L == 0)
+
+    def pdn_rope_table_f32(self, cos, sin, out, L, hd, stream):
+        c = flat(cos, L * hd // 2).reshape(L, hd // 2)
+        s = flat(sin, L * hd // 2).reshape(L, hd // 2)
+        t = flat(out, L * hd * 2).reshape(L, hd, 2)
+        t[:, :, 0] = np.repeat(c, 2, axis=1)
+        t[:, 0::2, 1] = -s
+        t[:, 1::2, 1] = s
+        return 0
+
+    def pdn_qkv_rope_fwd_f32(self, x, wq, w_stride, qkv, rope, M, D, K, L, hd, ldx, stream):
+        if M == 0 or D == 0:
+            return 0
+        if not self.pdn_qkv_rope_supported(M, D, K, L, hd) or w_stride % 4:
+            return -2
+        a = view(x, (M, K), (ldx, 1), np.float32)
+        w = [view(int(wq) + 4 * i * w_stride, (K, D), (D, 1), np.float32) for i in range(3)]
+        t = flat(rope, L * hd * 2).reshape(L, hd, 2)
+        out = flat(qkv, M * 3 * D).reshape(M, 3 * D)
+        pos = np.arange(M) % L
+        for i in range(3):
+            y = np.matmul(a, w[i])
+            if i < 2:                               # out = v cos + pair(v) * (-+sin): the table's second entry
+                yh = y.reshape(M, D // hd, hd)
+                pair = yh.reshape(M, D // hd, hd // 2, 2)[..., ::-1].reshape(M, D // hd, hd)
+                y = (yh * t[pos, None, :, 0] + pair * t[pos, None, :, 1]).reshape(M, D)
+            out[:, i * D:(i + 1) * D] = y
         return 0
 
     def pdn_gemm_outres_supported(self, M, N, K, lda, ldb, ldc, b_trans):
@@ -561,6 +629,20 @@ class EmulatedLib:
         DK[...] = self._rot(np.matmul(ds.swapaxes(-1, -2), Q), rc, rsn, L, hd, -1.0)
         return 0
 
+    def pdn_attention_bwd_rotated_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn,
+                                      ws, wsb, stream):
+        """q, k already rotated: nothing rotated on the way in, dq / dk rotated back on the way out."""
+        if not self.pdn_attention_supported(L, hd):
+            return -2
+        rc2 = self.pdn_attention_bwd_f32(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, None, None,
+                                         ws, wsb, stream)
+        if rc2:
+            return rc2
+        DQ, DK = self._att_views([dq, dk], B, H, L, hd, rs, bs)
+        DQ[...] = self._rot(np.array(DQ), rc, rsn, L, hd, -1.0)
+        DK[...] = self._rot(np.array(DK), rc, rsn, L, hd, -1.0)
+        return 0
+
     # -- general streaming attention -----------------------------------------------------------------
     def pdn_attention_stream_supported(self, hd): return 1 if hd in (16, 24, 32, 48, 64, 96, 128) else 0
     def pdn_attention_stream_bwd_workspace_bytes(self, B, H, Lq): return 4 * B * H * Lq
@@ -720,10 +802,19 @@ class EmulatedLib:
     def pdn_decode_block_supported(self, D, H, hd, ns):
         return int(hd in (48, 64) and H > 0 and D == H * hd and D <= 1024 and 1 <= ns <= 7 and (ns + 1) * H <= 256)
 
+    def pdn_decode_block_lds_bytes(self, D, H, hd, ns, max_len):
+        if ns < 1 or max_len < 1 or not self.pdn_decode_block_supported(D, H, hd, ns):
+            return 0
+        C = 4 if D % 16 == 0 else (3 if D % 12 == 0 else (2 if D % 8 == 0 else 1))
+        SL, G, nqd = 256 // (hd // 4), 256 // (D // 4), D // C // 4
+        Go = 256 // nqd
+        scf = max(-(-max_len // ns), (SL + 8) * hd, Go * nqd * 4)
+        return 4 * (D + max(G * D, 3 * SL * hd) + scf)
+
     def pdn_decode_block_f32(self, base, base_rs, parts, n_parts, parts_rs, x_out, x_out_rs, norm_w, eps, Wqkv, w_rs, w_bs,
                              cos, sin, kc, vc, cbs, pos, max_len, Wo, wo_rs, recs, B, H, hd, NS, stream):
         D, half = H * hd, hd // 2
-        if not self.pdn_decode_block_supported(D, H, hd, NS):
+        if not self.pdn_decode_block_supported(D, H, hd, NS) or self.pdn_decode_block_lds_bytes(D, H, hd, NS, max_len) > 65536:
             return -2
         if B > 8:
             return -1

@@ -350,17 +350,32 @@ def check_mlp_lenet_three_steps(dev):
         X, y = T(d[f"{name}_X"], dev), pdn.Tensor(d[f"{name}_y"], dtype=np.int64, device=dev)
         opt = Adam(net.parameters(), lr=1e-4)
         losses = []
-        for s in range(3):
-            loss = F.cross_entropy_loss(net(X), y)
-            opt.zero_grad(); loss.backward(); opt.step()
-            losses.append(loss.item())
-            if s == 0:
-                for n, p in net.named_parameters():
-                    g = float(np.linalg.norm(host(p.grad).astype(np.float64)))
-                    ref = float(d[f"{name}_gnorm/{n}"])
-                    assert abs(g - ref) <= RT * ref + 1e-9, (name, n, g, ref)
-                    if f"{name}_grad1/{n}" in d.files:
-                        close(p.grad, d[f"{name}_grad1/{n}"], RT, 1e-7)
+        # the path the golden is meant to pin: on a HIP device LeNet's conv -> relu -> max_pool(2, 2) chains must run as
+        # the ONE fused node (conv + bias + relu + pool epilogue, hit-map backward), counted by its forward launches
+        from pydynet_amd.core import fused
+        taken = []
+        crp_fwd = fused.conv2d_relu_pool.forward_
+
+        def spy(node, *a):
+            taken.append(type(node).__name__)
+            return crp_fwd(node, *a)
+        fused.conv2d_relu_pool.forward_ = spy
+        try:
+            for s in range(3):
+                loss = F.cross_entropy_loss(net(X), y)
+                opt.zero_grad(); loss.backward(); opt.step()
+                losses.append(loss.item())
+                if s == 0:
+                    for n, p in net.named_parameters():
+                        g = float(np.linalg.norm(host(p.grad).astype(np.float64)))
+                        ref = float(d[f"{name}_gnorm/{n}"])
+                        assert abs(g - ref) <= RT * ref + 1e-9, (name, n, g, ref)
+                        if f"{name}_grad1/{n}" in d.files:
+                            close(p.grad, d[f"{name}_grad1/{n}"], RT, 1e-7)
+        finally:
+            fused.conv2d_relu_pool.forward_ = crp_fwd
+        if name == "lenet" and dev != "cpu":
+            assert taken == ["conv2d_relu_pool"] * 6, f"LeNet did not take the fused conv -> relu -> pool node: {taken}"
         close(np.array(losses), d[f"{name}_losses"], RT, 0)
 
 

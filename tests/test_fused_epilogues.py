@@ -1,0 +1,246 @@
+"""Projections with the bandwidth pass next to them folded into the accumulator store (csrc/gemm_rowres.hip, round 4):
+
+* `pdn_gateup_swiglu_fwd_f32`  -- x [Wg | Wu] with h = silu(gate) * up written beside [gate | up]
+  (llm/llama/model.py:56-58, nn/functional.py:39-40),
+* `pdn_swiglu_bwd_gemm_f32`    -- d[gate | up] straight from dy W_down^T, dh never stored,
+* `pdn_qkv_rope_fwd_f32`       -- x [Wq | Wk | Wv] with RoPE on the q, k blocks (model.py:23-44, 93-104),
+* `pdn_attention_bwd_rotated_f32` -- the attention backward for q, k that arrive rotated,
+
+each against a float64 NumPy statement of the reference lines, and the tape nodes built on them (`fused.ffn_swiglu`,
+`fused.qkv_attention` with the rotated projection) against the same modules with the epilogues switched off.
+Tolerance 1e-4 relative to the tensor's largest entry (north_star).  Runs on the emulated C ABI and (-m gpu) on MI355X.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import pydynet_amd as pdn
+from pydynet_amd.core import fused
+from pydynet_amd.core.tensor import Graph
+from tests.conftest import device_variants
+
+RT = 1e-4
+
+
+def host(x):
+    return x.numpy() if isinstance(x, pdn.Tensor) else (x if isinstance(x, np.ndarray) else x.get())
+
+
+def close(a, b, what, rt=RT):
+    a, b = np.asarray(host(a), np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(np.abs(b).max()), 1e-30)
+    err = float(np.abs(a - b).max())
+    assert err <= 1e-7 + rt * scale, (what, err, scale)
+
+
+def _lib_hp():
+    from pydynet_amd import _lib, hipnp
+    return _lib.lib(), hipnp
+
+
+def _silu(g):
+    return g / (1 + np.exp(-g))
+
+
+def _stack(hp, mats):
+    """`mats` (equal shapes) in one buffer, equally spaced: (views, stride in floats)."""
+    buf = hp.empty((len(mats),) + mats[0].shape, np.float32)
+    views = []
+    for i, m in enumerate(mats):
+        buf[i] = hp.from_numpy(m)
+        views.append(buf[i])
+    return buf, views, int(np.prod(mats[0].shape))
+
+
+# ---- kernel level ------------------------------------------------------------------------------------------------
+def _gateup_case(M, F, seed, up_first=False):
+    L, hp = _lib_hp()
+    K = 288
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    wg = (0.08 * rng.standard_normal((K, F))).astype(np.float32)
+    wu = (0.08 * rng.standard_normal((K, F))).astype(np.float32)
+    assert L.query("pdn_gateup_swiglu_supported", M, F, K)
+    if up_first:                      # the up matrix BELOW the gate matrix in memory (how two parameters created
+        buf, (du, dg), stride = _stack(hp, [wu, wg])         # up-first happen to be laid out): negative stride
+        stride = -stride
+    else:
+        buf, (dg, du), stride = _stack(hp, [wg, wu])
+    xd = hp.from_numpy(x)
+    gu, h = hp.empty((M, 2 * F), np.float32), hp.empty((M, F), np.float32)
+    L.call("pdn_gateup_swiglu_fwd_f32", xd._ptr, dg._ptr, stride, gu._ptr, h._ptr, M, F, K, K, hp.stream())
+    g64, u64 = x.astype(np.float64) @ wg, x.astype(np.float64) @ wu
+    close(gu.get()[:, :F], g64, "gate")
+    close(gu.get()[:, F:], u64, "up")
+    close(h, _silu(g64) * u64, "h = silu(gate) * up")
+    # backward half: dgu from dy W_down^T and the saved gate | up
+    wd = (0.08 * rng.standard_normal((F, K))).astype(np.float32)
+    dy = rng.standard_normal((M, K)).astype(np.float32)
+    dgu = hp.empty((M, 2 * F), np.float32)
+    dyd, wdd = hp.from_numpy(dy), hp.from_numpy(wd)          # (named: a temporary's buffer is freed before the call)
+    L.call("pdn_swiglu_bwd_gemm_f32", dyd._ptr, wdd._ptr, gu._ptr, dgu._ptr, M, F, K, K, hp.stream())
+    gs, us = gu.get()[:, :F].astype(np.float64), gu.get()[:, F:].astype(np.float64)
+    dh = dy.astype(np.float64) @ wd.astype(np.float64).T
+    s = 1 / (1 + np.exp(-gs))
+    close(dgu.get()[:, :F], dh * us * s * (1 + gs * (1 - s)), "d gate")
+    close(dgu.get()[:, F:], dh * gs * s, "d up")
+
+
+def check_gateup_swiglu_full_blocks(dev):
+    _gateup_case(512, 192, 0)
+
+
+def check_gateup_swiglu_ragged_rows_ffn768(dev):
+    _gateup_case(300, 768, 1)             # 300 rows: the last wave is partly, the one after it wholly outside M
+
+
+def check_gateup_swiglu_up_matrix_first_in_memory(dev):
+    _gateup_case(256, 96, 7, up_first=True)
+
+
+def _rope_ref(y, cos, sin, L, hd):
+    """model.py:23-44 on (M, D) rows at positions m % L, interleaved pairs."""
+    M, D = y.shape
+    pos = np.arange(M) % L
+    yh = y.reshape(M, D // hd, hd // 2, 2)
+    c, s = cos[pos][:, None, :], sin[pos][:, None, :]
+    out = np.empty_like(yh)
+    out[..., 0] = yh[..., 0] * c - yh[..., 1] * s
+    out[..., 1] = yh[..., 0] * s + yh[..., 1] * c
+    return out.reshape(M, D)
+
+
+def _tables(L, hd):
+    inv = 1.0 / (10000 ** (np.arange(0, hd, 2)[: hd // 2] / hd))
+    fr = np.outer(np.arange(L), inv)
+    return np.cos(fr).astype(np.float32), np.sin(fr).astype(np.float32)
+
+
+def _qkv_rope_case(B, Lq, hd, seed):
+    L, hp = _lib_hp()
+    K = D = 288
+    M = B * Lq
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    ws = [(0.08 * rng.standard_normal((K, D))).astype(np.float32) for _ in range(3)]
+    cos, sin = _tables(Lq, hd)
+    assert L.query("pdn_qkv_rope_supported", M, D, K, Lq, hd)
+    buf, views, stride = _stack(hp, ws)
+    tab = hp.empty((Lq, hd, 2), np.float32)
+    cd, sd, xd = hp.from_numpy(cos), hp.from_numpy(sin), hp.from_numpy(x)
+    L.call("pdn_rope_table_f32", cd._ptr, sd._ptr, tab._ptr, Lq, hd, hp.stream())
+    t = tab.get()
+    assert np.array_equal(t[:, 0::2, 0], cos) and np.array_equal(t[:, 1::2, 0], cos)
+    assert np.array_equal(t[:, 0::2, 1], -sin) and np.array_equal(t[:, 1::2, 1], sin)
+    qkv = hp.empty((M, 3 * D), np.float32)
+    L.call("pdn_qkv_rope_fwd_f32", xd._ptr, views[0]._ptr, stride, qkv._ptr, tab._ptr, M, D, K, Lq, hd, K, hp.stream())
+    got = qkv.get()
+    x64 = x.astype(np.float64)
+    c64, s64 = cos.astype(np.float64), sin.astype(np.float64)
+    close(got[:, :D], _rope_ref(x64 @ ws[0], c64, s64, Lq, hd), "rotated q")
+    close(got[:, D:2 * D], _rope_ref(x64 @ ws[1], c64, s64, Lq, hd), "rotated k")
+    close(got[:, 2 * D:], x64 @ ws[2], "v (not rotated)")
+
+
+def check_qkv_rope_hd48(dev):
+    _qkv_rope_case(4, 64, 48, 2)
+
+
+def check_qkv_rope_hd96_ragged_tail(dev):
+    _qkv_rope_case(3, 32, 96, 3)          # 96 rows: waves past the end of M
+
+
+def check_attention_bwd_rotated_equals_plain(dev):
+    """Rotating q, k first and calling the `rotated` backward = the backward that rotates inside."""
+    L, hp = _lib_hp()
+    B, H, Lq, hd = 2, 6, 64, 48
+    D = H * hd
+    rng = np.random.default_rng(4)
+    qkv = rng.standard_normal((B * Lq, 3 * D)).astype(np.float32)
+    do = rng.standard_normal((B, Lq, H, hd)).astype(np.float32)
+    cos, sin = _tables(Lq, hd)
+    cd, sd = hp.from_numpy(cos), hp.from_numpy(sin)
+    rot = qkv.copy()
+    rot[:, :D] = _rope_ref(qkv[:, :D].astype(np.float64), cos, sin, Lq, hd)
+    rot[:, D:2 * D] = _rope_ref(qkv[:, D:2 * D].astype(np.float64), cos, sin, Lq, hd)
+    res = []
+    for data, fwd_rope, name in ((qkv, True, "pdn_attention_bwd_f32"), (rot, False, "pdn_attention_bwd_rotated_f32")):
+        a = hp.from_numpy(data)
+        o, lse = hp.empty((B, Lq, H, hd), np.float32), hp.empty((B, H, Lq), np.float32)
+        q, k, v = a._ptr, a._ptr + 4 * D, a._ptr + 8 * D
+        L.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, B, H, Lq, hd, 3 * D, Lq * 3 * D, D, Lq * D, 1,
+               cd._ptr if fwd_rope else None, sd._ptr if fwd_rope else None, hp.stream())
+        d = hp.empty((B * Lq, 3 * D), np.float32)
+        dod = hp.from_numpy(do)
+        ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
+        L.call(name, q, k, v, o._ptr, dod._ptr, lse._ptr, d._ptr, d._ptr + 4 * D, d._ptr + 8 * D, B, H, Lq,
+               hd, 3 * D, Lq * 3 * D, D, Lq * D, 1, cd._ptr, sd._ptr, ws, wsb, hp.stream())
+        res.append((o.get(), d.get()))
+    close(res[1][0], res[0][0], "o")
+    close(res[1][1], res[0][1], "dq | dk | dv", 2e-5)
+
+
+# ---- node level: one Llama block with the epilogues on / off --------------------------------------------------------
+def _block_step(dev, epilogues):
+    from pydynet_amd.llm.llama import Llama
+    saved = (fused.ffn_swiglu.enabled, fused.ffn_swiglu.epilogue_min_rows, fused.qkv_attention.rope_epilogue,
+             fused.qkv_attention.rope_min_rows)
+    fused.ffn_swiglu.enabled = epilogues
+    fused.ffn_swiglu.epilogue_min_rows = 32
+    fused.qkv_attention.rope_epilogue = epilogues
+    fused.qkv_attention.rope_min_rows = 32
+    try:
+        Graph.clear()
+        np.random.seed(5)
+        V, D, H, F, Lq, B = 64, 288, 6, 192, 64, 2
+        model = Llama(V, D, H, F, Lq, B, 2, np.float32)
+        rng = np.random.default_rng(6)
+        model.tok_embedding.weight.data[...] = (0.5 * rng.standard_normal((V, D))).astype(np.float32)
+        model.to(dev)
+        ids = rng.integers(0, V, (B, Lq))
+        tgt = rng.integers(0, V, (B, Lq))
+        made = {"ffn": 0, "ffn_epi": 0, "rot": 0}
+        ffn_init, qkv_fwd = fused.ffn_swiglu.forward_, fused.qkv_attention.forward_
+
+        def ffn_spy(self, *a):
+            out = ffn_init(self, *a)
+            made["ffn"] += 1
+            made["ffn_epi"] += bool(self.used_epilogue)
+            return out
+
+        def qkv_spy(self, *a):
+            out = qkv_fwd(self, *a)
+            made["rot"] += bool(self.rotated)
+            return out
+
+        fused.ffn_swiglu.forward_, fused.qkv_attention.forward_ = ffn_spy, qkv_spy
+        try:
+            loss = model.loss(ids, tgt)
+            loss.backward()
+        finally:
+            fused.ffn_swiglu.forward_, fused.qkv_attention.forward_ = ffn_init, qkv_fwd
+        grads = {n: host(p.grad) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+        return float(host(loss)), grads, made
+    finally:
+        (fused.ffn_swiglu.enabled, fused.ffn_swiglu.epilogue_min_rows, fused.qkv_attention.rope_epilogue,
+         fused.qkv_attention.rope_min_rows) = saved
+
+
+def check_llama_block_epilogues_vs_separate_kernels(dev):
+    l1, g1, m1 = _block_step(dev, True)
+    l0, g0, m0 = _block_step(dev, False)
+    assert m1 == {"ffn": 2, "ffn_epi": 2, "rot": 2}, m1     # both layers took the epilogue kernels
+    assert m0 == {"ffn": 0, "ffn_epi": 0, "rot": 0}, m0
+    assert abs(l1 - l0) <= RT * abs(l0), (l1, l0)
+    assert g1.keys() == g0.keys() and len(g1) >= 20
+    for n in g0:
+        close(g1[n], g0[n], f"grad {n}")
+
+
+for _fn in [check_gateup_swiglu_full_blocks, check_gateup_swiglu_ragged_rows_ffn768,
+            check_gateup_swiglu_up_matrix_first_in_memory, check_qkv_rope_hd48,
+            check_qkv_rope_hd96_ragged_tail, check_attention_bwd_rotated_equals_plain,
+            check_llama_block_epilogues_vs_separate_kernels]:
+    device_variants(globals(), _fn)

@@ -1,13 +1,24 @@
 """Training attention beyond 256 positions and at head dim 64 on the resident kernels (csrc/attention.hip: K / V --
 or Q / dO -- of a head pass through LDS in 256-row chunks, the forward carries (m, l, O) across chunks with one online
-rescale).  The reference's model allows max_seq_len 1024 (llm/llama/finetune.py:44, model.py:176-181).  A small Llama
-is trained one step on the "cpu" device -- the NumPy composition pinned to the reference by tests/test_llama_golden.py
--- and on the HIP device; loss and every gradient must agree to the north-star tolerance, and the step must have gone
-through the fused qkv_attention node on the RESIDENT kernels (not the streaming ones).  Runs on the real MI355X
-(-m gpu) and on the emulated C ABI."""
+rescale).  The reference's model allows max_seq_len 1024 (llm/llama/finetune.py:44, model.py:176-181).
+
+Pinned to the REAL reference (round 4): `tests/golden/long_attention.npz` holds the loss and every gradient of one
+training step of a one-layer Llama at L = 512 / hd 48 (two 256-key chunks) and L = 352 / hd 64 (ragged second chunk),
+produced by `tools/gen_golden_r2.py long_attention` importing /root/reference (llm/llama/model.py:23-44, 95-121,
+226-252).  The same seeded model is stepped here on the "cpu" device, on the emulated C ABI and (-m gpu) on the real
+MI355X; on the HIP devices the step must have gone through the fused qkv_attention node on the RESIDENT kernels (not
+the streaming ones)."""
+import os
+
 import numpy as np
 
 from tests.conftest import device_variants
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+CASES = {  # tag: V, D, H, F, L, B, seed -- tools/gen_golden_r2.py LONG_CASES
+    "seq512_hd48": (64, 96, 2, 128, 512, 2, 5),
+    "seq352_hd64": (64, 128, 2, 160, 352, 1, 6),
+}
 
 
 def _step(dev, V, D, H, F_, L, B, seed):
@@ -28,8 +39,10 @@ def _step(dev, V, D, H, F_, L, B, seed):
                                 for n, p in m.named_parameters()}
 
 
-def _check(dev, V, D, H, F_, L, B, seed):
+def _check(dev, tag):
     from pydynet_amd.core import fused
+    V, D, H, F_, L, B, seed = CASES[tag]
+    ref = np.load(os.path.join(G, "long_attention.npz"))
     kinds = []
     orig = fused.qkv_attention.forward_
 
@@ -42,21 +55,33 @@ def _check(dev, V, D, H, F_, L, B, seed):
         loss, grads = _step(dev, V, D, H, F_, L, B, seed)
     finally:
         fused.qkv_attention.forward_ = orig
-    assert kinds and all(kinds), "the step did not take the fused qkv_attention node on the resident kernels"
-    ref_loss, ref = _step("cpu", V, D, H, F_, L, B, seed)
+    if dev != "cpu":
+        assert kinds and all(kinds), "the step did not take the fused qkv_attention node on the resident kernels"
+    ref_loss = float(ref[f"{tag}/loss"])
     assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
-    for n, g in grads.items():
-        scale = max(float(np.abs(ref[n]).max()), 1e-30)
-        err = float(np.abs(g.astype(np.float64) - ref[n]).max())
+    names = [k[len(tag) + 6:] for k in ref.files if k.startswith(tag + "/grad/")]
+    assert sorted(names) == sorted(grads), (sorted(names), sorted(grads))
+    for n in names:
+        r = ref[f"{tag}/grad/{n}"]
+        scale = max(float(np.abs(r).max()), 1e-30)
+        err = float(np.abs(grads[n].astype(np.float64) - r).max())
         assert err <= 1e-4 * scale + 1e-7, (n, err, scale)
 
 
 def check_llama_step_seq512_hd48(dev):
-    _check(dev, 64, 96, 2, 128, 512, 2, 5)          # two 256-key chunks
+    _check(dev, "seq512_hd48")          # two 256-key chunks
 
 
 def check_llama_step_seq352_hd64(dev):
-    _check(dev, 64, 128, 2, 160, 352, 1, 6)         # head dim 64, ragged second chunk (11 tiles)
+    _check(dev, "seq352_hd64")          # head dim 64, ragged second chunk (11 tiles)
+
+
+def test_llama_step_seq512_hd48_cpu():
+    _check("cpu", "seq512_hd48")
+
+
+def test_llama_step_seq352_hd64_cpu():
+    _check("cpu", "seq352_hd64")
 
 
 for _f in (check_llama_step_seq512_hd48, check_llama_step_seq352_hd64):

@@ -13,6 +13,10 @@ reference's source.  Fixtures written here:
                       `save_finetuned_parameters` output (llm/llama/io.py:8-57)
     clip_blocks.npz   llm/clip/model.py:35-80,83-113: biased MHA (hd = 64, with and without the
                       causal mask), last-axis LayerNorm, quick-GELU MLP, one Transformer block
+    long_attention.npz   one training step (loss + all gradients) at L = 512 / hd 48 and L = 352 / hd 64: the chunked
+                      resident attention kernels against llm/llama/model.py:95-121 (finetune.py:44 allows 1024)
+    generate_full.json   64 greedy tokens of the FULL-width model (V 32000, D 288, 6 layers): ids + four scalars of
+                      every step's logits row (model.py:254-269)
     ops_r2.npz        split / vsplit / hsplit / dsplit (function.py:14-166) incl. gradients,
                       nll_loss (functional.py:353-361), float16 operator cases
                       (tests/test_tensor_basic.py:16,80-81)
@@ -281,8 +285,76 @@ def gen_ops_r2():
     print("ops_r2", len(d), "arrays")
 
 
+LONG_CASES = {  # tag: V, D, H, F, L, B, seed  (tests/test_long_sequence_attention.py builds the same models)
+    "seq512_hd48": (64, 96, 2, 128, 512, 2, 5),
+    "seq352_hd64": (64, 128, 2, 160, 352, 1, 6),
+}
+
+
+def gen_long_attention():
+    """One training step (loss + every gradient) of a one-layer Llama beyond 256 positions / at head dim 64 on the REAL
+    reference: pins the chunked resident attention kernels (round 3) to llm/llama/model.py:23-44, 95-121, 226-252
+    (the reference's own max_seq_len is 1024, finetune.py:44)."""
+    from llm.llama.model import Llama
+    d = {}
+    for tag, (V, D, H, Ff, L, B, seed) in LONG_CASES.items():
+        fresh()
+        np.random.seed(seed)
+        m = Llama(V, D, H, Ff, L, B, 1, np.float32)
+        m.tok_embedding.weight.data[...] = (0.05 * np.random.randn(V, D)).astype(np.float32)
+        rng = np.random.default_rng(seed)
+        ids, tgt = rng.integers(0, V, (B, L)), rng.integers(0, V, (B, L))
+        m.train(True)
+        logits = m.forward_logits(ids)
+        loss = F.cross_entropy_loss(logits.reshape(B * L, V), pdn.Tensor(tgt.reshape(-1), dtype=np.int64))
+        loss.backward()
+        d[f"{tag}/loss"] = np.array(float(loss.item()))
+        for n, p in m._parameters.items():
+            if p.requires_grad:
+                d[f"{tag}/grad/{n}"] = np.asarray(p.grad, np.float32).copy()
+        print("long attention", tag, float(loss.item()), len([k for k in d if k.startswith(tag + "/grad/")]), "gradients")
+    np.savez_compressed(os.path.join(OUT, "long_attention.npz"), **d)
+
+
+GEN_FULL = dict(V=32000, D=288, H=6, F=768, layers=6, max_seq=128, seed=0, prompt_len=8, total=72)
+
+
+def gen_generate_full():
+    """The reference's greedy KV-cache `generate` (llm/llama/model.py:105-110, 254-269; the loop infer.py:46-63 times)
+    at the FULL benchmark width: 64 new tokens; per step the token id and four scalars of the logits row (max, sum, l2
+    norm, top-2 margin) -- scalars only, no arrays of the 32000-wide rows."""
+    import json
+    from llm.llama.model import Llama
+    c = GEN_FULL
+    fresh()
+    np.random.seed(c["seed"])
+    m = Llama(c["V"], c["D"], c["H"], c["F"], c["max_seq"], 1, c["layers"], np.float32)
+    m.tok_embedding.weight.data[...] = (0.5 * np.random.randn(c["V"], c["D"])).astype(np.float32)
+    m.lm_head.weight.data[...] = (0.5 * np.random.randn(c["D"], c["V"])).astype(np.float32)     # argmax margins >> fp32 noise
+    prompt = np.random.randint(0, c["V"], (1, c["prompt_len"]))
+    m.eval()
+    rows = []
+    orig_forward = m.forward
+
+    def rec(input_ids, start_pos, _f=orig_forward):
+        out = _f(input_ids, start_pos)
+        r = out.data[0, -1].astype(np.float64)
+        top2 = np.sort(r)[-2:]
+        rows.append([float(r.max()), float(r.sum()), float(np.linalg.norm(r)), float(top2[1] - top2[0])])
+        return out
+    m.forward = rec
+    with pdn.no_grad():
+        toks = [int(t.data[0, 0]) for t in m.generate(prompt, c["total"])]
+    pdn.autograd.set_grad_enabled(True)
+    out = {"config": c, "prompt": prompt[0].tolist(), "tokens": toks, "logit_max": [r[0] for r in rows],
+           "logit_sum": [r[1] for r in rows], "logit_l2": [r[2] for r in rows], "top2_margin": [r[3] for r in rows]}
+    json.dump(out, open(os.path.join(OUT, "generate_full.json"), "w"), indent=1)
+    print("generate full:", len(toks), "tokens", toks[:8], "min top-2 margin", min(out["top2_margin"]),
+          "logit scale", max(out["logit_max"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fused_llama", "generate", "llama_io", "clip_blocks", "ops_r2"]
+    which = sys.argv[1:] or ["fused_llama", "generate", "llama_io", "clip_blocks", "ops_r2", "long_attention", "generate_full"]
     for w in which:
         globals()["gen_" + w]()
     for f in sorted(os.listdir(OUT)):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4, stage A: fused epilogues + persistent attention forward -- tests, probe, same-box A/B of the bench
+R=$PWD; O=$R/gpurun_out/stage_a; mkdir -p $O; rm -f $O/ab.txt
+timeout 600 python -m pytest tests/test_fused_epilogues.py tests/test_kernels_gpu.py -m gpu -q -x 2>&1 | tail -15 > $O/tests_epi.txt; cat $O/tests_epi.txt
+timeout 300 python tools/epilogue_probe.py > $O/probe.txt 2>&1; cat $O/probe.txt
+PDN_ATT_NO_PERSIST=1 timeout 300 python tools/epilogue_probe.py 2>&1 | grep attention
+line() { python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('$1', round(d['value'],1), round(d['ms_per_step'],3), d['final_loss'], d['batch_gate']['worst_grad_rel_err'] if d.get('batch_gate') else None, round(r['frac'],3), round(r['all_gemm']['frac'],3))"; }
+for i in 1 2; do
+  python bench.py --no-cpu-baseline 2>$O/err_new.txt | line new >> $O/ab.txt
+  PDN_NO_SWIGLU_EPILOGUE=1 PDN_NO_ROPE_EPILOGUE=1 python bench.py --no-cpu-baseline 2>$O/err_old.txt | line no_epilogues >> $O/ab.txt
+  PDN_ATT_NO_PERSIST=1 python bench.py --no-cpu-baseline 2>/dev/null | line new_no_persist >> $O/ab.txt
+  PDN_NO_ROPE_EPILOGUE=1 python bench.py --no-cpu-baseline 2>/dev/null | line swiglu_only >> $O/ab.txt
+done
+cat $O/ab.txt; tail -5 $O/err_new.txt
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 > $O/tests_all.txt; cat $O/tests_all.txt
