@@ -446,6 +446,11 @@ def main():
     if not args.no_gemm_prof:
         ms2, fl2, n2 = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
         lib.call("pdn_gemm_prof_enable", 0)
+        # the projections with a bandwidth pass folded into their store (SwiGLU forward / backward, RoPE) first: they
+        # are reported apart -- FLOPs against the MFMA peak AND algorithmic bytes against HBM -- so that the plain
+        # row-resident family stays comparable from round to round
+        fms, ffl, fby, fn = ctypes.c_double(), ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        lib.call("pdn_gemm_prof_collect_fused", ctypes.byref(fms), ctypes.byref(ffl), ctypes.byref(fby), ctypes.byref(fn))
         lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
         tf = lambda f, m: f / (m * 1e-3) / 1e12 if m > 0 else 0.0
         peak = PEAK_FP32_MFMA / 1e12
@@ -469,8 +474,18 @@ def main():
                 "time_share_of_step": f0["time_share_of_step"],
                 "algorithmic_flop_per_launch": f0["algorithmic_flop_per_launch"],
                 "other_gemm_families": {n: fams[n] for n in names if n != dom},
-                "all_gemm": {"achieved": tf(sum(fl2), sum(ms2)), "frac": tf(sum(fl2), sum(ms2)) / peak,
-                             "time_share_of_step": sum(ms2) * 1e-3 / dt},
+                "fused_epilogue_gemms": None if fn.value == 0 else {
+                    "what": "gemm_rowres_kernel<EPI>: gate|up + SwiGLU forward, dh + SwiGLU backward, q|k|v + RoPE "
+                            "(the elementwise pass rides in the accumulator store; swiglu_rows_* kernels are gone)",
+                    "launches": fn.value, "avg_launch_us": 1e3 * fms.value / fn.value,
+                    "achieved": tf(ffl.value, fms.value), "frac": tf(ffl.value, fms.value) / peak, "unit": "TFLOP/s",
+                    "hbm_achieved_GBps": fby.value / (fms.value * 1e-3) / 1e9,
+                    "hbm_frac": fby.value / (fms.value * 1e-3) / 8e12,
+                    "algorithmic_bytes_per_launch": fby.value / fn.value,
+                    "time_share_of_step": fms.value * 1e-3 / dt},
+                "all_gemm": {"achieved": tf(sum(fl2) + ffl.value, sum(ms2) + fms.value),
+                             "frac": tf(sum(fl2) + ffl.value, sum(ms2) + fms.value) / peak,
+                             "time_share_of_step": (sum(ms2) + fms.value) * 1e-3 / dt},
                 "traffic_source": traffic.get("_source"), "traffic_source_sha12": traffic.get("_sha12"),
                 "traffic_stale": traffic.get("_stale")}
         roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic) if rank == 0 else None

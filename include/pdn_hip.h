@@ -182,6 +182,10 @@ int pdn_gemm_prof_collect(double* total_ms, double* total_flops, int64_t* launch
  * [4] gemm_outres_tn_kernel (weight gradients out of the model width, incl. the fused lm_head one);
  * each argument points to FIVE values */
 int pdn_gemm_prof_collect_families(double* ms5, double* flops5, int64_t* launches5);
+/* the row-resident launches with a fused epilogue (SwiGLU forward / backward, RoPE), timed apart: total milliseconds,
+ * FLOPs, algorithmic HBM bytes (operands read + results written once) and launch count; removes their records -- if it
+ * is not called first, pdn_gemm_prof_collect_families counts them with the row-resident family */
+int pdn_gemm_prof_collect_fused(double* ms, double* flops, double* bytes, int64_t* launches);
 
 /* ---- broadcasting elementwise: + - * / ** maximum minimum, comparisons
  * (tensor.py:548,564,591,612,634,811,820; 289-316).  mode 0: a op b, 1: a op scalar,
@@ -194,6 +198,9 @@ int pdn_ew_binary(int dtype, int op, int mode, int ndim, const int64_t* shape, c
 int pdn_ew_unary(int dtype, int op, int ndim, const int64_t* shape, const void* a,
                  const int64_t* sa, void* out, const int64_t* so, void* stream);
 /* ndarray.astype / .copy() / `view[...] = array` (tensor.py:168-177, 279) */
+/* dst (cols x rows, leading dimension ld_dst) = src (rows x cols, leading dimension ld_src) transposed, through LDS
+ * tiles (keeps lm_head.weight^T row-major for the NT form of the vocabulary projection, llm/llama/model.py:179) */
+int pdn_transpose2d_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, void* stream);
 int pdn_cast(int src_dtype, int dst_dtype, int ndim, const int64_t* shape, const void* a,
              const int64_t* sa, void* out, const int64_t* so, void* stream);
 /* xp.zeros / xp.ones / `grad[...] = 0.` (tensor.py:90,355,380-383) */

@@ -477,6 +477,11 @@ int pdn_attention_p_fwd(const float* q, const float* k, const float* v, float* o
                         int head_dim, int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
                         int64_t o_batch_stride, int causal, void* stream);
 
+int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                        float* dq, float* dk, float* dv, int B, int H, int L, int head_dim, int64_t row_stride,
+                        int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
+                        const float* rope_cos, const float* rope_sin, float* delta, void* stream);
+
 static bool att_shape_ok(int L, int head_dim) {
   return (head_dim == 48 || head_dim == 64) && L % 32 == 0 && L >= 32 && L <= ATT_MAX_L;
 }
@@ -871,6 +876,12 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
     return PDN_EWORKSPACE;
   }
   float* delta = (float*)workspace;
+  // operands that need no rotation on the way in (never rotated, or rotated by the projection's epilogue) at the
+  // benchmark shape class: the persistent, DMA-staged kernels (csrc/attention_p.hip); dq / dk are rotated back there
+  // when the tables are given
+  if ((prerot || !rope_cos) && pdn_attention_p_supported(L, head_dim))
+    return pdn_attention_p_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
+                               o_batch_stride, causal, rope_cos, rope_sin, delta, stream);
   static bool attr_set = false;
   if (!attr_set) {
 #define ATT_ATTR(K_) PDN_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))

@@ -25,9 +25,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define AP_ROWS 256
 
+// 64 lanes x 16 bytes from HBM straight into LDS (lane i lands at `l` + 16 i; `l` wave-uniform).  Inline asm on purpose:
+// behind the builtin, hipcc (ROCm 7.2) treats every later LDS read it cannot prove disjoint as dependent on the DMA
+// and puts `s_waitcnt vmcnt(0)` in front of it -- the prefetched image was waited for at the first tile of the phase
+// it was meant to hide behind.  The landing of an image is ordered by hand instead (ap_landed + ap_barrier).
 __device__ __forceinline__ void ap_glds16(const float* g, float* l) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+  const unsigned a = (unsigned)(unsigned long)((__attribute__((address_space(3))) void*)l);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(a), "v"(g) : "memory");
 }
 __device__ __forceinline__ int ap_krow(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 __device__ __forceinline__ int ap_tile_of_wave(int w) { return w < 4 ? w : 11 - w; }   // SIMD s hosts tiles s and 7 - s
@@ -35,13 +39,15 @@ __device__ __forceinline__ int ap_tile_of_wave(int w) { return w < 4 ? w : 11 - 
 // One [256][HD] image: 256 * HD / 4 units of 16 bytes = NI wave instructions, 8 waves x NI / 8 each (rows >= L re-read
 // row L - 1: every wave always issues the same number of instructions, and nothing is written past the image).
 // ROT: unit `cu` of row r lands in slot (cu + ((r >> 2) & 3)) mod UPR of that row.
-template <int HD, bool ROT>
+// Q0 / Q1: the slice [Q0, Q1) of a wave's NI / 8 instructions -- instruction q of every wave together cover rows
+// 128 q / 3 .. 128 (q + 1) / 3, so [0, 3) is the first 128 rows of a 48-wide image and [3, 6) the rest.
+template <int HD, bool ROT, int Q0 = 0, int Q1 = AP_ROWS * (HD / 4) / 64 / 8>
 __device__ __forceinline__ void ap_dma_image(float* __restrict__ dst, const float* __restrict__ g, int L, int rs, int wave,
                                              int lane) {
   constexpr int UPR = HD / 4, NI = AP_ROWS * UPR / 64;
   static_assert(NI % 8 == 0, "instructions divide over 8 waves");
 #pragma unroll
-  for (int q = 0; q < NI / 8; ++q) {
+  for (int q = Q0; q < Q1; ++q) {
     const int I = wave + 8 * q, U = 64 * I + lane;
     const int row = UPR == 12 ? (U * 43691) >> 19 : U / UPR;
     int cu = U - UPR * row;
@@ -51,12 +57,58 @@ __device__ __forceinline__ void ap_dma_image(float* __restrict__ dst, const floa
   }
 }
 
-// a bare workgroup barrier behind "everything this wave has in flight has landed" (its DMA share, its operand loads)
-__device__ __forceinline__ void ap_sync_all() {
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+// Waits and barriers.  `ap_landed()` = everything this wave has in flight (its DMA share, its operand loads) has
+// landed -- the builtin, not inline asm, so that the compiler's own scoreboard knows it and does not drain the NEXT
+// DMA burst at the first use of an already-loaded register (hipcc waits vmcnt(0) for an ordinary load it still counts
+// as pending whenever an LDS-DMA is in flight).  It is placed in front of a head's STORES, never behind them: loads
+// and stores share the counter but complete independently, so a counted wait cannot tell "the loads are back" from
+// "a store was acknowledged early", and vmcnt(0) behind the stores would wait a full write round trip per head.
+// `ap_barrier()` is a bare workgroup barrier for LDS traffic (no vmcnt wait: stores and DMA stay in flight across it).
+__device__ __forceinline__ void ap_landed() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0), expcnt / lgkmcnt untouched
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void ap_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
+__device__ __forceinline__ void ap_sync_all() { ap_landed(); ap_barrier(); }
+
+// Row fragments of a ROTATED image (ds_read_b128, lane = row li of a tile): fragment t = logical 16-byte unit 2 t + lh
+// sits in slot (b0 + 2 t) mod UPR with b0 = lh + ((li >> 2) & 3) <= 4.  Only t = 4 (b0 = 4) and t = 5 (b0 >= 2) wrap
+// for UPR = 12, so three registers describe all six offsets and t < 4 are immediates of the first.
+struct ApRowOff {
+  int b, k4, k5;
+  __device__ __forceinline__ void init(int li, int lh, int HD) {
+    const int b0 = lh + ((li >> 2) & 3);
+    b = li * HD + 4 * b0;
+    k4 = b + 32 - (b0 == 4 ? 48 : 0);
+    k5 = b + 40 - (b0 >= 2 ? 48 : 0);
+  }
+  __device__ __forceinline__ int at(int t) const { return t < 4 ? b + 8 * t : (t == 4 ? k4 : k5); }
+};
+
+// Column reads of a ROTATED image (lane = head-dim index d, ds_read_b32: 32 banks, lane groups {0-31}, {32-63}):
+// element d of row kt * 32 + krow(r, lh), whose rotation is (2 (r >> 2) + lh) & 3 -- one offset per register group
+// g = r >> 2, relative to row kt * 32 + (r & 3) + 8 g.  c0: d = li (32 consecutive floats of the row: no conflicts);
+// c1: d = 32 + li for li < 16, and lanes 16 .. 31 -- rows 48 .. 63 of the padded tile, never stored -- re-read lane
+// li - 16's address (a broadcast) instead of the 16 floats behind the row, which would share banks with it.
+// The rotation only takes two values per lane (g even / odd), and (li >> 2) + f < UPR never wraps in the first tile:
+// three registers, the rest immediates.
+template <int HD>
+struct ApColOff {
+  int c0e, c1e, c1o;
+  __device__ __forceinline__ void init(int li, int lh) {
+    constexpr int UPR = HD / 4;
+    const int l1 = li & 15;
+    c0e = 4 * lh * HD + 4 * ((li >> 2) + lh) + (li & 3);                   // f = lh (g even), lh + 2 (g odd): + 8 floats
+    c1e = 4 * lh * HD + 4 * ((8 + (l1 >> 2) + lh) % UPR) + (l1 & 3);
+    c1o = 4 * lh * HD + 4 * ((8 + (l1 >> 2) + lh + 2) % UPR) + (l1 & 3);
+  }
+  __device__ __forceinline__ int first(int g) const { return c0e + 8 * (g & 1); }
+  __device__ __forceinline__ int second(int g) const { return (g & 1) ? c1o : c1e; }
+};
 
 template <int HD>
 __global__ __launch_bounds__(512, 1) void attention_p_fwd_kernel(
@@ -76,9 +128,8 @@ __global__ __launch_bounds__(512, 1) void attention_p_fwd_kernel(
   const int qpos = (active ? qtl : 0) * 32 + li;    // (an idle wave reads tile 0: unconditional loads)
   const int nk = active ? (causal ? qtl + 1 : ntile) : 0;
   const float inv_sqrt = 1.f / sqrt_hd, c1 = inv_sqrt * 1.4426950408889634f;
-  int koff[NT8];                                    // the lane's K fragments: row li of a tile, rotated units
-#pragma unroll
-  for (int t = 0; t < NT8; ++t) koff[t] = li * HD + 4 * ((2 * t + lh + ((li >> 2) & 3)) % UPR);
+  ApRowOff ko;                                      // the lane's K fragments: row li of a tile, rotated units
+  ko.init(li, lh, HD);
 
   int bh = blockIdx.x;
   if (bh >= BH) return;
@@ -90,12 +141,14 @@ __global__ __launch_bounds__(512, 1) void attention_p_fwd_kernel(
     const float* qrow = Q + base + (int64_t)qpos * row_stride + 4 * lh;
 #pragma unroll
     for (int t = 0; t < NT8; ++t) qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+    ap_landed();
   }
   for (int it = 0; bh < BH; ++it, bh += gridDim.x) {
     const float* Ks = lds + (it & 1) * IMG;
     const int64_t base = head_base(bh);
-    // ---- K of this head has landed (and every wave is done with the V of the previous one) ----
-    ap_sync_all();
+    // ---- K of this head has landed -- every wave waited for its share before its last stores -- and every wave is
+    //      done with the V of the previous head ----
+    ap_barrier();
     ap_dma_image<HD, false>(Vs, V + base, L, rs, wave, lane);
     // ---- S^T tiles ---------------------------------------------------------------------
     f32x16 s[8];
@@ -106,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void attention_p_fwd_kernel(
         const float* kb = Ks + kt * 32 * HD;
 #pragma unroll
         for (int t = 0; t < NT8; ++t) {
-          const float4 kf = *reinterpret_cast<const float4*>(kb + koff[t]);
+          const float4 kf = *reinterpret_cast<const float4*>(kb + ko.at(t));
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, t == 0 ? zero16 : s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s[kt], 0, 0, 0);
@@ -169,6 +222,7 @@ __global__ __launch_bounds__(512, 1) void attention_p_fwd_kernel(
         }
       }
     }
+    ap_landed();                                    // next K, next Q rows (a whole P V phase old): before the stores
     if (active) {
       const float inv_l = 1.f / l;
       if (lh == 0) LSE[(int64_t)bh * L + qpos] = m * inv_sqrt + logf(l);
@@ -277,7 +331,12 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
   static_assert(HD == 48, "head dim 48");
   constexpr int UPR = HD / 4, NT8 = HD / 8, IMG = AP_ROWS * HD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* Vs = lds + 2 * IMG;                        // lds: K (even) | K (odd) | V  -- all rotated images
+  // lds: K (even) | K (odd) | V  -- all rotated images.  (The V image starts 96 KB into the allocation, beyond the 64 KB
+  // an LDS instruction's immediate offset reaches: its position is kept opaque to the optimiser, which otherwise
+  // materialises one address register per (tile, fragment) -- 40 of them, spilled and reloaded inside the tile loop.)
+  int v_at = 2 * IMG;
+  asm volatile("" : "+s"(v_at));
+  float* Vs = lds + v_at;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -287,18 +346,10 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
   const int qpos = (active ? qtl : 0) * 32 + li;
   const int nk = active ? (causal ? qtl + 1 : ntile) : 0;
   const float inv_sqrt = 1.f / sqrt_hd, c1 = inv_sqrt * 1.4426950408889634f;
-  int koff[NT8];                                    // row fragments (S, dP): row li of a tile, rotated units
-#pragma unroll
-  for (int t = 0; t < NT8; ++t) koff[t] = li * HD + 4 * ((2 * t + lh + ((li >> 2) & 3)) % UPR);
-  // column reads (dQ): element d = li (first tile) / 32 + li (second) of row kt*32 + krow(r, lh), whose rotation is
-  // (2 (r >> 2) + lh) & 3: one offset per register group g = r >> 2
-  int c0[4], c1o[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int f = (2 * g + lh) & 3;
-    c0[g] = 4 * lh * HD + 4 * (((li >> 2) + f) % UPR) + (li & 3);
-    c1o[g] = 4 * lh * HD + 4 * ((8 + (li >> 2) + f) % UPR) + (li & 3);
-  }
+  ApRowOff ko;                                      // row fragments (S, dP): row li of a tile, rotated units
+  ko.init(li, lh, HD);
+  ApColOff<HD> co;                                  // column reads (dQ)
+  co.init(li, lh);
   int bh = blockIdx.x;
   if (bh >= BH) return;
   auto head_base = [&](int x) { return (int64_t)(x / H) * batch_stride + (int64_t)(x % H) * HD; };
@@ -319,26 +370,34 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
       of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
     }
     lse_q = LSE[(int64_t)bh * L + qpos];
+    ap_landed();
   }
-  for (int it = 0; bh < BH; ++it, bh += gridDim.x) {
-    const float* Ks = lds + (it & 1) * IMG;
-    // ---- K and V of this head have landed ----
-    ap_sync_all();
+  // delta[q] = sum_d dO O of the rows in gf / of_ (the O rows are dead afterwards)
+  auto row_delta = [&]() {
     float dpart = 0.f;
 #pragma unroll
     for (int t = 0; t < NT8; ++t)
       dpart += (of_[t].x * gf[t].x + of_[t].y * gf[t].y) + (of_[t].z * gf[t].z + of_[t].w * gf[t].w);
-    const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
-    if (active && lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
+    return dpart + __shfl_xor(dpart, 32, 64);
+  };
+  float delta_q = row_delta();
+  for (int it = 0; bh < BH; ++it, bh += gridDim.x) {
+    const float* Ks = lds + (it & 1) * IMG;
+    // ---- K and V of this head have landed (every wave waited for its share before its last stores); the other K
+    //      buffer is free: K of the next head goes out now and has the whole head to arrive ----
+    ap_barrier();
+    const int nxt = bh + gridDim.x;
+    if (nxt < BH) ap_dma_image<HD, true>(lds + ((it + 1) & 1) * IMG, K + head_base(nxt), L, rs, wave, lane);
+
     const float c2q = -lse_q * 1.4426950408889634f;
     // Two groups of four key tiles: dS^T of a group in registers (phase 1), then its share of dQ^T (phase 2).  V is dead
     // after phase 1 of the SECOND group, K only at the end: the workgroup meets there, and the next head's K, V and Q
     // rows are in flight during the last phase 2.  (All eight dS^T tiles at once would need 128 registers.)
     f32x16 ds[4];
     f32x16 dq0, dq1;
+    ApRope rr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
-    const int nxt = bh + gridDim.x;
 #pragma unroll
     for (int grp = 0; grp < 2; ++grp) {
       // ---- phase 1: dS^T tiles (lane = query, registers = keys) ----
@@ -352,8 +411,8 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
           const float* vb = Vs + kt * 32 * HD;
 #pragma unroll
           for (int t = 0; t < NT8; ++t) {
-            const float4 kf = *reinterpret_cast<const float4*>(kb + koff[t]);
-            const float4 vf = *reinterpret_cast<const float4*>(vb + koff[t]);
+            const float4 kf = *reinterpret_cast<const float4*>(kb + ko.at(t));
+            const float4 vf = *reinterpret_cast<const float4*>(vb + ko.at(t));
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, t == 0 ? zero16 : s, 0, 0, 0);
             dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, t == 0 ? zero16 : dp, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
@@ -375,17 +434,27 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
           }
         }
       }
-      if (grp == 1) {
-        // ---- every wave is done with V (and with the other K buffer since the last head): the next head's K, V and
-        //      this wave's next Q rows go out, to land during the last phase 2 ----
-        ap_sync_all();
+      // ---- every wave is done with this group's V rows: the same rows of the next head go out (first half: the rest
+      //      of the head to arrive; second half: the last phase 2), then this wave's next operand rows ----
+      ap_barrier();
+      if (grp == 0) {
+        if (nxt < BH) ap_dma_image<HD, true, 0, 3>(Vs, V + head_base(nxt), L, rs, wave, lane);
+      } else {
+        if (ROT) rr.load(RC, RS, qpos, lh);         // (for the dQ store: requested here, in the shadow of the last phase 2)
         if (nxt < BH) {
           const int64_t nb = head_base(nxt);
-          ap_dma_image<HD, true>(lds + ((it + 1) & 1) * IMG, K + nb, L, rs, wave, lane);
-          ap_dma_image<HD, true>(Vs, V + nb, L, rs, wave, lane);
+          ap_dma_image<HD, true, 3, 6>(Vs, V + nb, L, rs, wave, lane);
+          const int64_t nob = head_obase(nxt);
           const float* qrow = Q + nb + (int64_t)qpos * row_stride + 4 * lh;
+          const float* grow = dO + nob + (int64_t)qpos * o_row_stride + 4 * lh;
+          const float* orow = O + nob + (int64_t)qpos * o_row_stride + 4 * lh;
 #pragma unroll
-          for (int t = 0; t < NT8; ++t) qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+          for (int t = 0; t < NT8; ++t) {
+            qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
+            gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
+            of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
+          }
+          lse_q = LSE[(int64_t)nxt * L + qpos];
         }
       }
       // ---- phase 2: dQ^T[d][q] += K^T[d][key] dS^T[key][q] ----
@@ -396,30 +465,18 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float* kr = Ks + (kt * 32 + (r & 3) + 8 * (r >> 2)) * HD;
-            const float a0 = kr[c0[r >> 2]];
-            const float a1 = kr[c1o[r >> 2]];
+            const float a0 = kr[co.first(r >> 2)];
+            const float a1 = kr[co.second(r >> 2)];
             dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ds[j][r], dq0, 0, 0, 0);
             dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ds[j][r], dq1, 0, 0, 0);
           }
         }
       }
     }
-    if (nxt < BH) {                                 // behind the store and the next head's first barrier
-      const int64_t nob = head_obase(nxt);
-      const float* grow = dO + nob + (int64_t)qpos * o_row_stride + 4 * lh;
-      const float* orow = O + nob + (int64_t)qpos * o_row_stride + 4 * lh;
-#pragma unroll
-      for (int t = 0; t < NT8; ++t) {
-        gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
-        of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
-      }
-      lse_q = LSE[(int64_t)nxt * L + qpos];
-    }
-    if (active) {
-      ApRope rr;
-      if (ROT) rr.load(RC, RS, qpos, lh);
-      ap_store_rows<ROT>(dq0, dq1, dQ + head_base(bh) + (int64_t)qpos * row_stride + 4 * lh, inv_sqrt, rr);
-    }
+    ap_landed();                                    // the next head's K, V and operand rows: before the stores
+    if (active && lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
+    if (active) ap_store_rows<ROT>(dq0, dq1, dQ + head_base(bh) + (int64_t)qpos * row_stride + 4 * lh, inv_sqrt, rr);
+    if (nxt < BH) delta_q = row_delta();            // (the next head's rows, requested before the last phase 2)
   }
 }
 
@@ -442,16 +499,10 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
   const bool active = ktl < ntile;
   const int kpos = (active ? ktl : 0) * 32 + li;
   const float inv_sqrt = 1.f / sqrt_hd, c1 = inv_sqrt * 1.4426950408889634f;
-  int koff[NT8];
-#pragma unroll
-  for (int t = 0; t < NT8; ++t) koff[t] = li * HD + 4 * ((2 * t + lh + ((li >> 2) & 3)) % UPR);
-  int c0[4], c1o[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const int f = (2 * g + lh) & 3;
-    c0[g] = 4 * lh * HD + 4 * (((li >> 2) + f) % UPR) + (li & 3);
-    c1o[g] = 4 * lh * HD + 4 * ((8 + (li >> 2) + f) % UPR) + (li & 3);
-  }
+  ApRowOff ko;
+  ko.init(li, lh, HD);
+  ApColOff<HD> co;
+  co.init(li, lh);
   int bh = blockIdx.x;
   if (bh >= BH) return;
   auto head_base = [&](int x) { return (int64_t)(x / H) * batch_stride + (int64_t)(x % H) * HD; };
@@ -481,7 +532,7 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
     const float* lse_s = stat + (it & 1) * 512;
     const float* delta_s = lse_s + 256;
     // ---- every wave is done with the previous head: its dO image is replaced (exposed: see the header) ----
-    if (it) ap_sync_all();
+    if (it) ap_barrier();
     ap_dma_image<HD, true>(Gs, dO + head_obase(bh), L, ors, wave, lane);
     dma_stats(stat + (it & 1) * 512, bh);
     ap_sync_all();
@@ -499,8 +550,8 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
         const float* gb = Gs + qt * 32 * HD;
 #pragma unroll
         for (int t = 0; t < NT8; ++t) {
-          const float4 q4 = *reinterpret_cast<const float4*>(qb + koff[t]);
-          const float4 g4 = *reinterpret_cast<const float4*>(gb + koff[t]);
+          const float4 q4 = *reinterpret_cast<const float4*>(qb + ko.at(t));
+          const float4 g4 = *reinterpret_cast<const float4*>(gb + ko.at(t));
           s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.x, kf[t].x, t == 0 ? zero16 : s, 0, 0, 0);    // S[q][key]
           dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.x, vf[t].x, t == 0 ? zero16 : dp, 0, 0, 0);  // dP[q][key]
           s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.y, kf[t].y, s, 0, 0, 0);
@@ -532,8 +583,8 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int ro = (qt * 32 + (r & 3) + 8 * (r >> 2)) * HD;
-          const float g0 = Gs[ro + c0[r >> 2]], q0 = Qs[ro + c0[r >> 2]];
-          const float g1 = Gs[ro + c1o[r >> 2]], q1 = Qs[ro + c1o[r >> 2]];
+          const float g0 = Gs[ro + co.first(r >> 2)], q0 = Qs[ro + co.first(r >> 2)];
+          const float g1 = Gs[ro + co.second(r >> 2)], q1 = Qs[ro + co.second(r >> 2)];
           dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, s[r], dv0, 0, 0, 0);     // dV^T += dO^T P
           dk0 = __builtin_amdgcn_mfma_f32_32x32x2f32(q0, dp[r], dk0, 0, 0, 0);    // dK^T += Q^T dS
           dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, s[r], dv1, 0, 0, 0);
@@ -541,23 +592,29 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
         }
       }
     }
-    if (nxt < BH) {                                 // this wave's K, V rows of the next head: behind the store and the barrier
+    // the next head's Q image (a whole head old) has landed: every wave says so BEFORE its stores; the wave's next K / V
+    // rows then travel behind the stores and the barrier (the next head waits for them together with its dO image)
+    ap_landed();
+    ApRope rr;
+    if (ROT) rr.load(RC, RS, kpos, lh);
+    float4 kn[NT8], vn[NT8];
+    if (nxt < BH) {
       const int64_t nb = head_base(nxt);
       const float* krow = K + nb + (int64_t)kpos * row_stride + 4 * lh;
       const float* vrow = V + nb + (int64_t)kpos * row_stride + 4 * lh;
 #pragma unroll
       for (int t = 0; t < NT8; ++t) {
-        kf[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
-        vf[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
+        kn[t] = *reinterpret_cast<const float4*>(krow + 8 * t);
+        vn[t] = *reinterpret_cast<const float4*>(vrow + 8 * t);
       }
     }
     if (active) {
-      ApRope rr;
-      if (ROT) rr.load(RC, RS, kpos, lh);
       const int64_t base = head_base(bh);
       ap_store_rows<ROT>(dk0, dk1, dK + base + (int64_t)kpos * row_stride + 4 * lh, inv_sqrt, rr);
       ap_store_rows<false>(dv0, dv1, dV + base + (int64_t)kpos * row_stride + 4 * lh, 1.f, rr);
     }
+#pragma unroll
+    for (int t = 0; t < NT8; ++t) { kf[t] = kn[t]; vf[t] = vn[t]; }
   }
 }
 

@@ -1041,17 +1041,17 @@ static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
 static std::mutex g_prof_mu;
 static bool g_prof_on = false;
-struct ProfRec { hipEvent_t e0, e1; double flops; int family; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel, 3: output-resident kernel, 4: its weight-gradient (TN) form
+struct ProfRec { hipEvent_t e0, e1; double flops; int family; double bytes = 0.0; };   // family 0: tiled MFMA kernel, 1: wave-streaming TN kernel, 2: row-resident kernel, 3: output-resident kernel, 4: its weight-gradient (TN) form
 static std::vector<ProfRec> g_prof;
 
 // for the fused-epilogue entry points of the other GEMM files: time a launch under a family when profiling is on
 // (token = index + 1 of the open record, 0 when profiling is off)
-int pdn_gemm_prof_begin(int family, double flops, void* stream) {
+int pdn_gemm_prof_begin(int family, double flops, double bytes, void* stream) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_on) return 0;
   ProfRec rec;
   if (hipEventCreate(&rec.e0) != hipSuccess || hipEventCreate(&rec.e1) != hipSuccess) return 0;
-  rec.flops = flops; rec.family = family;
+  rec.flops = flops; rec.family = family; rec.bytes = bytes;
   (void)hipEventRecord(rec.e0, (hipStream_t)stream);
   g_prof.push_back(rec);
   return (int)g_prof.size();
@@ -1068,6 +1068,31 @@ extern "C" int pdn_gemm_prof_enable(int on) {
   return PDN_OK;
 }
 
+// The row-resident launches with a fused epilogue (family 5: SwiGLU forward / backward, RoPE -- csrc/gemm_rowres.hip) do
+// a bandwidth pass inside a GEMM: they are reported apart, with their algorithmic HBM bytes beside their FLOPs.  Collects
+// AND removes their records; records left in place are counted with the row-resident family by the call below.
+extern "C" int pdn_gemm_prof_collect_fused(double* ms, double* flops, double* bytes, int64_t* launches) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double tm = 0, tf = 0, tb = 0;
+  int64_t n = 0;
+  std::vector<ProfRec> keep;
+  for (auto& r : g_prof) {
+    if (r.family != 5) { keep.push_back(r); continue; }
+    PDN_HIP(hipEventSynchronize(r.e1));
+    float t = 0.f;
+    PDN_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+    tm += t; tf += r.flops; tb += r.bytes; n++;
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_prof.swap(keep);
+  if (ms) *ms = tm;
+  if (flops) *flops = tf;
+  if (bytes) *bytes = tb;
+  if (launches) *launches = n;
+  return PDN_OK;
+}
+
 // per kernel family: [0] gemm_f32_mfma_kernel (+ its split-K reduce), [1] gemm_tn_stream_*_kernel,
 // [2] gemm_rowres_kernel (csrc/gemm_rowres.hip), [3] gemm_outres_kernel, [4] gemm_outres_tn_kernel (csrc/gemm_outres.hip);
 // the three output arrays have FIVE entries each
@@ -1080,7 +1105,7 @@ extern "C" int pdn_gemm_prof_collect_families(double* ms5, double* flops5, int64
     PDN_HIP(hipEventSynchronize(r.e1));
     float t = 0.f;
     PDN_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-    const int f = r.family < 0 || r.family >= PDN_GEMM_FAMILIES ? 0 : r.family;
+    const int f = r.family == 5 ? 2 : (r.family < 0 || r.family >= PDN_GEMM_FAMILIES ? 0 : r.family);
     ms[f] += t; fl[f] += r.flops; n[f]++;
     (void)hipEventDestroy(r.e0);
     (void)hipEventDestroy(r.e1);

@@ -535,7 +535,7 @@ extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64
 // B as `nblocks` matrices side by side (block b at B + b * b_block_stride floats; NN: each (K x N / nblocks),
 // NT: each (N / nblocks x K)); nblocks > 1 needs N / nblocks to be a multiple of 96.
 // `epi` (may be null): fused epilogue request, EPI of the kernel template + its operands.
-int pdn_gemm_prof_begin(int family, double flops, void* stream);    // csrc/gemm.hip: bench.py's per-family timing
+int pdn_gemm_prof_begin(int family, double flops, double bytes, void* stream);    // csrc/gemm.hip: bench.py's per-family timing
 void pdn_gemm_prof_end(int token, void* stream);
 struct RowResEpi {
   int kind;                 // 1 SwiGLU forward, 2 SwiGLU backward, 3 RoPE
@@ -634,7 +634,7 @@ extern "C" int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, in
   e.g_off = w_stride < 0 ? (unsigned)ws : 0u;
   e.u_off = w_stride < 0 ? 0u : (unsigned)ws;
   const float* wbase = w_stride < 0 ? w_gate + w_stride : w_gate;
-  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (2.0 * F) * K, stream);
+  const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (2.0 * F) * K, 4.0 * ((double)M * K + 2.0 * K * F + 3.0 * M * F), stream);
   const int rc = rowres_launch(x, wbase, gu, nullptr, nullptr, M, 2 * F, K, ldx, F, 2 * F, 0, 2, ws, stream, &e);
   pdn_gemm_prof_end(tk, stream);
   return rc;
@@ -649,7 +649,7 @@ extern "C" int pdn_swiglu_bwd_gemm_f32(const float* dy, const float* w_down, con
     return PDN_EUNSUPPORTED;
   }
   RowResEpi e{2, nullptr, 0, gu, F, nullptr, 1, 1, 0};
-  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (double)F * K, stream);
+  const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (double)F * K, 4.0 * ((double)M * K + (double)K * F + 4.0 * M * F), stream);
   const int rc = rowres_launch(dy, w_down, dgu, nullptr, nullptr, M, F, K, ldy, K, 2 * F, 1, 1, 0, stream, &e);
   pdn_gemm_prof_end(tk, stream);
   return rc;
@@ -668,7 +668,7 @@ extern "C" int pdn_qkv_rope_fwd_f32(const float* x, const float* wq, int64_t w_s
     return PDN_EUNSUPPORTED;
   }
   RowResEpi e{3, nullptr, 0, nullptr, 0, rope, L, hd, 2 * D};
-  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (3.0 * D) * K, stream);
+  const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (3.0 * D) * K, 4.0 * ((double)M * K + 3.0 * K * D + 3.0 * M * D), stream);
   const int rc = rowres_launch(x, wq, qkv, nullptr, nullptr, M, 3 * D, K, ldx, D, 3 * D, 0, 3, w_stride, stream, &e);
   pdn_gemm_prof_end(tk, stream);
   return rc;

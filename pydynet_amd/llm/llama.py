@@ -53,7 +53,8 @@ class FeedForward(nn.Module):
         and being equally spaced lets both projections run as one batched GEMM."""
         from .. import hipnp as hp
         ws = [self.gate.weight, self.up.weight]
-        if hp.stacked_view([w.data for w in ws]) is not None:
+        st = hp.stacked_view([w.data for w in ws])
+        if st is not None and st._strides[0] == ws[0].data.size:      # already adjacent, gate first
             return
         buf = hp.empty((2,) + tuple(ws[0].shape), ws[0].dtype)
         for i, w in enumerate(ws):
@@ -99,7 +100,8 @@ class Attention(nn.Module):
         and being equally spaced lets the three projections run as one batched GEMM."""
         from .. import hipnp as hp
         ws = [self.Q.weight, self.K.weight, self.V.weight]
-        if hp.stacked_view([w.data for w in ws]) is not None:
+        st = hp.stacked_view([w.data for w in ws])
+        if st is not None and st._strides[0] == ws[0].data.size:      # already adjacent, in order
             return
         buf = hp.empty((3,) + tuple(ws[0].shape), ws[0].dtype)
         for i, w in enumerate(ws):

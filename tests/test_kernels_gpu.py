@@ -450,7 +450,10 @@ def test_cross_entropy_one_pass_forward_backward(hip):
                                              (1, 2, 1024, 1, 48),     # max_seq_len of llm/llama/finetune.py:44
                                              (1, 2, 512, 0, 48),      # not causal: every query group visits every chunk
                                              (1, 3, 736, 1, 48),      # ragged last chunk (23 tiles: 8 + 8 + 7)
-                                             (2, 4, 256, 1, 64), (1, 2, 96, 0, 64), (1, 2, 640, 1, 64)])   # head dim 64
+                                             (2, 4, 256, 1, 64), (1, 2, 96, 0, 64), (1, 2, 640, 1, 64),    # head dim 64
+                                             # more heads than CUs: the persistent kernels of csrc/attention_p.hip walk
+                                             # several heads per workgroup (double-buffered images, prefetched operands)
+                                             (101, 6, 64, 1, 48), (43, 7, 96, 0, 48), (3, 100, 256, 1, 48)])
 def test_fused_attention_forward_backward(hip, B, H, L, causal, hd):
     """Fused attention vs a float64 statement of llm/llama/model.py:112-121 and its gradients."""
     from pydynet_amd import _lib
