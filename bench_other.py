@@ -9,12 +9,14 @@ step -- forward, backward, Adam -- as ONE hipGraph by default (`--no-graph` time
 import ctypes
 import json
 import os
+import sys
 import time
 
 import numpy as np
 
 PEAK_FP32_MFMA = 157.3e12
 PEAK_HBM = 8.0e12
+ROOT = os.path.dirname(os.path.abspath(__file__))
 
 MLP_FLOP = 9_564_160           # 3 x 2 x (784*1024 + 1024*1024 + 1024*10) - dX of layer 1
 LENET_FLOP = 25_665_840
@@ -153,8 +155,7 @@ def run_train(args, which):
     value = B * args.steps / dt
     roof = _gemm_roofline(lib, step, hp)
     if which == "lenet":
-        roof = {"gemm": roof}
-        roof.update(_conv_roofline(lib, hp, B))
+        roof = dict(_conv_roofline(lib, hp, B), gemm=roof)
     out = {
         "metric": f"training-step samples/sec ({'3-layer MLP 784-1024-1024-10' if which == 'mlp' else 'LeNet, 3x32x32 inputs'})",
         "value": value, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -227,46 +228,107 @@ def _cpu_train(which, budget=12.0):
             "sample": f"{n} steps at batch {B} of the oracle (NumPy / BLAS default threads), after 1 warm-up step"}
 
 
+def _conv_pmc():
+    """HBM bytes per dispatch of the convolution kernels from the newest committed counter summary of the LeNet step
+    (profiles/r*_pmc_lenet_b4096.json: tools/pmc_cmd.sh + tools/stamp_pmc.py; FETCH_SIZE x 2 -- the gfx950 correction --
+    + WRITE_SIZE, KiB).  Keys: rocprofv3 kernel names (template arguments included)."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_lenet_b4096.json")))
+    if not files:
+        return {}, None
+    raw = open(files[-1], "rb").read()
+    rows = json.loads(raw)
+    meta = rows.pop("_meta", {})
+    stale = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import stamp_pmc
+        if meta.get("kernel_sources_sha16"):
+            stale = meta["kernel_sources_sha16"] != stamp_pmc.sources_sha()
+    except Exception:
+        pass
+    out = {}
+    for name, r in rows.items():
+        if "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+            out[name] = (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0
+    src = {"file": os.path.relpath(files[-1], ROOT), "sha12": hashlib.sha256(raw).hexdigest()[:12], "stale": stale,
+           "batch": 4096}
+    return out, src
+
+
 def _conv_roofline(lib, hp, B):
-    """The direct-convolution kernels of the LeNet step at its own shapes, each timed live with HIP events:
-    achieved = ALGORITHMIC bytes (inputs read once + outputs written once) / average launch time, peak 8 TB/s."""
+    """The convolution kernels the LeNet step really launches -- conv + bias + relu + 2x2 max-pool in one forward kernel,
+    data / weight gradients that expand the pooled gradient through the hit map while they stage it -- each timed live
+    with HIP events at the step's shapes.  Every kernel gets BOTH roofs: algorithmic FLOPs (2 O C k^2 OH OW per image)
+    against the fp32-MFMA peak and algorithmic bytes (operands read once, results written once) against HBM; `bound`
+    is the nearer roof (arithmetic intensity against the ridge 157.3 TFLOP/s / 8 TB/s = 19.7 FLOP/B: conv2 at 64 FLOP/B
+    is MFMA-bound, conv1 at ~12 is HBM-bound).  `traffic` = counter bytes per dispatch from the committed PMC summary of
+    the batch-4096 step, when the kernel name is in it."""
     rng = np.random.default_rng(0)
     out = {}
-    best = None
+    pmc, pmc_src = _conv_pmc()
+    ridge = PEAK_FP32_MFMA / PEAK_HBM
+
+    def traffic_of(prefix):
+        hits = [v for k, v in pmc.items() if k.startswith(prefix)]
+        return hits[0] if len(hits) == 1 and B == (pmc_src or {}).get("batch") else None
+
     for tag, (C, H, O) in (("conv1", (3, 32, 20)), ("conv2", (20, 16, 50))):
+        if lib.query("pdn_conv2d_relu_pool_supported", C, H, H, O, 3, 1, 1) != 7:
+            continue
+        P = H // 2
         x = hp.from_numpy(rng.standard_normal((B, C, H, H), dtype=np.float32))
-        w = hp.from_numpy(rng.standard_normal((O, C, 3, 3), dtype=np.float32))
+        w = hp.from_numpy((0.1 * rng.standard_normal((O, C, 3, 3))).astype(np.float32))
         b = hp.from_numpy(rng.standard_normal((O,), dtype=np.float32))
-        yv = hp.empty((B, O, H, H), np.float32)
+        pooled = hp.empty((B, O, P, P), np.float32)
+        maskp = hp.empty((B, O, H * H // 32), np.int32)          # (the hit map: one bit per conv output position)
+        dpool = hp.from_numpy(rng.standard_normal((B, O, P, P), dtype=np.float32))
         dx = hp.empty((B, C, H, H), np.float32)
         dw, db = hp.empty((O, C, 3, 3), np.float32), hp.empty((O,), np.float32)
-        if not lib.query("pdn_conv2d_direct_supported", C, H, H, O, 3, 1, 1):
-            continue
         wsb = lib.query("pdn_conv2d_bwd_weight_workspace_bytes", B, C, H, H, O, 3, 1, 1)
-        xb, yb = 4.0 * B * C * H * H, 4.0 * B * O * H * H
-        cases = [("fwd", lambda: lib.call("pdn_conv2d_fwd_f32", x._ptr, w._ptr, b._ptr, yv._ptr, B, C, H, H, O, 3, 1, 1,
-                                          hp.stream()), xb + yb)]
+        flop = 2.0 * B * O * C * 9 * H * H
+        xb, pb, mb = 4.0 * B * C * H * H, 4.0 * B * O * P * P, 4.0 * B * O * H * H / 32
+        lib.call("pdn_conv2d_relu_pool_fwd_f32", x._ptr, w._ptr, b._ptr, pooled._ptr, maskp._ptr, B, C, H, H, O, 3, 1, 1,
+                 hp.stream())
+        cases = [("fwd_relu_pool", lambda: lib.call("pdn_conv2d_relu_pool_fwd_f32", x._ptr, w._ptr, b._ptr, pooled._ptr,
+                                                    maskp._ptr, B, C, H, H, O, 3, 1, 1, hp.stream()), xb + pb + mb)]
         if C != 3:                                            # the first layer's input has no gradient
-            cases.append(("bwd_data", lambda: lib.call("pdn_conv2d_bwd_data_f32", yv._ptr, w._ptr, dx._ptr, B, C, H, H, O,
-                                                       3, 1, 1, hp.stream()), xb + yb))
+            cases.append(("bwd_data", lambda: lib.call("pdn_conv2d_relu_pool_bwd_data_f32", dpool._ptr, maskp._ptr, w._ptr,
+                                                       dx._ptr, B, C, H, H, O, 3, 1, 1, hp.stream()), pb + mb + xb))
 
         def wgrad():
             ws, n = hp.workspace(wsb)
-            lib.call("pdn_conv2d_bwd_weight_f32", x._ptr, yv._ptr, dw._ptr, db._ptr, 0, B, C, H, H, O, 3, 1, 1, ws, n,
-                     hp.stream())
-        cases.append(("bwd_weight", wgrad, xb + yb))
+            lib.call("pdn_conv2d_relu_pool_bwd_weight_f32", x._ptr, dpool._ptr, maskp._ptr, dw._ptr, db._ptr, 0, B, C, H, H,
+                     O, 3, 1, 1, ws, n, hp.stream())
+        cases.append(("bwd_weight", wgrad, xb + pb + mb))
         for kind, fn, nbytes in cases:
             us = _event_time_us(hp, fn)
-            rec = {"bound": "hbm", "achieved": nbytes / (us * 1e-6) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                   "frac": nbytes / (us * 1e-6) / PEAK_HBM, "traffic": None, "algorithmic_bytes_per_launch": nbytes,
-                   "avg_launch_us": us}
-            out[f"{tag}_{kind}"] = rec
-            if best is None or us > best[1]:
-                best = (f"{tag}_{kind}", us)
-    dom = out[best[0]]
-    return {"bound": "hbm", "kernel": best[0] + " (conv_direct.hip)", "achieved": dom["achieved"], "peak": dom["peak"],
-            "unit": "GB/s", "frac": dom["frac"], "traffic": None, "avg_launch_us": dom["avg_launch_us"],
-            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "conv_kernels": out}
+            tf, gb = flop / (us * 1e-6) / 1e12, nbytes / (us * 1e-6) / 1e9
+            mfma_bound = flop / nbytes > ridge
+            out[f"{tag}_{kind}"] = {
+                "bound": "mfma" if mfma_bound else "hbm",
+                "achieved": tf if mfma_bound else gb, "peak": (PEAK_FP32_MFMA / 1e12) if mfma_bound else PEAK_HBM / 1e9,
+                "unit": "TFLOP/s" if mfma_bound else "GB/s",
+                "frac": tf / (PEAK_FP32_MFMA / 1e12) if mfma_bound else gb / (PEAK_HBM / 1e9),
+                "mfma_frac": tf / (PEAK_FP32_MFMA / 1e12), "hbm_frac": gb / (PEAK_HBM / 1e9),
+                "flop_per_byte": flop / nbytes, "algorithmic_flop_per_launch": flop,
+                "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": us, "traffic": None}
+    # counter traffic: kernel names of the committed summary (template arguments identify layer and direction)
+    for key, prefix in (("conv1_fwd_relu_pool", "conv_direct_kernel<2, 2, 3, 8, 1, 0>"),
+                        ("conv2_fwd_relu_pool", "conv_direct_kernel<1, 4, 3, 4, 1, 0>"),
+                        ("conv2_bwd_data", "conv_direct_kernel<1, 2, 3, 16, 0, 1>"),
+                        ("conv1_bwd_weight", "conv_wgrad_kernel<1, 1, 8, 16, 1>"),
+                        ("conv2_bwd_weight", "conv_wgrad_kernel<3, 0, 8, 16, 1>")):
+        if key in out:
+            out[key]["traffic"] = traffic_of(prefix)
+    dom_key = max(out, key=lambda k: out[k]["avg_launch_us"])
+    dom = out[dom_key]
+    return {"bound": dom["bound"], "kernel": dom_key + " (conv_direct.hip)", "achieved": dom["achieved"], "peak": dom["peak"],
+            "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
+            "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
+            "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "traffic_source": pmc_src,
+            "conv_kernels": out}
 
 
 # ---------------------------------------------------------------------------------------------------------------

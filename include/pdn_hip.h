@@ -198,9 +198,6 @@ int pdn_ew_binary(int dtype, int op, int mode, int ndim, const int64_t* shape, c
 int pdn_ew_unary(int dtype, int op, int ndim, const int64_t* shape, const void* a,
                  const int64_t* sa, void* out, const int64_t* so, void* stream);
 /* ndarray.astype / .copy() / `view[...] = array` (tensor.py:168-177, 279) */
-/* dst (cols x rows, leading dimension ld_dst) = src (rows x cols, leading dimension ld_src) transposed, through LDS
- * tiles (keeps lm_head.weight^T row-major for the NT form of the vocabulary projection, llm/llama/model.py:179) */
-int pdn_transpose2d_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst, void* stream);
 int pdn_cast(int src_dtype, int dst_dtype, int ndim, const int64_t* shape, const void* a,
              const int64_t* sa, void* out, const int64_t* so, void* stream);
 /* xp.zeros / xp.ones / `grad[...] = 0.` (tensor.py:90,355,380-383) */

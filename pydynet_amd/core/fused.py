@@ -810,8 +810,6 @@ class linear_cross_entropy(_Operator):
     folds_existing = True
     enabled = True
     min_rows = int(os.environ.get("PDN_LINCE_MIN_ROWS", "16384"))
-    nt_forward = os.environ.get("PDN_LINCE_NT", "1") != "0"      # forward product through a per-step W^T (same-box A/B switch)
-    nt_min_rows = 32768
 
     @staticmethod
     def applicable(x, w, b, targets, reduction="mean"):
@@ -845,16 +843,7 @@ class linear_cross_entropy(_Operator):
             self._t = hp.from_numpy(np.asarray(self._t).astype(np.int64))
         self._t = _contig(self._t)
         logits = hp.empty((n, V), np.float32)
-        wd = w.data
-        if (linear_cross_entropy.nt_forward and n >= linear_cross_entropy.nt_min_rows and wd.is_contiguous()
-                and fin % 4 == 0):
-            # the NT form of the row-resident kernel (B^T row-major: one ds_read_b128 per four MFMAs instead of four
-            # conflict-free dwords) is the faster one -- 87 vs 84 % of the fp32-MFMA peak at 65536 x 32000 x 288 --
-            # and a row-major W^T costs one tiled transpose of the weight per step (~15 us for 37 MB)
-            wt = hp.empty((V, fin), np.float32)
-            L.call("pdn_transpose2d_f32", wd._ptr, wt._ptr, fin, V, V, fin, hp.stream())
-            wd = wt.T
-        hp.gemm(x2, wd, logits, bias=b.data.reshape(-1) if b is not None else None)
+        hp.gemm(x2, w.data, logits, bias=b.data.reshape(-1) if b is not None else None)
         loss_row, lse, out = hp.empty((n,), np.float32), hp.empty((n,), np.float32), hp.empty((1,), np.float32)
         L.call("pdn_cross_entropy_fwd_f32", logits._ptr, self._t._ptr, n, V, 1 if self.reduction == "mean" else 0,
                loss_row._ptr, lse._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())

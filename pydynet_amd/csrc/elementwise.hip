@@ -489,57 +489,3 @@ extern "C" int pdn_masked_fill(int dtype, double value, int ndim, const int64_t*
   return PDN_OK;
 }
 
-// ======================================================================================
-// 2-D transpose through LDS: dst (cols x rows, leading dimension ldd) = src (rows x cols, leading dimension lds)^T.
-// 64 x 64 tiles, 16-byte global accesses on both sides, LDS rows padded to 65 floats (conflict-free columns).
-// Used to keep a row-major copy of lm_head.weight^T for the NT form of the vocabulary projection
-// (llm/llama/model.py:179; the generic strided copy took 70 us for the 37 MB matrix, this one ~15 us).
-// ======================================================================================
-__global__ __launch_bounds__(256) void transpose2d_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows,
-                                                          int cols, int64_t lds_, int64_t ldd) {
-  __shared__ float tile[64][65];
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64, tid = threadIdx.x;
-  const bool vec = ((lds_ | ldd) & 3) == 0 && ((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
-  // load: thread -> (row tid / 16 + 16 i, four columns 4 (tid % 16))
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = tid / 16 + 16 * i, c = 4 * (tid % 16);
-    if (r0 + r < rows) {
-      const float* p = src + (int64_t)(r0 + r) * lds_ + c0 + c;
-      if (vec && c0 + c + 3 < cols) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        tile[r][c] = v.x; tile[r][c + 1] = v.y; tile[r][c + 2] = v.z; tile[r][c + 3] = v.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (c0 + c + e < cols) tile[r][c + e] = p[e];
-      }
-    }
-  }
-  __syncthreads();
-  // store: thread -> (output row = source column tid / 16 + 16 i, four output columns = source rows 4 (tid % 16))
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = tid / 16 + 16 * i, r = 4 * (tid % 16);
-    if (c0 + c < cols) {
-      float* p = dst + (int64_t)(c0 + c) * ldd + r0 + r;
-      if (vec && r0 + r + 3 < rows) {
-        *reinterpret_cast<float4*>(p) = make_float4(tile[r][c], tile[r + 1][c], tile[r + 2][c], tile[r + 3][c]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (r0 + r + e < rows) p[e] = tile[r + e][c];
-      }
-    }
-  }
-}
-
-extern "C" int pdn_transpose2d_f32(const float* src, float* dst, int rows, int cols, int64_t ld_src, int64_t ld_dst,
-                                   void* stream) {
-  if (rows == 0 || cols == 0) return PDN_OK;
-  PDN_CHECK_ARG(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "pdn_transpose2d_f32: bad arguments");
-  hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, dst,
-                     rows, cols, ld_src, ld_dst);
-  PDN_LAUNCH_CHECK();
-  return PDN_OK;
-}

@@ -180,10 +180,6 @@ class EmulatedLib:
     def pdn_gemm_prof_collect_families(self, ms, fl, n): return 0
     def pdn_gemm_prof_collect_fused(self, ms, fl, by, n): return 0
 
-    def pdn_transpose2d_f32(self, src, dst, rows, cols, lds, ldd, stream):
-        view(dst, (cols, rows), (ldd, 1), np.float32)[...] = view(src, (rows, cols), (lds, 1), np.float32).T
-        return 0
-
     # -- gemm -------------------------------------------------------------------------------
     def pdn_gemm_f32(self, M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, nb1, nb2,
                      a1, a2, b1, b2, c1, c2, residual, colsum, colsum_acc, ws, wsb, stream):

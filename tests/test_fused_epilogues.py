@@ -182,19 +182,6 @@ def check_attention_bwd_rotated_equals_plain(dev):
     close(res[1][1], res[0][1], "dq | dk | dv", 2e-5)
 
 
-def check_transpose2d(dev):
-    """pdn_transpose2d_f32 (the per-step W^T of the lm_head's NT forward) on aligned and ragged shapes: bit-exact."""
-    L, hp = _lib_hp()
-    rng = np.random.default_rng(9)
-    for rows, cols, lds, ldd in ((288, 32000 // 50, 640, 288), (37, 101, 101, 37), (64, 64, 72, 68), (130, 257, 260, 132)):
-        a = rng.standard_normal((rows, lds)).astype(np.float32)
-        src, dst = hp.from_numpy(a), hp.zeros((cols, ldd), np.float32)
-        L.call("pdn_transpose2d_f32", src._ptr, dst._ptr, rows, cols, lds, ldd, hp.stream())
-        got = dst.get()
-        assert np.array_equal(got[:, :rows], a[:, :cols].T), (rows, cols)
-        assert not got[:, rows:].any()                          # nothing written beyond the matrix
-
-
 # ---- node level: one Llama block with the epilogues on / off --------------------------------------------------------
 def _block_step(dev, epilogues):
     from pydynet_amd.llm.llama import Llama
@@ -254,6 +241,6 @@ def check_llama_block_epilogues_vs_separate_kernels(dev):
 
 for _fn in [check_gateup_swiglu_full_blocks, check_gateup_swiglu_ragged_rows_ffn768,
             check_gateup_swiglu_up_matrix_first_in_memory, check_qkv_rope_hd48,
-            check_qkv_rope_hd96_ragged_tail, check_attention_bwd_rotated_equals_plain, check_transpose2d,
+            check_qkv_rope_hd96_ragged_tail, check_attention_bwd_rotated_equals_plain,
             check_llama_block_epilogues_vs_separate_kernels]:
     device_variants(globals(), _fn)

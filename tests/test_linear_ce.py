@@ -26,12 +26,9 @@ def close(a, b, what):
     assert float(np.abs(a - b).max()) <= 1e-7 + RT * scale, (what, float(np.abs(a - b).max()), scale)
 
 
-def _case(dev, rows, V, reduction, upstream, seed, nt=False):
+def _case(dev, rows, V, reduction, upstream, seed):
     D = 288
     fused.linear_cross_entropy.min_rows = 32          # (the model only takes the node from 32768 tokens up)
-    # nt: the forward product through a per-step row-major W^T (pdn_transpose2d_f32 + the NT form of the GEMM), as the
-    # benchmarked step runs it from 32768 tokens up
-    fused.linear_cross_entropy.nt_min_rows = 32 if nt else 1 << 30
     rng = np.random.default_rng(seed)
     x0 = rng.standard_normal((rows, D)).astype(np.float32)
     w0 = (0.05 * rng.standard_normal((D, V))).astype(np.float32)
@@ -75,9 +72,6 @@ def check_linear_ce_mean(dev):
     _case(dev, 64, 96, "mean", 1.0, 0)
 
 
-def check_linear_ce_nt_forward(dev):
-    _case(dev, 160, 224, "mean", 1.0, 3, nt=True)
-
 
 def check_linear_ce_sum_scaled_upstream(dev):
     _case(dev, 96, 160, "sum", 0.5, 1)
@@ -108,7 +102,7 @@ def check_linear_ce_not_applicable_falls_back(dev):
     assert not fused.linear_cross_entropy.applicable(x2, head2.weight, head2.bias, t2)   # rows not a multiple of 32
 
 
-for _f in (check_linear_ce_mean, check_linear_ce_nt_forward, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
+for _f in (check_linear_ce_mean, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
            check_linear_ce_not_applicable_falls_back):
     device_variants(globals(), _f)
 
