@@ -35,7 +35,29 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Division by a launch-time constant without the ~40-instruction integer-division sequence: the staging code turns a
+// flat element index into (channel, row, column) several times per element, and in the first version those divisions
+// were most of what the kernels executed (counters: 14 VALU instructions per LDS instruction).  Powers of two are a
+// shift; anything else is one multiply-high + shift (exact for 0 <= x < 2^31).
+struct FastDiv {
+  unsigned mul;                 // 0: shift only
+  int sh;
+};
+static inline FastDiv make_fastdiv(int d) {
+  FastDiv f{0u, 0};
+  if (d <= 1) return f;
+  int s = 0;
+  while ((1 << (s + 1)) <= d) ++s;              // floor(log2 d)
+  f.sh = s;
+  if ((d & (d - 1)) != 0) f.mul = (unsigned)(((1ull << (32 + s)) + (unsigned)d - 1) / (unsigned)d);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int x, const FastDiv& f) {
+  return f.mul ? (int)(__umulhi((unsigned)x, f.mul) >> f.sh) : (x >> f.sh);
+}
+
 struct ConvGeom {
+  FastDiv fw, fplane, fow, fopad, fcp;   // Win, Hin * Win, OW, OPAD, Cp
   int N, Cin, Hin, Win, Cout, k, stride, pad, OH, OW;
   int Cp;      // Cin rounded up to even
   int PH, PW;  // padded image extent held in LDS
@@ -53,15 +75,15 @@ __device__ __forceinline__ void stage_image(const float* __restrict__ src, float
   if ((g.Win & 3) == 0) {
     for (int e = threadIdx.x * 4; e < total; e += blockDim.x * 4) {
       const float4 v = *reinterpret_cast<const float4*>(src + e);
-      const int c = e / plane, rem = e - c * plane;
-      const int y = rem / g.Win, x = rem - y * g.Win;
+      const int c = fdiv(e, g.fplane), rem = e - c * plane;
+      const int y = fdiv(rem, g.fw), x = rem - y * g.Win;
       float* d = img + (c * g.PH + y + pad) * g.PW + x + pad;
       d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
   } else {
     for (int e = threadIdx.x; e < total; e += blockDim.x) {
-      const int c = e / plane, rem = e - c * plane;
-      const int y = rem / g.Win, x = rem - y * g.Win;
+      const int c = fdiv(e, g.fplane), rem = e - c * plane;
+      const int y = fdiv(rem, g.fw), x = rem - y * g.Win;
       img[(c * g.PH + y + pad) * g.PW + x + pad] = src[e];
     }
   }
@@ -91,14 +113,14 @@ struct TilePrefetch {
   }
   // (c, y, x) of element e in a (C, H, W) block -> frame[(c * PH + y + pad) * PW + x + pad]
   __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
-                                               int pad) {
+                                               int pad, const FastDiv& fplane, const FastDiv& fw) {
     const int plane = H * W;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = (threadIdx.x + i * 256) * 4;
       if (e < total) {
-        const int c = e / plane, rem = e - c * plane;
-        const int y = rem / W, x = rem - y * W;
+        const int c = fdiv(e, fplane), rem = e - c * plane;
+        const int y = fdiv(rem, fw), x = rem - y * W;
         lds_store4(frame + (c * PH + y + pad) * PW + x + pad, v[i]);
       }
     }
@@ -121,26 +143,26 @@ struct PooledPrefetch {
   unsigned m[NV > 0 ? NV : 1];
   // dp of ONE image: (C, H / 2, W / 2); hit words of one image: (C, H * W / 32); piece e covers (c, y, x .. x + 3)
   __device__ __forceinline__ void issue(const float* __restrict__ dp, const unsigned* __restrict__ hit, int total,
-                                        int H, int W) {
+                                        int H, int W, const FastDiv& fplane, const FastDiv& fw) {
     const int plane = H * W, hw = W >> 1;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e0 = (threadIdx.x + i * 256) * 4, e = e0 < total ? e0 : 0;      // (unconditional loads: see TilePrefetch)
-      const int c = e / plane, rem = e - c * plane;
-      const int y = rem / W, x = rem - y * W;
+      const int c = fdiv(e, fplane), rem = e - c * plane;
+      const int y = fdiv(rem, fw), x = rem - y * W;
       v[i] = *reinterpret_cast<const float2*>(dp + (c * (H >> 1) + (y >> 1)) * hw + (x >> 1));
       m[i] = hit[e >> 5];
     }
   }
   __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
-                                               int pad) {
+                                               int pad, const FastDiv& fplane, const FastDiv& fw) {
     const int plane = H * W;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = (threadIdx.x + i * 256) * 4;
       if (e < total) {
-        const int c = e / plane, rem = e - c * plane;
-        const int y = rem / W, x = rem - y * W;
+        const int c = fdiv(e, fplane), rem = e - c * plane;
+        const int y = fdiv(rem, fw), x = rem - y * W;
         lds_store4(frame + (c * PH + y + pad) * PW + x + pad, expand_pooled(v[i], (m[i] >> (e & 31)) & 15u));
       }
     }
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
 
   // weights, transposed to [tap][cin][cout] (cout fastest: A-operand reads are conflict-free)
   for (int e = threadIdx.x; e < taps * g.Cp * g.OPAD; e += blockDim.x) {
-    const int co = e % g.OPAD, t2 = e / g.OPAD, ci = t2 % g.Cp, tap = t2 / g.Cp;
+    const int t2 = fdiv(e, g.fopad), co = e - t2 * g.OPAD, tap = fdiv(t2, g.fcp), ci = t2 - tap * g.Cp;
     float v = 0.f;
     if (co < g.Cout && ci < g.Cin)
       v = g.mode == 0 ? w[((int64_t)co * g.wC + ci) * taps + tap]
@@ -196,14 +218,14 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
   typename std::conditional<SRC == 1, PooledPrefetch<NV>, TilePrefetch<NV>>::type pf;
   auto pf_issue = [&](int n) {
     if constexpr (SRC == 1)
-      pf.issue(x + (int64_t)n * (in_elems >> 2), pmask + (int64_t)n * (in_elems >> 5), in_elems, g.Hin, g.Win);
+      pf.issue(x + (int64_t)n * (in_elems >> 2), pmask + (int64_t)n * (in_elems >> 5), in_elems, g.Hin, g.Win, g.fplane, g.fw);
     else
       pf.issue(x + (int64_t)n * in_elems, in_elems);
   };
   if (NV > 0 && blockIdx.x < g.N) pf_issue(blockIdx.x);
   for (int n = blockIdx.x; n < g.N; n += gridDim.x) {
     if (NV > 0) {
-      pf.commit_image(img, in_elems, g.Hin, g.Win, g.PH, g.PW, g.pad);
+      pf.commit_image(img, in_elems, g.Hin, g.Win, g.PH, g.PW, g.pad, g.fplane, g.fw);
       __syncthreads();
       if (n + (int)gridDim.x < g.N) pf_issue(n + gridDim.x);
     } else {
@@ -218,7 +240,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
         const int chunk = (pass * 4 + wave) * CH + c;
         pos[c] = chunk * 32 + l31;
         const int pc = pos[c] < M ? pos[c] : M - 1;
-        const int oy = pc / g.OW, ox = pc - oy * g.OW;
+        const int oy = fdiv(pc, g.fow), ox = pc - oy * g.OW;
         poff[c] = oy * g.stride * g.PW + ox * g.stride + half * plane;   // half-wave h reads channel c0 + h
       }
       if ((pass * 4 + wave) * CH * 32 >= M) continue;                    // wave-uniform: nothing to do
@@ -367,6 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
 }
 
 struct WgradGeom {
+  FastDiv fw, fplane, fow, fq;   // W, H * W, OW, MB / 4
   int N, C, H, W, O, k, stride, pad, OH, OW;
   int PH, PW, OPAD, K1, KCOLS;   // K1 = C*k*k + 1 (bias column), KCOLS = K1 rounded up to 32
   int MB;                        // output positions staged per pass (a multiple of 8, or all of them)
@@ -428,9 +451,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
       const int e0 = threadIdx.x + i * 256, e = e0 < g.O * q ? e0 : 0;         // (unconditional loads: see TilePrefetch)
-      const int o = e / q, p = (e - o * q) * 4;
+      const int o = mb == g.MB ? fdiv(e, g.fq) : e / q, p = (e - o * q) * 4;
       if constexpr (SRC == 1) {
-        const int gp = m0 + p, oy = gp / g.OW, ox = gp - oy * g.OW;
+        const int gp = m0 + p, oy = fdiv(gp, g.fow), ox = gp - oy * g.OW;
         const int pi = (o * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
         dpv[i] = *reinterpret_cast<const float2*>(dyn + pi);
         dpm[i] = dmask[((int64_t)(n * g.O + o) * M + gp) >> 5];
@@ -441,12 +464,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   };
   auto commit = [&](int it) {
     const int m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
-    if (m0 == 0) px.commit_image(img, x_elems, g.H, g.W, g.PH, g.PW, g.pad);
+    if (m0 == 0) px.commit_image(img, x_elems, g.H, g.W, g.PH, g.PW, g.pad, g.fplane, g.fw);
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
       const int e = threadIdx.x + i * 256;
       if (e < g.O * q) {
-        const int o = e / q, p = (e - o * q) * 4;
+        const int o = mb == g.MB ? fdiv(e, g.fq) : e / q, p = (e - o * q) * 4;
         if constexpr (SRC == 1)
           lds_store4(dyl + o * g.DYS + p, expand_pooled(dpv[i], (dpm[i] >> ((m0 + p) & 31)) & 15u));
         else
@@ -466,6 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
       if (m0 == 0) {
         ConvGeom cg;
         cg.Cin = g.C; cg.Hin = g.H; cg.Win = g.W; cg.PH = g.PH; cg.PW = g.PW;
+        cg.fw = g.fw; cg.fplane = g.fplane;
         stage_image(x + (int64_t)n * x_elems, img, cg, g.pad);
       }
       const float* dyn = dy + (int64_t)n * g.O * M;
@@ -554,6 +578,211 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Lean weight gradient (round 4).  Same product as conv_wgrad_kernel -- dW[o][j] = sum over images and positions of
+// dy[o][pos] * col[pos][j], j = (c, kh, kw), + the bias column -- restructured around what the counters of the first
+// version showed (MFMA pipe 0.22 / 0.44 busy, 14 VALU per LDS instruction, as many bank-conflict cycles as LDS cycles):
+//   * a wave owns ONE 32-row tile of output channels and ALL column tiles of it (<= 6 accumulator tiles): the dy
+//     fragment of a position pair is read once for up to six MFMAs (1 + KT LDS reads per KT MFMAs instead of 2 KT);
+//     the 4 / OTN waves that share a row tile split the position pairs and are summed through LDS at the end;
+//   * the COLUMN ORDER inside the tiles is a permutation chosen on the host so that the 32 gather addresses of a
+//     tile -- c * plane + kh * PW + kw (+ a lane-uniform position offset) -- fall into 32 different banks (natural
+//     order: 2-3 lanes per bank); the reduce kernel undoes it (`WgradPerm`: tile lane -> weight column);
+//   * the bias column and the padding lanes read a plane of ones / of zeros behind the image planes with the SAME
+//     address arithmetic as a gather: no per-lane select in the loop;
+//   * the position walk is wave-uniform (scalar registers): per pair one vector add per LDS read and nothing else.
+// ---------------------------------------------------------------------------------------------------------
+struct WgradPerm {
+  unsigned short col[6 * 32];                        // tile lane -> weight column j (c * taps + tap), K = bias, 0xFFFF = padding
+};
+
+template <int KT, int OTN, int NVX, int NVD, int SRC>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_lean_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ partial, WgradGeom g, WgradPerm perm,
+                                                               const unsigned* __restrict__ dmask) {
+  constexpr int NPS = 4 / OTN;                        // waves sharing a row tile = slices of the position pairs
+  constexpr int G = KT >= 5 ? 1 : 2;                  // position pairs per prefetch group
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int plane = g.PH * g.PW, taps = g.k * g.k, K = g.C * taps;
+  float* img = lds;                                   // [C + 2][PH][PW]: image planes, a plane of ones, a plane of zeros
+  float* dyl = img + (g.C + 2) * plane;               // [O + 1][DYS], columns >= MB stay zero
+  const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ot = wave % OTN, ps = wave / OTN;
+  const int M = g.OH * g.OW;
+  for (int e = threadIdx.x; e < (g.C + 2) * plane; e += blockDim.x) img[e] = (e >= g.C * plane && e < (g.C + 1) * plane) ? 1.f : 0.f;
+  for (int e = threadIdx.x; e < (g.O + 1) * g.DYS; e += blockDim.x) dyl[e] = 0.f;
+  int cvo[KT];                                        // gather offset of this lane's column in every tile + its half's position
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) {
+    const int j = perm.col[kt * 32 + l31];
+    int off;
+    if (j < K) {
+      const int c = j / taps, tap = j - c * taps, kh = tap / g.k, kw = tap - kh * g.k;
+      off = c * plane + kh * g.PW + kw;
+    } else {
+      off = (j == K ? g.C : g.C + 1) * plane;         // ones (the bias column) / zeros
+    }
+    cvo[kt] = off + half * g.stride;
+  }
+  const int o = ot * 32 + l31;
+  const int arow = (o < g.O ? o : g.O) * g.DYS + half;
+  f32x16 acc[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[kt][r] = 0.f;
+  __syncthreads();
+
+  const int n0 = blockIdx.x * g.per_block, n1 = min(g.N, n0 + g.per_block);
+  const int nblk = (M + g.MB - 1) / g.MB, items = (n1 - n0) * nblk, x_elems = g.C * g.H * g.W;
+  const int zcol = g.DYS - 2;                         // an even column pair of the dy tile that is never written: zeros
+  TilePrefetch<NVX> px;
+  float4 dv[SRC == 0 ? NVD : 1];
+  float2 dpv[SRC == 1 ? NVD : 1];
+  unsigned dpm[SRC == 1 ? NVD : 1];
+  auto issue = [&](int it) {
+    const int n = n0 + it / nblk, m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
+    if (m0 == 0) px.issue(x + (int64_t)n * x_elems, x_elems);
+    const float* dyn = dy + (int64_t)n * g.O * (SRC == 1 ? (M >> 2) : M) + (SRC == 1 ? 0 : m0);
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) {
+      const int e0 = threadIdx.x + i * 256, e = e0 < g.O * q ? e0 : 0;         // (unconditional loads: see TilePrefetch)
+      const int oo = mb == g.MB ? fdiv(e, g.fq) : e / q, p = (e - oo * q) * 4;
+      if constexpr (SRC == 1) {
+        const int gp = m0 + p, oy = fdiv(gp, g.fow), ox = gp - oy * g.OW;
+        const int pi = (oo * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
+        dpv[i] = *reinterpret_cast<const float2*>(dyn + pi);
+        dpm[i] = dmask[((int64_t)(n * g.O + oo) * M + gp) >> 5];
+      } else {
+        dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)oo * M + p);
+      }
+    }
+  };
+  auto commit = [&](int it) {
+    const int m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
+    if (m0 == 0) px.commit_image(img, x_elems, g.H, g.W, g.PH, g.PW, g.pad, g.fplane, g.fw);
+#pragma unroll
+    for (int i = 0; i < NVD; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < g.O * q) {
+        const int oo = mb == g.MB ? fdiv(e, g.fq) : e / q, p = (e - oo * q) * 4;
+        if constexpr (SRC == 1)
+          lds_store4(dyl + oo * g.DYS + p, expand_pooled(dpv[i], (dpm[i] >> ((m0 + p) & 31)) & 15u));
+        else
+          lds_store4(dyl + oo * g.DYS + p, dv[i]);
+      }
+    }
+  };
+  if (items > 0) issue(0);
+  for (int it = 0; it < items; ++it) {
+    const int m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0);
+    if (it) __syncthreads();                          // previous item fully consumed
+    commit(it);
+    __syncthreads();
+    if (it + 1 < items) issue(it + 1);                // in flight during this item's MFMAs
+    // this wave's pairs: pp = ps, ps + NPS, ...; positions 2 pp (+ half); all of it in scalar registers
+    const int pairs = mb >> 1;                        // (mb is a multiple of 4)
+    int pp = ps;
+    int gp = m0 + 2 * pp;
+    int oy = fdiv(gp, g.fow), ox = gp - oy * g.OW;
+    float a[2][G], b[2][G][KT];
+    auto load = [&](int buf) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        const bool live = pp < pairs;                 // (uniform) past the end: the zero columns of the dy tile
+        const int col = live ? 2 * pp : zcol;
+        const int po = live ? (oy * g.PW + ox) * g.stride : 0;
+        a[buf][q] = dyl[arow + col];
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) b[buf][q][kt] = img[cvo[kt] + po];
+        pp += NPS;
+        ox += 2 * NPS;
+        if (ox >= g.OW) { ox -= g.OW; ++oy; }
+        if (ox >= g.OW) { ox -= g.OW; ++oy; }
+      }
+    };
+    auto mul = [&](int buf) {
+#pragma unroll
+      for (int q = 0; q < G; ++q)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+          acc[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[buf][q], b[buf][q][kt], acc[kt], 0, 0, 0);
+    };
+    const int iters = (pairs - ps + NPS - 1) / NPS;
+    const int groups = (iters + G - 1) / G;
+    if (groups > 0) load(0);
+    for (int gi = 0; gi < groups; gi += 2) {
+      if (gi + 1 < groups) load(1);
+      mul(0);
+      if (gi + 2 < groups) load(0);
+      if (gi + 1 < groups) mul(1);
+    }
+  }
+  __syncthreads();
+  // the NPS waves of a row tile: summed through LDS (the image space is free now), slice 0 stores
+  float* out = partial + (int64_t)blockIdx.x * g.OPAD * g.KCOLS;
+  if (NPS > 1) {
+    float* red = lds;                                 // [NPS - 1 slices][OTN][KT][16][64]: slice 0 keeps its own in registers
+    if (ps != 0) {
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((((ps - 1) * OTN + ot) * KT + kt) * 16 + r) * 64 + lane] = acc[kt][r];
+    }
+    __syncthreads();
+    if (ps != 0) return;
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sum = acc[kt][r];
+#pragma unroll
+        for (int sl = 1; sl < NPS; ++sl) sum += red[((((sl - 1) * OTN + ot) * KT + kt) * 16 + r) * 64 + lane];
+        acc[kt][r] = sum;
+      }
+  }
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      out[(int64_t)(ot * 32 + acc_row(r, half)) * g.KCOLS + kt * 32 + l31] = acc[kt][r];
+}
+
+// the reduce of the lean kernel: slab column p holds weight column perm[p]
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_perm_kernel(const float* __restrict__ partial, int slabs, int OPAD,
+                                                                      int KCOLS, int O, int K, WgradPerm perm,
+                                                                      float* __restrict__ dw, float* __restrict__ db,
+                                                                      int accumulate) {
+  __shared__ float red[8][32];
+  const int total = O * KCOLS;
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  float s = 0.f;
+  int o = 0, j = 0xFFFF;
+  if (e < total) {
+    o = e / KCOLS;
+    const int pcol = e - o * KCOLS;
+    j = perm.col[pcol];
+    if (j <= K) {
+      const float* p = partial + (int64_t)o * KCOLS + pcol;
+      const int64_t stride = (int64_t)OPAD * KCOLS;
+      for (int b = grp; b < slabs; b += 8) s += p[b * stride];
+    }
+  }
+  red[grp][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (grp == 0 && e < total && j <= K) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][threadIdx.x];
+    if (j < K) {
+      if (dw) dw[(int64_t)o * K + j] = accumulate ? dw[(int64_t)o * K + j] + t : t;
+    } else if (db) {
+      db[o] = accumulate ? db[o] + t : t;
+    }
+  }
+}
+
 // dw[o][j] (+)= sum_slabs partial[slab][o][j] (j < K), db[o] (+)= column K.  A workgroup owns 32
 // consecutive elements; its 8 thread groups sum interleaved slabs and combine through LDS in a fixed
 // order: deterministic, and 8x the memory parallelism of one thread per element.
@@ -614,6 +843,8 @@ bool fwd_geom(ConvGeom& g, int N, int Cin, int Hin, int Win, int Cout, int k, in
   g.PH = Hin + 2 * pad; g.PW = Win + 2 * pad;
   g.OPAD = (Cout + 31) / 32 * 32;
   g.mode = mode; g.wC = wC; g.wO = wO;
+  g.fw = make_fastdiv(Win); g.fplane = make_fastdiv(Hin * Win); g.fow = make_fastdiv(g.OW > 0 ? g.OW : 1);
+  g.fopad = make_fastdiv(g.OPAD); g.fcp = make_fastdiv(g.Cp);
   return g.OH > 0 && g.OW > 0;
 }
 int64_t fwd_lds(const ConvGeom& g) {
@@ -692,6 +923,8 @@ bool wgrad_geom(WgradGeom& g, int N, int C, int H, int W, int O, int k, int stri
   const int64_t img_b = 4ll * C * g.PH * g.PW;
   if (img_b + 4ll * (O + 1) * (M | 1) > 78 * 1024 && M > 512) g.MB = 512;
   g.DYS = g.MB | 1;
+  g.fw = make_fastdiv(W); g.fplane = make_fastdiv(H * W); g.fow = make_fastdiv(g.OW > 0 ? g.OW : 1);
+  g.fq = make_fastdiv(g.MB / 4 > 0 ? g.MB / 4 : 1);
   return g.OH > 0 && g.OW > 0;
 }
 int64_t wgrad_lds(const WgradGeom& g) {
@@ -704,6 +937,48 @@ bool wgrad_prefetch(const WgradGeom& g) {     // operands of one item fit the re
   const int M = g.OH * g.OW;
   return (g.W & 3) == 0 && (M & 3) == 0 && (g.MB & 3) == 0 && g.C * g.H * g.W <= 8 * 1024 &&
          g.O * (g.MB < M ? g.MB : M) <= 16 * 1024;
+}
+// Column order of the lean kernel: tile lane -> weight column, chosen so that the gather addresses of a tile's 32 lanes
+// (c * plane + kh * PW + kw) occupy 32 different LDS banks wherever the columns allow it (greedy colouring; the bias
+// column reads the ones plane, padding lanes the zeros plane: all padding lanes share ONE address = a broadcast).
+bool wgrad_lean_geom(const WgradGeom& g, int& KT, int& OTN) {
+  KT = g.KCOLS / 32; OTN = g.OPAD / 32;
+  return KT >= 1 && KT <= 6 && (OTN == 1 || OTN == 2) && (g.MB & 3) == 0 && g.C * g.k * g.k + 1 <= 6 * 32;
+}
+int64_t wgrad_lean_lds(const WgradGeom& g) {
+  const int KT = g.KCOLS / 32;
+  int64_t b = 4ll * ((int64_t)(g.C + 2) * g.PH * g.PW + (int64_t)(g.O + 1) * g.DYS) + 64;
+  const int OTN = g.OPAD / 32;
+  const int64_t red = 4ll * (4 / OTN - 1) * OTN * KT * 16 * 64;
+  return b > red ? b : red;
+}
+void wgrad_build_perm(const WgradGeom& g, WgradPerm& pm) {
+  const int KT = g.KCOLS / 32, taps = g.k * g.k, K = g.C * taps, plane = g.PH * g.PW;
+  int fill[6] = {0, 0, 0, 0, 0, 0};
+  unsigned used[6] = {0, 0, 0, 0, 0, 0};             // banks taken per tile
+  for (int i = 0; i < 6 * 32; ++i) pm.col[i] = 0xFFFF;
+  auto bank_of = [&](int j) {
+    if (j == K) return (g.C * plane) & 31;
+    const int c = j / taps, tap = j - c * taps, kh = tap / g.k, kw = tap - kh * g.k;
+    return (c * plane + kh * g.PW + kw) & 31;
+  };
+  // two passes: conflict-free placements first, whatever is left goes where there is room (the padding lanes that
+  // fill the tiles up afterwards share one address: at worst one two-way conflict per tile)
+  unsigned char placed[6 * 32 + 1] = {0};
+  for (int pass = 0; pass < 2; ++pass)
+    for (int j = 0; j <= K; ++j) {
+      if (placed[j]) continue;
+      const unsigned bit = 1u << bank_of(j);
+      for (int t = 0; t < KT; ++t) {
+        const unsigned busy = used[t];
+        if (fill[t] < 32 && (pass == 1 || !(busy & bit))) {
+          pm.col[t * 32 + fill[t]++] = (unsigned short)j;
+          used[t] |= bit;
+          placed[j] = 1;
+          break;
+        }
+      }
+    }
 }
 bool wgrad_ok(const WgradGeom& g) { return wgrad_tiles(g) <= 16 && wgrad_lds(g) <= kMaxLds; }
 int wgrad_blocks(const WgradGeom& g) {
@@ -784,6 +1059,55 @@ int launch_wgrad(const float* x, const float* dy, const unsigned* dmask, float* 
   g.per_block = (N + blocks - 1) / blocks;
   const int used = (N + g.per_block - 1) / g.per_block;
   const int T = wgrad_tiles(g);
+  {
+    // the lean kernel (one row tile and all column tiles per wave, conflict-free column order): LeNet-class shapes
+    static const int lean_env = getenv("PDN_CONV_WGRAD_LEAN") ? atoi(getenv("PDN_CONV_WGRAD_LEAN")) : 1;
+    int KT = 0, OTN = 0;
+    const int M_ = g.OH * g.OW;
+    const int mb_keep = g.MB;
+    g.DYS = (g.MB + 2) | 1;                           // two zero columns behind the staged positions
+    if (wgrad_lean_lds(g) > 80 * 1024 && (g.MB & 7) == 0 && g.MB > 128) {      // two workgroups per CU: half the positions
+      g.MB >>= 1;
+      g.DYS = (g.MB + 2) | 1;
+    }
+    g.fq = make_fastdiv(g.MB / 4);
+    const bool lean = lean_env && wgrad_lean_geom(g, KT, OTN) && wgrad_prefetch(g) && wgrad_lean_lds(g) <= 80 * 1024 &&
+                      (!dmask || ((g.OW & 3) == 0 && (g.OH & 1) == 0 && (M_ & 31) == 0)) && (g.OW & 1) == 0 &&
+                      workspace && workspace_bytes >= 4ll * used * g.OPAD * g.KCOLS;
+    if (lean) {
+      WgradPerm pm;
+      wgrad_build_perm(g, pm);
+      const int64_t lds = wgrad_lean_lds(g);
+      hipStream_t st = (hipStream_t)stream;
+      float* partial = (float*)workspace;
+#define PDN_LEAN_GO(KT_, OTN_, SRC_)                                                                       \
+  do {                                                                                                    \
+    auto kern = conv_wgrad_lean_kernel<KT_, OTN_, 8, 16, SRC_>;                                           \
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) { pdn_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
+    hipLaunchKernelGGL(kern, dim3(used), dim3(256), lds, st, x, dy, partial, g, pm, dmask);               \
+  } while (0)
+#define PDN_LEAN_KT(OTN_, SRC_)                                                                           \
+  switch (KT) {                                                                                           \
+    case 1: PDN_LEAN_GO(1, OTN_, SRC_); break; case 2: PDN_LEAN_GO(2, OTN_, SRC_); break;                 \
+    case 3: PDN_LEAN_GO(3, OTN_, SRC_); break; case 4: PDN_LEAN_GO(4, OTN_, SRC_); break;                 \
+    case 5: PDN_LEAN_GO(5, OTN_, SRC_); break; default: PDN_LEAN_GO(6, OTN_, SRC_); break;                \
+  }
+      if (OTN == 1) { if (dmask) { PDN_LEAN_KT(1, 1) } else { PDN_LEAN_KT(1, 0) } }
+      else { if (dmask) { PDN_LEAN_KT(2, 1) } else { PDN_LEAN_KT(2, 0) } }
+#undef PDN_LEAN_KT
+#undef PDN_LEAN_GO
+      PDN_LAUNCH_CHECK();
+      const int total = O * g.KCOLS;
+      hipLaunchKernelGGL(conv_wgrad_reduce_perm_kernel, dim3((total + 31) / 32), dim3(256), 0, st, partial, used, g.OPAD,
+                         g.KCOLS, O, g.K1 - 1, pm, dw, db, accumulate);
+      PDN_LAUNCH_CHECK();
+      return PDN_OK;
+    }
+    g.MB = mb_keep;
+    g.DYS = g.MB | 1;
+    g.fq = make_fastdiv(g.MB / 4);
+  }
   const int ps = T < 4 ? 1 : 0;
   const int slabs = used;
   if (!workspace || workspace_bytes < 4ll * slabs * g.OPAD * g.KCOLS) {
