@@ -98,9 +98,25 @@ __device__ __forceinline__ void lds_store4(float* __restrict__ d, const float4& 
   d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 }
 
-template <int NV>
+// HO: the (c, y, x) -> frame offset of every piece a thread stages is the same for every image: worked out once
+// (`init`) and kept in registers instead of redone per image (kernels with registers to spare).
+template <int NV, bool HO = false>
 struct TilePrefetch {
   float4 v[NV > 0 ? NV : 1];
+  int foff[(HO && NV > 0) ? NV : 1];                  // frame offset of piece i, -1: not this thread's
+  __device__ __forceinline__ void init(int total, int H, int W, int PH, int PW, int pad, const FastDiv& fplane,
+                                       const FastDiv& fw) {
+    if constexpr (HO) {
+      const int plane = H * W;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e = (threadIdx.x + i * 256) * 4;
+        const int c = fdiv(e, fplane), rem = e - c * plane;
+        const int y = fdiv(rem, fw), x = rem - y * W;
+        foff[i] = e < total ? (c * PH + y + pad) * PW + x + pad : -1;
+      }
+    }
+  }
   __device__ __forceinline__ void issue(const float* __restrict__ src, int total) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -115,6 +131,12 @@ struct TilePrefetch {
   __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
                                                int pad, const FastDiv& fplane, const FastDiv& fw) {
     const int plane = H * W;
+    if constexpr (HO) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (foff[i] >= 0) lds_store4(frame + foff[i], v[i]);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e = (threadIdx.x + i * 256) * 4;
@@ -137,14 +159,38 @@ __device__ __forceinline__ float4 expand_pooled(const float2& v, unsigned bits) 
   return make_float4((bits & 1u) ? v.x : 0.f, (bits & 2u) ? v.x : 0.f, (bits & 4u) ? v.y : 0.f, (bits & 8u) ? v.y : 0.f);
 }
 
-template <int NV>
+template <int NV, bool HO = false>
 struct PooledPrefetch {
   float2 v[NV > 0 ? NV : 1];
   unsigned m[NV > 0 ? NV : 1];
+  int foff[(HO && NV > 0) ? NV : 1], soff[(HO && NV > 0) ? NV : 1];   // frame offset (-1: none) / pooled source offset
+  __device__ __forceinline__ void init(int total, int H, int W, int PH, int PW, int pad, const FastDiv& fplane,
+                                       const FastDiv& fw) {
+    if constexpr (HO) {
+      const int plane = H * W, hw = W >> 1;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e0 = (threadIdx.x + i * 256) * 4, e = e0 < total ? e0 : 0;
+        const int c = fdiv(e, fplane), rem = e - c * plane;
+        const int y = fdiv(rem, fw), x = rem - y * W;
+        soff[i] = (c * (H >> 1) + (y >> 1)) * hw + (x >> 1);
+        foff[i] = e0 < total ? (c * PH + y + pad) * PW + x + pad : -1;
+      }
+    }
+  }
   // dp of ONE image: (C, H / 2, W / 2); hit words of one image: (C, H * W / 32); piece e covers (c, y, x .. x + 3)
   __device__ __forceinline__ void issue(const float* __restrict__ dp, const unsigned* __restrict__ hit, int total,
                                         int H, int W, const FastDiv& fplane, const FastDiv& fw) {
     const int plane = H * W, hw = W >> 1;
+    if constexpr (HO) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int e0 = (threadIdx.x + i * 256) * 4, e = e0 < total ? e0 : 0;
+        v[i] = *reinterpret_cast<const float2*>(dp + (unsigned)soff[i]);
+        m[i] = hit[(unsigned)(e >> 5)];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int e0 = (threadIdx.x + i * 256) * 4, e = e0 < total ? e0 : 0;      // (unconditional loads: see TilePrefetch)
@@ -156,6 +202,13 @@ struct PooledPrefetch {
   }
   __device__ __forceinline__ void commit_image(float* __restrict__ frame, int total, int H, int W, int PH, int PW,
                                                int pad, const FastDiv& fplane, const FastDiv& fw) {
+    if constexpr (HO) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (foff[i] >= 0)
+          lds_store4(frame + foff[i], expand_pooled(v[i], (m[i] >> (((threadIdx.x + i * 256) * 4) & 31)) & 15u));
+      return;
+    }
     const int plane = H * W;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -215,7 +268,9 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
   const int chunks = (M + 31) / 32, per_pass = 4 * CH, passes = (chunks + per_pass - 1) / per_pass;
   const int plane = g.PH * g.PW, npair = g.Cp / 2, wstep = 2 * g.OPAD, tapw = g.Cp * g.OPAD;
   const int in_elems = g.Cin * g.Hin * g.Win;
-  typename std::conditional<SRC == 1, PooledPrefetch<NV>, TilePrefetch<NV>>::type pf;
+  constexpr bool HO = NV > 0 && NV <= 8;            // staging offsets kept in registers where there is room
+  typename std::conditional<SRC == 1, PooledPrefetch<NV, HO>, TilePrefetch<NV, HO>>::type pf;
+  pf.init(in_elems, g.Hin, g.Win, g.PH, g.PW, g.pad, g.fplane, g.fw);
   auto pf_issue = [&](int n) {
     if constexpr (SRC == 1)
       pf.issue(x + (int64_t)n * (in_elems >> 2), pmask + (int64_t)n * (in_elems >> 5), in_elems, g.Hin, g.Win, g.fplane, g.fw);
@@ -637,40 +692,62 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_lean_kernel(const float* __
   const int n0 = blockIdx.x * g.per_block, n1 = min(g.N, n0 + g.per_block);
   const int nblk = (M + g.MB - 1) / g.MB, items = (n1 - n0) * nblk, x_elems = g.C * g.H * g.W;
   const int zcol = g.DYS - 2;                         // an even column pair of the dy tile that is never written: zeros
-  TilePrefetch<NVX> px;
+  TilePrefetch<NVX, (KT <= 3)> px;
+  px.init(x_elems, g.H, g.W, g.PH, g.PW, g.pad, g.fplane, g.fw);
   float4 dv[SRC == 0 ? NVD : 1];
   float2 dpv[SRC == 1 ? NVD : 1];
   unsigned dpm[SRC == 1 ? NVD : 1];
-  auto issue = [&](int it) {
-    const int n = n0 + it / nblk, m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
-    if (m0 == 0) px.issue(x + (int64_t)n * x_elems, x_elems);
-    const float* dyn = dy + (int64_t)n * g.O * (SRC == 1 ? (M >> 2) : M) + (SRC == 1 ? 0 : m0);
+  // Which element of the dy block a thread stages, where it comes from and where it goes, depend on the thread and
+  // the piece index only (every block has MB positions, MB a multiple of two output rows and of 32): worked out ONCE
+  // here -- in the first version this index arithmetic, redone per piece and item with 64-bit addresses, was most
+  // of the kernel's instruction stream.  Per item only two scalar bases change.
+  const int q = g.MB >> 2;
+  int src_off[NVD], msk_off[SRC == 1 ? NVD : 1], dst_sh[NVD];
+  unsigned vbits = 0;
 #pragma unroll
-    for (int i = 0; i < NVD; ++i) {
-      const int e0 = threadIdx.x + i * 256, e = e0 < g.O * q ? e0 : 0;         // (unconditional loads: see TilePrefetch)
-      const int oo = mb == g.MB ? fdiv(e, g.fq) : e / q, p = (e - oo * q) * 4;
-      if constexpr (SRC == 1) {
-        const int gp = m0 + p, oy = fdiv(gp, g.fow), ox = gp - oy * g.OW;
-        const int pi = (oo * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
-        dpv[i] = *reinterpret_cast<const float2*>(dyn + pi);
-        dpm[i] = dmask[((int64_t)(n * g.O + oo) * M + gp) >> 5];
-      } else {
-        dv[i] = *reinterpret_cast<const float4*>(dyn + (int64_t)oo * M + p);
+  for (int i = 0; i < NVD; ++i) {
+    const int e0 = threadIdx.x + i * 256;
+    const bool ok = e0 < g.O * q;
+    const int e = ok ? e0 : 0;                        // (threads past the end re-read piece 0 and never commit it)
+    const int oo = fdiv(e, g.fq), p = (e - oo * q) * 4;
+    if constexpr (SRC == 1) {
+      const int oy = fdiv(p, g.fow), ox = p - oy * g.OW;
+      src_off[i] = (oo * (g.OH >> 1) + (oy >> 1)) * (g.OW >> 1) + (ox >> 1);
+      msk_off[i] = oo * (M >> 5) + (p >> 5);
+      dst_sh[i] = (oo * g.DYS + p) | ((p & 31) << 24);
+    } else {
+      src_off[i] = oo * M + p;
+      dst_sh[i] = oo * g.DYS + p;
+    }
+    vbits |= (ok ? 1u : 0u) << i;
+  }
+  auto issue = [&](int it) {
+    const int n = n0 + it / nblk, m0 = (it % nblk) * g.MB;
+    if (m0 == 0) px.issue(x + (int64_t)n * x_elems, x_elems);
+    if constexpr (SRC == 1) {
+      const float* dp_base = dy + (int64_t)n * g.O * (M >> 2) + (m0 >> 2);
+      const unsigned* m_base = dmask + (((int64_t)n * g.O * M + m0) >> 5);
+#pragma unroll
+      for (int i = 0; i < NVD; ++i) {
+        dpv[i] = *reinterpret_cast<const float2*>(dp_base + (unsigned)src_off[i]);
+        dpm[i] = m_base[(unsigned)msk_off[i]];
       }
+    } else {
+      const float* d_base = dy + (int64_t)n * g.O * M + m0;
+#pragma unroll
+      for (int i = 0; i < NVD; ++i) dv[i] = *reinterpret_cast<const float4*>(d_base + (unsigned)src_off[i]);
     }
   };
   auto commit = [&](int it) {
-    const int m0 = (it % nblk) * g.MB, mb = min(g.MB, M - m0), q = mb >> 2;
+    const int m0 = (it % nblk) * g.MB;
     if (m0 == 0) px.commit_image(img, x_elems, g.H, g.W, g.PH, g.PW, g.pad, g.fplane, g.fw);
 #pragma unroll
     for (int i = 0; i < NVD; ++i) {
-      const int e = threadIdx.x + i * 256;
-      if (e < g.O * q) {
-        const int oo = mb == g.MB ? fdiv(e, g.fq) : e / q, p = (e - oo * q) * 4;
+      if ((vbits >> i) & 1u) {
         if constexpr (SRC == 1)
-          lds_store4(dyl + oo * g.DYS + p, expand_pooled(dpv[i], (dpm[i] >> ((m0 + p) & 31)) & 15u));
+          lds_store4(dyl + (dst_sh[i] & 0xFFFFFF), expand_pooled(dpv[i], (dpm[i] >> (dst_sh[i] >> 24)) & 15u));
         else
-          lds_store4(dyl + oo * g.DYS + p, dv[i]);
+          lds_store4(dyl + dst_sh[i], dv[i]);
       }
     }
   };
@@ -1066,14 +1143,22 @@ int launch_wgrad(const float* x, const float* dy, const unsigned* dmask, float* 
     const int M_ = g.OH * g.OW;
     const int mb_keep = g.MB;
     g.DYS = (g.MB + 2) | 1;                           // two zero columns behind the staged positions
-    if (wgrad_lean_lds(g) > 80 * 1024 && (g.MB & 7) == 0 && g.MB > 128) {      // two workgroups per CU: half the positions
+    // half the positions per item when two workgroups would not fit a CU, or when the wide (>= 4 column tiles) forms
+    // would need more than 8 staging pieces per thread (their accumulators leave no registers for 16)
+    if ((wgrad_lean_lds(g) > 80 * 1024 || (g.KCOLS >= 128 && O * (g.MB / 4) > 8 * 256)) && (g.MB & 7) == 0 && g.MB > 128) {
       g.MB >>= 1;
       g.DYS = (g.MB + 2) | 1;
     }
     g.fq = make_fastdiv(g.MB / 4);
+    const int need = (O * (g.MB / 4) + 255) / 256;    // 16-byte pieces of the dy block per thread
     const bool lean = lean_env && wgrad_lean_geom(g, KT, OTN) && wgrad_prefetch(g) && wgrad_lean_lds(g) <= 80 * 1024 &&
+                      M_ % g.MB == 0 && g.MB % 32 == 0 && g.MB % (2 * g.OW) == 0 && need <= (KT >= 4 ? 8 : 16) &&
                       (!dmask || ((g.OW & 3) == 0 && (g.OH & 1) == 0 && (M_ & 31) == 0)) && (g.OW & 1) == 0 &&
                       workspace && workspace_bytes >= 4ll * used * g.OPAD * g.KCOLS;
+    if (getenv("PDN_CONV_DEBUG"))
+      fprintf(stderr, "wgrad %s: lean=%d geom=%d (KT %d OTN %d) prefetch=%d lds=%lld MB=%d M=%d need=%d ws=%lld/%lld\n", who, (int)lean,
+              (int)wgrad_lean_geom(g, KT, OTN), KT, OTN, (int)wgrad_prefetch(g), (long long)wgrad_lean_lds(g), g.MB, M_, need,
+              (long long)workspace_bytes, (long long)(4ll * used * g.OPAD * g.KCOLS));
     if (lean) {
       WgradPerm pm;
       wgrad_build_perm(g, pm);
@@ -1082,7 +1167,9 @@ int launch_wgrad(const float* x, const float* dy, const unsigned* dmask, float* 
       float* partial = (float*)workspace;
 #define PDN_LEAN_GO(KT_, OTN_, SRC_)                                                                       \
   do {                                                                                                    \
-    auto kern = conv_wgrad_lean_kernel<KT_, OTN_, 8, 16, SRC_>;                                           \
+    auto kern8 = conv_wgrad_lean_kernel<KT_, OTN_, 8, 8, SRC_>;                                           \
+    auto kern16 = conv_wgrad_lean_kernel<KT_, OTN_, 8, 16, SRC_>;                                         \
+    auto kern = need <= 8 ? kern8 : kern16;                                                               \
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
     if (e != hipSuccess) { pdn_set_error("conv: LDS attribute: %s", hipGetErrorString(e)); return (int)e; } \
     hipLaunchKernelGGL(kern, dim3(used), dim3(256), lds, st, x, dy, partial, g, pm, dmask);               \
