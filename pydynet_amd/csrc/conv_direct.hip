@@ -253,22 +253,22 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
   for (int e = threadIdx.x; e < img_elems; e += blockDim.x) img[e] = 0.f;   // halo + padded channel stay 0
   __syncthreads();
 
-  float breg[EP == 1 ? 1 : OT][EP == 1 ? 1 : 16];      // (the fused epilogue re-reads the bias from LDS: its
-  unsigned rowmask[OT];                                //  registers are needed for the pooling)
+  // (the bias is re-read from LDS in the epilogue -- sixteen reads per stored tile: keeping it in registers cost the
+  //  data-gradient form, which has none, sixteen registers it needs for its prefetch)
+  unsigned rowmask[OT];
 #pragma unroll
   for (int o = 0; o < OT; ++o) {
     rowmask[o] = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int oc = o * 32 + acc_row(r, half);
-      if constexpr (EP != 1) breg[o][r] = bs[oc];
       rowmask[o] |= (oc < g.Cout ? 1u : 0u) << r;
     }
   }
   const int chunks = (M + 31) / 32, per_pass = 4 * CH, passes = (chunks + per_pass - 1) / per_pass;
   const int plane = g.PH * g.PW, npair = g.Cp / 2, wstep = 2 * g.OPAD, tapw = g.Cp * g.OPAD;
   const int in_elems = g.Cin * g.Hin * g.Win;
-  constexpr bool HO = NV > 0 && NV <= 8;            // staging offsets kept in registers where there is room
+  constexpr bool HO = NV > 0 && (NV <= 8 || OT * CH <= 2);   // staging offsets kept in registers where there is room
   typename std::conditional<SRC == 1, PooledPrefetch<NV, HO>, TilePrefetch<NV, HO>>::type pf;
   pf.init(in_elems, g.Hin, g.Win, g.PH, g.PW, g.pad, g.fplane, g.fw);
   auto pf_issue = [&](int n) {
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, 2) void conv_direct_kernel(const float* __rest
           float* yp = yn + pos[c];
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            if (rowmask[o] >> r & 1) yp[(int64_t)(o * 32 + acc_row(r, half)) * M] = acc[o][c][r] + breg[o][r];
+            if (rowmask[o] >> r & 1) yp[(int64_t)(o * 32 + acc_row(r, half)) * M] = acc[o][c][r] + bs[o * 32 + acc_row(r, half)];
         }
       }
     }

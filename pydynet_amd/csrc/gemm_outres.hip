@@ -441,6 +441,7 @@ struct OutResTnParams {
   // at C + b * blk_stride + s * slab, rows of `ldc` floats; nb_cols = N for a single matrix
   int nb_cols;
   int64_t blk_stride;
+  int xcd_swizzle;                // 1: K ranges dealt to XCDs (the number of K ranges is a multiple of 8)
 };
 
 template <int NW, bool CE = false>
@@ -452,10 +453,20 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
-  const int n0_raw = (blockIdx.x * NW + wave) * 32;
+  // Workgroup -> (column block bx, K range by).  Hardware deals consecutive workgroups to the 8 XCDs round-robin: in
+  // launch order the column blocks that read the SAME x rows (one K range) land on different XCDs and every private
+  // L2 fetches those rows again (counters of the packed layer weight gradients, round 3: 1.77 x the operand bytes,
+  // L2 hit rate 0.10).  Re-dealt here so that the column blocks of one K range are consecutive on ONE XCD.
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (p.xcd_swizzle) {
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, xcd = L & 7, slot = L >> 3;
+    bx = slot % (int)gridDim.x;
+    by = (slot / (int)gridDim.x) * 8 + xcd;
+  }
+  const int n0_raw = (bx * NW + wave) * 32;
   const bool active = n0_raw < p.N;
   const int n0 = active ? n0_raw : p.N - 32;          // idle waves still stage X and meet the barriers
-  const int k_begin = blockIdx.y * p.k_per_split;
+  const int k_begin = by * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int npieces = (k_end - k_begin) / OR_KP;
   const unsigned ldx = (unsigned)p.ldx, ldg = (unsigned)p.ldg;
@@ -584,11 +595,11 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
   if (!active) return;
   if (CE && p.colsum) {                             // both half-waves saw disjoint token rows
     csum += __shfl_xor(csum, 32, 64);
-    if (lh == 0) p.colsum[(int64_t)blockIdx.y * p.N + n0 + li] = csum;
+    if (lh == 0) p.colsum[(int64_t)by * p.N + n0 + li] = csum;
   }
   // accumulator register r of tile i = row 32 i + (r & 3) + 8 (r >> 2) + 4 h, column n0 + lane
   const int blk = n0 / p.nb_cols;                   // (a wave's 32 columns never straddle two blocks: nb_cols % 32 == 0)
-  float* __restrict__ Cw = p.C + blk * p.blk_stride + (int64_t)blockIdx.y * p.slab + (n0 - blk * p.nb_cols) + li;
+  float* __restrict__ Cw = p.C + blk * p.blk_stride + (int64_t)by * p.slab + (n0 - blk * p.nb_cols) + li;
   const unsigned ldc = (unsigned)p.ldc;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
@@ -608,6 +619,7 @@ int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out) {
   const int col_wgs = (N / 32 + nw - 1) / nw;
   int splits = (nw == 8 ? 256 : 512) / (col_wgs > 0 ? col_wgs : 1);
   if (splits < 1) splits = 1;
+  if (splits >= 16 && col_wgs > 1) splits &= ~7;     // whole octets of K ranges: one per XCD (see the kernel's block mapping)
   const int pieces = K / OR_KP;
   if (splits > pieces) splits = pieces > 0 ? pieces : 1;
   const int kps = ((pieces + splits - 1) / splits) * OR_KP;
@@ -620,6 +632,8 @@ int pdn_gemm_outres_tn_plan(int N, int K, int* nw_out, int* k_per_split_out) {
 static int outres_tn_launch(OutResTnParams& p, int nw, bool ce, void* stream) {
   const int splits = (p.K + p.k_per_split - 1) / p.k_per_split;
   const dim3 grid((p.N / 32 + nw - 1) / nw, splits);
+  static const int swz_env = getenv("PDN_OUTRES_TN_SWIZZLE") ? atoi(getenv("PDN_OUTRES_TN_SWIZZLE")) : 1;
+  p.xcd_swizzle = (swz_env && splits % 8 == 0 && grid.x > 1) ? 1 : 0;
   const size_t shm = (size_t)(2 * OR_KP * OR_N + nw * 2 * OR_KP * 32 + 4 * 32) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
