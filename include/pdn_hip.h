@@ -141,6 +141,12 @@ int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* b
  *  - q | k | v projection + RoPE on the q and k blocks (model.py:23-44, 93-104): qkv (M x 3D) = x [Wq | Wk | Wv], row m is
  *    position m % L; `rope` is the (L x hd x 2) table pdn_rope_table_f32 expands from the reference's (L x hd/2)
  *    cos / sin tables: (cos, sin with the sign of the column's place in its pair). */
+/* dX (M x 288) = [d_1 | ... | d_nb] (M x nb * kb) [W_1 | ... | W_nb]^T (+ residual): the input gradient of projections
+ * that share their input, the weights W_i (288 x kb, row-major, `b_block_stride` floats apart) read where they live
+ * (csrc/gemm_outres.hip; `grad @ W^T` of tensor.py:670, one contraction over all projections) */
+int pdn_gemm_outres_blocks_supported(int M, int kb, int nb);
+int pdn_gemm_outres_blocks_nt_f32(const float* A, const float* W, int64_t b_block_stride, int kb, int nb, float* C,
+                                  const float* residual, int M, int64_t lda, int64_t ldc, void* stream);
 int pdn_gateup_swiglu_supported(int M, int F, int K);
 int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, int64_t w_stride, float* gu, float* h, int M,
                               int F, int K, int64_t ldx, void* stream);

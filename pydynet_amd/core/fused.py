@@ -1388,6 +1388,29 @@ def _pack_columns(hp, weights):
     return cat
 
 
+def _dx_of_shared_input(hp, node, x, dcat, weights, T, fin):
+    """dx = [d_1 | d_2 | ...] @ [W_1 | W_2 | ...]^T (+ the gradient x already holds) for projections that share their
+    input: ONE contraction over all of them.  With the weights equally spaced in memory (how `Attention.move` /
+    `FeedForward.move` pack them) and enough rows the product reads them where they live
+    (`pdn_gemm_outres_blocks_nt_f32`); otherwise against a column-packed copy made here."""
+    L = _L()
+    dx = hp.empty(x.shape, np.float32)
+    ex = _foldable(node, 0, x)
+    exr = ex.reshape(T, fin) if ex is not None else None
+    ws = [_contig(w.data) for w in weights]
+    stack = hp.stacked_view(ws)
+    kb = ws[0].shape[1]
+    if (fin == 288 and stack is not None and abs(stack._strides[0]) < (1 << 40) and dcat.is_contiguous()
+            and os.environ.get("PDN_NO_DX_BLOCKS", "0") != "1"
+            and L.query("pdn_gemm_outres_blocks_supported", T, kb, len(ws))):
+        L.call("pdn_gemm_outres_blocks_nt_f32", dcat._ptr, ws[0]._ptr, stack._strides[0], kb, len(ws),
+               dx._ptr, exr._ptr if exr is not None else None, T, dcat.shape[1], fin, hp.stream())
+    else:
+        wcat = _pack_columns(hp, [w.data for w in weights])                    # (fin, sum out_i)
+        hp.gemm(dcat, wcat.T, dx.reshape(T, fin), residual=exr)
+    return dx
+
+
 class qkv_attention(_Operator):
     """Training-path self-attention front end as ONE tape node (llm/llama/model.py:92-121):
     the three bias-free projections write the column blocks of ONE packed (tokens, 3 * dim) buffer
@@ -1527,11 +1550,7 @@ class qkv_attention(_Operator):
                         hp.gemm(x2.T, dblocks[i], dws[i])
                         grads[1 + i] = dws[i]
         if x.requires_grad:
-            dx = hp.empty(x.shape, np.float32)
-            ex = _foldable(self, 0, x)
-            wcat = _pack_columns(hp, [wq.data, wk.data, wv.data])                  # (D, 3D)
-            hp.gemm(dqkv, wcat.T, dx.reshape(T, D), residual=ex.reshape(T, D) if ex is not None else None)
-            grads[0] = dx
+            grads[0] = _dx_of_shared_input(hp, self, x, dqkv, (wq, wk, wv), T, D)
         if side is not None:
             side.join()
         return grads
@@ -1725,12 +1744,8 @@ class ffn_swiglu(_Operator):
                     grads[1 + i] = hp.empty(w.shape, np.float32)
                     hp.gemm(x2.T, dhalves[i], grads[1 + i])
         if x.requires_grad:
-            dx = hp.empty(x.shape, np.float32)
-            ex = _foldable(self, 0, x)
             # (a residual that IS x hands its gradient g over separately: the engine adds it)
-            wcat = _pack_columns(hp, [wg.data, wu.data])                           # (fin, 2F)
-            hp.gemm(dgu, wcat.T, dx.reshape(T, fin), residual=ex.reshape(T, fin) if ex is not None else None)
-            grads[0] = dx
+            grads[0] = _dx_of_shared_input(hp, self, x, dgu, (wg, wu), T, fin)
         return grads
 
 

@@ -44,6 +44,12 @@ struct OutResParams {
   // [y * kps, (y + 1) * kps) into slab y of `slab` (M x 288 each, no bias / residual); outres_splitk_reduce adds them up
   int kps;
   float* slab;
+  // NT form with B^T in BLOCKS along the contraction (dX = [d_1 | d_2 | ...] [W_1 | W_2 | ...]^T with the weights where
+  // they live -- equally spaced (288 x kb) matrices -- instead of a column-packed copy made every step): piece s comes
+  // from block s / ppb (ppb = kb / 32 pieces per block; `ppb_magic` = ceil(2^32 / ppb)).  ppb = 0: one matrix.
+  int ppb;
+  unsigned ppb_magic;
+  int64_t b_bstride;
 };
 
 // gradient of the mean cross entropy w.r.t. one logit
@@ -93,7 +99,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
       const int k = u / 72, n4 = u - 72 * k;
       o = (unsigned)k * ldb + 4u * (unsigned)n4;
     }
-    const float* src = BT ? p.B + (int64_t)piece * OR_KP : p.B + (int64_t)piece * OR_KP * p.ldb;
+    const float* src;
+    if (BT && p.ppb) {
+      const int blk = (int)__umulhi((unsigned)piece, p.ppb_magic);
+      src = p.B + (int64_t)blk * p.b_bstride + (piece - blk * p.ppb) * OR_KP;
+    } else {
+      src = BT ? p.B + (int64_t)piece * OR_KP : p.B + (int64_t)piece * OR_KP * p.ldb;
+    }
     return src + o;
   };
   float4 rb[STAGE ? NQ : 1];                      // STAGE 1: the wave's share of the next piece on its way to LDS
@@ -321,7 +333,7 @@ extern "C" int pdn_gemm_outres_supported(int M, int N, int K, int64_t lda, int64
 
 static int outres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M, int N,
                          int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* workspace,
-                         int64_t workspace_bytes, void* stream);
+                         int64_t workspace_bytes, void* stream, int kb = 0, int64_t b_bstride = 0);
 
 extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, const float* bias,
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
@@ -337,18 +349,51 @@ extern "C" int pdn_gemm_outres_ws_f32(const float* A, const float* B, float* C, 
   return outres_launch(A, B, C, bias, residual, M, N, K, lda, ldb, ldc, b_trans, workspace, workspace_bytes, stream);
 }
 
+int pdn_gemm_prof_begin(int family, double flops, double bytes, void* stream);    // csrc/gemm.hip
+void pdn_gemm_prof_end(int token, void* stream);
+
+// dX (M x 288) = [d_1 | ... | d_nb] (M x nb * kb) * [W_1 | ... | W_nb]^T (+ residual), W_i (288 x kb) row-major and
+// `b_block_stride` floats apart -- the input gradient of projections that share their input (q | k | v, gate | up:
+// llm/llama/model.py:93-104, 56-58; `grad @ W^T` of tensor.py:670 summed over the projections by ONE contraction)
+// with the weights read where they live.  kb a multiple of 32; M large enough for unsplit 8- / 4-wave workgroups to
+// fill the chip (pdn_gemm_outres_blocks_supported), else PDN_EUNSUPPORTED and the caller packs the weights.
+extern "C" int pdn_gemm_outres_blocks_supported(int M, int kb, int nb) {
+  const int K = kb * nb;
+  const bool big = (M + 255) / 256 >= 224, mid = (M + 127) / 128 >= 224 && K >= 1536;
+  return (kb > 0 && kb % OR_KP == 0 && nb >= 1 && (big || mid)) ? 1 : 0;
+}
+extern "C" int pdn_gemm_outres_blocks_nt_f32(const float* A, const float* W, int64_t b_block_stride, int kb, int nb, float* C,
+                                             const float* residual, int M, int64_t lda, int64_t ldc, void* stream) {
+  if (M == 0) return PDN_OK;
+  const int K = kb * nb;
+  if (!pdn_gemm_outres_blocks_supported(M, kb, nb) || (b_block_stride & 3) || (kb & 3) ||
+      !pdn_gemm_outres_supported(M, OR_N, K, lda, K, ldc, 1)) {        // (row stride of a block = kb: checked here)
+    pdn_set_error("pdn_gemm_outres_blocks_nt_f32: unsupported shape M=%d kb=%d nb=%d", M, kb, nb);
+    return PDN_EUNSUPPORTED;
+  }
+  const int tk = pdn_gemm_prof_begin(3, 2.0 * M * (double)OR_N * K, 0.0, stream);
+  const int rc = outres_launch(A, W, C, nullptr, residual, M, OR_N, K, lda, kb, ldc, 1, nullptr, 0, stream, kb, b_block_stride);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+
 static int outres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M, int N,
                          int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* workspace,
-                         int64_t workspace_bytes, void* stream) {
+                         int64_t workspace_bytes, void* stream, int kb, int64_t b_bstride) {
   if (M == 0 || N == 0) return PDN_OK;
   PDN_CHECK_ARG(A && B && C, "pdn_gemm_outres_f32: null operand");
-  if (!pdn_gemm_outres_supported(M, N, K, lda, ldb, ldc, b_trans)) {
+  if (!pdn_gemm_outres_supported(M, N, K, lda, kb > 0 ? K : ldb, ldc, b_trans)) {
     pdn_set_error("pdn_gemm_outres_f32: unsupported shape M=%d N=%d K=%d (N 288, K a multiple of 32, leading "
                   "dimensions multiples of 4)", M, N, K);
     return PDN_EUNSUPPORTED;
   }
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_outres_f32: 16-byte alignment required");
   OutResParams p{A, B, C, bias, residual, M, K, lda, ldb, ldc, nullptr, nullptr, nullptr, 0.f, K / OR_KP, nullptr};
+  if (kb > 0) {
+    p.ppb = kb / OR_KP;
+    p.ppb_magic = (unsigned)(((1ull << 32) + (unsigned)p.ppb - 1) / (unsigned)p.ppb);
+    p.b_bstride = b_bstride;
+  }
   hipStream_t st = (hipStream_t)stream;
   int plan_nw = 8, kps = K / OR_KP;
   int splits = pdn_gemm_outres_plan(M, K, &plan_nw, &kps);

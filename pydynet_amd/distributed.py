@@ -51,6 +51,14 @@ class RcclComm:
         L = self._L
         hipnp.set_device(device_index)
         self.device_index = device_index
+        # CU budget of the collectives: an RCCL channel is one workgroup, and the GEMMs of the training step keep ONE
+        # 8-wave workgroup on every CU -- a channel's workgroup co-resides with it and takes issue slots from it.  The
+        # gradient exchange of a step (97.8 MB, ring all-reduce: 2 (N - 1) / N x that per GPU = 171 MB at N = 8) needs
+        # ~0.5 ms of the seven xGMI links spread over a 57 ms backward, so a handful of channels is plenty: 8 (one per
+        # link + one) unless the launcher says otherwise (NCCL_MAX_NCHANNELS / PDN_RCCL_MAX_CHANNELS; 0 = RCCL's default).
+        ch = os.environ.get("PDN_RCCL_MAX_CHANNELS", "8")
+        if ch != "0":
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", ch)
         uid = None
         if self.rank == 0:
             buf = ctypes.create_string_buffer(128)

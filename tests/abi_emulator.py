@@ -221,6 +221,26 @@ class EmulatedLib:
         view(C, (M, N), (ldc, 1), np.float32)[...] = r
         return 0
 
+    def pdn_gemm_outres_blocks_supported(self, M, kb, nb):
+        K = kb * nb
+        big, mid = (M + 255) // 256 >= 224, (M + 127) // 128 >= 224 and K >= 1536
+        return int(kb > 0 and kb % 32 == 0 and nb >= 1 and (big or mid))
+
+    def pdn_gemm_outres_blocks_nt_f32(self, A, W, bstride, kb, nb, C, residual, M, lda, ldc, stream):
+        if M == 0:
+            return 0
+        if not self.pdn_gemm_outres_blocks_supported(M, kb, nb) or bstride % 4:
+            return -2
+        a = view(A, (M, nb * kb), (lda, 1), np.float32)
+        r = np.zeros((M, 288), np.float32)
+        for i in range(nb):
+            w = view(int(W) + 4 * i * bstride, (288, kb), (kb, 1), np.float32)
+            r += np.matmul(a[:, i * kb:(i + 1) * kb], w.T)
+        if residual:
+            r = r + view(residual, (M, 288), (ldc, 1), np.float32)
+        view(C, (M, 288), (ldc, 1), np.float32)[...] = r
+        return 0
+
     # -- projections with a fused epilogue (csrc/gemm_rowres.hip, round 4) ----------------------------------
     def pdn_gateup_swiglu_supported(self, M, F, K):
         return int(K == 288 and F % 96 == 0 and F >= 96 and M >= 1 and 64 * F < (1 << 29))

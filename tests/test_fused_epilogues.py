@@ -182,6 +182,35 @@ def check_attention_bwd_rotated_equals_plain(dev):
     close(res[1][1], res[0][1], "dq | dk | dv", 2e-5)
 
 
+def _blocks_dx_case(M, kb, nb, seed, reverse=False):
+    """dX = [d_1 | ... | d_nb] [W_1 | ... | W_nb]^T + residual with the weights read where they live."""
+    L, hp = _lib_hp()
+    rng = np.random.default_rng(seed)
+    assert L.query("pdn_gemm_outres_blocks_supported", M, kb, nb)
+    ws = [(0.05 * rng.standard_normal((288, kb))).astype(np.float32) for _ in range(nb)]
+    d = rng.standard_normal((M, nb * kb)).astype(np.float32)
+    res = rng.standard_normal((M, 288)).astype(np.float32)
+    buf, views, stride = _stack(hp, ws[::-1] if reverse else ws)
+    if reverse:                                       # block i BELOW block i - 1 in memory: negative stride
+        views, stride = views[::-1], -stride
+    dd, rd, out = hp.from_numpy(d), hp.from_numpy(res), hp.empty((M, 288), np.float32)
+    L.call("pdn_gemm_outres_blocks_nt_f32", dd._ptr, views[0]._ptr, stride, kb, nb, out._ptr, rd._ptr, M, nb * kb, 288,
+           hp.stream())
+    rows = np.r_[0:64, M // 2:M // 2 + 64, M - 64:M]          # (float64 on a sample of rows: the product is 14+ GFLOP)
+    ref = res[rows].astype(np.float64)
+    for i, w in enumerate(ws):
+        ref += d[rows, i * kb:(i + 1) * kb].astype(np.float64) @ w.astype(np.float64).T
+    close(out.get()[rows], ref, "dX over weight blocks")
+
+
+def check_dx_over_qkv_weight_blocks(dev):
+    _blocks_dx_case(57344 + 96, 288, 3, 11)           # 8-wave workgroups, ragged last row block
+
+
+def check_dx_over_gate_up_weight_blocks_reversed(dev):
+    _blocks_dx_case(28672, 768, 2, 12, reverse=True)  # 4-wave workgroups (K >= 1536), weights in descending order
+
+
 # ---- node level: one Llama block with the epilogues on / off --------------------------------------------------------
 def _block_step(dev, epilogues):
     from pydynet_amd.llm.llama import Llama
@@ -242,5 +271,6 @@ def check_llama_block_epilogues_vs_separate_kernels(dev):
 for _fn in [check_gateup_swiglu_full_blocks, check_gateup_swiglu_ragged_rows_ffn768,
             check_gateup_swiglu_up_matrix_first_in_memory, check_qkv_rope_hd48,
             check_qkv_rope_hd96_ragged_tail, check_attention_bwd_rotated_equals_plain,
+            check_dx_over_qkv_weight_blocks, check_dx_over_gate_up_weight_blocks_reversed,
             check_llama_block_epilogues_vs_separate_kernels]:
     device_variants(globals(), _fn)
