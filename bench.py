@@ -278,11 +278,18 @@ def pmc_traffic():
     except Exception:
         pass
     for fam in ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel",
-                "gemm_outres_tn_kernel", "ce_fwd_bwd_reg_kernel", "adam_multi_kernel", "swiglu_rows_bwd_kernel",
+                "gemm_outres_tn_kernel", "ce_fwd_bwd_reg_kernel", "adam_multi_kernel", "gemm_rowres_kernel<EPI>",
                 "rmsnorm_bwd_kernel"):
         n = tot = 0.0
         for name, r in rows.items():
-            if name.startswith(fam) and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
+            # (the row-resident launches with a fused epilogue -- last template argument 1 / 2 / 3 -- are a family
+            #  of their own: `gemm_rowres_kernel<EPI>` below)
+            epi = name.startswith("gemm_rowres_kernel") and not name.rstrip().endswith(", 0>")
+            if fam == "gemm_rowres_kernel<EPI>":
+                match = epi
+            else:
+                match = name.startswith(fam) and not epi
+            if match and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
                 d = r.get("dispatches", 1)
                 n += d
                 tot += d * (2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0        # counters are in KiB
@@ -482,6 +489,7 @@ def main():
                     "hbm_achieved_GBps": fby.value / (fms.value * 1e-3) / 1e9,
                     "hbm_frac": fby.value / (fms.value * 1e-3) / 8e12,
                     "algorithmic_bytes_per_launch": fby.value / fn.value,
+                    "traffic": traffic.get("gemm_rowres_kernel<EPI>"),
                     "time_share_of_step": fms.value * 1e-3 / dt},
                 "all_gemm": {"achieved": tf(sum(fl2) + ffl.value, sum(ms2) + fms.value),
                              "frac": tf(sum(fl2) + ffl.value, sum(ms2) + fms.value) / peak,

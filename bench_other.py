@@ -318,8 +318,8 @@ def _conv_roofline(lib, hp, B):
     for key, prefix in (("conv1_fwd_relu_pool", "conv_direct_kernel<2, 2, 3, 8, 1, 0>"),
                         ("conv2_fwd_relu_pool", "conv_direct_kernel<1, 4, 3, 4, 1, 0>"),
                         ("conv2_bwd_data", "conv_direct_kernel<1, 2, 3, 16, 0, 1>"),
-                        ("conv1_bwd_weight", "conv_wgrad_kernel<1, 1, 8, 16, 1>"),
-                        ("conv2_bwd_weight", "conv_wgrad_kernel<3, 0, 8, 16, 1>")):
+                        ("conv1_bwd_weight", "conv_wgrad_lean_kernel<1, 1, 8, 16, 1>"),
+                        ("conv2_bwd_weight", "conv_wgrad_lean_kernel<6, 2, 8, 8, 1>")):
         if key in out:
             out[key]["traffic"] = traffic_of(prefix)
     dom_key = max(out, key=lambda k: out[k]["avg_launch_us"])

@@ -39,7 +39,13 @@ r_f = timed(lambda: L_.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, 
 r_b = timed(lambda: L_.call("pdn_attention_bwd_f32", q, k, v, o._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1, C._ptr, S._ptr, ws, wsb, st))
 s_f = timed(lambda: L_.call("pdn_attention_stream_fwd_f32", qd._ptr, k, v, o._ptr, lse._ptr, B, H, L, L, hd, D, L * D, 3 * D, L * 3 * D, 1, 0, None, 0, 0, 0, 0, C._ptr, S._ptr, st))
 s_b = timed(lambda: L_.call("pdn_attention_stream_bwd_f32", qd._ptr, k, v, o._ptr, do._ptr, lse._ptr, dqd._ptr, dk, dv, B, H, L, L, hd, D, L * D, 3 * D, L * 3 * D, 1, 0, None, 0, 0, 0, 0, C._ptr, S._ptr, ws, wsb, st))
+rows = [("resident", r_f, r_b), ("stream", s_f, s_b)]
+if hd == 48 and L <= 256:
+    # round 4: q, k rotated by the projection's epilogue -> the persistent, DMA-staged kernels (csrc/attention_p.hip)
+    p_f = timed(lambda: L_.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1, None, None, st))
+    p_b = timed(lambda: L_.call("pdn_attention_bwd_rotated_f32", q, k, v, o._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1, C._ptr, S._ptr, ws, wsb, st))
+    rows.insert(0, ("persistent", p_f, p_b))
 pairs = (L // 32) * (L // 32 + 1) / 2 * B * H
 print(f"B*H = {B * H} heads, L = {L}, hd = {hd}: {pairs:.0f} causal tile pairs")
-for name, f, b in (("resident", r_f, r_b), ("stream", s_f, s_b)):
-    print(f"{name:9s} {1e3 * f / pairs:6.3f} / {1e3 * b / pairs:6.3f} ns per pair   fwd {f:8.1f} us ({flops_fwd / f / 1e6:6.1f} TFLOP/s causal-useful = {100 * flops_fwd / f / 1e6 / 157.3:4.1f} % of fp32 MFMA)   bwd {b:8.1f} us", flush=True)
+for name, f, b in rows:
+    print(f"{name:10s} {1e3 * f / pairs:6.3f} / {1e3 * b / pairs:6.3f} ns per pair   fwd {f:8.1f} us ({flops_fwd / f / 1e6:6.1f} TFLOP/s causal-useful = {100 * flops_fwd / f / 1e6 / 157.3:4.1f} % of fp32 MFMA)   bwd {b:8.1f} us", flush=True)

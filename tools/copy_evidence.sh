@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/$ROUND (scratch, written by tools/round_evidence.sh on the GPU box) -> profiles/ (tracked)
-ROUND=${ROUND:-r03}; S=gpurun_out/$ROUND; D=profiles
+ROUND=${ROUND:-r04}; S=gpurun_out/$ROUND; D=profiles
 cp $S/bench_default.json $D/${ROUND}_bench_default.json
 tail -1 $S/bench_force_dp.json > $D/${ROUND}_bench_force_dp.json
 for b in 128 64; do cp $S/bench_b$b.json $D/${ROUND}_bench_b$b.json; done
@@ -15,6 +15,7 @@ cp $S/decode_kernel_stats.txt $D/${ROUND}_decode_kernel_stats.txt
 cp $S/attn_pmc.txt $D/${ROUND}_attention_pmc.txt
 cp $S/all_configs.txt $D/${ROUND}_all_configs.txt
 cp $S/decode_trace.txt $D/${ROUND}_decode_trace.txt
-cp $S/attn_trace.txt $D/${ROUND}_attention_fwd_trace.txt
+cp $S/epilogue_probe.txt $D/${ROUND}_epilogue_probe.txt
+cp $S/pmc_lenet_b4096.json $D/${ROUND}_pmc_lenet_b4096.json
 { grep -E "passed|failed|error" $S/pytest_gpu.log | tail -2; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt
 ls -la $D | grep ${ROUND}_

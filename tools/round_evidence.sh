@@ -4,7 +4,7 @@
 #   rocprofv3 kernel stats of the bench command, PMC passes (SQ / LDS / L2 / FETCH / WRITE) of the same command
 #   -- regenerated EVERY time (the summary records a hash of the kernel sources it was measured on; bench.py flags
 #   `traffic_stale` when the sources have changed since) -- the LeNet profile, attention / GEMM probes.
-ROUND=${ROUND:-r03}
+ROUND=${ROUND:-r04}
 R=$PWD; O=$R/gpurun_out/$ROUND; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -16,12 +16,14 @@ PDN_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline > $O/bench_force_dp.json 
 python bench.py --no-cpu-baseline --batch 128 > $O/bench_b128.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --batch 64 > $O/bench_b64.json 2>> $O/bench_default.err
 for c in mlp lenet gru decode; do python bench.py --config $c --steps 200 --warmup 20 > $O/bench_$c.json 2>> $O/bench_default.err; done
+# (the LeNet line reads the counter summary of its own kernels: collected and stamped first)
+bash tools/pmc_cmd.sh ${ROUND}_lenet conv python tools/bench_configs.py 3 lenet:4096 > $O/lenet_pmc.txt 2>&1
+python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_lenet/summary.json $O/pmc_lenet_b4096.json && cp $O/pmc_lenet_b4096.json profiles/${ROUND}_pmc_lenet_b4096.json
 python bench.py --config lenet --batch 4096 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_lenet_b4096.json 2>> $O/bench_default.err
 python bench.py --config mlp --batch 65536 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_mlp_b65536.json 2>> $O/bench_default.err
 bash tools/prof_cmd.sh ${ROUND}_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate > $O/bench_kernel_stats.txt 2>&1
 cp gpurun_out/prof_${ROUND}_bench/p_kernel_stats.csv $O/bench_b256_kernel_stats.csv 2>/dev/null
 bash tools/prof_cmd.sh ${ROUND}_lenet python tools/bench_configs.py 10 lenet:4096 > $O/lenet_kernel_stats.txt 2>&1
-bash tools/pmc_cmd.sh ${ROUND}_lenet conv python tools/bench_configs.py 3 lenet:4096 > $O/lenet_pmc.txt 2>&1
 bash tools/prof_cmd.sh ${ROUND}_decode python tools/bench_decode.py 256 8 > $O/decode_kernel_stats.txt 2>&1
 bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 256 48 > $O/attn_pmc.txt 2>&1
 { python tools/bench_configs.py 10; python tools/bench_graph.py 30; python tools/bench_decode.py 256 8; python tools/bench_decode.py 900 8;
@@ -33,5 +35,5 @@ bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 2
   python bench.py --config decode --steps 900 --warmup 20 --no-cpu-baseline; } > $O/all_configs.txt 2>&1
 # phase timestamps from inside the decode kernels / the attention forward (traced builds made by the same scripts here)
 bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
-bash tools/attn_trace.sh > $O/attn_trace.txt 2>&1
+python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
 ls -la $O
