@@ -147,6 +147,17 @@ int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* b
 int pdn_gemm_outres_blocks_supported(int M, int kb, int nb);
 int pdn_gemm_outres_blocks_nt_f32(const float* A, const float* W, int64_t b_block_stride, int kb, int nb, float* C,
                                   const float* residual, int M, int64_t lda, int64_t ldc, void* stream);
+/* vocabulary projection WITH the row statistics of cross entropy (llm/llama/model.py:179 + nn/functional.py:364-381):
+ * logits (M x V) = x (M x 288) W (288 x V) + bias and lse[m] = log sum_v exp(logits[m][v]) in one launch (transposed
+ * accumulators: a lane owns a token); pdn_cross_entropy_from_lse_f32 then forms the loss with one gather per row --
+ * loss_row[r] = lse[r] - logits[r][target[r]], loss_out = their sum (mean != 0: mean) -- instead of the pass over the
+ * logits pdn_cross_entropy_fwd_f32 makes.  err_flag is set to 1 on an out-of-range target. */
+int pdn_linear_lse_supported(int64_t M, int V, int K);
+int pdn_linear_lse_fwd_f32(const float* x, const float* w, const float* bias, float* logits, float* lse, int M, int V,
+                           int K, int64_t ldx, int64_t ldw, int64_t ldl, void* stream);
+int pdn_cross_entropy_from_lse_f32(const float* logits, int64_t ldl, const float* lse, const int64_t* targets,
+                                   int64_t rows, int V, int mean, float* loss_row, float* loss_out, int* err_flag,
+                                   void* stream);
 int pdn_gateup_swiglu_supported(int M, int F, int K);
 int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, int64_t w_stride, float* gu, float* h, int M,
                               int F, int K, int64_t ldx, void* stream);

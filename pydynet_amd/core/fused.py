@@ -810,6 +810,7 @@ class linear_cross_entropy(_Operator):
     folds_existing = True
     enabled = True
     min_rows = int(os.environ.get("PDN_LINCE_MIN_ROWS", "16384"))
+    lse_epilogue = os.environ.get("PDN_NO_LSE_EPILOGUE", "0") != "1"      # row statistics in the projection's store (A/B switch)
 
     @staticmethod
     def applicable(x, w, b, targets, reduction="mean"):
@@ -843,10 +844,21 @@ class linear_cross_entropy(_Operator):
             self._t = hp.from_numpy(np.asarray(self._t).astype(np.int64))
         self._t = _contig(self._t)
         logits = hp.empty((n, V), np.float32)
-        hp.gemm(x2, w.data, logits, bias=b.data.reshape(-1) if b is not None else None)
         loss_row, lse, out = hp.empty((n,), np.float32), hp.empty((n,), np.float32), hp.empty((1,), np.float32)
-        L.call("pdn_cross_entropy_fwd_f32", logits._ptr, self._t._ptr, n, V, 1 if self.reduction == "mean" else 0,
-               loss_row._ptr, lse._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
+        wd = w.data
+        self.stats_in_gemm = bool(linear_cross_entropy.lse_epilogue and wd.is_contiguous() and x2._strides[1] == 1
+                                  and L.query("pdn_linear_lse_supported", n, V, fin))
+        if self.stats_in_gemm:
+            # the projection leaves the rows' log-sum-exp itself (transposed accumulators: a lane owns a token): no
+            # pass over the logits for the statistics, the loss is one gather per row
+            L.call("pdn_linear_lse_fwd_f32", x2._ptr, wd._ptr, b.data._ptr if b is not None else None, logits._ptr, lse._ptr,
+                   n, V, fin, x2._strides[0], V, V, hp.stream())
+            L.call("pdn_cross_entropy_from_lse_f32", logits._ptr, V, lse._ptr, self._t._ptr, n, V,
+                   1 if self.reduction == "mean" else 0, loss_row._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
+        else:
+            hp.gemm(x2, wd, logits, bias=b.data.reshape(-1) if b is not None else None)
+            L.call("pdn_cross_entropy_fwd_f32", logits._ptr, self._t._ptr, n, V, 1 if self.reduction == "mean" else 0,
+                   loss_row._ptr, lse._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
         self._saved = (x2, logits, lse)
         return out.reshape(())
 

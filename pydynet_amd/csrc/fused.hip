@@ -814,6 +814,31 @@ extern "C" int pdn_cross_entropy_fwd_f32(const float* logits, const int64_t* tar
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
+// loss from row statistics that already exist (the vocabulary projection left lse[row], csrc/gemm_rowres.hip EPI 4):
+// loss_row[r] = lse[r] - logits[r][target[r]], loss_out = (mean ? 1 / rows : 1) * sum -- one 4-byte gather per row
+// instead of a pass over the logits.
+__global__ void ce_rows_from_lse_kernel(const float* __restrict__ logits, int64_t ldl, const float* __restrict__ lse,
+                                        const int64_t* __restrict__ tgt, int64_t rows, int V, float* __restrict__ loss_row,
+                                        int* __restrict__ err) {
+  const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int64_t t = tgt[r];
+  if (t < 0 || t >= V) { *err = 1; t = 0; }
+  loss_row[r] = lse[r] - logits[r * ldl + t];
+}
+extern "C" int pdn_cross_entropy_from_lse_f32(const float* logits, int64_t ldl, const float* lse, const int64_t* targets,
+                                              int64_t rows, int V, int mean, float* loss_row, float* loss_out,
+                                              int* err_flag, void* stream) {
+  PDN_CHECK_ARG(rows > 0 && V > 0, "pdn_cross_entropy_from_lse_f32: empty input");
+  PDN_CHECK_ARG(logits && lse && targets && loss_row && loss_out && err_flag, "pdn_cross_entropy_from_lse_f32: null operand");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_from_lse_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, logits, ldl, lse,
+                     targets, rows, V, loss_row, err_flag);
+  PDN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ce_reduce_kernel, dim3(1), dim3(1024), 0, st, loss_row, rows, mean ? 1.f / (float)rows : 1.f, loss_out);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
 // dlogits = (softmax(logits) - onehot) * gscale * (upstream ? upstream[0] : 1).
 // `dlogits` may alias `logits` (in-place).  gscale is 1/rows for reduction='mean'.
 extern "C" int pdn_cross_entropy_bwd_f32(const float* logits, const int64_t* targets,

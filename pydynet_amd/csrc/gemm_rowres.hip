@@ -48,6 +48,7 @@ struct RowResParams {
   int L, hd, rope_chunks;         // EPI 3: positions per sequence, head dim, chunks (of 96 columns) that are rotated
   unsigned hd_magic;              //        2^32 / hd rounded up (x / hd = umulhi(x, magic) for x < 2^16)
   unsigned g_off, u_off;          // EPI 1: first float of the gate / up matrix relative to B
+  float* lse;                     // EPI 4: log-sum-exp of every output row (M)
 };
 
 __device__ __forceinline__ void rr_glds16(const float* g, float* l) {
@@ -272,6 +273,54 @@ __device__ __forceinline__ void rr_store_rope(const RowResParams& p, f32x16 (&ac
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 }
 
+//   EPI 4  vocabulary projection with the ROW STATISTICS of cross entropy (llm/llama/model.py:179 feeding
+//          nn/functional.py:364-381): the MFMA operands are swapped -- D^T[vocabulary][token] = W^T x^T, the S^T = K Q^T
+//          trick of the attention kernels -- so that a LANE owns a token and the registers run over the vocabulary:
+//          the running row maximum and sum of exponentials are in-lane arithmetic plus ONE cross-half shuffle per
+//          96-column chunk (with lane = column they were five cross-lane steps per row and statistic: tried in round
+//          3, +1.95 ms).  The logits leave as 16-byte pieces of the lane's own row (the two half-waves complete a
+//          128-byte line between them); the separate statistics pass over the logits (8.4 GB read, 1.5 ms) is gone.
+template <bool GUARD>
+__device__ __forceinline__ void rr_store_lse(const RowResParams& p, f32x16 (&acc)[3], int m0, int c, int li, int lh, int nt,
+                                             float& m_run, float& z_run) {
+  const bool ok = !GUARD || m0 + li < p.M;
+  float* __restrict__ Cw = p.C + (int64_t)(m0 + (ok ? li : 0)) * p.ldc + c * RR_NC + 4 * lh;
+  const float* __restrict__ Bw = p.bias ? p.bias + c * RR_NC + 4 * lh : nullptr;
+  // bias of the lane's vocabulary entries (register group g of tile j: columns 32 j + 8 g + 4 h + 0..3), then the chunk's maximum
+  float mc = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (Bw) {
+          const float4 b = *reinterpret_cast<const float4*>(Bw + 32 * j + 8 * g);
+          acc[j][4 * g] += b.x; acc[j][4 * g + 1] += b.y; acc[j][4 * g + 2] += b.z; acc[j][4 * g + 3] += b.w;
+        }
+        mc = fmaxf(mc, fmaxf(fmaxf(acc[j][4 * g], acc[j][4 * g + 1]), fmaxf(acc[j][4 * g + 2], acc[j][4 * g + 3])));
+        if (ok) *reinterpret_cast<float4*>(Cw + 32 * j + 8 * g) =
+            make_float4(acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]);
+      }
+    }
+  }
+  mc = fmaxf(mc, __shfl_xor(mc, 32, 64));           // the row's other 48 columns of this chunk
+  const float mn = fmaxf(m_run, mc);
+  const float L2E = 1.4426950408889634f, c2 = -mn * L2E;
+  float zc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+    if (j < nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zc += __builtin_amdgcn_exp2f(fmaf(acc[j][r], L2E, c2));
+    }
+  z_run = z_run * __builtin_amdgcn_exp2f((m_run - mn) * L2E) + zc;     // (first chunk: exp2(-inf) = 0)
+  m_run = mn;
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+}
+
 // KG = K / 8.  BT: B is given as the row-major (N x K) matrix whose transpose is meant.
 // ABLATE (timing experiments only, 0 in the library): 2 = no B DMA after the first two pieces,
 // 32 = the DMA of a piece issued as one burst.
@@ -283,6 +332,7 @@ template <int KG, bool BT, int NW, int STAGE, int ABLATE = 0, int EPI = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(RowResParams p) {
   static_assert(EPI != 1 || (!BT && NW == 8), "SwiGLU forward epilogue: NN form, one 8-wave workgroup per CU");
   static_assert(EPI != 2 || BT, "SwiGLU backward epilogue: NT form");
+  static_assert(EPI != 4 || !BT, "row-statistics epilogue: NN form");
   constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
   constexpr int NPK = KG / 12;                    // pieces along K
   constexpr int PIECE = RR_KP * RR_NC;            // floats
@@ -417,6 +467,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   for (int q = 0; q < 4; ++q) bq[q] = BT ? li * RR_KP + 4 * ((2 * q + lh) ^ xl) : 0;
   const int bnn = (4 * lh) * RR_NC + li;
 
+  float m_run = -INFINITY, z_run = 0.f;             // EPI 4: running maximum / sum of exponentials of the lane's row
   int s = 0;
   for (int ci = 0; ci < nloc; ++ci) {
     const int c = chunk_of(ci);
@@ -460,10 +511,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
 #define RR_MFMA(BX, G)                                                               \
   {                                                                                  \
     const float4 av = a[kc * 12 + (G)];                                              \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, BX[j][0], acc[j], 0, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, BX[j][1], acc[j], 0, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, BX[j][2], acc[j], 0, 0, 0); \
-    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, BX[j][3], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][0], av.x, acc[j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, BX[j][0], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][1], av.y, acc[j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, BX[j][1], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][2], av.z, acc[j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, BX[j][2], acc[j], 0, 0, 0); \
+    _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = EPI == 4 ? __builtin_amdgcn_mfma_f32_32x32x2f32(BX[j][3], av.w, acc[j], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, BX[j][3], acc[j], 0, 0, 0); \
   }
       // slot t (one per 12 MFMAs) issues DMA instructions PER t .. PER t + PER - 1 of the next piece
       constexpr int PER = NW == 4 ? 2 : 1;
@@ -518,9 +569,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       if (full) rr_store_swiglu_bwd<false>(p, acc, m0, c, li, lh); else rr_store_swiglu_bwd<true>(p, acc, m0, c, li, lh);
     } else if constexpr (EPI == 3) {
       if (full) rr_store_rope<false>(p, acc, m0, c, li, lh); else rr_store_rope<true>(p, acc, m0, c, li, lh);
+    } else if constexpr (EPI == 4) {
+      const int nt = c == c_tail ? nt_tail : 3;
+      if (full) rr_store_lse<false>(p, acc, m0, c, li, lh, nt, m_run, z_run); else rr_store_lse<true>(p, acc, m0, c, li, lh, nt, m_run, z_run);
     } else {
       rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
     }
+  }
+  if constexpr (EPI == 4) {
+    const float z = z_run + __shfl_xor(z_run, 32, 64);
+    if (lh == 0 && m0 + li < p.M) p.lse[m0 + li] = m_run + logf(z);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
 }
@@ -544,6 +602,7 @@ struct RowResEpi {
   int F;                    // 1, 2
   const float* rope; int L, hd, rope_cols;   // 3
   unsigned g_off = 0, u_off = 0;              // 1
+  float* lse = nullptr;                       // 4
 };
 
 static int rowres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M,
@@ -561,7 +620,7 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_rowres_f32: 16-byte alignment required");
   RowResParams p{A, B, C, bias, residual, M, N, lda, ldb, ldc, (N + RR_NC - 1) / RR_NC, 0, 0, b_block_stride};
   p.cpb = nblocks > 1 ? nper / RR_NC : p.chunks;
-  p.H = nullptr; p.GU = nullptr; p.rope = nullptr; p.ldh = 0; p.F = 0; p.L = 1; p.hd = 1; p.rope_chunks = 0; p.hd_magic = 0; p.g_off = 0; p.u_off = 0;
+  p.H = nullptr; p.GU = nullptr; p.rope = nullptr; p.ldh = 0; p.F = 0; p.L = 1; p.hd = 1; p.rope_chunks = 0; p.hd_magic = 0; p.g_off = 0; p.u_off = 0; p.lse = nullptr;
   const int kind = epi ? epi->kind : 0;
   if (kind) {
     p.H = epi->H; p.ldh = epi->ldh; p.GU = epi->GU; p.F = epi->F;
@@ -569,6 +628,7 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     p.rope_chunks = epi->rope_cols / RR_NC;
     p.hd_magic = (unsigned)(((1ull << 32) + (unsigned)epi->hd - 1) / (unsigned)epi->hd);
     p.g_off = epi->g_off; p.u_off = epi->u_off;
+    p.lse = epi->lse;
   }
   hipStream_t st = (hipStream_t)stream;
   static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
@@ -590,6 +650,7 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   while (row_blocks * nsplit < target && nsplit < p.chunks) ++nsplit;
   p.chunks_per_wg = (p.chunks + nsplit - 1) / nsplit;
   if (kind == 1) p.chunks_per_wg += p.chunks_per_wg & 1;       // gate / up tiles meet inside a PAIR of chunks
+  if (kind == 4) p.chunks_per_wg = p.chunks;                   // a row's statistics are one workgroup's
   nsplit = (p.chunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
   const dim3 grid(row_blocks, nsplit);
 #define RR_LAUNCH(BT_, NW_, AB_) if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 1, 0>), grid, dim3(NW_ * 64), 0, st, p); else hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 0, AB_>), grid, dim3(NW_ * 64), 0, st, p)
@@ -599,6 +660,8 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     hipLaunchKernelGGL((gemm_rowres_kernel<36, true, 8, 1, 0, 2>), grid, dim3(512), 0, st, p);
   } else if (kind == 3) {
     hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 3>), grid, dim3(512), 0, st, p);
+  } else if (kind == 4) {
+    hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 4>), grid, dim3(512), 0, st, p);
   } else if (nw == 8) {
     if (b_trans) RR_LAUNCH(true, 8, 0); else RR_LAUNCH(false, 8, 0);
   } else if (b_trans) {
@@ -670,6 +733,28 @@ extern "C" int pdn_qkv_rope_fwd_f32(const float* x, const float* wq, int64_t w_s
   RowResEpi e{3, nullptr, 0, nullptr, 0, rope, L, hd, 2 * D};
   const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (3.0 * D) * K, 4.0 * ((double)M * K + 3.0 * K * D + 3.0 * M * D), stream);
   const int rc = rowres_launch(x, wq, qkv, nullptr, nullptr, M, 3 * D, K, ldx, D, 3 * D, 0, 3, w_stride, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+
+// logits (M x V) = x (M x 288) W (288 x V) + bias and lse[m] = log sum_v exp(logits[m][v]) in ONE launch (EPI 4).
+// V a multiple of 32 (>= 96); enough rows for one 8-wave workgroup per CU to own whole rows (M >= 49152), else
+// PDN_EUNSUPPORTED and the caller runs the product and pdn_cross_entropy_fwd_f32.
+extern "C" int pdn_linear_lse_supported(int64_t M, int V, int K) {
+  return (K == 288 && V % 32 == 0 && V >= RR_NC && M >= 49152 && M < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int pdn_linear_lse_fwd_f32(const float* x, const float* w, const float* bias, float* logits, float* lse, int M,
+                                      int V, int K, int64_t ldx, int64_t ldw, int64_t ldl, void* stream) {
+  if (M == 0 || V == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && w && logits && lse, "pdn_linear_lse_fwd_f32: null operand");
+  if (!pdn_linear_lse_supported(M, V, K) || (ldl & 3) || ((uintptr_t)logits & 15) || ((uintptr_t)bias & 15)) {
+    pdn_set_error("pdn_linear_lse_fwd_f32: unsupported shape M=%d V=%d K=%d", M, V, K);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{4, nullptr, 0, nullptr, 0, nullptr, 1, 1, 0};
+  e.lse = lse;
+  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (double)V * K, 0.0, stream);
+  const int rc = rowres_launch(x, w, logits, bias, nullptr, M, V, K, ldx, ldw, ldl, 0, 1, 0, stream, &e);
   pdn_gemm_prof_end(tk, stream);
   return rc;
 }

@@ -221,6 +221,32 @@ class EmulatedLib:
         view(C, (M, N), (ldc, 1), np.float32)[...] = r
         return 0
 
+    def pdn_linear_lse_supported(self, M, V, K):
+        return int(K == 288 and V % 32 == 0 and V >= 96 and M >= 49152)
+
+    def pdn_linear_lse_fwd_f32(self, x, w, bias, logits, lse, M, V, K, ldx, ldw, ldl, stream):
+        if not self.pdn_linear_lse_supported(M, V, K) or ldl % 4:
+            return -2
+        z = np.matmul(view(x, (M, K), (ldx, 1), np.float32), view(w, (K, V), (ldw, 1), np.float32))
+        if bias:
+            z = z + flat(bias, V)
+        view(logits, (M, V), (ldl, 1), np.float32)[...] = z
+        m = z.max(-1, keepdims=True)
+        flat(lse, M)[...] = (m + np.log(np.exp(z - m).sum(-1, keepdims=True)))[:, 0]
+        return 0
+
+    def pdn_cross_entropy_from_lse_f32(self, logits, ldl, lse, targets, rows, V, mean, loss_row, loss_out, err, stream):
+        t = np.array(flat(targets, rows, np.int64))
+        bad = (t < 0) | (t >= V)
+        if bad.any():
+            ctypes.cast(err, ctypes.POINTER(ctypes.c_int))[0] = 1
+            t[bad] = 0
+        z = view(logits, (rows, V), (ldl, 1), np.float32)
+        lr = flat(lse, rows) - z[np.arange(rows), t]
+        flat(loss_row, rows)[...] = lr
+        flat(loss_out, 1)[0] = lr.sum(dtype=np.float32) * np.float32(1.0 / rows if mean else 1.0)
+        return 0
+
     def pdn_gemm_outres_blocks_supported(self, M, kb, nb):
         K = kb * nb
         big, mid = (M + 255) // 256 >= 224, (M + 127) // 128 >= 224 and K >= 1536

@@ -211,6 +211,47 @@ def check_dx_over_gate_up_weight_blocks_reversed(dev):
     _blocks_dx_case(28672, 768, 2, 12, reverse=True)  # 4-wave workgroups (K >= 1536), weights in descending order
 
 
+def _linear_lse_case(M, V, seed, sample=None):
+    """logits = x W + b with the rows' log-sum-exp from the same launch (transposed accumulators), then the loss from one
+    gather per row -- against float64 (llm/llama/model.py:179 + nn/functional.py:364-381)."""
+    L, hp = _lib_hp()
+    K = 288
+    rng = np.random.default_rng(seed)
+    assert L.query("pdn_linear_lse_supported", M, V, K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    x[5] *= 6.0                                          # a row with large logits: the running maximum has to move
+    w = (0.2 * rng.standard_normal((K, V))).astype(np.float32)
+    b = rng.standard_normal(V).astype(np.float32)
+    t = rng.integers(0, V, M)
+    t[:3] = (0, V - 1, V // 2)
+    xd, wd, bd, td = hp.from_numpy(x), hp.from_numpy(w), hp.from_numpy(b), hp.from_numpy(t.astype(np.int64))
+    logits, lse = hp.empty((M, V), np.float32), hp.empty((M,), np.float32)
+    L.call("pdn_linear_lse_fwd_f32", xd._ptr, wd._ptr, bd._ptr, logits._ptr, lse._ptr, M, V, K, K, V, V, hp.stream())
+    loss_row, out = hp.empty((M,), np.float32), hp.empty((1,), np.float32)
+    L.call("pdn_cross_entropy_from_lse_f32", logits._ptr, V, lse._ptr, td._ptr, M, V, 1, loss_row._ptr, out._ptr,
+           hp.err_flag_ptr(), hp.stream())
+    rows = np.arange(M) if sample is None else np.r_[0:sample, M // 2:M // 2 + sample, M - sample:M]
+    z = x[rows].astype(np.float64) @ w.astype(np.float64) + b
+    m = z.max(-1, keepdims=True)
+    ref_lse = (m + np.log(np.exp(z - m).sum(-1, keepdims=True)))[:, 0]
+    got = logits.get()
+    close(got[rows], z, "logits")
+    assert np.abs(lse.get()[rows] - ref_lse).max() <= 1e-5 * np.abs(ref_lse).max() + 1e-5
+    ref_rows = ref_lse - z[np.arange(len(rows)), t[rows]]
+    assert np.abs(loss_row.get()[rows] - ref_rows).max() <= 2e-5 * np.abs(ref_rows).max() + 2e-5
+    if sample is None:
+        assert abs(float(out.get()[0]) - ref_rows.mean()) <= 1e-5 * abs(ref_rows.mean())
+    hp.check_index_errors()
+
+
+def check_linear_lse_tail_chunk_and_ragged_rows(dev):
+    _linear_lse_case(49152 + 40, 352, 21)              # 3 chunks + a 64-column tail; the last wave partly outside M
+
+
+def check_linear_lse_single_tile_tail(dev):
+    _linear_lse_case(49152, 128, 22)                   # 1 chunk + a 32-column tail
+
+
 # ---- node level: one Llama block with the epilogues on / off --------------------------------------------------------
 def _block_step(dev, epilogues):
     from pydynet_amd.llm.llama import Llama
@@ -272,5 +313,6 @@ for _fn in [check_gateup_swiglu_full_blocks, check_gateup_swiglu_ragged_rows_ffn
             check_gateup_swiglu_up_matrix_first_in_memory, check_qkv_rope_hd48,
             check_qkv_rope_hd96_ragged_tail, check_attention_bwd_rotated_equals_plain,
             check_dx_over_qkv_weight_blocks, check_dx_over_gate_up_weight_blocks_reversed,
+            check_linear_lse_tail_chunk_and_ragged_rows, check_linear_lse_single_tile_tail,
             check_llama_block_epilogues_vs_separate_kernels]:
     device_variants(globals(), _fn)

@@ -72,6 +72,23 @@ def check_linear_ce_mean(dev):
     _case(dev, 64, 96, "mean", 1.0, 0)
 
 
+def check_linear_ce_statistics_in_the_projection(dev):
+    """Enough rows for the projection to leave the log-sum-exp itself (pdn_linear_lse_fwd_f32): the node must take it."""
+    taken = []
+    fwd = fused.linear_cross_entropy.forward_
+
+    def spy(node, *a):
+        out = fwd(node, *a)
+        taken.append(node.stats_in_gemm)
+        return out
+    fused.linear_cross_entropy.forward_ = spy
+    try:
+        _case(dev, 49152, 128, "mean", 1.0, 5)
+    finally:
+        fused.linear_cross_entropy.forward_ = fwd
+    assert taken == [True], taken
+
+
 
 def check_linear_ce_sum_scaled_upstream(dev):
     _case(dev, 96, 160, "sum", 0.5, 1)
@@ -102,7 +119,7 @@ def check_linear_ce_not_applicable_falls_back(dev):
     assert not fused.linear_cross_entropy.applicable(x2, head2.weight, head2.bias, t2)   # rows not a multiple of 32
 
 
-for _f in (check_linear_ce_mean, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
+for _f in (check_linear_ce_mean, check_linear_ce_statistics_in_the_projection, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
            check_linear_ce_not_applicable_falls_back):
     device_variants(globals(), _f)
 
