@@ -322,6 +322,12 @@ __device__ __forceinline__ void ap_store_rows(const f32x16& t0, const f32x16& t1
   }
 }
 
+// dQ kernel: a wave owns a query tile; the (S^T, dP^T, dS^T, dQ^T) work of a key tile runs back to back -- no dS^T tiles
+// kept in registers, no barriers inside a head.  K of the next head is prefetched into the other K buffer; V is fetched at
+// the head switch (exposed, like dO in the dK/dV kernel).  (First form of this round: dS^T of four key tiles at a time in
+// registers, V halves of the next head issued at two barriers inside the head -- nothing exposed, but three barriers per
+// head whose causal skew -- SIMD s hosts tiles s and 7 - s: equal totals, unequal per phase -- cost more: 225 vs 197 us
+// at 1536 heads, same box.)
 template <int HD, bool ROT>
 __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
@@ -329,12 +335,9 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
     int H, int L, int64_t row_stride, int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd,
     int causal, const float* __restrict__ RC, const float* __restrict__ RS) {
   static_assert(HD == 48, "head dim 48");
-  constexpr int UPR = HD / 4, NT8 = HD / 8, IMG = AP_ROWS * HD;
+  constexpr int NT8 = HD / 8, IMG = AP_ROWS * HD;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // lds: K (even) | K (odd) | V  -- all rotated images.  (The V image starts 96 KB into the allocation, beyond the 64 KB
-  // an LDS instruction's immediate offset reaches: its position is kept opaque to the optimiser, which otherwise
-  // materialises one address register per (tile, fragment) -- 40 of them, spilled and reloaded inside the tile loop.)
-  int v_at = 2 * IMG;
+  int v_at = 2 * IMG;                               // (beyond the 64 KB an LDS immediate reaches: kept opaque, see above)
   asm volatile("" : "+s"(v_at));
   float* Vs = lds + v_at;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
   const int qpos = (active ? qtl : 0) * 32 + li;
   const int nk = active ? (causal ? qtl + 1 : ntile) : 0;
   const float inv_sqrt = 1.f / sqrt_hd, c1 = inv_sqrt * 1.4426950408889634f;
-  ApRowOff ko;                                      // row fragments (S, dP): row li of a tile, rotated units
+  ApRowOff ko;
   ko.init(li, lh, HD);
-  ApColOff<HD> co;                                  // column reads (dQ)
+  ApColOff<HD> co;
   co.init(li, lh);
   int bh = blockIdx.x;
   if (bh >= BH) return;
@@ -356,10 +359,8 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
   auto head_obase = [&](int x) { return (int64_t)(x / H) * o_batch_stride + (int64_t)(x % H) * HD; };
   float4 qf[NT8], gf[NT8], of_[NT8];
   float lse_q;
-  {
-    const int64_t base = head_base(bh), ob = head_obase(bh);
-    ap_dma_image<HD, true>(lds, K + base, L, rs, wave, lane);
-    ap_dma_image<HD, true>(Vs, V + base, L, rs, wave, lane);
+  auto load_rows = [&](int x) {
+    const int64_t base = head_base(x), ob = head_obase(x);
     const float* qrow = Q + base + (int64_t)qpos * row_stride + 4 * lh;
     const float* grow = dO + ob + (int64_t)qpos * o_row_stride + 4 * lh;
     const float* orow = O + ob + (int64_t)qpos * o_row_stride + 4 * lh;
@@ -369,114 +370,71 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
       gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
       of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
     }
-    lse_q = LSE[(int64_t)bh * L + qpos];
-    ap_landed();
-  }
-  // delta[q] = sum_d dO O of the rows in gf / of_ (the O rows are dead afterwards)
-  auto row_delta = [&]() {
+    lse_q = LSE[(int64_t)x * L + qpos];
+  };
+  ap_dma_image<HD, true>(lds, K + head_base(bh), L, rs, wave, lane);
+  load_rows(bh);
+  ap_landed();
+  for (int it = 0; bh < BH; ++it, bh += gridDim.x) {
+    const float* Ks = lds + (it & 1) * IMG;
+    // ---- every wave is done with the previous head: its V image is replaced ----
+    if (it) ap_barrier();
+    ap_dma_image<HD, true>(Vs, V + head_base(bh), L, rs, wave, lane);
     float dpart = 0.f;
 #pragma unroll
     for (int t = 0; t < NT8; ++t)
       dpart += (of_[t].x * gf[t].x + of_[t].y * gf[t].y) + (of_[t].z * gf[t].z + of_[t].w * gf[t].w);
-    return dpart + __shfl_xor(dpart, 32, 64);
-  };
-  float delta_q = row_delta();
-  for (int it = 0; bh < BH; ++it, bh += gridDim.x) {
-    const float* Ks = lds + (it & 1) * IMG;
-    // ---- K and V of this head have landed (every wave waited for its share before its last stores); the other K
-    //      buffer is free: K of the next head goes out now and has the whole head to arrive ----
-    ap_barrier();
+    const float delta_q = dpart + __shfl_xor(dpart, 32, 64);
+    const float c2q = -lse_q * 1.4426950408889634f;
+    ap_sync_all();
     const int nxt = bh + gridDim.x;
     if (nxt < BH) ap_dma_image<HD, true>(lds + ((it + 1) & 1) * IMG, K + head_base(nxt), L, rs, wave, lane);
-
-    const float c2q = -lse_q * 1.4426950408889634f;
-    // Two groups of four key tiles: dS^T of a group in registers (phase 1), then its share of dQ^T (phase 2).  V is dead
-    // after phase 1 of the SECOND group, K only at the end: the workgroup meets there, and the next head's K, V and Q
-    // rows are in flight during the last phase 2.  (All eight dS^T tiles at once would need 128 registers.)
-    f32x16 ds[4];
     f32x16 dq0, dq1;
-    ApRope rr;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq0[r] = 0.f; dq1[r] = 0.f; }
+    for (int kt = 0; kt < nk; ++kt) {
+      f32x16 s, dp;
+      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* kb = Ks + kt * 32 * HD;
+      const float* vb = Vs + kt * 32 * HD;
 #pragma unroll
-    for (int grp = 0; grp < 2; ++grp) {
-      // ---- phase 1: dS^T tiles (lane = query, registers = keys) ----
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kt = 4 * grp + j;
-        if (kt < nk) {
-          f32x16 s, dp;
-          const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          const float* kb = Ks + kt * 32 * HD;
-          const float* vb = Vs + kt * 32 * HD;
-#pragma unroll
-          for (int t = 0; t < NT8; ++t) {
-            const float4 kf = *reinterpret_cast<const float4*>(kb + ko.at(t));
-            const float4 vf = *reinterpret_cast<const float4*>(vb + ko.at(t));
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, t == 0 ? zero16 : s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, t == 0 ? zero16 : dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t].y, dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, gf[t].z, dp, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
-          }
-          if (causal && kt == qtl) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (ap_krow(r, lh) > li) s[r] = -INFINITY;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, c2q));
-            ds[j][r] = p * (dp[r] - delta_q);         // (the 1/sqrt(hd) of dS is applied once, when dQ is stored)
-          }
-        }
+      for (int t = 0; t < NT8; ++t) {
+        const float4 kf = *reinterpret_cast<const float4*>(kb + ko.at(t));
+        const float4 vf = *reinterpret_cast<const float4*>(vb + ko.at(t));
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qf[t].x, t == 0 ? zero16 : s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.x, gf[t].x, t == 0 ? zero16 : dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.y, gf[t].y, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.z, gf[t].z, dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
       }
-      // ---- every wave is done with this group's V rows: the same rows of the next head go out (first half: the rest
-      //      of the head to arrive; second half: the last phase 2), then this wave's next operand rows ----
-      ap_barrier();
-      if (grp == 0) {
-        if (nxt < BH) ap_dma_image<HD, true, 0, 3>(Vs, V + head_base(nxt), L, rs, wave, lane);
-      } else {
-        if (ROT) rr.load(RC, RS, qpos, lh);         // (for the dQ store: requested here, in the shadow of the last phase 2)
-        if (nxt < BH) {
-          const int64_t nb = head_base(nxt);
-          ap_dma_image<HD, true, 3, 6>(Vs, V + nb, L, rs, wave, lane);
-          const int64_t nob = head_obase(nxt);
-          const float* qrow = Q + nb + (int64_t)qpos * row_stride + 4 * lh;
-          const float* grow = dO + nob + (int64_t)qpos * o_row_stride + 4 * lh;
-          const float* orow = O + nob + (int64_t)qpos * o_row_stride + 4 * lh;
+      if (causal && kt == qtl) {
 #pragma unroll
-          for (int t = 0; t < NT8; ++t) {
-            qf[t] = *reinterpret_cast<const float4*>(qrow + 8 * t);
-            gf[t] = *reinterpret_cast<const float4*>(grow + 8 * t);
-            of_[t] = *reinterpret_cast<const float4*>(orow + 8 * t);
-          }
-          lse_q = LSE[(int64_t)nxt * L + qpos];
-        }
+        for (int r = 0; r < 16; ++r)
+          if (ap_krow(r, lh) > li) s[r] = -INFINITY;
       }
-      // ---- phase 2: dQ^T[d][q] += K^T[d][key] dS^T[key][q] ----
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int kt = 4 * grp + j;
-        if (kt < nk) {
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[r], c1, c2q));
+        s[r] = p * (dp[r] - delta_q);                 // (the 1/sqrt(hd) of dS is applied once, when dQ is stored)
+      }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float* kr = Ks + (kt * 32 + (r & 3) + 8 * (r >> 2)) * HD;
-            const float a0 = kr[co.first(r >> 2)];
-            const float a1 = kr[co.second(r >> 2)];
-            dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ds[j][r], dq0, 0, 0, 0);
-            dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ds[j][r], dq1, 0, 0, 0);
-          }
-        }
+      for (int r = 0; r < 16; ++r) {
+        const float* kr = Ks + (kt * 32 + (r & 3) + 8 * (r >> 2)) * HD;
+        const float a0 = kr[co.first(r >> 2)];
+        const float a1 = kr[co.second(r >> 2)];
+        dq0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], dq0, 0, 0, 0);
+        dq1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], dq1, 0, 0, 0);
       }
     }
-    ap_landed();                                    // the next head's K, V and operand rows: before the stores
+    ApRope rr;
+    if (ROT) rr.load(RC, RS, qpos, lh);
+    if (nxt < BH) load_rows(nxt);                   // (qf / gf / of_ of this head are dead)
+    ap_landed();                                    // next K (a head old), rope factors, next rows: before the stores
     if (active && lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
     if (active) ap_store_rows<ROT>(dq0, dq1, dQ + head_base(bh) + (int64_t)qpos * row_stride + 4 * lh, inv_sqrt, rr);
-    if (nxt < BH) delta_q = row_delta();            // (the next head's rows, requested before the last phase 2)
   }
 }
 

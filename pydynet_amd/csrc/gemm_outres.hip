@@ -489,7 +489,11 @@ struct OutResTnParams {
   int xcd_swizzle;                // 1: K ranges dealt to XCDs (the number of K ranges is a multiple of 8)
 };
 
-template <int NW, bool CE = false>
+// WIDE: the X fragments of FOUR row tiles in one ds_read_b128.  A lane of the MFMA A operand supplies one row of the
+// output tile; WHICH row of C that is, is free: with row 128 g + 4 l + c given to lane l of tile 4 g + c, the four values a
+// lane needs for tiles 4 g .. 4 g + 3 at one k are adjacent in the X piece.  Rows 256 .. 287 (tile 8) keep the dword reads:
+// 3 LDS instructions per k step instead of 9; the permutation is undone by the addresses of the final stores.
+template <int NW, bool CE = false, bool WIDE = false>
 __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnParams p) {
   constexpr int PIECE = OR_KP * OR_N;
   constexpr int NQ = (36 + NW - 1) / NW;
@@ -580,6 +584,64 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
     const float* Bp = smem + (s & 1) * PIECE;
     const float* Gp = Gs + (s & 1) * GP + gnn;
     const int nxt = min(s + 1, npieces - 1);
+    if constexpr (WIDE) {
+      const float* Bw = Bp + (4 * lh) * OR_N + 4 * li;
+      const float* Bt = Bp + (4 * lh) * OR_N + 256 + li;
+      float4 wa[2][2];
+      float wt[2];
+      auto loadx = [&](int slot, int kk) {            // kk = 8 g + q: rows kk (h = 0) and kk + 4 (h = 1) of the piece
+        wa[slot][0] = *reinterpret_cast<const float4*>(Bw + kk * OR_N);
+        wa[slot][1] = *reinterpret_cast<const float4*>(Bw + kk * OR_N + 128);
+        wt[slot] = Bt[kk * OR_N];
+      };
+      loadx(0, 0);
+      float gn[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gn[q] = Gp[q * 32];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float gv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[q] = gn[q];
+        if (CE) {
+          const float4 l4 = *reinterpret_cast<const float4*>(Ls + (s & 1) * 32 + 8 * g + 4 * lh);
+          const float4 t4 = *reinterpret_cast<const float4*>(Ls + (2 + (s & 1)) * 32 + 8 * g + 4 * lh);
+          const int col = n0 + li;
+          gv[0] = ce_grad(gv[0], l4.x, __float_as_int(t4.x) == col, ce_sc);
+          gv[1] = ce_grad(gv[1], l4.y, __float_as_int(t4.y) == col, ce_sc);
+          gv[2] = ce_grad(gv[2], l4.z, __float_as_int(t4.z) == col, ce_sc);
+          gv[3] = ce_grad(gv[3], l4.w, __float_as_int(t4.w) == col, ce_sc);
+          csum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
+        }
+        if (g + 1 < 4) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gn[q] = Gp[(8 * (g + 1) + q) * 32];
+        }
+        if (g == 0) { fetch_g(nxt); fetch_rows(nxt); }
+        if (g < 3) {
+#pragma unroll
+          for (int e = 0; e < 3; ++e)
+            if (3 * g + e < NQ) fetch(nxt, 3 * g + e);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int cur = q & 1;
+          if (4 * g + q + 1 < 16) loadx(cur ^ 1, 8 * ((4 * g + q + 1) >> 2) + ((4 * g + q + 1) & 3));
+          __builtin_amdgcn_sched_barrier(0);
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][0].x, gv[q], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][0].y, gv[q], acc[1], 0, 0, 0);
+          acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][0].z, gv[q], acc[2], 0, 0, 0);
+          acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][0].w, gv[q], acc[3], 0, 0, 0);
+          acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][1].x, gv[q], acc[4], 0, 0, 0);
+          acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][1].y, gv[q], acc[5], 0, 0, 0);
+          acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][1].z, gv[q], acc[6], 0, 0, 0);
+          acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[cur][1].w, gv[q], acc[7], 0, 0, 0);
+          acc[8] = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[cur], gv[q], acc[8], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     float x0[3][4], x1[3][4];
 #define TN_LOADX(BX, G, T)                                                                       \
   _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                  \
@@ -635,6 +697,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
 #undef TN_STEP
 #undef TN_LOADX
 #undef TN_MFMA
+    }
     park((s + 1) & 1);
   }
   if (!active) return;
@@ -643,16 +706,23 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
     if (lh == 0) p.colsum[(int64_t)by * p.N + n0 + li] = csum;
   }
   // accumulator register r of tile i = row 32 i + (r & 3) + 8 (r >> 2) + 4 h, column n0 + lane
+  // (WIDE, tiles 0 .. 7: row 128 (i >> 2) + 4 ((r & 3) + 8 (r >> 2) + 4 h) + (i & 3), see above)
   const int blk = n0 / p.nb_cols;                   // (a wave's 32 columns never straddle two blocks: nb_cols % 32 == 0)
   float* __restrict__ Cw = p.C + blk * p.blk_stride + (int64_t)by * p.slab + (n0 - blk * p.nb_cols) + li;
   const unsigned ldc = (unsigned)p.ldc;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    unsigned o = (unsigned)(32 * i + 4 * lh) * ldc;
+    if (WIDE && i < 8) {
+      const unsigned o = (unsigned)(128 * (i >> 2) + (i & 3) + 16 * lh) * ldc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      Cw[o] = acc[i][r];
-      o += ((r & 3) == 3) ? 5 * ldc : ldc;
+      for (int r = 0; r < 16; ++r) Cw[o + (unsigned)(4 * ((r & 3) + 8 * (r >> 2))) * ldc] = acc[i][r];
+    } else {
+      unsigned o = (unsigned)(32 * i + 4 * lh) * ldc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        Cw[o] = acc[i][r];
+        o += ((r & 3) == 3) ? 5 * ldc : ldc;
+      }
     }
   }
 }
@@ -680,22 +750,22 @@ static int outres_tn_launch(OutResTnParams& p, int nw, bool ce, void* stream) {
   static const int swz_env = getenv("PDN_OUTRES_TN_SWIZZLE") ? atoi(getenv("PDN_OUTRES_TN_SWIZZLE")) : 1;
   p.xcd_swizzle = (swz_env && splits % 8 == 0 && grid.x > 1) ? 1 : 0;
   const size_t shm = (size_t)(2 * OR_KP * OR_N + nw * 2 * OR_KP * 32 + 4 * 32) * sizeof(float);
+  static const int wide = getenv("PDN_OUTRES_TN_WIDE") ? atoi(getenv("PDN_OUTRES_TN_WIDE")) : 1;
   static bool attr_set = false;
+#define TN_EACH(X) X(8, false, false) X(4, false, false) X(8, true, false) X(4, true, false) X(8, false, true) X(4, false, true) X(8, true, true) X(4, true, true)
   if (!attr_set) {
-    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define TN_ATTR(NW_, CE_, W_) \
+    PDN_HIP(hipFuncSetAttribute((const void*)gemm_outres_tn_kernel<NW_, CE_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    TN_EACH(TN_ATTR)
+#undef TN_ATTR
     attr_set = true;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (nw == 8) {
-    if (ce) hipLaunchKernelGGL((gemm_outres_tn_kernel<8, true>), grid, dim3(512), shm, st, p);
-    else hipLaunchKernelGGL((gemm_outres_tn_kernel<8, false>), grid, dim3(512), shm, st, p);
-  } else {
-    if (ce) hipLaunchKernelGGL((gemm_outres_tn_kernel<4, true>), grid, dim3(256), shm, st, p);
-    else hipLaunchKernelGGL((gemm_outres_tn_kernel<4, false>), grid, dim3(256), shm, st, p);
-  }
+#define TN_GO(NW_, CE_, W_) \
+  if (nw == NW_ && ce == CE_ && (wide != 0) == W_) hipLaunchKernelGGL((gemm_outres_tn_kernel<NW_, CE_, W_>), grid, dim3(NW_ * 64), shm, st, p);
+  TN_EACH(TN_GO)
+#undef TN_GO
+#undef TN_EACH
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
