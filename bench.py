@@ -321,7 +321,16 @@ def hbm_kernels(lib, hp, B, traffic):
             for _ in range(5):
                 fn()
         us = t.ms / 5 * 1e3
+        from pydynet_amd.core import fused
+        lce = fused.linear_cross_entropy
+        split = bool(lce.deferred_norm and lib.query("pdn_linear_lse_supported", T, V, 288)
+                     and lib.query("pdn_linear_ce_dx_deferred_supported", T, V, 288))
+        in_gemm = bool(lce.lse_epilogue and lib.query("pdn_linear_lse_supported", T, V, 288))
         out[name] = {"bound": "hbm", "what": "cross-entropy row statistics (read-only pass over the logits)",
+                     # at this many tokens the step takes the statistics from the two lm_head products instead
+                     # (fused.linear_cross_entropy: row maxima in the projection's store, the sum of exponentials in the
+                     # input-gradient product); the pass is timed here as the HBM-bound reference kernel it replaces
+                     "in_step": not (split or in_gemm),
                      "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
                      "avg_launch_us": us, "traffic": traffic.get(name)}

@@ -811,6 +811,9 @@ class linear_cross_entropy(_Operator):
     enabled = True
     min_rows = int(os.environ.get("PDN_LINCE_MIN_ROWS", "16384"))
     lse_epilogue = os.environ.get("PDN_NO_LSE_EPILOGUE", "0") != "1"      # row statistics in the projection's store (A/B switch)
+    # statistics split over the projection (row maxima) and the input-gradient product (sum of exponentials), the latter
+    # run in the forward pass of a training step (A/B switch)
+    deferred_norm = os.environ.get("PDN_NO_CE_DEFERRED", "0") != "1"
 
     @staticmethod
     def applicable(x, w, b, targets, reduction="mean"):
@@ -846,19 +849,36 @@ class linear_cross_entropy(_Operator):
         logits = hp.empty((n, V), np.float32)
         loss_row, lse, out = hp.empty((n,), np.float32), hp.empty((n,), np.float32), hp.empty((1,), np.float32)
         wd = w.data
-        self.stats_in_gemm = bool(linear_cross_entropy.lse_epilogue and wd.is_contiguous() and x2._strides[1] == 1
-                                  and L.query("pdn_linear_lse_supported", n, V, fin))
-        if self.stats_in_gemm:
+        in_gemm = bool(wd.is_contiguous() and x2._strides[1] == 1 and L.query("pdn_linear_lse_supported", n, V, fin))
+        self.deferred = bool(linear_cross_entropy.deferred_norm and in_gemm and is_grad_enable() and x.requires_grad
+                             and L.query("pdn_linear_ce_dx_deferred_supported", n, V, fin))
+        self.stats_in_gemm = bool(linear_cross_entropy.lse_epilogue and in_gemm and not self.deferred)
+        self._dxu = None
+        bp = b.data._ptr if b is not None else None
+        mean = 1 if self.reduction == "mean" else 0
+        if self.deferred:
+            # the projection leaves the row maxima; the input-gradient product -- it needs exp(logit - max) anyway, and not
+            # the upstream gradient, a scalar applied in backward -- sums the exponentials as it multiplies: it runs HERE,
+            # the loss follows from its log-sum-exp with one gather per row, and no pass over the logits exists
+            rowmax = hp.empty((n,), np.float32)
+            L.call("pdn_linear_rowmax_fwd_f32", x2._ptr, wd._ptr, bp, logits._ptr, rowmax._ptr, n, V, fin, x2._strides[0],
+                   V, V, hp.stream())
+            self._dxu = hp.empty((n, fin), np.float32)
+            L.call("pdn_linear_ce_dx_deferred_f32", logits._ptr, rowmax._ptr, self._t._ptr, 1.0 / n if mean else 1.0,
+                   wd._ptr, self._dxu._ptr, lse._ptr, n, V, fin, hp.stream())
+            L.call("pdn_cross_entropy_from_lse_f32", logits._ptr, V, lse._ptr, self._t._ptr, n, V, mean, loss_row._ptr,
+                   out._ptr, hp.err_flag_ptr(), hp.stream())
+        elif self.stats_in_gemm:
             # the projection leaves the rows' log-sum-exp itself (transposed accumulators: a lane owns a token): no
             # pass over the logits for the statistics, the loss is one gather per row
-            L.call("pdn_linear_lse_fwd_f32", x2._ptr, wd._ptr, b.data._ptr if b is not None else None, logits._ptr, lse._ptr,
-                   n, V, fin, x2._strides[0], V, V, hp.stream())
-            L.call("pdn_cross_entropy_from_lse_f32", logits._ptr, V, lse._ptr, self._t._ptr, n, V,
-                   1 if self.reduction == "mean" else 0, loss_row._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
+            L.call("pdn_linear_lse_fwd_f32", x2._ptr, wd._ptr, bp, logits._ptr, lse._ptr, n, V, fin, x2._strides[0], V, V,
+                   hp.stream())
+            L.call("pdn_cross_entropy_from_lse_f32", logits._ptr, V, lse._ptr, self._t._ptr, n, V, mean, loss_row._ptr,
+                   out._ptr, hp.err_flag_ptr(), hp.stream())
         else:
             hp.gemm(x2, wd, logits, bias=b.data.reshape(-1) if b is not None else None)
-            L.call("pdn_cross_entropy_fwd_f32", logits._ptr, self._t._ptr, n, V, 1 if self.reduction == "mean" else 0,
-                   loss_row._ptr, lse._ptr, out._ptr, hp.err_flag_ptr(), hp.stream())
+            L.call("pdn_cross_entropy_fwd_f32", logits._ptr, self._t._ptr, n, V, mean, loss_row._ptr, lse._ptr, out._ptr,
+                   hp.err_flag_ptr(), hp.stream())
         self._saved = (x2, logits, lse)
         return out.reshape(())
 
@@ -873,7 +893,11 @@ class linear_cross_entropy(_Operator):
         g = _contig(g)
         grads = [None] * len(self.last)
         dx = ex = None
-        if x.requires_grad:
+        dxu, self._dxu = self._dxu, None
+        if x.requires_grad and dxu is not None:
+            dxu *= g.reshape(())                           # formed in the forward pass, up to the upstream scalar
+            grads[0] = dxu.reshape(x.shape)
+        elif x.requires_grad:
             dx = hp.empty(x.shape, np.float32)
             ex = _foldable(self, 0, x)
             grads[0] = dx

@@ -50,6 +50,10 @@ struct OutResParams {
   int ppb;
   unsigned ppb_magic;
   int64_t b_bstride;
+  // CE == 2 (deferred normalisation): `lse` holds the ROW MAXIMUM m of the logits; the operand is exp(logit - m), its row
+  // sums Z accumulate beside the product, and the rows leave as gscale * (acc / Z - W^T[target]) -- the same gradient,
+  // with the softmax denominator found on the way: lse_out[row] = m + log Z (the statistics pass over the logits is gone)
+  float* lse_out;
 };
 
 // gradient of the mean cross entropy w.r.t. one logit
@@ -68,8 +72,9 @@ __device__ __forceinline__ void or_glds16(const float* g, float* l) {
 // BT: B is given as the row-major (288 x K) matrix whose transpose is meant.  NW: waves per workgroup.
 // ABLATE (timing experiments only): 1 = A loaded once, 2 = no B DMA after the first two pieces.
 // STAGE: the B piece reaches LDS by LDS-DMA (0) or through registers, global_load_dwordx4 + ds_write_b128 (1).
-template <bool BT, int NW, int STAGE, int ABLATE = 0, bool CE = false>
+template <bool BT, int NW, int STAGE, int ABLATE = 0, int CE = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(OutResParams p) {
+  static_assert(CE != 2 || BT, "deferred cross-entropy normalisation: NT form (W as stored)");
   constexpr int PIECE = OR_KP * OR_N;             // floats: 36 KiB
   constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
   static_assert(NQ <= 9, "the DMA of a piece must be issued within its first three k-groups");
@@ -143,11 +148,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
   }
   float ce_lse = 0.f, ce_sc = 0.f;
   int ce_rel = 0;                                   // target column relative to this lane's first column (4 h)
-  if (CE) {
+  if (CE == 1) {
     ce_lse = p.lse[arow_i];
     ce_rel = (int)p.targets[arow_i] - 4 * lh;
     ce_sc = p.gscale * (p.gdev ? p.gdev[0] : 1.f);
   }
+  float ce_c2 = 0.f, ce_z = 0.f;                    // CE 2: -max * log2(e); this lane's share of the row's sum of exponentials
+  if (CE == 2) ce_c2 = -p.lse[arow_i] * 1.4426950408889634f;
 
   f32x16 acc[9];
 #pragma unroll
@@ -205,10 +212,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 av = a[g];
-      if (CE) {                                     // this lane's four columns: 32 s + 8 g + 4 h + 0..3
+      if (CE == 1) {                                // this lane's four columns: 32 s + 8 g + 4 h + 0..3
         const int c0 = ce_rel - (OR_KP * s + 8 * g);
         av.x = ce_grad(av.x, ce_lse, c0 == 0, ce_sc); av.y = ce_grad(av.y, ce_lse, c0 == 1, ce_sc);
         av.z = ce_grad(av.z, ce_lse, c0 == 2, ce_sc); av.w = ce_grad(av.w, ce_lse, c0 == 3, ce_sc);
+      }
+      if (CE == 2) {
+        const float L2E = 1.4426950408889634f;
+        av.x = __builtin_amdgcn_exp2f(fmaf(av.x, L2E, ce_c2)); av.y = __builtin_amdgcn_exp2f(fmaf(av.y, L2E, ce_c2));
+        av.z = __builtin_amdgcn_exp2f(fmaf(av.z, L2E, ce_c2)); av.w = __builtin_amdgcn_exp2f(fmaf(av.w, L2E, ce_c2));
+        ce_z += (av.x + av.y) + (av.z + av.w);
       }
       // the fetch of the next piece first (three instructions at the head of groups 0..2; spread one per step
       // it measured 66 instead of 77 % at K = 32000), so that only the A loads of groups 2 and 3 follow its last one
@@ -237,6 +250,32 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
 
   // ---- C rows: accumulator register r of tile j = row (r & 3) + 8 (r >> 2) + 4 h, column 32 j + lane -----------
+  if constexpr (CE == 2) {
+    // lane l (both halves) knows row l's statistics; the accumulators hold row rho(r, h) in register r: one cross-lane
+    // read of 1 / Z and of the target per register row, then nine column tiles of  gscale * (acc / Z - W[:, target])
+    const float z = ce_z + __shfl_xor(ce_z, 32, 64);
+    const float izl = 1.f / z;
+    const int tgl = min(max((int)p.targets[arow_i], 0), p.K - 1);   // (an out-of-range target is reported by the loss kernel)
+    if (lh == 0 && m0 + li < p.M) p.lse_out[m0 + li] = p.lse[arow_i] + __logf(z);
+    const int mrem2 = p.M - m0;
+    float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + li;
+    const float* __restrict__ Wc = p.B + (unsigned)li * ldb;
+    const float sc = p.gscale;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rho = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const float iz = __shfl(izl, rho, 64);
+      const int tg = __shfl(tgl, rho, 64);
+      if (rho < mrem2) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+          const float wt = Wc[(unsigned)(32 * j) * ldb + (unsigned)tg];
+          Cw[(unsigned)rho * (unsigned)p.ldc + 32 * j] = sc * (acc[j][r] * iz - wt);
+        }
+      }
+    }
+    return;
+  }
   const bool to_slab = p.slab != nullptr;
   float* __restrict__ Cw = to_slab ? p.slab + ((int64_t)blockIdx.y * p.M + m0) * OR_N : p.C + (int64_t)m0 * p.ldc;
   const float* __restrict__ Rw = (p.residual && !to_slab) ? p.residual + (int64_t)m0 * p.ldc : nullptr;
@@ -443,8 +482,8 @@ int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, 
   }
   if (splits > 1) { p.kps = kps; p.slab = (float*)workspace; }
   const dim3 grid((M + 32 * nw - 1) / (32 * nw), splits);
-  if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, true>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, true>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, 1>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, 1>), grid, dim3(256), 0, (hipStream_t)stream, p);
   PDN_LAUNCH_CHECK();
   if (splits > 1) {
     const int64_t n4 = (int64_t)M * (OR_N / 4);
@@ -452,6 +491,30 @@ int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, 
                        p.slab, splits, M, (const float*)nullptr, residual, dx, ldc);
     PDN_LAUNCH_CHECK();
   }
+  return PDN_OK;
+}
+
+// The same product with the softmax denominator found on the way (CE == 2, see OutResParams): rowmax in, lse out.
+// Needs the unsplit form (every row's whole vocabulary in one workgroup): M large enough to fill the chip by rows.
+extern "C" int pdn_linear_ce_dx_deferred_supported(int64_t M, int V, int K) {
+  if (!(K == OR_N && V % OR_KP == 0 && V >= OR_KP && M >= 1 && M < (1ll << 31) && (int64_t)OR_N * V < (1ll << 30))) return 0;
+  int nw, kps;
+  return pdn_gemm_outres_plan((int)M, V, &nw, &kps) == 1 ? 1 : 0;
+}
+int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const float* rowmax, const int64_t* targets,
+                                     float gscale, const float* W, int64_t ldw, float* dx, int64_t ldc, float* lse_out,
+                                     int M, int V, void* stream) {
+  OutResParams p{logits, W, dx, nullptr, nullptr, M, V, ldl, ldw, ldc, rowmax, targets, nullptr, gscale, V / OR_KP, nullptr};
+  p.lse_out = lse_out;
+  int nw = 8, kps = V / OR_KP;
+  if (pdn_gemm_outres_plan(M, V, &nw, &kps) != 1) {
+    pdn_set_error("pdn_linear_ce_dx_deferred_f32: %d rows do not fill the chip without splitting the vocabulary", M);
+    return PDN_EUNSUPPORTED;
+  }
+  const dim3 grid((M + 32 * nw - 1) / (32 * nw), 1);
+  if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
 

@@ -48,7 +48,8 @@ struct RowResParams {
   int L, hd, rope_chunks;         // EPI 3: positions per sequence, head dim, chunks (of 96 columns) that are rotated
   unsigned hd_magic;              //        2^32 / hd rounded up (x / hd = umulhi(x, magic) for x < 2^16)
   unsigned g_off, u_off;          // EPI 1: first float of the gate / up matrix relative to B
-  float* lse;                     // EPI 4: log-sum-exp of every output row (M)
+  float* lse;                     // EPI 4: log-sum-exp of every output row (M); EPI 5: their maxima
+  int epi_ablate;                 // timing experiments (PDN_ROWRES_EPI_ABLATE; 0 in the library): 2 = EPI 5 without its maximum
 };
 
 __device__ __forceinline__ void rr_glds16(const float* g, float* l) {
@@ -280,6 +281,49 @@ __device__ __forceinline__ void rr_store_rope(const RowResParams& p, f32x16 (&ac
 //          96-column chunk (with lane = column they were five cross-lane steps per row and statistic: tried in round
 //          3, +1.95 ms).  The logits leave as 16-byte pieces of the lane's own row (the two half-waves complete a
 //          128-byte line between them); the separate statistics pass over the logits (8.4 GB read, 1.5 ms) is gone.
+//   EPI 5  the row MAXIMUM only, in the plain orientation (lane = column) and with the plain store.  Measured on the 9.0 ms
+//          product (tools/lmhead_probe.py): the transposed form costs +0.6 ms even without a single exponential --
+//          0.5 ms of it the store, 64 pieces of 16 bytes in 32 rows per instruction instead of two 128-byte row segments
+//          -- and all of it exposed, because the waves of a workgroup finish their chunks together.  Here the 16 x 64
+//          candidates of a chunk (16 register rows per lane, after the in-lane maximum over the three tiles) shrink by a
+//          HALVING butterfly: at lane distance 16 each lane keeps 8 of its rows and hands the other 8 to its partner, then
+//          4, 2, 1 -- 16 cross-lane moves per chunk instead of 80 -- and lane l ends with the maximum of register row
+//          l >> 1.  The sum of exponentials is a by-product of the input-gradient product, which forms exp(logit - max)
+//          anyway (csrc/gemm_outres.hip, CE == 2).
+__device__ __forceinline__ void rr_rowmax(const RowResParams& p, const f32x16 (&acc)[3], int c, int li, int nt, float& m_run) {
+  float bv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bv[j] = (p.bias && j < nt) ? p.bias[c * RR_NC + 32 * j + li] : 0.f;
+  auto row3 = [&](int r) {                          // in-lane maximum of register row r over the chunk's tiles
+    float m = acc[0][r] + bv[0];
+    if (nt > 1) m = fmaxf(m, acc[1][r] + bv[1]);
+    if (nt > 2) m = fmaxf(m, acc[2][r] + bv[2]);
+    return m;
+  };
+  float v[8];
+  {
+    const bool up = (li & 16) != 0;                 // lane distance 16: keep 8 rows, pass 8 rows on
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float a = row3(r), b = row3(r + 8);
+      v[r] = fmaxf(up ? b : a, __shfl_xor(up ? a : b, 16, 64));
+    }
+  }
+  // lane distance 2 D: keep D rows, pass D rows on (D a literal: with a loop over D the compiler indexed v[] dynamically
+  // -- select chains and scratch -- and the epilogue measured 1.3 ms on the 9 ms product)
+#define RR_BFLY(D)                                                                   \
+  {                                                                                  \
+    const bool up = (li & (2 * (D))) != 0;                                           \
+    _Pragma("unroll") for (int r = 0; r < (D); ++r) {                                \
+      const float send = up ? v[r] : v[r + (D)], keep = up ? v[r + (D)] : v[r];      \
+      v[r] = fmaxf(keep, __shfl_xor(send, 2 * (D), 64));                             \
+    }                                                                                \
+  }
+  RR_BFLY(4) RR_BFLY(2) RR_BFLY(1)
+#undef RR_BFLY
+  m_run = fmaxf(m_run, fmaxf(v[0], __shfl_xor(v[0], 1, 64)));
+}
+
 template <bool GUARD>
 __device__ __forceinline__ void rr_store_lse(const RowResParams& p, f32x16 (&acc)[3], int m0, int c, int li, int lh, int nt,
                                              float& m_run, float& z_run) {
@@ -332,7 +376,7 @@ template <int KG, bool BT, int NW, int STAGE, int ABLATE = 0, int EPI = 0>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(RowResParams p) {
   static_assert(EPI != 1 || (!BT && NW == 8), "SwiGLU forward epilogue: NN form, one 8-wave workgroup per CU");
   static_assert(EPI != 2 || BT, "SwiGLU backward epilogue: NT form");
-  static_assert(EPI != 4 || !BT, "row-statistics epilogue: NN form");
+  static_assert((EPI != 4 && EPI != 5) || !BT, "row-statistics epilogues: NN form");
   constexpr int NQ = (36 + NW - 1) / NW;          // DMA instructions per wave and piece
   constexpr int NPK = KG / 12;                    // pieces along K
   constexpr int PIECE = RR_KP * RR_NC;            // floats
@@ -571,7 +615,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       if (full) rr_store_rope<false>(p, acc, m0, c, li, lh); else rr_store_rope<true>(p, acc, m0, c, li, lh);
     } else if constexpr (EPI == 4) {
       const int nt = c == c_tail ? nt_tail : 3;
-      if (full) rr_store_lse<false>(p, acc, m0, c, li, lh, nt, m_run, z_run); else rr_store_lse<true>(p, acc, m0, c, li, lh, nt, m_run, z_run);
+      if (full) rr_store_lse<false>(p, acc, m0, c, li, lh, nt, m_run, z_run);
+      else rr_store_lse<true>(p, acc, m0, c, li, lh, nt, m_run, z_run);
+    } else if constexpr (EPI == 5) {
+      const int nt = c == c_tail ? nt_tail : 3;
+      if (!(p.epi_ablate & 2)) rr_rowmax(p, acc, c, li, nt, m_run);
+      rr_store(p, acc, m0, c, li, lh, full, nt);
     } else {
       rr_store(p, acc, m0, c, li, lh, full, c == c_tail ? nt_tail : 3);
     }
@@ -579,6 +628,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
   if constexpr (EPI == 4) {
     const float z = z_run + __shfl_xor(z_run, 32, 64);
     if (lh == 0 && m0 + li < p.M) p.lse[m0 + li] = m_run + logf(z);
+  }
+  if constexpr (EPI == 5) {                          // lane l: register row l >> 1 = row (r & 3) + 8 (r >> 2) + 4 h of the block
+    const int r = li >> 1, row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (!(li & 1) && row < p.M) p.lse[row] = m_run;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
 }
@@ -630,6 +683,7 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     p.g_off = epi->g_off; p.u_off = epi->u_off;
     p.lse = epi->lse;
   }
+  p.epi_ablate = getenv("PDN_ROWRES_EPI_ABLATE") ? atoi(getenv("PDN_ROWRES_EPI_ABLATE")) : 0;
   hipStream_t st = (hipStream_t)stream;
   static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
   static const int nw_env = getenv("PDN_ROWRES_NW") ? atoi(getenv("PDN_ROWRES_NW")) : 0;
@@ -650,7 +704,7 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   while (row_blocks * nsplit < target && nsplit < p.chunks) ++nsplit;
   p.chunks_per_wg = (p.chunks + nsplit - 1) / nsplit;
   if (kind == 1) p.chunks_per_wg += p.chunks_per_wg & 1;       // gate / up tiles meet inside a PAIR of chunks
-  if (kind == 4) p.chunks_per_wg = p.chunks;                   // a row's statistics are one workgroup's
+  if (kind == 4 || kind == 5) p.chunks_per_wg = p.chunks;      // a row's statistics are one workgroup's
   nsplit = (p.chunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
   const dim3 grid(row_blocks, nsplit);
 #define RR_LAUNCH(BT_, NW_, AB_) if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 1, 0>), grid, dim3(NW_ * 64), 0, st, p); else hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 0, AB_>), grid, dim3(NW_ * 64), 0, st, p)
@@ -662,6 +716,8 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 3>), grid, dim3(512), 0, st, p);
   } else if (kind == 4) {
     hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 4>), grid, dim3(512), 0, st, p);
+  } else if (kind == 5) {
+    hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 5>), grid, dim3(512), 0, st, p);
   } else if (nw == 8) {
     if (b_trans) RR_LAUNCH(true, 8, 0); else RR_LAUNCH(false, 8, 0);
   } else if (b_trans) {
@@ -753,6 +809,24 @@ extern "C" int pdn_linear_lse_fwd_f32(const float* x, const float* w, const floa
   }
   RowResEpi e{4, nullptr, 0, nullptr, 0, nullptr, 1, 1, 0};
   e.lse = lse;
+  const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (double)V * K, 0.0, stream);
+  const int rc = rowres_launch(x, w, logits, bias, nullptr, M, V, K, ldx, ldw, ldl, 0, 1, 0, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+
+// The same product leaving rowmax[m] = max_v logits[m][v] only (EPI 5): the first half of a cross entropy whose sum of
+// exponentials comes out of the input-gradient product (pdn_linear_ce_dx_deferred_f32).  Shapes as above.
+extern "C" int pdn_linear_rowmax_fwd_f32(const float* x, const float* w, const float* bias, float* logits, float* rowmax,
+                                         int M, int V, int K, int64_t ldx, int64_t ldw, int64_t ldl, void* stream) {
+  if (M == 0 || V == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && w && logits && rowmax, "pdn_linear_rowmax_fwd_f32: null operand");
+  if (!pdn_linear_lse_supported(M, V, K) || (ldl & 3) || ((uintptr_t)logits & 15) || ((uintptr_t)bias & 15)) {
+    pdn_set_error("pdn_linear_rowmax_fwd_f32: unsupported shape M=%d V=%d K=%d", M, V, K);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{5, nullptr, 0, nullptr, 0, nullptr, 1, 1, 0};
+  e.lse = rowmax;
   const int tk = pdn_gemm_prof_begin(2, 2.0 * M * (double)V * K, 0.0, stream);
   const int rc = rowres_launch(x, w, logits, bias, nullptr, M, V, K, ldx, ldw, ldl, 0, 1, 0, stream, &e);
   pdn_gemm_prof_end(tk, stream);

@@ -235,6 +235,50 @@ class EmulatedLib:
         flat(lse, M)[...] = (m + np.log(np.exp(z - m).sum(-1, keepdims=True)))[:, 0]
         return 0
 
+    def pdn_linear_rowmax_fwd_f32(self, x, w, bias, logits, rowmax, M, V, K, ldx, ldw, ldl, stream):
+        if not self.pdn_linear_lse_supported(M, V, K) or ldl % 4:
+            return -2
+        z = np.matmul(view(x, (M, K), (ldx, 1), np.float32), view(w, (K, V), (ldw, 1), np.float32))
+        if bias:
+            z = z + flat(bias, V)
+        view(logits, (M, V), (ldl, 1), np.float32)[...] = z
+        flat(rowmax, M)[...] = z.max(-1)
+        return 0
+
+    @staticmethod
+    def _outres_unsplit(M, K):
+        """pdn_gemm_outres_plan(M, K) == 1 (csrc/gemm_outres.hip): the rows alone fill the chip."""
+        npieces, wg8, wg4 = K // 32, (M + 255) // 256, (M + 127) // 128
+        if wg8 >= 224:
+            return True
+        s8 = min((256 + wg8 - 1) // wg8, npieces // 24)
+        if s8 >= 2 and wg8 * s8 >= 224:
+            kps = (npieces + s8 - 1) // s8
+            return (npieces + kps - 1) // kps == 1
+        if wg4 >= 224:
+            return True
+        splits = min((448 + wg4 - 1) // wg4, npieces // 24)
+        if splits < 2:
+            return True
+        kps = (npieces + splits - 1) // splits
+        return (npieces + kps - 1) // kps == 1
+
+    def pdn_linear_ce_dx_deferred_supported(self, rows, V, fin):
+        return int(fin == 288 and V % 32 == 0 and V >= 32 and rows >= 1 and self._outres_unsplit(rows, V))
+
+    def pdn_linear_ce_dx_deferred_f32(self, logits, rowmax, targets, gscale, W, dx, lse, rows, V, fin, stream):
+        if not self.pdn_linear_ce_dx_deferred_supported(rows, V, fin):
+            return -2
+        a = flat(logits, rows * V).reshape(rows, V)
+        m = flat(rowmax, rows)
+        t = np.clip(flat(targets, rows, np.int64), 0, V - 1)
+        e = np.exp(a - m[:, None])
+        z = e.sum(-1)
+        w = flat(W, fin * V).reshape(fin, V)
+        flat(dx, rows * fin).reshape(rows, fin)[...] = np.float32(gscale) * ((e @ w.T) / z[:, None] - w.T[t])
+        flat(lse, rows)[...] = m + np.log(z)
+        return 0
+
     def pdn_cross_entropy_from_lse_f32(self, logits, ldl, lse, targets, rows, V, mean, loss_row, loss_out, err, stream):
         t = np.array(flat(targets, rows, np.int64))
         bad = (t < 0) | (t >= V)

@@ -72,22 +72,37 @@ def check_linear_ce_mean(dev):
     _case(dev, 64, 96, "mean", 1.0, 0)
 
 
-def check_linear_ce_statistics_in_the_projection(dev):
-    """Enough rows for the projection to leave the log-sum-exp itself (pdn_linear_lse_fwd_f32): the node must take it."""
-    taken = []
-    fwd = fused.linear_cross_entropy.forward_
+def _spied(dev, attr, flags, *case):
+    """Runs `_case(*case)` with the class switches `flags` and returns the node's `attr` per forward pass."""
+    taken, fwd = [], fused.linear_cross_entropy.forward_
+    saved = {k: getattr(fused.linear_cross_entropy, k) for k in flags}
 
     def spy(node, *a):
         out = fwd(node, *a)
-        taken.append(node.stats_in_gemm)
+        taken.append(getattr(node, attr))
         return out
     fused.linear_cross_entropy.forward_ = spy
+    for k, v in flags.items():
+        setattr(fused.linear_cross_entropy, k, v)
     try:
-        _case(dev, 49152, 128, "mean", 1.0, 5)
+        _case(dev, *case)
     finally:
         fused.linear_cross_entropy.forward_ = fwd
-    assert taken == [True], taken
+        for k, v in saved.items():
+            setattr(fused.linear_cross_entropy, k, v)
+    return taken
 
+
+def check_linear_ce_statistics_in_the_projection(dev):
+    """Enough rows for the projection to leave the log-sum-exp itself (pdn_linear_lse_fwd_f32): the node must take it."""
+    assert _spied(dev, "stats_in_gemm", {"deferred_norm": False}, 49152, 128, "mean", 1.0, 5) == [True]
+
+
+def check_linear_ce_statistics_split_over_both_products(dev):
+    """Row maxima from the projection, the sum of exponentials from the input-gradient product run in the forward pass
+    (pdn_linear_rowmax_fwd_f32 + pdn_linear_ce_dx_deferred_f32); the upstream scalar is applied in backward."""
+    assert _spied(dev, "deferred", {}, 49152, 160, "mean", 0.5, 6) == [True]
+    assert _spied(dev, "deferred", {}, 57344 + 32, 96, "sum", 1.0, 7) == [True]      # 8-wave workgroups, a ragged last one
 
 
 def check_linear_ce_sum_scaled_upstream(dev):
@@ -119,7 +134,8 @@ def check_linear_ce_not_applicable_falls_back(dev):
     assert not fused.linear_cross_entropy.applicable(x2, head2.weight, head2.bias, t2)   # rows not a multiple of 32
 
 
-for _f in (check_linear_ce_mean, check_linear_ce_statistics_in_the_projection, check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
+for _f in (check_linear_ce_mean, check_linear_ce_statistics_in_the_projection, check_linear_ce_statistics_split_over_both_products,
+           check_linear_ce_sum_scaled_upstream, check_linear_ce_many_rows_two_k_splits,
            check_linear_ce_not_applicable_falls_back):
     device_variants(globals(), _f)
 
