@@ -323,7 +323,7 @@ def hbm_kernels(lib, hp, B, traffic):
         us = t.ms / 5 * 1e3
         from pydynet_amd.core import fused
         lce = fused.linear_cross_entropy
-        split = bool(lce.deferred_norm and lib.query("pdn_linear_lse_supported", T, V, 288)
+        split = bool(lce.deferred_norm and lib.query("pdn_linear_rowmax_supported", T, V, 288)
                      and lib.query("pdn_linear_ce_dx_deferred_supported", T, V, 288))
         in_gemm = bool(lce.lse_epilogue and lib.query("pdn_linear_lse_supported", T, V, 288))
         out[name] = {"bound": "hbm", "what": "cross-entropy row statistics (read-only pass over the logits)",

@@ -160,18 +160,22 @@ int pdn_cross_entropy_from_lse_f32(const float* logits, int64_t ldl, const float
                                    void* stream);
 /* the same cross entropy with its statistics split over the two products that touch every logit anyway
  * (nn/functional.py:364-381 after llm/llama/model.py:179): the projection leaves rowmax[m] = max_v logits[m][v]
- * (pdn_linear_rowmax_fwd_f32; shapes of pdn_linear_lse_supported), the input-gradient product forms exp(logit - max),
+ * (pdn_linear_rowmax_fwd_f32: `pdn_linear_rowmax_parts` vectors of M, the row's maximum is the maximum over them -- with
+ * few rows the chunks of the vocabulary are split over the grid), the input-gradient product forms exp(logit - max),
  * sums it per row while it multiplies, and normalises its rows at the end:
  *   dx[t] = gscale * (sum_v exp(l[t][v] - max[t]) W[:, v] / Z[t] - W[:, target[t]]),  lse[t] = max[t] + log Z[t]
  * (W (in x V) row-major, in = 288; independent of the upstream gradient, a scalar the caller applies).  Run in the
  * forward pass of a training step, the loss follows from lse by pdn_cross_entropy_from_lse_f32 and backward only has
  * the weight gradient left (pdn_linear_ce_backward_f32 with dx = NULL). */
+int pdn_linear_rowmax_supported(int64_t M, int V, int K);
+int pdn_linear_rowmax_parts(int64_t M, int V, int K);      /* vectors of M maxima `rowmax` must hold (few rows: the chunk ranges) */
 int pdn_linear_rowmax_fwd_f32(const float* x, const float* w, const float* bias, float* logits, float* rowmax, int M,
                               int V, int K, int64_t ldx, int64_t ldw, int64_t ldl, void* stream);
 int pdn_linear_ce_dx_deferred_supported(int64_t rows, int V, int in_features);
-int pdn_linear_ce_dx_deferred_f32(const float* logits, const float* rowmax, const int64_t* targets, float gscale,
-                                  const float* W, float* dx, float* lse, int64_t rows, int V, int in_features,
-                                  void* stream);
+int64_t pdn_linear_ce_dx_deferred_workspace_bytes(int64_t rows, int V, int in_features);
+int pdn_linear_ce_dx_deferred_f32(const float* logits, const float* rowmax, int max_parts, const int64_t* targets,
+                                  float gscale, const float* W, float* dx, float* lse, int64_t rows, int V,
+                                  int in_features, void* workspace, int64_t workspace_bytes, void* stream);
 int pdn_gateup_swiglu_supported(int M, int F, int K);
 int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, int64_t w_stride, float* gu, float* h, int M,
                               int F, int K, int64_t ldx, void* stream);

@@ -850,7 +850,9 @@ class linear_cross_entropy(_Operator):
         loss_row, lse, out = hp.empty((n,), np.float32), hp.empty((n,), np.float32), hp.empty((1,), np.float32)
         wd = w.data
         in_gemm = bool(wd.is_contiguous() and x2._strides[1] == 1 and L.query("pdn_linear_lse_supported", n, V, fin))
-        self.deferred = bool(linear_cross_entropy.deferred_norm and in_gemm and is_grad_enable() and x.requires_grad
+        self.deferred = bool(linear_cross_entropy.deferred_norm and wd.is_contiguous() and x2._strides[1] == 1
+                             and is_grad_enable() and x.requires_grad
+                             and L.query("pdn_linear_rowmax_supported", n, V, fin)
                              and L.query("pdn_linear_ce_dx_deferred_supported", n, V, fin))
         self.stats_in_gemm = bool(linear_cross_entropy.lse_epilogue and in_gemm and not self.deferred)
         self._dxu = None
@@ -860,12 +862,16 @@ class linear_cross_entropy(_Operator):
             # the projection leaves the row maxima; the input-gradient product -- it needs exp(logit - max) anyway, and not
             # the upstream gradient, a scalar applied in backward -- sums the exponentials as it multiplies: it runs HERE,
             # the loss follows from its log-sum-exp with one gather per row, and no pass over the logits exists
-            rowmax = hp.empty((n,), np.float32)
+            # (few rows: both products cut the vocabulary into ranges over the grid -- `parts` vectors of maxima, a
+            #  workspace of unnormalised rows and row sums)
+            parts = L.query("pdn_linear_rowmax_parts", n, V, fin)
+            rowmax = hp.empty((parts * n,), np.float32)
             L.call("pdn_linear_rowmax_fwd_f32", x2._ptr, wd._ptr, bp, logits._ptr, rowmax._ptr, n, V, fin, x2._strides[0],
                    V, V, hp.stream())
             self._dxu = hp.empty((n, fin), np.float32)
-            L.call("pdn_linear_ce_dx_deferred_f32", logits._ptr, rowmax._ptr, self._t._ptr, 1.0 / n if mean else 1.0,
-                   wd._ptr, self._dxu._ptr, lse._ptr, n, V, fin, hp.stream())
+            ws, wsb = hp.workspace(L.query("pdn_linear_ce_dx_deferred_workspace_bytes", n, V, fin))
+            L.call("pdn_linear_ce_dx_deferred_f32", logits._ptr, rowmax._ptr, parts, self._t._ptr,
+                   1.0 / n if mean else 1.0, wd._ptr, self._dxu._ptr, lse._ptr, n, V, fin, ws, wsb, hp.stream())
             L.call("pdn_cross_entropy_from_lse_f32", logits._ptr, V, lse._ptr, self._t._ptr, n, V, mean, loss_row._ptr,
                    out._ptr, hp.err_flag_ptr(), hp.stream())
         elif self.stats_in_gemm:

@@ -1593,29 +1593,33 @@ int pdn_outres_ce_dw_launch(const float* X, const float* logits, float* C, int N
                             int64_t ldc, int64_t slab, int nw, int k_per_split, const float* lse,
                             const int64_t* targets, float gscale, const float* gdev, float* colsum, void* stream);
 
-int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const float* rowmax, const int64_t* targets,
-                                     float gscale, const float* W, int64_t ldw, float* dx, int64_t ldc, float* lse_out,
-                                     int M, int V, void* stream);
+int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const float* rowmax, int max_parts,
+                                     const int64_t* targets, float gscale, const float* W, int64_t ldw, float* dx,
+                                     int64_t ldc, float* lse_out, int M, int V, void* workspace, int64_t workspace_bytes,
+                                     void* stream);
 extern "C" int pdn_linear_ce_dx_deferred_supported(int64_t M, int V, int K);
 
-// Input gradient of `linear -> cross entropy` from the logits and their ROW MAXIMA (pdn_linear_rowmax_fwd_f32), leaving the
-// rows' log-sum-exp as a by-product:  dx[t] = gscale * (sum_v exp(l[t][v] - max[t]) W[:, v] / Z[t] - W[:, target[t]]),
-// lse[t] = max[t] + log Z[t], Z[t] = sum_v exp(l[t][v] - max[t]).  Independent of the upstream gradient (a scalar factor
-// the caller applies), so a training step can run it in the FORWARD pass: the loss is then sum(lse - l[target]) and no
-// pass over the logits for the statistics exists.  W (in x V) row-major, in = 288.
-extern "C" int pdn_linear_ce_dx_deferred_f32(const float* logits, const float* rowmax, const int64_t* targets, float gscale,
-                                             const float* W, float* dx, float* lse, int64_t rows, int V, int in_features,
-                                             void* stream) {
+// Input gradient of `linear -> cross entropy` from the logits and their ROW MAXIMA (pdn_linear_rowmax_fwd_f32: `max_parts`
+// vectors of `rows` maxima), leaving the rows' log-sum-exp as a by-product:
+//   dx[t] = gscale * (sum_v exp(l[t][v] - max[t]) W[:, v] / Z[t] - W[:, target[t]]),  Z[t] = sum_v exp(l[t][v] - max[t]),
+//   lse[t] = max[t] + log Z[t].
+// Independent of the upstream gradient (a scalar factor the caller applies), so a training step can run it in the FORWARD
+// pass: the loss is then sum(lse - l[target]) and no pass over the logits for the statistics exists.  W (in x V)
+// row-major, in = 288.  workspace: pdn_linear_ce_dx_deferred_workspace_bytes (few rows: the vocabulary is cut into
+// ranges over the grid, whose unnormalised rows and row sums a second kernel adds up).
+extern "C" int pdn_linear_ce_dx_deferred_f32(const float* logits, const float* rowmax, int max_parts, const int64_t* targets,
+                                             float gscale, const float* W, float* dx, float* lse, int64_t rows, int V,
+                                             int in_features, void* workspace, int64_t workspace_bytes, void* stream) {
   if (rows == 0 || V == 0) return PDN_OK;
-  PDN_CHECK_ARG(logits && rowmax && targets && W && dx && lse, "pdn_linear_ce_dx_deferred_f32: null operand");
+  PDN_CHECK_ARG(logits && rowmax && targets && W && dx && lse && max_parts >= 1, "pdn_linear_ce_dx_deferred_f32: null operand");
   if (!pdn_linear_ce_dx_deferred_supported(rows, V, in_features)) {
     pdn_set_error("pdn_linear_ce_dx_deferred_f32: unsupported shape rows=%lld V=%d in=%d", (long long)rows, V, in_features);
     return PDN_EUNSUPPORTED;
   }
   PDN_CHECK_ARG(((((uintptr_t)logits | (uintptr_t)W) & 15) == 0), "pdn_linear_ce_dx_deferred_f32: 16-byte alignment required");
   const int tk = pdn_gemm_prof_begin(3, 2.0 * (double)rows * (double)V * (double)in_features, 0.0, stream);
-  const int rc = pdn_outres_ce_dx_deferred_launch(logits, V, rowmax, targets, gscale, W, V, dx, in_features, lse, (int)rows, V,
-                                                  stream);
+  const int rc = pdn_outres_ce_dx_deferred_launch(logits, V, rowmax, max_parts, targets, gscale, W, V, dx, in_features, lse,
+                                                  (int)rows, V, workspace, workspace_bytes, stream);
   pdn_gemm_prof_end(tk, stream);
   return rc;
 }

@@ -54,6 +54,9 @@ struct OutResParams {
   // sums Z accumulate beside the product, and the rows leave as gscale * (acc / Z - W^T[target]) -- the same gradient,
   // with the softmax denominator found on the way: lse_out[row] = m + log Z (the statistics pass over the logits is gone)
   float* lse_out;
+  int max_parts;                  // the row maxima come as `max_parts` vectors of M (the projection's chunk ranges)
+  float* zslab;                   // K split over grid.y: split y leaves its UNNORMALISED rows in slab y and its row sums in
+                                  // zslab + y * M; outres_ce2_reduce_kernel normalises
 };
 
 // gradient of the mean cross entropy w.r.t. one logit
@@ -154,7 +157,12 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
     ce_sc = p.gscale * (p.gdev ? p.gdev[0] : 1.f);
   }
   float ce_c2 = 0.f, ce_z = 0.f;                    // CE 2: -max * log2(e); this lane's share of the row's sum of exponentials
-  if (CE == 2) ce_c2 = -p.lse[arow_i] * 1.4426950408889634f;
+  float ce_m = 0.f;
+  if (CE == 2) {
+    ce_m = p.lse[arow_i];
+    for (int q = 1; q < p.max_parts; ++q) ce_m = fmaxf(ce_m, p.lse[(int64_t)q * p.M + arow_i]);
+    ce_c2 = -ce_m * 1.4426950408889634f;
+  }
 
   f32x16 acc[9];
 #pragma unroll
@@ -250,13 +258,17 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
 
   // ---- C rows: accumulator register r of tile j = row (r & 3) + 8 (r >> 2) + 4 h, column 32 j + lane -----------
-  if constexpr (CE == 2) {
+  if (CE == 2 && p.slab) {                          // (the rows themselves: the plain slab store below)
+    const float z = ce_z + __shfl_xor(ce_z, 32, 64);
+    if (lh == 0 && m0 + li < p.M) p.zslab[(int64_t)blockIdx.y * p.M + m0 + li] = z;
+  }
+  if (CE == 2 && !p.slab) {
     // lane l (both halves) knows row l's statistics; the accumulators hold row rho(r, h) in register r: one cross-lane
     // read of 1 / Z and of the target per register row, then nine column tiles of  gscale * (acc / Z - W[:, target])
     const float z = ce_z + __shfl_xor(ce_z, 32, 64);
     const float izl = 1.f / z;
     const int tgl = min(max((int)p.targets[arow_i], 0), p.K - 1);   // (an out-of-range target is reported by the loss kernel)
-    if (lh == 0 && m0 + li < p.M) p.lse_out[m0 + li] = p.lse[arow_i] + __logf(z);
+    if (lh == 0 && m0 + li < p.M) p.lse_out[m0 + li] = ce_m + __logf(z);
     const int mrem2 = p.M - m0;
     float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + li;
     const float* __restrict__ Wc = p.B + (unsigned)li * ldb;
@@ -494,27 +506,77 @@ int pdn_outres_ce_dx_launch(const float* logits, int64_t ldl, const float* lse, 
   return PDN_OK;
 }
 
-// The same product with the softmax denominator found on the way (CE == 2, see OutResParams): rowmax in, lse out.
-// Needs the unsplit form (every row's whole vocabulary in one workgroup): M large enough to fill the chip by rows.
-extern "C" int pdn_linear_ce_dx_deferred_supported(int64_t M, int V, int K) {
-  if (!(K == OR_N && V % OR_KP == 0 && V >= OR_KP && M >= 1 && M < (1ll << 31) && (int64_t)OR_N * V < (1ll << 30))) return 0;
-  int nw, kps;
-  return pdn_gemm_outres_plan((int)M, V, &nw, &kps) == 1 ? 1 : 0;
+// The same product with the softmax denominator found on the way (CE == 2, see OutResParams): row maxima in, lse out.
+// Rows that fill the chip: every row's whole vocabulary in one workgroup, normalised in its store.  Fewer rows: the
+// vocabulary is cut into ranges over grid.y as for the plain product; the ranges leave unnormalised rows and their row
+// sums, and this kernel adds them up:  dx = gscale * (sum_s acc_s / sum_s Z_s - W[:, target]),  lse = max + log sum_s Z_s.
+__global__ __launch_bounds__(256) void outres_ce2_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ zslab,
+                                                                int splits, int M, const float* __restrict__ rowmax,
+                                                                int max_parts, const int64_t* __restrict__ targets,
+                                                                const float* __restrict__ W, int64_t ldw, int V, float gscale,
+                                                                float* __restrict__ dx, int64_t ldc, float* __restrict__ lse_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte piece of a row
+  if (i >= (int64_t)M * (OR_N / 4)) return;
+  const int row = (int)(i / (OR_N / 4)), c4 = (int)(i - (int64_t)row * (OR_N / 4));
+  float4 a = *reinterpret_cast<const float4*>(slab + (int64_t)row * OR_N + 4 * c4);
+  float z = zslab[row];
+  for (int s = 1; s < splits; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(slab + ((int64_t)s * M + row) * OR_N + 4 * c4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    z += zslab[(int64_t)s * M + row];
+  }
+  const int t = min(max((int)targets[row], 0), V - 1);
+  const float iz = 1.f / z;
+  const float* __restrict__ wt = W + (int64_t)(4 * c4) * ldw + t;
+  float4 o;
+  o.x = gscale * (a.x * iz - wt[0]); o.y = gscale * (a.y * iz - wt[ldw]);
+  o.z = gscale * (a.z * iz - wt[2 * ldw]); o.w = gscale * (a.w * iz - wt[3 * ldw]);
+  *reinterpret_cast<float4*>(dx + (int64_t)row * ldc + 4 * c4) = o;
+  if (c4 == 0) {
+    float m = rowmax[row];
+    for (int q = 1; q < max_parts; ++q) m = fmaxf(m, rowmax[(int64_t)q * M + row]);
+    lse_out[row] = m + __logf(z);
+  }
 }
-int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const float* rowmax, const int64_t* targets,
-                                     float gscale, const float* W, int64_t ldw, float* dx, int64_t ldc, float* lse_out,
-                                     int M, int V, void* stream) {
+
+extern "C" int pdn_linear_ce_dx_deferred_supported(int64_t M, int V, int K) {
+  return (K == OR_N && V % OR_KP == 0 && V >= OR_KP && M >= 1 && M < (1ll << 31) && (int64_t)OR_N * V < (1ll << 30)) ? 1 : 0;
+}
+// workspace of the split form: [splits x M x 288 rows | splits x M row sums]; 0 when the rows fill the chip
+extern "C" int64_t pdn_linear_ce_dx_deferred_workspace_bytes(int64_t M, int V, int K) {
+  if (!pdn_linear_ce_dx_deferred_supported(M, V, K)) return 0;
+  int nw, kps;
+  const int splits = pdn_gemm_outres_plan((int)M, V, &nw, &kps);
+  return splits > 1 ? (int64_t)splits * M * (OR_N + 1) * 4 : 0;
+}
+int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const float* rowmax, int max_parts,
+                                     const int64_t* targets, float gscale, const float* W, int64_t ldw, float* dx,
+                                     int64_t ldc, float* lse_out, int M, int V, void* workspace, int64_t workspace_bytes,
+                                     void* stream) {
   OutResParams p{logits, W, dx, nullptr, nullptr, M, V, ldl, ldw, ldc, rowmax, targets, nullptr, gscale, V / OR_KP, nullptr};
   p.lse_out = lse_out;
+  p.max_parts = max_parts;
   int nw = 8, kps = V / OR_KP;
-  if (pdn_gemm_outres_plan(M, V, &nw, &kps) != 1) {
-    pdn_set_error("pdn_linear_ce_dx_deferred_f32: %d rows do not fill the chip without splitting the vocabulary", M);
-    return PDN_EUNSUPPORTED;
+  const int splits = pdn_gemm_outres_plan(M, V, &nw, &kps);
+  if (splits > 1) {
+    PDN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)splits * M * (OR_N + 1) * 4 && (((uintptr_t)workspace | (uintptr_t)dx) & 15) == 0 &&
+                      (ldc & 3) == 0,
+                  "pdn_linear_ce_dx_deferred_f32: workspace too small or misaligned");
+    p.kps = kps;
+    p.slab = (float*)workspace;
+    p.zslab = p.slab + (int64_t)splits * M * OR_N;
   }
-  const dim3 grid((M + 32 * nw - 1) / (32 * nw), 1);
-  if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, 2>), grid, dim3(512), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, 2>), grid, dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid((M + 32 * nw - 1) / (32 * nw), splits);
+  hipStream_t st = (hipStream_t)stream;
+  if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, 2>), grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, 2>), grid, dim3(256), 0, st, p);
   PDN_LAUNCH_CHECK();
+  if (splits > 1) {
+    const int64_t n4 = (int64_t)M * (OR_N / 4);
+    hipLaunchKernelGGL(outres_ce2_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.slab, p.zslab, splits, M,
+                       rowmax, max_parts, targets, W, ldw, V, gscale, dx, ldc, lse_out);
+    PDN_LAUNCH_CHECK();
+  }
   return PDN_OK;
 }
 

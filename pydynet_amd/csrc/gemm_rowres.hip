@@ -630,8 +630,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
     if (lh == 0 && m0 + li < p.M) p.lse[m0 + li] = m_run + logf(z);
   }
   if constexpr (EPI == 5) {                          // lane l: register row l >> 1 = row (r & 3) + 8 (r >> 2) + 4 h of the block
+    // (chunks split over grid.y when the rows alone do not fill the chip: one vector of maxima per range, part y at
+    //  lse + y * M -- the consumer takes the maximum over the parts)
     const int r = li >> 1, row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (!(li & 1) && row < p.M) p.lse[row] = m_run;
+    if (!(li & 1) && row < p.M) p.lse[(int64_t)blockIdx.y * p.M + row] = m_run;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the redundant last fetch must not outlive the workgroup's LDS
 }
@@ -655,7 +657,8 @@ struct RowResEpi {
   int F;                    // 1, 2
   const float* rope; int L, hd, rope_cols;   // 3
   unsigned g_off = 0, u_off = 0;              // 1
-  float* lse = nullptr;                       // 4
+  float* lse = nullptr;                       // 4, 5
+  int parts = 0;                              // 5, plan only (lse == nullptr): the number of chunk ranges = vectors of maxima
 };
 
 static int rowres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M,
@@ -704,8 +707,9 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   while (row_blocks * nsplit < target && nsplit < p.chunks) ++nsplit;
   p.chunks_per_wg = (p.chunks + nsplit - 1) / nsplit;
   if (kind == 1) p.chunks_per_wg += p.chunks_per_wg & 1;       // gate / up tiles meet inside a PAIR of chunks
-  if (kind == 4 || kind == 5) p.chunks_per_wg = p.chunks;      // a row's statistics are one workgroup's
+  if (kind == 4) p.chunks_per_wg = p.chunks;                   // a row's statistics are one workgroup's
   nsplit = (p.chunks + p.chunks_per_wg - 1) / p.chunks_per_wg;
+  if (kind == 5 && !epi->lse) { const_cast<RowResEpi*>(epi)->parts = nsplit; return PDN_OK; }
   const dim3 grid(row_blocks, nsplit);
 #define RR_LAUNCH(BT_, NW_, AB_) if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 1, 0>), grid, dim3(NW_ * 64), 0, st, p); else hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 0, AB_>), grid, dim3(NW_ * 64), 0, st, p)
   if (kind == 1) {
@@ -815,13 +819,25 @@ extern "C" int pdn_linear_lse_fwd_f32(const float* x, const float* w, const floa
   return rc;
 }
 
-// The same product leaving rowmax[m] = max_v logits[m][v] only (EPI 5): the first half of a cross entropy whose sum of
-// exponentials comes out of the input-gradient product (pdn_linear_ce_dx_deferred_f32).  Shapes as above.
+// The same product leaving the row maxima of the logits only (EPI 5): the first half of a cross entropy whose sum of
+// exponentials comes out of the input-gradient product (pdn_linear_ce_dx_deferred_f32).  With few rows the column chunks
+// are split into `pdn_linear_rowmax_parts` ranges over the grid: `rowmax` holds that many vectors of M maxima (part p at
+// rowmax + p * M), the maximum of a row is the maximum over the parts.
+extern "C" int pdn_linear_rowmax_supported(int64_t M, int V, int K) {
+  return (K == 288 && V % 32 == 0 && V >= RR_NC && M >= 1 && M < (1ll << 31)) ? 1 : 0;
+}
+extern "C" int pdn_linear_rowmax_parts(int64_t M, int V, int K) {
+  if (!pdn_linear_rowmax_supported(M, V, K)) return 0;
+  RowResEpi e{5, nullptr, 0, nullptr, 0, nullptr, 1, 1, 0};
+  alignas(16) static float dummy[4];                 // (plan only: nothing is launched, the operands are never touched)
+  if (rowres_launch(dummy, dummy, dummy, nullptr, nullptr, (int)M, V, K, K, V, V, 0, 1, 0, nullptr, &e) != PDN_OK) return 0;
+  return e.parts;
+}
 extern "C" int pdn_linear_rowmax_fwd_f32(const float* x, const float* w, const float* bias, float* logits, float* rowmax,
                                          int M, int V, int K, int64_t ldx, int64_t ldw, int64_t ldl, void* stream) {
   if (M == 0 || V == 0) return PDN_OK;
   PDN_CHECK_ARG(x && w && logits && rowmax, "pdn_linear_rowmax_fwd_f32: null operand");
-  if (!pdn_linear_lse_supported(M, V, K) || (ldl & 3) || ((uintptr_t)logits & 15) || ((uintptr_t)bias & 15)) {
+  if (!pdn_linear_rowmax_supported(M, V, K) || (ldl & 3) || ((uintptr_t)logits & 15) || ((uintptr_t)bias & 15)) {
     pdn_set_error("pdn_linear_rowmax_fwd_f32: unsupported shape M=%d V=%d K=%d", M, V, K);
     return PDN_EUNSUPPORTED;
   }

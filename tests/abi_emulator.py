@@ -235,42 +235,66 @@ class EmulatedLib:
         flat(lse, M)[...] = (m + np.log(np.exp(z - m).sum(-1, keepdims=True)))[:, 0]
         return 0
 
+    def pdn_linear_rowmax_supported(self, M, V, K):
+        return int(K == 288 and V % 32 == 0 and V >= 96 and M >= 1)
+
+    def pdn_linear_rowmax_parts(self, M, V, K):
+        """As csrc/gemm_rowres.hip: the chunks of 96 columns are split over the grid until the chip is full."""
+        if not self.pdn_linear_rowmax_supported(M, V, K):
+            return 0
+        chunks, row_blocks, nsplit = (V + 95) // 96, (M + 255) // 256, 1
+        while row_blocks * nsplit < 256 and nsplit < chunks:
+            nsplit += 1
+        cpw = (chunks + nsplit - 1) // nsplit
+        return (chunks + cpw - 1) // cpw
+
     def pdn_linear_rowmax_fwd_f32(self, x, w, bias, logits, rowmax, M, V, K, ldx, ldw, ldl, stream):
-        if not self.pdn_linear_lse_supported(M, V, K) or ldl % 4:
+        if not self.pdn_linear_rowmax_supported(M, V, K) or ldl % 4:
             return -2
         z = np.matmul(view(x, (M, K), (ldx, 1), np.float32), view(w, (K, V), (ldw, 1), np.float32))
         if bias:
             z = z + flat(bias, V)
         view(logits, (M, V), (ldl, 1), np.float32)[...] = z
-        flat(rowmax, M)[...] = z.max(-1)
+        parts = self.pdn_linear_rowmax_parts(M, V, K)
+        chunks = (V + 95) // 96
+        cpw = (chunks + parts - 1) // parts
+        out = flat(rowmax, parts * M).reshape(parts, M)
+        for q in range(parts):
+            out[q] = z[:, q * cpw * 96:min(V, (q + 1) * cpw * 96)].max(-1)
         return 0
 
     @staticmethod
-    def _outres_unsplit(M, K):
-        """pdn_gemm_outres_plan(M, K) == 1 (csrc/gemm_outres.hip): the rows alone fill the chip."""
+    def _outres_splits(M, K):
+        """pdn_gemm_outres_plan(M, K) (csrc/gemm_outres.hip): ranges of the contraction over the grid (1 = none)."""
         npieces, wg8, wg4 = K // 32, (M + 255) // 256, (M + 127) // 128
         if wg8 >= 224:
-            return True
+            return 1
         s8 = min((256 + wg8 - 1) // wg8, npieces // 24)
         if s8 >= 2 and wg8 * s8 >= 224:
             kps = (npieces + s8 - 1) // s8
-            return (npieces + kps - 1) // kps == 1
+            return (npieces + kps - 1) // kps
         if wg4 >= 224:
-            return True
+            return 1
         splits = min((448 + wg4 - 1) // wg4, npieces // 24)
         if splits < 2:
-            return True
+            return 1
         kps = (npieces + splits - 1) // splits
-        return (npieces + kps - 1) // kps == 1
+        return (npieces + kps - 1) // kps
 
     def pdn_linear_ce_dx_deferred_supported(self, rows, V, fin):
-        return int(fin == 288 and V % 32 == 0 and V >= 32 and rows >= 1 and self._outres_unsplit(rows, V))
+        return int(fin == 288 and V % 32 == 0 and V >= 32 and rows >= 1)
 
-    def pdn_linear_ce_dx_deferred_f32(self, logits, rowmax, targets, gscale, W, dx, lse, rows, V, fin, stream):
+    def pdn_linear_ce_dx_deferred_workspace_bytes(self, rows, V, fin):
+        s_ = self._outres_splits(rows, V)
+        return s_ * rows * 289 * 4 if s_ > 1 else 0
+
+    def pdn_linear_ce_dx_deferred_f32(self, logits, rowmax, parts, targets, gscale, W, dx, lse, rows, V, fin, ws, wsb, stream):
         if not self.pdn_linear_ce_dx_deferred_supported(rows, V, fin):
             return -2
+        if wsb < self.pdn_linear_ce_dx_deferred_workspace_bytes(rows, V, fin):
+            return -1
         a = flat(logits, rows * V).reshape(rows, V)
-        m = flat(rowmax, rows)
+        m = flat(rowmax, parts * rows).reshape(parts, rows).max(0)
         t = np.clip(flat(targets, rows, np.int64), 0, V - 1)
         e = np.exp(a - m[:, None])
         z = e.sum(-1)

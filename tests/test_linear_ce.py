@@ -103,6 +103,8 @@ def check_linear_ce_statistics_split_over_both_products(dev):
     (pdn_linear_rowmax_fwd_f32 + pdn_linear_ce_dx_deferred_f32); the upstream scalar is applied in backward."""
     assert _spied(dev, "deferred", {}, 49152, 160, "mean", 0.5, 6) == [True]
     assert _spied(dev, "deferred", {}, 57344 + 32, 96, "sum", 1.0, 7) == [True]      # 8-wave workgroups, a ragged last one
+    # few rows: the projection splits its chunks, the input-gradient product its contraction, over the grid
+    assert _spied(dev, "deferred", {}, 4096, 1536, "mean", 1.0, 8) == [True]
 
 
 def check_linear_ce_sum_scaled_upstream(dev):
@@ -145,3 +147,6 @@ def test_linear_ce_few_rows_input_gradient_split_over_the_vocabulary_gpu(hip):
     # (real kernels only: the emulated ABI has no K split to exercise, and the float64 statement is slow on CPU)
     Graph.clear()
     check_linear_ce_few_rows_input_gradient_split_over_the_vocabulary("hip:0")
+    # the same with the statistics taken from the two products (vocabulary ranges: 2 in the projection, 4 in the gradient)
+    assert _spied("hip:0", "deferred", {}, 16384, 3072, "mean", 0.25, 4) == [True]
+    assert _spied("hip:0", "deferred", {"deferred_norm": False}, 16384, 3072, "mean", 1.0, 3) == [False]
