@@ -36,4 +36,5 @@ bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 2
 # phase timestamps from inside the decode kernels / the attention forward (traced builds made by the same scripts here)
 bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
 python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
+python tools/lmhead_probe.py > $O/lmhead_probe.txt 2>&1
 ls -la $O
