@@ -699,11 +699,8 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   // 74 / 83 / 85 % on the lm_head forward against 70 / 77 / 79 % for two 4-wave workgroups per CU, 1-4 points
   // on the layer projections: the threshold of round 2, 49152 rows, only looked at the row blocks)
   const int rb8 = (M + 255) / 256;
-  static const int epi_nw = getenv("PDN_ROWRES_EPI_NW") ? atoi(getenv("PDN_ROWRES_EPI_NW")) : 8;
-  static const int epi_stage = getenv("PDN_ROWRES_EPI_STAGE") ? atoi(getenv("PDN_ROWRES_EPI_STAGE")) : 1;
-  const bool epi4 = (kind == 2 || kind == 3) && epi_nw == 4;    // experiment: two 4-wave workgroups per CU (their store phases alternate)
-  const int nw = epi4 ? 4 : kind ? 8 : nw_env ? nw_env : (rb8 >= 192 || (int64_t)rb8 * p.chunks >= 256) ? 8 : 4;
-  const int stage = epi4 ? epi_stage : kind ? 1 : stage_env >= 0 ? stage_env : (nw == 8 ? 1 : 0);
+  const int nw = kind ? 8 : nw_env ? nw_env : (rb8 >= 192 || (int64_t)rb8 * p.chunks >= 256) ? 8 : 4;
+  const int stage = kind ? 1 : stage_env >= 0 ? stage_env : (nw == 8 ? 1 : 0);
   const int row_blocks = (M + 32 * nw - 1) / (32 * nw), target = nw == 4 ? 512 : 256;
   // fill every CU (two 4-wave or one 8-wave workgroup each): split the chunks over grid.y
   int nsplit = 1;
@@ -717,12 +714,6 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
 #define RR_LAUNCH(BT_, NW_, AB_) if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 1, 0>), grid, dim3(NW_ * 64), 0, st, p); else hipLaunchKernelGGL((gemm_rowres_kernel<36, BT_, NW_, 0, AB_>), grid, dim3(NW_ * 64), 0, st, p)
   if (kind == 1) {
     hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 8, 1, 0, 1>), grid, dim3(512), 0, st, p);
-  } else if (kind == 2 && epi4) {
-    if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, true, 4, 1, 0, 2>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_rowres_kernel<36, true, 4, 0, 0, 2>), grid, dim3(256), 0, st, p);
-  } else if (kind == 3 && epi4) {
-    if (stage) hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 4, 1, 0, 3>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_rowres_kernel<36, false, 4, 0, 0, 3>), grid, dim3(256), 0, st, p);
   } else if (kind == 2) {
     hipLaunchKernelGGL((gemm_rowres_kernel<36, true, 8, 1, 0, 2>), grid, dim3(512), 0, st, p);
   } else if (kind == 3) {
