@@ -298,7 +298,7 @@ def pmc_traffic():
     return out
 
 
-def hbm_kernels(lib, hp, B, traffic):
+def hbm_kernels(lib, hp, B, traffic, opt=None, nparams=0):
     """The HBM-bound kernels of the step, timed live with HIP events on the launch stream at the step's own
     shapes: achieved = ALGORITHMIC bytes per launch / average launch duration, against the 8 TB/s HBM3E peak."""
     import ctypes
@@ -334,6 +334,19 @@ def hbm_kernels(lib, hp, B, traffic):
                      "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                      "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
                      "avg_launch_us": us, "traffic": traffic.get(name)}
+    if opt is not None and nparams:
+        # the optimizer: one multi-tensor launch reading p, g, m, v and writing p, m, v (28 B per parameter).  Timed on the
+        # job's own optimizer AFTER the timed region (it moves the weights five more steps along the last gradient).
+        opt.step(); hp.synchronize()
+        with hp.Timer() as t:
+            for _ in range(5):
+                opt.step()
+        us = t.ms / 5 * 1e3
+        nbytes = 28.0 * nparams
+        out["adam_multi_kernel"] = {"bound": "hbm", "what": "Adam over every parameter in one launch (optim/optimizer.py:160-196)",
+                                    "in_step": True, "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                    "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
+                                    "avg_launch_us": us, "traffic": traffic.get("adam_multi_kernel")}
     return out
 
 
@@ -505,7 +518,8 @@ def main():
                              "time_share_of_step": (sum(ms2) + fms.value) * 1e-3 / dt},
                 "traffic_source": traffic.get("_source"), "traffic_source_sha12": traffic.get("_sha12"),
                 "traffic_stale": traffic.get("_stale")}
-        roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic) if rank == 0 else None
+        roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic, opt if dp is None else None,
+                                                sum(int(p.size) for p in model.parameters())) if rank == 0 else None
     per_rank = [B * args.steps / dt]
     if world > 1:
         mine = np.zeros((world,), np.float32)
