@@ -1265,7 +1265,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     }
   }
   // A batch whose members share A and write side by side into one packed buffer (x against Wq | Wk | Wv,
-  // x against Wg | Wu: fused.py) is ONE such product with B in equally spaced column blocks.
+  // x against Wg | Wu: core/fused/) is ONE such product with B in equally spaced column blocks.
   {
     const bool one_dim = nb1 == 1 || nb2 == 1;
     const int64_t a_bs = nb1 == 1 ? a_bs2 : a_bs1, b_bs = nb1 == 1 ? b_bs2 : b_bs1, c_bs = nb1 == 1 ? c_bs2 : c_bs1;

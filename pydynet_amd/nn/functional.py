@@ -1,6 +1,6 @@
 """Functional layer API (surface of pydynet/nn/functional.py).  Where the reference composes
 several generic nodes, the same mathematical function is issued as ONE fused node
-(pydynet_amd/core/fused.py) -- on a HIP device that is one hand-written kernel per direction."""
+(pydynet_amd/core/fused/) -- on a HIP device that is one hand-written kernel per direction."""
 import numpy as np
 
 from ..core import tensor, function, fused

@@ -1,4 +1,4 @@
-"""`linear -> cross entropy` as one tape node (pydynet_amd/core/fused.py: linear_cross_entropy; C ABI
+"""`linear -> cross entropy` as one tape node (pydynet_amd/core/fused/dense.py: linear_cross_entropy; C ABI
 pdn_linear_ce_backward_f32) against (a) the same module with the node disabled -- separate Linear and
 cross-entropy nodes, the (rows, V) gradient of the logits in memory -- and (b) a float64 NumPy statement of
 llm/llama/model.py:179 + nn/functional.py:364-381.  Tolerance: 1e-4 relative (north_star), gradients against
