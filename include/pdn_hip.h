@@ -327,6 +327,19 @@ int pdn_attention_bwd_rotated_f32(const float* q, const float* k, const float* v
                           int64_t o_row_stride, int64_t o_batch_stride,
                           int causal, const float* rope_cos, const float* rope_sin, void* workspace,
                           int64_t workspace_bytes, void* stream);
+/* the fused kernels with an additive KEY bias (B x L; `kb_batch_stride` floats between batches, 0 = one vector for all
+ * batches): the (B, 1, 1, L) padding mask of examples/pydynet/transformer.py:92-96 (-inf = masked key), and the way keys
+ * beyond a length that is not a multiple of 32 are switched off after zero-padding q / k / v.  One extra rank-1 MFMA step
+ * per score tile ([k | b sqrt(hd)] . [q | 1]); no RoPE inside; non-causal or causal. */
+int pdn_attention_fwd_bias_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L,
+                               int head_dim, int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                               int64_t o_batch_stride, int causal, const float* key_bias, int64_t kb_batch_stride,
+                               void* stream);
+int pdn_attention_bwd_bias_f32(const float* q, const float* k, const float* v, const float* o, const float* d_o,
+                               const float* lse, float* dq, float* dk, float* dv, int B, int H, int L, int head_dim,
+                               int64_t row_stride, int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride,
+                               int causal, const float* key_bias, int64_t kb_batch_stride, void* workspace,
+                               int64_t workspace_bytes, void* stream);
 int64_t pdn_attention_bwd_workspace_bytes(int B, int H, int L);   /* delta = rowsum(dO * O) */
 /* Decode step (model.py:105-121 in eval mode, L = 1): q, o (B, H, head_dim); the new token attends to
  * positions [0, T) of the KV cache (max_batch, max_len, H, head_dim); no mask. */

@@ -37,19 +37,31 @@ def _attn_mask_args(mask, B, H, Lq, Lk):
     return m._ptr, st[0], st[1], st[2], st[3], m
 
 
-def _attn_kernel(B, H, hd, Lq, Lk, start_pos, has_mask, layouts):
-    """'resident' (K/V of a head held in LDS 256 rows at a time: hd 48 / 64, L <= 1024 -- the benchmark shape is
-    one chunk), 'stream' (general kernels) or None (GEMM + softmax composition)."""
-    if not attention.use_flash or any(l is None for l in layouts):
+def _key_bias_of(mask, B, H, Lq, Lk):
+    """An additive mask that is a function of (batch, key) only -- the (B, 1, 1, Lk) padding mask of
+    examples/pydynet/transformer.py:92-96 -- as a contiguous (b, Lk) float32 device array, b in {1, B}; else None."""
+    shape = (1,) * (4 - mask.ndim) + tuple(mask.shape) if mask.ndim <= 4 else None
+    if shape is None or shape[1] != 1 or shape[2] != 1 or shape[3] != Lk or shape[0] not in (1, B):
         return None
+    m = mask if mask.dtype == np.float32 else mask.astype(np.float32)
+    return _contig(m).reshape(shape[0], Lk)
+
+
+def _attn_kernel(B, H, hd, Lq, Lk, start_pos, mask, layouts):
+    """'resident' (K/V of a head held in LDS 256 rows at a time: hd 48 / 64, L <= 1024 -- the benchmark shape is
+    one chunk; masks that only depend on the key and lengths that are not multiples of 32 ride in as a key bias),
+    'stream' (general kernels) or None (GEMM + softmax composition).  Returns (kind, key bias or None)."""
+    if not attention.use_flash or any(l is None for l in layouts):
+        return None, None
     ql, kl, vl = layouts
-    dense = (H * hd, Lq * H * hd if B > 1 else 0)
-    if (Lq == Lk and start_pos == 0 and not has_mask and attention.use_resident and ql == kl == vl == dense
-            and _L().query("pdn_attention_supported", Lq, hd)):
-        return "resident"
+    if Lq == Lk and start_pos == 0 and attention.use_resident and ql == kl == vl:
+        Lp = -(-Lq // 32) * 32
+        kb = _key_bias_of(mask, B, H, Lq, Lk) if mask is not None else None
+        if (mask is None or kb is not None) and _L().query("pdn_attention_supported", Lp, hd):
+            return "resident", kb
     if _L().query("pdn_attention_stream_supported", hd) and kl == vl:
-        return "stream"
-    return None
+        return "stream", None
+    return None, None
 
 
 class attention(_Operator):
@@ -95,19 +107,43 @@ class attention(_Operator):
         hp, L = _hip(), _L()
         causal = 1 if (self.causal and Lq > 1) else 0
         layouts = (_attn_layout(q.data), _attn_layout(k.data), _attn_layout(v.data))
-        self._kind = _attn_kernel(B, H, hd, Lq, Lk, self.start_pos, self._mask is not None, layouts)
+        mask_dev = hp.asarray(self._mask) if self._mask is not None else None
+        self._kind, kb = _attn_kernel(B, H, hd, Lq, Lk, self.start_pos, mask_dev, layouts)
         if self._kind == "resident":
             # scores stay in registers: one kernel, nothing of size L x L in HBM; lse kept for backward
-            out = hp.empty((B, Lq, H, hd), np.float32)
-            self._lse = hp.empty((B, H, Lq), np.float32)
-            L.call("pdn_attention_fwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, out._ptr, self._lse._ptr,
-                   B, H, Lq, hd, H * hd, Lq * H * hd, H * hd, Lq * H * hd, causal, None, None, hp.stream())
-            return out
+            Lp = -(-Lq // 32) * 32
+            qd, kd, vd = q.data, k.data, v.data
+            rs, bs = layouts[0]
+            if Lp != Lq:
+                # a length that is not a multiple of 32 (CLIP: 50 / 77): zero rows up to the next tile, the keys among
+                # them switched off by the key bias; the padded query rows are dropped again below
+                def padded(a):
+                    z = hp.zeros((B, Lp, H, hd), np.float32)
+                    z[:, :Lq] = a
+                    return z
+                qd, kd, vd = padded(qd), padded(kd), padded(vd)
+                rs, bs = H * hd, Lp * H * hd
+                kbp = np.zeros((kb.shape[0] if kb is not None else 1, Lp), np.float32)
+                kbp[:, Lq:] = -np.inf
+                kbp = hp.from_numpy(kbp)
+                if kb is not None:
+                    kbp[:, :Lq] = kb
+                kb = kbp
+            out = hp.empty((B, Lp, H, hd), np.float32)
+            self._lse = hp.empty((B, H, Lp), np.float32)
+            self._res = (qd, kd, vd, out, kb, rs, bs, Lp)
+            if kb is None:
+                L.call("pdn_attention_fwd_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, self._lse._ptr,
+                       B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd, causal, None, None, hp.stream())
+            else:
+                L.call("pdn_attention_fwd_bias_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, self._lse._ptr,
+                       B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd, causal, kb._ptr, Lp if kb.shape[0] > 1 else 0,
+                       hp.stream())
+            return out if Lp == Lq else out[:, :Lq].copy()
         if self._kind == "stream":
             out = hp.empty((B, Lq, H, hd), np.float32)
             self._lse = hp.empty((B, H, Lq), np.float32)
-            mp, sb, sh, sq, sk, self._mask_dev = _attn_mask_args(
-                hp.asarray(self._mask) if self._mask is not None else None, B, H, Lq, Lk)
+            mp, sb, sh, sq, sk, self._mask_dev = _attn_mask_args(mask_dev, B, H, Lq, Lk)
             # the output is written with the QUERY strides: give the kernel a q-shaped contiguous view
             if layouts[0] != (H * hd, Lq * H * hd if B > 1 else 0):
                 self._q_used = q.data.copy()
@@ -139,12 +175,30 @@ class attention(_Operator):
         causal = 1 if (self.causal and Lq > 1) else 0
         if self.xp is not np and self._kind == "resident":
             hp, L = _hip(), _L()
+            qd, kd, vd, out, kb, rs, bs, Lp = self._res
+            self._res = None
             do = _contig(do)
-            dq, dk, dv = (hp.empty(q.shape, np.float32) for _ in range(3))
-            ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
-            L.call("pdn_attention_bwd_f32", q.data._ptr, k.data._ptr, v.data._ptr, self.data._ptr, do._ptr,
-                   self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, H * hd, Lq * H * hd, H * hd, Lq * H * hd,
-                   causal, None, None, ws, wsb, hp.stream())
+            if Lp != Lq:
+                dop = hp.zeros((B, Lp, H, hd), np.float32)
+                dop[:, :Lq] = do
+                do = dop
+            dq, dk, dv = (hp.empty((B, Lp, H, hd), np.float32) for _ in range(3))
+            if rs != H * hd or (B > 1 and bs != Lp * H * hd):
+                # gradients are written with the operand strides: strided views (a packed q | k | v projection) get
+                # contiguous copies of the operands here
+                qd, kd, vd = qd.copy(), kd.copy(), vd.copy()
+                rs, bs = H * hd, Lp * H * hd
+            ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lp))
+            if kb is None:
+                L.call("pdn_attention_bwd_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, do._ptr,
+                       self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd,
+                       causal, None, None, ws, wsb, hp.stream())
+            else:
+                L.call("pdn_attention_bwd_bias_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, do._ptr,
+                       self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd,
+                       causal, kb._ptr, Lp if kb.shape[0] > 1 else 0, ws, wsb, hp.stream())
+            if Lp != Lq:
+                dq, dk, dv = dq[:, :Lq].copy(), dk[:, :Lq].copy(), dv[:, :Lq].copy()
             return [dq, dk, dv]
         if self.xp is not np and self._kind == "stream":
             hp, L = _hip(), _L()

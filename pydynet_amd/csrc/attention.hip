@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
     float* __restrict__ O, float* __restrict__ LSE, int H, int L, int64_t row_stride,
     int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
-    const float* __restrict__ RC, const float* __restrict__ RS) {
+    const float* __restrict__ RC, const float* __restrict__ RS, const float* __restrict__ KB, int64_t kb_bs) {
   static_assert(HD % 8 == 0 && HD > 32 && HD <= 64, "head dim: two 32-row MFMA tiles");
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;                    // k-groups of 8 along the head dim
@@ -378,6 +378,12 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qf[t].y, s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qf[t].z, s[kt], 0, 0, 0);
           s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s[kt], 0, 0, 0);
+        }
+        // additive KEY bias (padding masks, padded keys of a ragged length): one more rank-1 step of the same product,
+        // [k | b sqrt(hd)] . [q | 1] -- the lower half-wave carries the extra contraction index, the upper one zeros
+        if (KB) {
+          const float kb = lh == 0 ? KB[(int64_t)b * kb_bs + row0 + kt * 32 + li] * sqrt_hd : 0.f;
+          s[kt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kb, lh == 0 ? 1.f : 0.f, s[kt], 0, 0, 0);
         }
       }
     }
@@ -498,11 +504,11 @@ extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
 // q, k, v (and dq, dk, dv): (B, L, H, head_dim) contiguous in head_dim, `row_stride` between consecutive
 // positions, `batch_stride` between batches -- e.g. column blocks of one packed (B*L, 3*H*hd) projection;
 // o (and d_o) have strides of their own.  lse: (B, H, L).  causal: keys > query masked.
-extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o,
-                                     float* lse, int B, int H, int L, int head_dim,
-                                     int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
-                                     int64_t o_batch_stride, int causal,
-                                     const float* rope_cos, const float* rope_sin, void* stream) {
+static int att_fwd_impl(const float* q, const float* k, const float* v, float* o,
+                        float* lse, int B, int H, int L, int head_dim,
+                        int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                        int64_t o_batch_stride, int causal,
+                        const float* rope_cos, const float* rope_sin, const float* key_bias, int64_t kb_bs, void* stream) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
   PDN_CHECK_ARG(q && k && v && o && lse, "pdn_attention_fwd_f32: null operand");
   PDN_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) &&
@@ -517,7 +523,7 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0),
                 "pdn_attention_fwd_f32: 16-byte alignment required");
   // rotation-free operands at the benchmark shape class: the persistent, DMA-staged kernels (csrc/attention_p.hip)
-  if (!rope_cos && pdn_attention_p_supported(L, head_dim))
+  if (!rope_cos && !key_bias && pdn_attention_p_supported(L, head_dim))
     return pdn_attention_p_fwd(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride,
                                causal, stream);
   const size_t shm = (size_t)pdn_attention_lds_bytes(L, head_dim);
@@ -534,12 +540,32 @@ extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float
   const bool multi = L > ATT_CHUNK;
 #define ATT_FWD(HD_, M_)                                                                                              \
   hipLaunchKernelGGL((attention_fwd_kernel<HD_, 0, M_>), grid, dim3(512), shm, (hipStream_t)stream, q, k, v, o, lse, H, L, \
-                     row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos, rope_sin)
+                     row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos, rope_sin, key_bias, kb_bs)
   if (head_dim == 48) { if (multi) ATT_FWD(48, true); else ATT_FWD(48, false); }
   else { if (multi) ATT_FWD(64, true); else ATT_FWD(64, false); }
 #undef ATT_FWD
   PDN_LAUNCH_CHECK();
   return PDN_OK;
+}
+
+extern "C" int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o,
+                                     float* lse, int B, int H, int L, int head_dim,
+                                     int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
+                                     int64_t o_batch_stride, int causal,
+                                     const float* rope_cos, const float* rope_sin, void* stream) {
+  return att_fwd_impl(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride, causal,
+                      rope_cos, rope_sin, nullptr, 0, stream);
+}
+// The same with an additive KEY bias (B x L, `kb_batch_stride` floats between batches, 0 = one vector for all): what the
+// reference adds to the scores as a (B, 1, 1, L) padding mask (examples/pydynet/transformer.py:92-96; -inf = masked),
+// and how keys beyond a length that is not a multiple of 32 are switched off.  No RoPE inside.
+extern "C" int pdn_attention_fwd_bias_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
+                                          int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                                          int64_t o_row_stride, int64_t o_batch_stride, int causal, const float* key_bias,
+                                          int64_t kb_batch_stride, void* stream) {
+  PDN_CHECK_ARG(key_bias, "pdn_attention_fwd_bias_f32: null key bias");
+  return att_fwd_impl(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride, causal,
+                      nullptr, nullptr, key_bias, kb_batch_stride, stream);
 }
 
 // ======================================================================================
@@ -566,7 +592,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
     const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ LSE,
     float* __restrict__ dQ, float* __restrict__ Delta, int H, int L, int64_t row_stride,
     int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
-    const float* __restrict__ RC, const float* __restrict__ RS, int prerot) {
+    const float* __restrict__ RC, const float* __restrict__ RS, int prerot, const float* __restrict__ KB, int64_t kb_bs) {
   constexpr int LD = ATT_LD(HD);
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -664,6 +690,10 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dq_kernel(
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qf[t].w, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf.w, gf[t].w, dp, 0, 0, 0);
       }
+      if (KB) {                                     // additive key bias: the rank-1 step of the forward kernel
+        const float kb = lh == 0 ? KB[(int64_t)b * kb_bs + row0 + kt * 32 + li] * sqrt_hd : 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(kb, lh == 0 ? 1.f : 0.f, s, 0, 0, 0);
+      }
       // dS^T[key][q] = P^T o (dP^T - delta_q) / sqrt(hd)   (lane = q);  P = exp2(s * c1 - lse * log2(e)), the causal
       // compare only on the diagonal tile
       if (diag && kt == qtl) {
@@ -699,7 +729,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
     const float* __restrict__ dO, const float* __restrict__ LSE, const float* __restrict__ Delta,
     float* __restrict__ dK, float* __restrict__ dV, int H, int L, int64_t row_stride,
     int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, float sqrt_hd, int causal,
-    const float* __restrict__ RC, const float* __restrict__ RS, int prerot) {
+    const float* __restrict__ RC, const float* __restrict__ RS, int prerot, const float* __restrict__ KB, int64_t kb_bs) {
   constexpr int NT8 = HD / 8;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int LDP = ATT_LDP;
@@ -732,6 +762,8 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
   const float inv_sqrt = 1.f / sqrt_hd;
   const float c1 = inv_sqrt * 1.4426950408889634f;
   const int kpos = kt * 32 + li;
+  // additive key bias of this wave's key tile (lane = key): the B operand of one extra rank-1 step per score tile
+  const float kbias = (KB && lh == 0) ? KB[(int64_t)b * kb_bs + kpos_l] * sqrt_hd : 0.f;
   float4 kf[NT8], vf[NT8];                          // (issued before the staging, consumed after the barrier: see dQ)
   {
     const float* krow = Kb + (int64_t)kpos_l * row_stride + 4 * lh;
@@ -798,6 +830,7 @@ __global__ __launch_bounds__(512, 1) void attention_bwd_dkv_kernel(
         s = __builtin_amdgcn_mfma_f32_32x32x2f32(q4.w, kf[t].w, s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x2f32(g4.w, vf[t].w, dp, 0, 0, 0);
       }
+      if (KB) s = __builtin_amdgcn_mfma_f32_32x32x2f32(lh == 0 ? 1.f : 0.f, kbias, s, 0, 0, 0);
       // lane = key, registers = queries;  P = exp2(s * c1 - lse * log2(e)) (lse_s holds lse * log2(e)), the causal
       // compare only on the diagonal tile
       if (diag && qt == ktl) {
@@ -856,7 +889,8 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
                         int64_t row_stride, int64_t batch_stride, int64_t o_row_stride,
                         int64_t o_batch_stride, int causal,
                         const float* rope_cos, const float* rope_sin, void* workspace,
-                        int64_t workspace_bytes, void* stream, int prerot) {
+                        int64_t workspace_bytes, void* stream, int prerot, const float* key_bias = nullptr,
+                        int64_t kb_bs = 0) {
   if (B == 0 || H == 0 || L == 0) return PDN_OK;
   PDN_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr) &&
                     ((((uintptr_t)rope_cos | (uintptr_t)rope_sin) & 7) == 0),
@@ -879,7 +913,7 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
   // operands that need no rotation on the way in (never rotated, or rotated by the projection's epilogue) at the
   // benchmark shape class: the persistent, DMA-staged kernels (csrc/attention_p.hip); dq / dk are rotated back there
   // when the tables are given
-  if ((prerot || !rope_cos) && pdn_attention_p_supported(L, head_dim))
+  if ((prerot || !rope_cos) && !key_bias && pdn_attention_p_supported(L, head_dim))
     return pdn_attention_p_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
                                o_batch_stride, causal, rope_cos, rope_sin, delta, stream);
   static bool attr_set = false;
@@ -898,11 +932,11 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
 #define ATT_BWD(HD_, M_)                                                                                               \
   hipLaunchKernelGGL((attention_bwd_dq_kernel<HD_, M_>), grid, dim3(512), (size_t)att_dq_lds_bytes(L, head_dim), st, q, k, v, \
                      o, d_o, lse, dq, delta, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal,    \
-                     rope_cos, rope_sin, prerot);                                                                         \
+                     rope_cos, rope_sin, prerot, key_bias, kb_bs);                                                        \
   PDN_LAUNCH_CHECK();                                                                                                     \
   hipLaunchKernelGGL((attention_bwd_dkv_kernel<HD_, M_>), grid, dim3(512), (size_t)pdn_attention_bwd_lds_bytes(L, head_dim),  \
                      st, q, k, v, d_o, lse, delta, dk, dv, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride,  \
-                     sq, causal, rope_cos, rope_sin, prerot);                                                             \
+                     sq, causal, rope_cos, rope_sin, prerot, key_bias, kb_bs);                                            \
   PDN_LAUNCH_CHECK();
   const bool multi = L > ATT_CHUNK;
   if (head_dim == 48) { if (multi) { ATT_BWD(48, true) } else { ATT_BWD(48, false) } }
@@ -920,6 +954,16 @@ extern "C" int pdn_attention_bwd_f32(const float* q, const float* k, const float
                                      int64_t workspace_bytes, void* stream) {
   return att_bwd_impl(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
                       o_batch_stride, causal, rope_cos, rope_sin, workspace, workspace_bytes, stream, 0);
+}
+extern "C" int pdn_attention_bwd_bias_f32(const float* q, const float* k, const float* v, const float* o,
+                                          const float* d_o, const float* lse, float* dq, float* dk, float* dv, int B,
+                                          int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
+                                          int64_t o_row_stride, int64_t o_batch_stride, int causal, const float* key_bias,
+                                          int64_t kb_batch_stride, void* workspace, int64_t workspace_bytes, void* stream) {
+  PDN_CHECK_ARG(key_bias, "pdn_attention_bwd_bias_f32: null key bias");
+  return att_bwd_impl(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
+                      o_batch_stride, causal, nullptr, nullptr, workspace, workspace_bytes, stream, 0, key_bias,
+                      kb_batch_stride);
 }
 // q and k are given ALREADY ROTATED (the q | k | v projection applied RoPE in its epilogue, pdn_qkv_rope_fwd_f32);
 // dq and dk are still rotated back to the un-rotated projections' gradients as they are stored.

@@ -20,7 +20,9 @@ from ..core import Tensor, fused, function as fn
 
 def build_attention_mask(context_length: int):
     """Additive causal mask tensor (llm/clip/model.py:8-13): -inf above the diagonal."""
-    return Tensor(np.triu(np.full((context_length, context_length), -np.inf, dtype=np.float32), 1), dtype=np.float32)
+    mask = Tensor(np.triu(np.full((context_length, context_length), -np.inf, dtype=np.float32), 1), dtype=np.float32)
+    mask.causal_pattern = True          # (the attention node then takes its causal flag instead of a general L x L mask)
+    return mask
 
 
 class MultiHeadAttention(nn.Module):
@@ -34,9 +36,12 @@ class MultiHeadAttention(nn.Module):
         B, L, _ = x.shape
         xq, xk, xv = fn.split(self.QKV(x), 3, -1)                  # views into the packed projection
         shape = (B, L, self.n_heads, self.head_dim)
-        if mask is not None and mask.device != x.device:
+        causal = bool(getattr(mask, "causal_pattern", False)) and mask.shape == (L, L)
+        if causal:
+            mask = None                 # exactly the -inf upper triangle: the fused kernels' own causal flag
+        elif mask is not None and mask.device != x.device:
             mask = Tensor(mask.numpy(), dtype=np.float32, device=x.device)
-        ctx = fused.attention(xq.reshape(*shape), xk.reshape(*shape), xv.reshape(*shape), causal=False, mask=mask)
+        ctx = fused.attention(xq.reshape(*shape), xk.reshape(*shape), xv.reshape(*shape), causal=causal, mask=mask)
         return self.O(ctx.reshape(B, L, -1))
 
 

@@ -744,6 +744,43 @@ class EmulatedLib:
         DK[...] = self._rot(np.matmul(ds.swapaxes(-1, -2), Q), rc, rsn, L, hd, -1.0)
         return 0
 
+    def _key_bias(self, kb, kbs, B, L):
+        return view(kb, (B, 1, 1, L), (kbs, 0, 0, 1), np.float32)
+
+    def pdn_attention_fwd_bias_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, ors, obs, causal, kb, kbs, stream):
+        if not self.pdn_attention_supported(L, hd):
+            return -2
+        Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
+        O, = self._att_views([o], B, H, L, hd, ors, obs)
+        s = np.matmul(Q, K.swapaxes(-1, -2)) / np.float32(math.sqrt(hd)) + self._key_bias(kb, kbs, B, L)
+        if causal:
+            s = s + np.triu(np.full((L, L), -np.inf, np.float32), 1)
+        m = s.max(-1, keepdims=True)
+        e = np.exp(s - m)
+        z = e.sum(-1, keepdims=True)
+        O[...] = np.matmul(e / z, V)
+        flat(lse, B * H * L).reshape(B, H, L)[...] = (m + np.log(z))[..., 0]
+        return 0
+
+    def pdn_attention_bwd_bias_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, kb, kbs,
+                                   ws, wsb, stream):
+        if not self.pdn_attention_supported(L, hd):
+            return -2
+        Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
+        O, DO = [np.array(a) for a in self._att_views([o, do], B, H, L, hd, ors, obs)]
+        DQ, DK, DV = self._att_views([dq, dk, dv], B, H, L, hd, rs, bs)
+        s = np.matmul(Q, K.swapaxes(-1, -2)) / np.float32(math.sqrt(hd)) + self._key_bias(kb, kbs, B, L)
+        p = np.exp(s - flat(lse, B * H * L).reshape(B, H, L, 1))
+        if causal:
+            p = p * np.tril(np.ones((L, L), np.float32))
+        delta = (DO * O).sum(-1, keepdims=True)
+        dp = np.matmul(DO, V.swapaxes(-1, -2))
+        ds = p * (dp - delta) / np.float32(math.sqrt(hd))
+        DV[...] = np.matmul(p.swapaxes(-1, -2), DO)
+        DQ[...] = np.matmul(ds, K)
+        DK[...] = np.matmul(ds.swapaxes(-1, -2), Q)
+        return 0
+
     def pdn_attention_bwd_rotated_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn,
                                       ws, wsb, stream):
         """q, k already rotated: nothing rotated on the way in, dq / dk rotated back on the way out."""

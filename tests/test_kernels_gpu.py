@@ -488,6 +488,88 @@ def test_fused_attention_forward_backward(hip, B, H, L, causal, hd):
         assert np.allclose(o.get()[:, 0], v[:, 0], rtol=1e-6)   # query attends only to key 0
 
 
+@pytest.mark.parametrize("B,H,L,causal,hd,shared", [(3, 4, 64, 0, 48, False), (2, 2, 256, 1, 48, False), (2, 3, 96, 0, 64, True),
+                                                    (1, 2, 512, 0, 48, False),     # two key chunks, online rescale
+                                                    (2, 2, 640, 1, 64, False), (70, 6, 64, 0, 48, False)])
+def test_fused_attention_key_bias(hip, B, H, L, causal, hd, shared):
+    """The resident kernels with an additive key bias -- the (B, 1, 1, L) padding mask of examples/pydynet/transformer.py:92-96
+    (-inf on masked keys) plus finite entries -- vs a float64 statement of `softmax(q k^T / sqrt(hd) + mask) v`."""
+    from pydynet_amd import _lib
+    Lb = _lib.lib()
+    rng = np.random.default_rng(300 + L + hd)
+    q, k, v, do = (rng.standard_normal((B, L, H, hd), dtype=np.float32) for _ in range(4))
+    nb = 1 if shared else B
+    kb = (0.5 * rng.standard_normal((nb, L))).astype(np.float32)
+    for b in range(nb):                            # ragged valid lengths: the tail of every row is masked out
+        kb[b, L - 5 - (9 * b) % (L // 2):] = -np.inf
+        kb[b, 3 + b % 8] = -np.inf                     # and one key in the middle (never key 0: causal rows stay non-empty)
+    Q, K, V, DO, KB = map(hip.from_numpy, (q, k, v, do, kb))
+    o, dq, dk, dv = (hip.empty((B, L, H, hd)) for _ in range(4))
+    lse = hip.empty((B, H, L))
+    kbs = 0 if shared else L
+    Lb.call("pdn_attention_fwd_bias_f32", Q._ptr, K._ptr, V._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd,
+            H * hd, L * H * hd, causal, KB._ptr, kbs, hip.stream())
+    q64, k64, v64, g64 = (a.astype(np.float64).transpose(0, 2, 1, 3) for a in (q, k, v, do))
+    s = q64 @ k64.swapaxes(-1, -2) / math.sqrt(hd) + np.broadcast_to(kb.astype(np.float64)[:, None, None, :], (nb, 1, 1, L))
+    if causal:
+        s = s + np.triu(np.full((L, L), -np.inf), 1)
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m)
+    p = e / e.sum(-1, keepdims=True)
+    assert rel_err(o.get(), (p @ v64).transpose(0, 2, 1, 3)) < 2e-5
+    assert np.allclose(lse.get(), (m + np.log(e.sum(-1, keepdims=True)))[..., 0], rtol=1e-5, atol=1e-5)
+    ws, wsb = hip.workspace(Lb.query("pdn_attention_bwd_workspace_bytes", B, H, L))
+    Lb.call("pdn_attention_bwd_bias_f32", Q._ptr, K._ptr, V._ptr, o._ptr, DO._ptr, lse._ptr, dq._ptr, dk._ptr, dv._ptr,
+            B, H, L, hd, H * hd, L * H * hd, H * hd, L * H * hd, causal, KB._ptr, kbs, ws, wsb, hip.stream())
+    dp = g64 @ v64.swapaxes(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / math.sqrt(hd)
+    assert rel_err(dv.get(), (p.swapaxes(-1, -2) @ g64).transpose(0, 2, 1, 3)) < 5e-5
+    assert rel_err(dq.get(), (ds @ k64).transpose(0, 2, 1, 3)) < 5e-5
+    assert rel_err(dk.get(), (ds.swapaxes(-1, -2) @ q64).transpose(0, 2, 1, 3)) < 5e-5
+    masked = ~np.isfinite(kb)
+    got_dk, got_dv = dk.get(), dv.get()
+    for b in range(B):                             # a masked key receives no gradient at all
+        assert not got_dk[b][masked[b if not shared else 0]].any() and not got_dv[b][masked[b if not shared else 0]].any()
+
+
+@pytest.mark.parametrize("B,H,L,causal,hd,with_mask", [(2, 2, 50, 0, 64, False),      # CLIP vision: 49 patches + class token
+                                                       (2, 2, 77, 1, 64, False),      # CLIP text, its causal mask as the flag
+                                                       (3, 4, 40, 0, 48, True), (2, 3, 128, 0, 64, True)])
+def test_attention_node_masks_and_ragged_lengths_take_the_resident_kernels(hip, B, H, L, causal, hd, with_mask):
+    """`fused.attention` with a (B, 1, 1, L) padding mask and / or a length that is not a multiple of 32: the node must
+    run the resident kernels (zero-padded rows, padded keys switched off by the key bias) and agree with float64."""
+    import pydynet_amd as pdn
+    from pydynet_amd.core import fused
+    from pydynet_amd.core.tensor import Graph
+    Graph.clear()
+    rng = np.random.default_rng(17 * L + hd)
+    q, k, v, w = (rng.standard_normal((B, L, H, hd), dtype=np.float32) for _ in range(4))
+    mask = None
+    if with_mask:
+        mask = np.zeros((B, 1, 1, L), np.float32)
+        for b in range(B):
+            mask[b, 0, 0, L - 3 - 4 * b:] = -np.inf
+    tq, tk, tv = (pdn.Tensor(a, dtype=np.float32, device="hip:0", requires_grad=True) for a in (q, k, v))
+    node = fused.attention(tq, tk, tv, causal=bool(causal),
+                           mask=pdn.Tensor(mask, dtype=np.float32, device="hip:0") if with_mask else None)
+    assert node._kind == "resident", node._kind
+    (node * pdn.Tensor(w, dtype=np.float32, device="hip:0")).sum().backward()
+    q64, k64, v64, g64 = (a.astype(np.float64).transpose(0, 2, 1, 3) for a in (q, k, v, w))
+    s = q64 @ k64.swapaxes(-1, -2) / math.sqrt(hd)
+    if with_mask:
+        s = s + mask.astype(np.float64)
+    if causal:
+        s = s + np.triu(np.full((L, L), -np.inf), 1)
+    e = np.exp(s - s.max(-1, keepdims=True))
+    p = e / e.sum(-1, keepdims=True)
+    assert rel_err(node.numpy(), (p @ v64).transpose(0, 2, 1, 3)) < 2e-5
+    dp = g64 @ v64.swapaxes(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / math.sqrt(hd)
+    assert rel_err(tv.grad.get(), (p.swapaxes(-1, -2) @ g64).transpose(0, 2, 1, 3)) < 5e-5
+    assert rel_err(tq.grad.get(), (ds @ k64).transpose(0, 2, 1, 3)) < 5e-5
+    assert rel_err(tk.grad.get(), (ds.swapaxes(-1, -2) @ q64).transpose(0, 2, 1, 3)) < 5e-5
+
+
 def test_colnorm_forward_backward_large_offset(hip):
     """Reference-LayerNorm kernels on the transformer example's shape, with a large common offset
     (a one-pass E[x^2]-E[x]^2 variance would lose every digit here)."""
