@@ -49,15 +49,16 @@ def _key_bias_of(mask, B, H, Lq, Lk):
 
 def _attn_kernel(B, H, hd, Lq, Lk, start_pos, mask, layouts):
     """'resident' (K/V of a head held in LDS 256 rows at a time: hd 48 / 64, L <= 1024 -- the benchmark shape is
-    one chunk; masks that only depend on the key and lengths that are not multiples of 32 ride in as a key bias),
-    'stream' (general kernels) or None (GEMM + softmax composition).  Returns (kind, key bias or None)."""
+    one chunk; masks that only depend on the key ride in as a key bias), 'stream' (general kernels: other masks, other
+    head dims, lengths that are not multiples of 32 -- zero-padding those up to a tile for the resident kernels was
+    measured at CLIP's 50 / 77 positions: 1045 / 976 us against 668 / 645 us, the copies cost more than the kernels
+    gain) or None (GEMM + softmax composition).  Returns (kind, key bias or None)."""
     if not attention.use_flash or any(l is None for l in layouts):
         return None, None
     ql, kl, vl = layouts
     if Lq == Lk and start_pos == 0 and attention.use_resident and ql == kl == vl:
-        Lp = -(-Lq // 32) * 32
         kb = _key_bias_of(mask, B, H, Lq, Lk) if mask is not None else None
-        if (mask is None or kb is not None) and _L().query("pdn_attention_supported", Lp, hd):
+        if (mask is None or kb is not None) and _L().query("pdn_attention_supported", Lq, hd):
             return "resident", kb
     if _L().query("pdn_attention_stream_supported", hd) and kl == vl:
         return "stream", None
@@ -111,35 +112,20 @@ class attention(_Operator):
         self._kind, kb = _attn_kernel(B, H, hd, Lq, Lk, self.start_pos, mask_dev, layouts)
         if self._kind == "resident":
             # scores stay in registers: one kernel, nothing of size L x L in HBM; lse kept for backward
-            Lp = -(-Lq // 32) * 32
             qd, kd, vd = q.data, k.data, v.data
             rs, bs = layouts[0]
-            if Lp != Lq:
-                # a length that is not a multiple of 32 (CLIP: 50 / 77): zero rows up to the next tile, the keys among
-                # them switched off by the key bias; the padded query rows are dropped again below
-                def padded(a):
-                    z = hp.zeros((B, Lp, H, hd), np.float32)
-                    z[:, :Lq] = a
-                    return z
-                qd, kd, vd = padded(qd), padded(kd), padded(vd)
-                rs, bs = H * hd, Lp * H * hd
-                kbp = np.zeros((kb.shape[0] if kb is not None else 1, Lp), np.float32)
-                kbp[:, Lq:] = -np.inf
-                kbp = hp.from_numpy(kbp)
-                if kb is not None:
-                    kbp[:, :Lq] = kb
-                kb = kbp
-            out = hp.empty((B, Lp, H, hd), np.float32)
-            self._lse = hp.empty((B, H, Lp), np.float32)
-            self._res = (qd, kd, vd, out, kb, rs, bs, Lp)
+            out = hp.empty((B, Lq, H, hd), np.float32)
+            self._lse = hp.empty((B, H, Lq), np.float32)
+            self._res = (qd, kd, vd, kb, rs, bs)
             if kb is None:
                 L.call("pdn_attention_fwd_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, self._lse._ptr,
-                       B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd, causal, None, None, hp.stream())
+                       B, H, Lq, hd, rs, bs, H * hd, Lq * H * hd, causal, None, None, hp.stream())
             else:
+                # a mask that depends on (batch, key) only: one more rank-1 step of the score product inside the kernels
                 L.call("pdn_attention_fwd_bias_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, self._lse._ptr,
-                       B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd, causal, kb._ptr, Lp if kb.shape[0] > 1 else 0,
+                       B, H, Lq, hd, rs, bs, H * hd, Lq * H * hd, causal, kb._ptr, Lq if kb.shape[0] > 1 else 0,
                        hp.stream())
-            return out if Lp == Lq else out[:, :Lq].copy()
+            return out
         if self._kind == "stream":
             out = hp.empty((B, Lq, H, hd), np.float32)
             self._lse = hp.empty((B, H, Lq), np.float32)
@@ -175,30 +161,24 @@ class attention(_Operator):
         causal = 1 if (self.causal and Lq > 1) else 0
         if self.xp is not np and self._kind == "resident":
             hp, L = _hip(), _L()
-            qd, kd, vd, out, kb, rs, bs, Lp = self._res
+            qd, kd, vd, kb, rs, bs = self._res
             self._res = None
             do = _contig(do)
-            if Lp != Lq:
-                dop = hp.zeros((B, Lp, H, hd), np.float32)
-                dop[:, :Lq] = do
-                do = dop
-            dq, dk, dv = (hp.empty((B, Lp, H, hd), np.float32) for _ in range(3))
-            if rs != H * hd or (B > 1 and bs != Lp * H * hd):
+            dq, dk, dv = (hp.empty((B, Lq, H, hd), np.float32) for _ in range(3))
+            if rs != H * hd or (B > 1 and bs != Lq * H * hd):
                 # gradients are written with the operand strides: strided views (a packed q | k | v projection) get
                 # contiguous copies of the operands here
                 qd, kd, vd = qd.copy(), kd.copy(), vd.copy()
-                rs, bs = H * hd, Lp * H * hd
-            ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lp))
+                rs, bs = H * hd, Lq * H * hd
+            ws, wsb = hp.workspace(L.query("pdn_attention_bwd_workspace_bytes", B, H, Lq))
             if kb is None:
-                L.call("pdn_attention_bwd_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, do._ptr,
-                       self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd,
+                L.call("pdn_attention_bwd_f32", qd._ptr, kd._ptr, vd._ptr, self.data._ptr, do._ptr,
+                       self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, rs, bs, H * hd, Lq * H * hd,
                        causal, None, None, ws, wsb, hp.stream())
             else:
-                L.call("pdn_attention_bwd_bias_f32", qd._ptr, kd._ptr, vd._ptr, out._ptr, do._ptr,
-                       self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lp, hd, rs, bs, H * hd, Lp * H * hd,
-                       causal, kb._ptr, Lp if kb.shape[0] > 1 else 0, ws, wsb, hp.stream())
-            if Lp != Lq:
-                dq, dk, dv = dq[:, :Lq].copy(), dk[:, :Lq].copy(), dv[:, :Lq].copy()
+                L.call("pdn_attention_bwd_bias_f32", qd._ptr, kd._ptr, vd._ptr, self.data._ptr, do._ptr,
+                       self._lse._ptr, dq._ptr, dk._ptr, dv._ptr, B, H, Lq, hd, rs, bs, H * hd, Lq * H * hd,
+                       causal, kb._ptr, Lq if kb.shape[0] > 1 else 0, ws, wsb, hp.stream())
             return [dq, dk, dv]
         if self.xp is not np and self._kind == "stream":
             hp, L = _hip(), _L()

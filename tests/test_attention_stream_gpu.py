@@ -139,16 +139,16 @@ def test_stream_kernels_equal_resident_kernels_on_the_benchmark_shape(hip):
     assert np.allclose(l1.get(), l2.get(), rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("hd,kind", [(32, "stream"), (64, "resident")])
-def test_attention_node_on_strided_views_and_cache_prefill(hip, hd, kind):
+@pytest.mark.parametrize("hd,L,kind", [(32, 40, "stream"), (64, 40, "stream"), (64, 96, "resident")])
+def test_attention_node_on_strided_views_and_cache_prefill(hip, hd, L, kind):
     """q / k / v that are VIEWS (packed QKV projection, llm/clip/model.py:44-46; KV cache slices,
-    llm/llama/model.py:105-110): head dim 32 takes the streaming kernels, head dim 64 the resident ones (round 4: L = 40
-    rides as 64 rows with a key bias) -- both match the GEMM + softmax composition of the same node."""
+    llm/llama/model.py:105-110): the streaming kernels, or -- head dim 64 and a whole number of 32-row tiles -- the
+    resident ones reading the views through their strides; both match the GEMM + softmax composition of the same node."""
     import pydynet_amd as pdn
     from pydynet_amd.core import fused
     from pydynet_amd.core.tensor import Graph
     rng = np.random.default_rng(2)
-    B, L, H = 2, 40, 2
+    B, H = 2, 2
     qkv_np = rng.standard_normal((B, L, 3 * H * hd), dtype=np.float32)
     w_np = rng.standard_normal((B, L, H, hd), dtype=np.float32)
     res = []

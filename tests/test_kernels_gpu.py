@@ -532,12 +532,14 @@ def test_fused_attention_key_bias(hip, B, H, L, causal, hd, shared):
         assert not got_dk[b][masked[b if not shared else 0]].any() and not got_dv[b][masked[b if not shared else 0]].any()
 
 
-@pytest.mark.parametrize("B,H,L,causal,hd,with_mask", [(2, 2, 50, 0, 64, False),      # CLIP vision: 49 patches + class token
-                                                       (2, 2, 77, 1, 64, False),      # CLIP text, its causal mask as the flag
-                                                       (3, 4, 40, 0, 48, True), (2, 3, 128, 0, 64, True)])
-def test_attention_node_masks_and_ragged_lengths_take_the_resident_kernels(hip, B, H, L, causal, hd, with_mask):
-    """`fused.attention` with a (B, 1, 1, L) padding mask and / or a length that is not a multiple of 32: the node must
-    run the resident kernels (zero-padded rows, padded keys switched off by the key bias) and agree with float64."""
+@pytest.mark.parametrize("B,H,L,causal,hd,with_mask,kind", [(2, 2, 50, 0, 64, False, "stream"),   # CLIP vision: 49 patches + class token
+                                                            (2, 2, 77, 1, 64, False, "stream"),   # CLIP text
+                                                            (3, 4, 64, 0, 48, True, "resident"),
+                                                            (2, 3, 128, 1, 64, True, "resident"),
+                                                            (2, 2, 40, 0, 48, True, "stream")])
+def test_attention_node_masks_and_ragged_lengths(hip, B, H, L, causal, hd, with_mask, kind):
+    """`fused.attention` with a (B, 1, 1, L) padding mask and / or a length that is not a multiple of 32: key-only masks
+    on whole tiles take the resident kernels (key bias), everything else the streaming ones; both agree with float64."""
     import pydynet_amd as pdn
     from pydynet_amd.core import fused
     from pydynet_amd.core.tensor import Graph
@@ -552,7 +554,7 @@ def test_attention_node_masks_and_ragged_lengths_take_the_resident_kernels(hip, 
     tq, tk, tv = (pdn.Tensor(a, dtype=np.float32, device="hip:0", requires_grad=True) for a in (q, k, v))
     node = fused.attention(tq, tk, tv, causal=bool(causal),
                            mask=pdn.Tensor(mask, dtype=np.float32, device="hip:0") if with_mask else None)
-    assert node._kind == "resident", node._kind
+    assert node._kind == kind, node._kind
     (node * pdn.Tensor(w, dtype=np.float32, device="hip:0")).sum().backward()
     q64, k64, v64, g64 = (a.astype(np.float64).transpose(0, 2, 1, 3) for a in (q, k, v, w))
     s = q64 @ k64.swapaxes(-1, -2) / math.sqrt(hd)

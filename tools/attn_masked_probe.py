@@ -1,6 +1,6 @@
 """`fused.attention` outside the benchmark class -- padding masks, lengths that are not multiples of 32, no causal mask
-(llm/clip/model.py:35-63, examples/pydynet/transformer.py:92-96) -- on the resident kernels (zero rows + key bias,
-round 4) against the streaming kernels that took these shapes before.  Forward + backward of the node, per call.
+(llm/clip/model.py:35-63, examples/pydynet/transformer.py:92-96): which kernels the node picks and what a forward +
+backward of the node costs; where both the resident (key bias, round 4) and the streaming kernels take the shape, both.
 usage: python tools/attn_masked_probe.py"""
 import os
 import sys
