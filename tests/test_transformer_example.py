@@ -117,3 +117,32 @@ def test_transformer_example_fused_attention_cpu():
 
 device_variants(globals(), check_transformer_example)
 device_variants(globals(), check_transformer_example_fused_attention)
+
+
+def check_masked_attention_vs_reference(dev):
+    """The attention chain of examples/pydynet/transformer.py:84-101 with its (B, 1, 1, L) padding mask, as computed by the
+    REAL reference's operators (tests/golden/masked_attention.npz, tools/gen_golden_r2.py masked_attention), through
+    `fused.attention`: head dim 48 / 64 on whole tiles -- on a GPU the resident kernels with the key bias (round 4)."""
+    import os
+    import pydynet_amd as pdn
+    from pydynet_amd.core import fused
+    from pydynet_amd.core.tensor import Graph
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "masked_attention.npz"))
+    for tag in ("hd48", "hd64"):
+        Graph.clear()
+        q, k, v = (pdn.Tensor(d[f"{tag}/{n}"], dtype=np.float32, device=dev, requires_grad=True) for n in "qkv")
+        mask = pdn.Tensor(d[f"{tag}/pad"].copy(), dtype=np.float32, device=dev)
+        with pdn.no_grad():
+            mask[mask.eq(1)] = np.float32("-inf")                       # transformer.py:93
+        node = fused.attention(q, k, v, causal=False, mask=mask)
+        if dev != "cpu":
+            assert node._kind == "resident", node._kind
+        (node * pdn.Tensor(d[f"{tag}/w"], dtype=np.float32, device=dev)).sum().backward()
+        for name, got in (("out", node), ("dq", q.grad), ("dk", k.grad), ("dv", v.grad)):
+            got = got.numpy() if isinstance(got, pdn.Tensor) else (got if isinstance(got, np.ndarray) else got.get())
+            ref = d[f"{tag}/{name}"]
+            err = float(np.abs(got.astype(np.float64) - ref).max())
+            assert err <= 1e-6 + 1e-4 * float(np.abs(ref).max()), (tag, name, err)
+
+
+device_variants(globals(), check_masked_attention_vs_reference)

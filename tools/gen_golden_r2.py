@@ -17,6 +17,9 @@ reference's source.  Fixtures written here:
                       resident attention kernels against llm/llama/model.py:95-121 (finetune.py:44 allows 1024)
     generate_full.json   64 greedy tokens of the FULL-width model (V 32000, D 288, 6 layers): ids + four scalars of
                       every step's logits row (model.py:254-269)
+    masked_attention.npz   the attention chain of examples/pydynet/transformer.py:84-101 (matmul, / sqrt(hd), + (B, 1, 1, L)
+                      padding mask with -inf, softmax, matmul) on the reference's own operators at head dim 48 / 64 and
+                      whole 32-row tiles, non-causal: output and the three input gradients
     ops_r2.npz        split / vsplit / hsplit / dsplit (function.py:14-166) incl. gradients,
                       nll_loss (functional.py:353-361), float16 operator cases
                       (tests/test_tensor_basic.py:16,80-81)
@@ -353,8 +356,40 @@ def gen_generate_full():
           "logit scale", max(out["logit_max"]))
 
 
+MASKED_CASES = {"hd48": (2, 64, 2, 48, 11), "hd64": (2, 96, 1, 64, 12)}       # B, L, H, hd, seed
+
+
+def gen_masked_attention():
+    """The Transformer example's attention chain with its padding mask on the REAL reference's operators
+    (examples/pydynet/transformer.py:84-101; nn/functional.py:43-49 softmax): pins the key-bias form of the resident
+    attention kernels (round 4)."""
+    d = {}
+    for tag, (B, L, H, hd, seed) in MASKED_CASES.items():
+        fresh()
+        rng = np.random.default_rng(seed)
+        q, k, v, w = (rng.standard_normal((B, L, H, hd)).astype(np.float32) for _ in range(4))
+        pad = np.zeros((B, 1, 1, L), np.float32)
+        for b in range(B):
+            pad[b, 0, 0, L - 3 - 7 * b:] = 1.0                         # construct_mask: 1 where the token is padding
+        tq, tk, tv = (pdn.Tensor(a, dtype=np.float32, requires_grad=True) for a in (q, k, v))
+        mask = pdn.Tensor(pad.copy(), dtype=np.float32)
+        xq, xkT = tq.transpose(0, 2, 1, 3), tk.transpose(0, 2, 3, 1)
+        att = xq @ xkT / hd ** .5
+        mask[mask.eq(1)] = np.float32("-inf")                           # transformer.py:93
+        att = att + mask
+        att = F.softmax(att, axis=-1)
+        out = (att @ tv.transpose(0, 2, 1, 3)).transpose(0, 2, 1, 3)
+        (out * pdn.Tensor(w, dtype=np.float32)).sum().backward()
+        for n, a in (("q", q), ("k", k), ("v", v), ("w", w), ("pad", pad), ("out", out.data), ("dq", tq.grad), ("dk", tk.grad),
+                     ("dv", tv.grad)):
+            d[f"{tag}/{n}"] = np.asarray(a, np.float32).copy()
+        print("masked attention", tag, float(np.abs(out.data).max()), float(np.abs(tk.grad).max()))
+    np.savez_compressed(os.path.join(OUT, "masked_attention.npz"), **d)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fused_llama", "generate", "llama_io", "clip_blocks", "ops_r2", "long_attention", "generate_full"]
+    which = sys.argv[1:] or ["fused_llama", "generate", "llama_io", "clip_blocks", "ops_r2", "long_attention", "generate_full",
+                             "masked_attention"]
     for w in which:
         globals()["gen_" + w]()
     for f in sorted(os.listdir(OUT)):
