@@ -462,10 +462,13 @@ def main():
         lib.call("pdn_gemm_prof_enable", 1)
     losses = []
     t0 = time.perf_counter()
+    # every step's loss is read, one step behind and through an event of its own (hipnp.read_later): a blocking copy
+    # on the compute stream would wait for the step just queued and start every step on an empty queue
+    prev = hipnp.read_later(prev.data) if prev is not None else None
     for _ in range(args.steps):
-        cur = step()
+        cur = hipnp.read_later(step().data)
         if prev is not None:
-            losses.append(prev.item())                      # loss read-back pipelined one step behind
+            losses.append(prev.item())
         prev = cur
     fence()
     dt = time.perf_counter() - t0

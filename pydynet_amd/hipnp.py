@@ -682,6 +682,50 @@ class _MappedHost:
                 pass
 
 
+class read_later:
+    """Host value of a device array WITHOUT synchronising the compute stream: the copy into pinned host memory is queued
+    behind the array's producers and an event behind the copy; `get()` / `item()` wait for that event only.  A training
+    loop that reads step i's loss after queueing step i + 1 never lets the GPU run dry (`ndarray.get()` -- a blocking
+    copy on the compute stream -- waits for everything queued so far, i.e. also for the step just launched: measured
+    0.25 ms of idle GPU per 53 ms step in bench.py)."""
+
+    __slots__ = ("_mem", "_event", "_shape", "_dtype", "_value")
+
+    def __init__(self, a: "ndarray"):
+        a = a if a.is_contiguous() else a.copy()
+        L = _lib.lib()
+        self._shape, self._dtype, self._value = a.shape, a.dtype, None
+        self._mem = _MappedHost(_bi.max(a.size, 1) * a.dtype.itemsize)
+        ev = ctypes.c_void_p()
+        L.call("pdn_event_create", ctypes.byref(ev), 0)
+        self._event = ev.value
+        if a.size:
+            L.call("pdn_memcpy_d2h_async", self._mem.host, a._ptr, a.size * a.dtype.itemsize, stream())
+        L.call("pdn_event_record", self._event, stream())
+
+    def get(self) -> np.ndarray:
+        if self._value is None:
+            L = _lib.lib()
+            L.call("pdn_event_synchronize", self._event)
+            buf = (ctypes.c_char * self._mem.nbytes).from_address(self._mem.host)
+            n = int(np.prod(self._shape, dtype=np.int64))
+            self._value = np.frombuffer(buf, dtype=self._dtype, count=n).reshape(self._shape).copy()
+            L.call("pdn_event_destroy", self._event)
+            self._event, self._mem = None, None
+        return self._value
+
+    def item(self):
+        return self.get().item()
+
+    def __del__(self):
+        ev = getattr(self, "_event", None)
+        if ev:
+            try:
+                _lib.lib().call("pdn_event_destroy", ev)
+            except Exception:                      # interpreter shutdown
+                pass
+
+
 class Mailbox:
     """(n, *shape) int64 slots in host memory the GPU writes directly: a kernel stores slot i (system scope), the host
     reads it by polling -- no copy command, no event, nothing queued between two graph replays.  Slots start at -1

@@ -174,3 +174,22 @@ def test_replay_survives_a_later_eager_op_that_grows_the_workspace(hip):
         # iteration; a stray scratch write would be orders of magnitude away (and is what the canaries catch)
         bad = np.abs(p0[n] - p1[n]) > 2e-6 + 1e-4 * np.abs(p0[n])
         assert bad.mean() <= 2e-3 and np.abs(p0[n] - p1[n]).max() <= 5 * 2e-3, (n, bad.mean(), np.abs(p0[n] - p1[n]).max())
+
+
+def test_read_later_returns_the_value_without_draining_the_stream(hip):
+    """hipnp.read_later: the host value of an array through a copy + event of its own.  Values equal `.get()`; a value
+    requested BEFORE more work is queued is still the value of that moment (the copy is ordered behind the producers only)."""
+    rng = np.random.default_rng(3)
+    a_np = rng.standard_normal((37, 5)).astype(np.float32)
+    a = hip.from_numpy(a_np)
+    b = a * 2.0
+    later = hip.read_later(b)
+    b += 1.0                                         # queued after the copy: must not be seen by it
+    big = hip.from_numpy(rng.standard_normal((2048, 2048)).astype(np.float32))
+    for _ in range(4):
+        big = big @ big * 1e-3                       # keeps the stream busy behind the event
+    assert np.array_equal(later.get(), a_np * 2.0)
+    assert np.array_equal(later.get(), a_np * 2.0)   # cached
+    assert np.array_equal(b.get(), a_np * 2.0 + 1.0)
+    s = hip.read_later((a * a).sum())
+    assert abs(s.item() - float((a_np.astype(np.float64) ** 2).sum())) < 1e-3
