@@ -17,6 +17,8 @@ cp $S/all_configs.txt $D/${ROUND}_all_configs.txt
 cp $S/decode_trace.txt $D/${ROUND}_decode_trace.txt
 cp $S/epilogue_probe.txt $D/${ROUND}_epilogue_probe.txt
 cp $S/lmhead_probe.txt $D/${ROUND}_lmhead_probe.txt
+cp $S/attn_masked_probe.txt $D/${ROUND}_attn_masked_probe.txt
+cp $S/step_gaps.txt $D/${ROUND}_step_gaps.txt
 cp $S/pmc_lenet_b4096.json $D/${ROUND}_pmc_lenet_b4096.json
 { grep -E "passed|failed|error" $S/pytest_gpu.log | tail -2; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt
 ls -la $D | grep ${ROUND}_

@@ -37,4 +37,6 @@ bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 2
 bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
 python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
 python tools/lmhead_probe.py > $O/lmhead_probe.txt 2>&1
+python tools/attn_masked_probe.py > $O/attn_masked_probe.txt 2>&1
+bash tools/step_gaps.sh > $O/step_gaps.txt 2>&1
 ls -la $O
