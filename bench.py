@@ -284,7 +284,9 @@ def pmc_traffic():
         for name, r in rows.items():
             # (the row-resident launches with a fused epilogue -- last template argument 1 / 2 / 3 -- are a family
             #  of their own: `gemm_rowres_kernel<EPI>` below)
-            epi = name.startswith("gemm_rowres_kernel") and not name.rstrip().endswith(", 0>")
+            # (epilogues 4 / 5 -- the lm_head forward with row statistics -- are counted with the plain family, as
+            #  their launches are in the GEMM profile)
+            epi = name.startswith("gemm_rowres_kernel") and name.rstrip().endswith((", 1>", ", 2>", ", 3>"))
             if fam == "gemm_rowres_kernel<EPI>":
                 match = epi
             else:
