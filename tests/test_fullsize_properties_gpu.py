@@ -126,3 +126,46 @@ def test_adam_and_embedding_gradient_full_size(hip):
     assert np.array_equal(after[~used], before[~used])                   # zero gradient: parameter unchanged
     moved = np.abs(after[used] - before[used])
     assert moved.max() <= 1e-3 * (1 + 1e-3) and moved.max() > 0.5e-3    # first Adam step: |u| <= lr (+ fp32 round-off of w)
+
+
+def test_split_cross_entropy_statistics_full_size_properties(hip):
+    """lm_head -> cross entropy at the benchmark's full shape (65536 tokens x 32000 entries) with the statistics taken
+    from the two products (pdn_linear_rowmax_fwd_f32 + pdn_linear_ce_dx_deferred_f32).  Size-independent properties:
+    the row maxima bound every logit of their row and are attained; a constant added to every entry of the bias shifts
+    every log-sum-exp by exactly that constant and leaves the input gradient alone (softmax is shift invariant); the
+    gradient of a row whose target holds (numerically) all the probability vanishes; sampled rows agree with float64."""
+    from pydynet_amd import _lib
+    Lb = _lib.lib()
+    rng = np.random.default_rng(9)
+    T = 65536
+    x = rng.standard_normal((T, D), dtype=np.float32)
+    w = (0.05 * rng.standard_normal((D, V))).astype(np.float32)
+    b = (0.1 * rng.standard_normal(V)).astype(np.float32)
+    t = rng.integers(0, V, T)
+    x[7] = 40.0 * w[:, t[7]] / np.linalg.norm(w[:, t[7]])          # row 7: its target takes all the probability
+    X, W, Tg = hip.from_numpy(x), hip.from_numpy(w), hip.from_numpy(t)
+    parts = Lb.query("pdn_linear_rowmax_parts", T, V, D)
+    res = []
+    for shift in (0.0, 5.0):
+        Bv = hip.from_numpy(b + np.float32(shift))
+        logits, rowmax = hip.empty((T, V)), hip.empty((parts * T,))
+        Lb.call("pdn_linear_rowmax_fwd_f32", X._ptr, W._ptr, Bv._ptr, logits._ptr, rowmax._ptr, T, V, D, D, V, V, hip.stream())
+        dx, lse = hip.empty((T, D)), hip.empty((T,))
+        ws, wsb = hip.workspace(Lb.query("pdn_linear_ce_dx_deferred_workspace_bytes", T, V, D))
+        Lb.call("pdn_linear_ce_dx_deferred_f32", logits._ptr, rowmax._ptr, parts, Tg._ptr, 1.0 / T, W._ptr, dx._ptr, lse._ptr,
+                T, V, D, ws, wsb, hip.stream())
+        res.append((dx.get(), lse.get(), rowmax.get().reshape(parts, T).max(0), logits))
+    (dx0, lse0, m0, lg0), (dx1, lse1, m1, _) = res
+    rows = np.array([0, 7, 4097, 65535])
+    z = x[rows].astype(np.float64) @ w.astype(np.float64) + b
+    assert np.allclose(m0[rows], z.max(-1), rtol=1e-6, atol=1e-5)
+    chunk = lg0[:2048].get()
+    assert (chunk <= m0[:2048, None] + 1e-6).all() and np.allclose(chunk.max(-1), m0[:2048], rtol=0, atol=0)
+    assert np.allclose(lse1 - lse0, 5.0, atol=2e-5) and np.allclose(m1 - m0, 5.0, atol=2e-5)
+    assert rel_err(dx1, dx0) < 2e-6
+    ref_lse = np.log(np.exp(z - z.max(-1, keepdims=True)).sum(-1)) + z.max(-1)
+    assert np.allclose(lse0[rows], ref_lse, rtol=1e-6, atol=1e-5)
+    p = np.exp(z - ref_lse[:, None])
+    p[np.arange(len(rows)), t[rows]] -= 1.0
+    assert rel_err(dx0[rows], (p / T) @ w.astype(np.float64).T) < 2e-5
+    assert np.abs(dx0[7]).max() < 1e-9                      # p(target) = 1: (softmax - onehot) W^T = 0
