@@ -725,6 +725,15 @@ class read_later:
     def item(self):
         return self.get().item()
 
+    def __del__(self):
+        slot = getattr(self, "_slot", None)            # dropped unread: the slot goes back once its copy is through
+        if slot is not None:
+            try:
+                _lib.lib().call("pdn_event_synchronize", slot[1])
+                read_later._free.setdefault(slot[0].device, []).append(slot)
+            except Exception:                          # interpreter shutdown
+                pass
+
 
 class Mailbox:
     """(n, *shape) int64 slots in host memory the GPU writes directly: a kernel stores slot i (system scope), the host
