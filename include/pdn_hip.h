@@ -132,6 +132,12 @@ int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
 int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
+/* Round 5: which kernel the row-resident entry points below and above launch.  The tile-piece kernel
+ * (csrc/gemm_rowtile.hip: one 32-column tile of B over the whole contraction per piece, rotating accumulator sets, stores
+ * and epilogue reads drained under the next tile's MFMAs) takes a shape when every CU gets an 8-wave workgroup; the chunk
+ * kernel of csrc/gemm_rowres.hip the rest.  mode 0 = chunk kernel only, 1 = as described (default), 2 = tile-piece kernel
+ * for every valid shape (tests), anything else = query.  Returns the previous mode.  Results are bit-identical. */
+int pdn_gemm_rowtile_mode(int mode);
 /* Projections with the bandwidth pass next to them folded into the store of the accumulators (round 4;
  * csrc/gemm_rowres.hip, contraction 288 only -- `*_supported` says whether a shape is taken; PDN_EUNSUPPORTED otherwise):
  *  - gate | up projection + SwiGLU (llm/llama/model.py:56-58, nn/functional.py:39-40): gu (M x 2F) = x [Wg | Wu] and

@@ -24,6 +24,7 @@
 // The k-order of every output element is the same as in csrc/gemm.hip (k = 8t + 4h + j inside an MFMA
 // group, groups ascending), so both kernels give bit-identical results.
 #include "common.h"
+#include "gemm_rowtile.h"
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -94,7 +95,8 @@ __device__ __forceinline__ void rr_store(const RowResParams& p, f32x16 (&acc)[3]
       }                                                                          \
     }                                                                            \
   }
-  if (full && nt == 3) {
+  if (p.epi_ablate & 4) {
+  } else if (full && nt == 3) {
     if (Rw) RR_ROWS(false, true) else RR_ROWS(false, false)
   } else {
     if (Rw) RR_ROWS(true, true) else RR_ROWS(true, false)
@@ -610,7 +612,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
       float* park = smem + 2 * PIECE + wave * 1024 + lane;
       if (full) rr_store_swiglu<false>(p, acc, m0, c, li, lh, park); else rr_store_swiglu<true>(p, acc, m0, c, li, lh, park);
     } else if constexpr (EPI == 2) {
-      if (full) rr_store_swiglu_bwd<false>(p, acc, m0, c, li, lh); else rr_store_swiglu_bwd<true>(p, acc, m0, c, li, lh);
+      if (p.epi_ablate & 4) { for (int j = 0; j < 3; ++j) for (int r = 0; r < 16; ++r) acc[j][r] = 0.f; }
+      else if (full) rr_store_swiglu_bwd<false>(p, acc, m0, c, li, lh); else rr_store_swiglu_bwd<true>(p, acc, m0, c, li, lh);
     } else if constexpr (EPI == 3) {
       if (full) rr_store_rope<false>(p, acc, m0, c, li, lh); else rr_store_rope<true>(p, acc, m0, c, li, lh);
     } else if constexpr (EPI == 4) {
@@ -674,6 +677,20 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     return PDN_EUNSUPPORTED;
   }
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_rowres_f32: 16-byte alignment required");
+  // round 5: the tile-piece kernel (csrc/gemm_rowtile.hip) takes every shape that gives each CU an 8-wave workgroup --
+  // its stores and epilogue reads leave under the next tile's MFMAs instead of in a store phase of their own
+  if (!residual) {
+    RowTileArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.A = A; ta.B = B; ta.C = C; ta.bias = bias; ta.M = M; ta.N = N; ta.lda = lda; ta.ldb = ldb; ta.ldc = ldc;
+    ta.b_trans = b_trans; ta.nblocks = nblocks; ta.b_block_stride = b_block_stride; ta.epi = epi ? epi->kind : 0;
+    if (epi) {
+      ta.H = epi->H; ta.ldh = epi->ldh; ta.GU = epi->GU; ta.F = epi->F; ta.rope = epi->rope; ta.L = epi->L; ta.hd = epi->hd;
+      ta.rope_cols = epi->rope_cols; ta.g_off = epi->g_off; ta.u_off = epi->u_off; ta.lse = epi->lse;
+      ta.parts = &const_cast<RowResEpi*>(epi)->parts;
+    }
+    if (pdn_rowtile_takes(ta)) return pdn_rowtile_launch(ta, stream);
+  }
   RowResParams p{A, B, C, bias, residual, M, N, lda, ldb, ldc, (N + RR_NC - 1) / RR_NC, 0, 0, b_block_stride};
   p.cpb = nblocks > 1 ? nper / RR_NC : p.chunks;
   p.H = nullptr; p.GU = nullptr; p.rope = nullptr; p.ldh = 0; p.F = 0; p.L = 1; p.hd = 1; p.rope_chunks = 0; p.hd_magic = 0; p.g_off = 0; p.u_off = 0; p.lse = nullptr;

@@ -202,6 +202,8 @@ class EmulatedLib:
         c[...] = r
         return 0
 
+    def pdn_gemm_rowtile_mode(self, mode): return 1       # (kernel selection only: results are bit-identical)
+
     def pdn_gemm_rowres_supported(self, M, N, K, lda, ldb, ldc, b_trans):
         return int(K == 288 and N % 32 == 0 and N >= 96 and M >= 1 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K
                    and ldb >= (K if b_trans else N) and ldc >= N and 32 * ldc < (1 << 30))
