@@ -56,6 +56,7 @@ struct RowTileParams {
   int F, L, hd, rope_tiles;
   unsigned g_off, u_off;
   float* lse;
+  int ablate;                     // timing experiments (PDN_ROWTILE_ABLATE; 0 in the library): 1 = no barriers after the first
 };
 
 template <int V> using rt_ic = std::integral_constant<int, V>;
@@ -103,29 +104,48 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   // NN image [k][32]:  unit U = row k = U / 8, column unit U % 8.
   // NT image [n][288]: unit U = row n = U / 72, k unit (U % 72) ^ ((n >> 1) & 7) -- the swizzle of gemm_rowres.hip on the
   // source side, so that one ds_read_b128 per four MFMAs is conflict free without padding.
-  unsigned soff[5];                                 // BYTES: a 32-bit lane offset beside a wave-uniform base
+  unsigned soff[BT ? 5 : 1];                        // BYTES: a 32-bit lane offset beside a wave-uniform base
+  if (BT) {
 #pragma unroll
-  for (int q = 0; q < 5; ++q) {
-    const int I = min(q * 8 + wave, 35), U = 64 * I + lane;
-    if (BT) {
+    for (int q = 0; q < 5; ++q) {
+      const int I = min(q * 8 + wave, 35), U = 64 * I + lane;
       const int n = U / 72, cu = U - 72 * n;
-      soff[q] = 4u * ((unsigned)n * ldb + 4u * (unsigned)(cu ^ ((n >> 1) & 7)));
-    } else {
-      soff[q] = 4u * ((unsigned)(U >> 3) * ldb + 4u * (unsigned)(U & 7));
+      soff[BT ? q : 0] = 4u * ((unsigned)n * ldb + 4u * (unsigned)(cu ^ ((n >> 1) & 7)));
     }
+  } else {
+    // row k = 8 I + (lane >> 3): the 8 I rows go to the (uniform) base, one lane offset serves every instruction
+    soff[0] = 4u * ((unsigned)(lane >> 3) * ldb + 4u * (unsigned)(lane & 7));
   }
+  // source of instruction q of a piece that starts at `base`: uniform pointer + lane offset in bytes
+  auto stage_src = [&](const float* base, int q) __attribute__((always_inline)) -> const float4* {
+    unsigned o = soff[BT ? q : 0];
+    asm volatile("" : "+v"(o));                     // (widened HERE, next to the load: the saddr + 32-bit voffset form)
+    const float* b = BT ? base : base + (int64_t)(8 * min(q * 8 + wave, 35)) * p.ldb;
+    return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(b) + o);
+  };
   float4 rb[3];
   auto issue_one = [&](const float* base, int q) __attribute__((always_inline)) {
-    unsigned o = soff[q];
-    asm volatile("" : "+v"(o));                     // (widened HERE, next to the load: the saddr + 32-bit voffset form)
-    const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + o);
+    const float4 v = *stage_src(base, q);
     rb[q % 3].x = v.x; rb[q % 3].y = v.y; rb[q % 3].z = v.z; rb[q % 3].w = v.w;
   };
-  auto park_one = [&](int buf, int q) __attribute__((always_inline)) {
+  // registers -> LDS.  The image is [n][288] with the 16-byte units of row n XOR-swizzled by (n >> 1) & 7 in BOTH forms, so
+  // that the MFMA B fragments of a k-group are ONE conflict-free ds_read_b128 per lane.  NT: a staged float4 is such a unit
+  // (the swizzle was applied on the source side: the write is linear in the lane).  NN: a staged float4 holds row k of
+  // columns 4u .. 4u + 3, i.e. one float of four image rows: four ds_write_b32 (two lanes per bank -- the price of not
+  // keeping a transposed copy of the weights; the chunk kernel read NN fragments as four ds_read_b32 per k-group instead).
+  const int nn_pbase = (4 * (lane & 7)) * 288 + ((lane >> 3) & 3), nn_sw0 = (2 * (lane & 7)) & 7;
+  auto park_v = [&](int buf, int q, const float4& v) __attribute__((always_inline)) {
     const int I = min(q * 8 + wave, 35);
-    float* dst = smem + buf * RT_PIECE + I * 256 + 4 * lane;
-    *reinterpret_cast<float4*>(dst) = rb[q % 3];
+    if (BT) {
+      *reinterpret_cast<float4*>(smem + buf * RT_PIECE + I * 256 + 4 * lane) = v;
+    } else {
+      const int t0 = (2 * I + lh) ^ nn_sw0;         // k >> 2 = 2 I + (lane >> 5); columns 4u, 4u + 1 share (n >> 1) & 7
+      float* d01 = smem + buf * RT_PIECE + nn_pbase + 4 * t0;
+      float* d23 = smem + buf * RT_PIECE + nn_pbase + 2 * 288 + 4 * (t0 ^ 1);
+      d01[0] = v.x; d01[288] = v.y; d23[0] = v.z; d23[288] = v.w;
+    }
   };
+  auto park_one = [&](int buf, int q) __attribute__((always_inline)) { park_v(buf, q, rb[q % 3]); };
 
   // ---- prologue: first piece into buffer 0, the wave's 32 rows of A into registers (requested behind the piece, which
   // is parked while they are still on their way) ------------------------------------------------------------------
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
     const float* b0p = piece_b(P_begin);
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(b0p) + soff[q]);
+      const float4 v = *stage_src(b0p, q);
       t5[q].x = v.x; t5[q].y = v.y; t5[q].z = v.z; t5[q].w = v.w;
     }
   }
@@ -151,8 +171,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
-    const int I = min(q * 8 + wave, 35);
-    *reinterpret_cast<float4*>(smem + I * 256 + 4 * lane) = t5[q];
+    park_v(0, q, t5[q]);
   }
 
   f32x16 acc[NSET];
@@ -162,10 +181,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
     for (int r = 0; r < 16; ++r) acc[s][r] = (EPI == 5 && s == 1) ? -INFINITY : 0.f;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  // B fragment addressing (floats from smem).  NN: lane (li, lh) reads [8 g + 4 lh + q][li]; the second buffer gets its
-  // own (opaque) base -- its immediates would not reach past 64 KiB.  NT: row li, 16-byte unit (2 g + lh) ^ ((li >> 1) & 7).
-  int fb0 = (4 * lh) * 32 + li, fb1 = fb0 + RT_PIECE;
-  asm volatile("" : "+v"(fb1));
+  // B fragment addressing (floats from smem), both forms: row li of the image, 16-byte unit (2 g + lh) ^ ((li >> 1) & 7)
   const int xl = (li >> 1) & 7;
   int bq[4];
 #pragma unroll
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   auto run_piece = [&](auto uc, int P) __attribute__((always_inline)) {
     constexpr int U = decltype(uc)::value;
     constexpr int S = U % NSET, BUF = U & 1;
-    rt_barrier();
+    if (!(p.ablate & 1) || P == P_begin) rt_barrier();
     const int Pn = min(P + 1, P_end - 1);           // (after the last piece: a redundant fetch into the idle buffer)
     const float* nb = piece_b(Pn);
     // what leaves during this piece
@@ -306,19 +322,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
     unsigned ot = (unsigned)(4 * lh) * hdb + 8u * colh_d;
 
     // (fragment bases opaque per piece: the k-group addresses of one buffer are common subexpressions of every second
-    //  piece body, and the optimiser keeps all 36 of them alive -- in scratch -- rather than adding a constant again)
-    int fbp = BUF ? fb1 : fb0, bq0 = bq[0], bq1 = bq[1], bq2 = bq[2], bq3 = bq[3];
-    if (BT) asm volatile("" : "+v"(bq0), "+v"(bq1), "+v"(bq2), "+v"(bq3));
-    else asm volatile("" : "+v"(fbp));
+    //  piece body, and the optimiser keeps them alive -- in scratch -- rather than adding a constant again)
+    asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
     float bf[2][4];
 #define RT_LOADB(X, G)                                                                          \
-  if (BT) {                                                                                     \
-    const int bqg = ((G) & 3) == 0 ? bq0 : ((G) & 3) == 1 ? bq1 : ((G) & 3) == 2 ? bq2 : bq3;    \
-    const float4 v = *reinterpret_cast<const float4*>(smem + bqg + BUF * RT_PIECE + 32 * ((G) >> 2)); \
+  {                                                                                             \
+    const float4 v = *reinterpret_cast<const float4*>(                                          \
+        __builtin_assume_aligned(smem + bq[(G) & 3] + BUF * RT_PIECE + 32 * ((G) >> 2), 16));   \
     bf[X][0] = v.x; bf[X][1] = v.y; bf[X][2] = v.z; bf[X][3] = v.w;                             \
-  } else {                                                                                      \
-    const float* fp = smem + fbp;                                                               \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) bf[X][q] = fp[(8 * (G) + q) * 32];            \
   }
     RT_LOADB(0, 0)
 #pragma unroll
@@ -481,6 +492,7 @@ int pdn_rowtile_launch(const RowTileArgs& a, void* stream) {
   p.H = a.H; p.GU = a.GU; p.rope = reinterpret_cast<const float2*>(a.rope); p.ldh = a.ldh;
   p.F = a.F; p.L = a.L > 0 ? a.L : 1; p.hd = a.hd > 0 ? a.hd : 32; p.rope_tiles = a.rope_cols / 32;
   p.g_off = a.g_off; p.u_off = a.u_off; p.lse = a.lse;
+  p.ablate = getenv("PDN_ROWTILE_ABLATE") ? atoi(getenv("PDN_ROWTILE_ABLATE")) : 0;
   const dim3 grid((a.M + 255) / 256, nsplit), block(512);
   hipStream_t st = (hipStream_t)stream;
   const bool guard = a.M % 256 != 0;
