@@ -81,7 +81,73 @@ GATE_GRAD_NORMS = {"lm_head.weight": 1.060440380538923, "tok_embedding.weight": 
 GATE_RTOL = 1e-4
 
 
-def parity_gate(model, dev, pdn):
+COUNTER_SLOTS = ("rowres_chunk", "rowtile_plain", "rowtile_swiglu_fwd", "rowtile_swiglu_bwd", "rowtile_rope", "rowtile_rowmax",
+                 "rowres_chunk_epilogue", "attention_p_fwd", "attention_p_bwd", "attention_resident_fwd",
+                 "attention_resident_bwd", "attention_stream", "lm_head_dx_sumexp", "lm_head_dw_ce", "outres", "outres_tn")
+
+
+def kernel_counters(lib, reset=False):
+    """Launches per kernel since the last reset, from the library's own counters (include/pdn_hip.h: pdn_kernel_counters)."""
+    import ctypes
+    buf = (ctypes.c_int64 * 16)()
+    lib.call("pdn_kernel_counters", buf, 16, 1 if reset else 0)
+    return dict(zip(COUNTER_SLOTS, (int(v) for v in buf)))
+
+
+class count_nodes:
+    """Counts constructions of the fused tape nodes the timed step is made of (and lowers their row thresholds, so that a
+    256-token gate step takes the nodes AND kernels the 65536-token step takes)."""
+
+    def __init__(self):
+        from pydynet_amd.core import fused
+        self.fused = fused
+        self.classes = {"qkv_attention": fused.qkv_attention, "ffn_swiglu": fused.ffn_swiglu,
+                        "linear_cross_entropy": fused.linear_cross_entropy}
+        self.counts = {k: 0 for k in self.classes}
+
+    def __enter__(self):
+        f = self.fused
+        self.saved = (f.linear_cross_entropy.min_rows, f.ffn_swiglu.epilogue_min_rows, f.qkv_attention.rope_min_rows)
+        f.linear_cross_entropy.min_rows, f.ffn_swiglu.epilogue_min_rows, f.qkv_attention.rope_min_rows = 32, 1, 1
+        self.orig = {}
+        for name, cls in self.classes.items():
+            self.orig[name] = cls.__init__
+
+            def counting(obj, *a, _n=name, _o=cls.__init__, **k):
+                self.counts[_n] += 1
+                _o(obj, *a, **k)
+            cls.__init__ = counting
+        return self
+
+    def __exit__(self, *exc):
+        f = self.fused
+        for name, cls in self.classes.items():
+            cls.__init__ = self.orig[name]
+        f.linear_cross_entropy.min_rows, f.ffn_swiglu.epilogue_min_rows, f.qkv_attention.rope_min_rows = self.saved
+        return False
+
+
+def require_path(what, nodes, kernels, layers, full_size):
+    """Raise unless the step was made of the fused nodes and launched the kernels the timed step is priced on.
+    `full_size`: enough tokens for the tile-piece projections (else the same entry points run the chunk kernel)."""
+    want_nodes = {"qkv_attention": layers, "ffn_swiglu": layers, "linear_cross_entropy": 1}
+    for k, n in want_nodes.items():
+        if nodes is not None and nodes.get(k, 0) != n:
+            raise SystemExit(f"bench.py {what} FAILED: fused node {k} was built {nodes.get(k, 0)} times, expected {n} "
+                             "-- the step fell back to the unfused composition")
+    epi = ("rowtile_swiglu_fwd", "rowtile_swiglu_bwd", "rowtile_rope", "rowtile_rowmax") if full_size else ()
+    want = {"attention_p_fwd": layers, "attention_p_bwd": layers, "lm_head_dx_sumexp": 1, "lm_head_dw_ce": 1}
+    want.update({k: (1 if k == "rowtile_rowmax" else layers) for k in epi})
+    for k, n in want.items():
+        if kernels.get(k, 0) < n:
+            raise SystemExit(f"bench.py {what} FAILED: kernel {k} was launched {kernels.get(k, 0)} times, expected >= {n} "
+                             f"(launches per kernel: {kernels})")
+    if not full_size:      # the fused-epilogue entry points must have run, on either kernel
+        if kernels["rowres_chunk_epilogue"] + sum(kernels[k] for k in COUNTER_SLOTS[2:6]) < 3 * layers + 1:
+            raise SystemExit(f"bench.py {what} FAILED: the fused-epilogue projections were not launched ({kernels})")
+
+
+def parity_gate(model, dev, pdn, lib=None):
     """One forward + backward of the seed-0 model on the reference's seed-0 batch; raises unless the
     loss and the gradient norms match what the reference computed (1e-4 relative)."""
     ids = np.random.randint(0, V, (1, L))               # same RNG stream as the generator: seed 0, model
@@ -97,21 +163,15 @@ def parity_gate(model, dev, pdn):
         p.zero_grad()
     # the gate must take the nodes the timed steps take: at 256 tokens the model would otherwise use the separate
     # lm_head / cross-entropy nodes (the fused one starts at 32768 tokens, where its kernels fill the chip)
-    from pydynet_amd.core import fused
-    calls = {"n": 0}
-    orig_init, min_rows = fused.linear_cross_entropy.__init__, fused.linear_cross_entropy.min_rows
-
-    def counting_init(self, *a, **k):
-        calls["n"] += 1
-        orig_init(self, *a, **k)
-    fused.linear_cross_entropy.__init__, fused.linear_cross_entropy.min_rows = counting_init, 32
-    try:
+    if lib is None:
+        from pydynet_amd import _lib
+        lib = _lib.lib()
+    kernel_counters(lib, reset=True)
+    with count_nodes() as cn:
         loss = model.loss(ids, tgt)
         loss.backward()
-    finally:
-        fused.linear_cross_entropy.__init__, fused.linear_cross_entropy.min_rows = orig_init, min_rows
-    if calls["n"] != 1:
-        raise SystemExit("bench.py parity gate FAILED: the step did not take the fused lm_head + cross-entropy node")
+    launched = kernel_counters(lib, reset=True)
+    require_path("parity gate", cn.counts, launched, LAYERS, full_size=False)
     got = float(loss.item())
     if not abs(got - GATE_LOSS) <= GATE_RTOL * GATE_LOSS:
         raise SystemExit(f"bench.py parity gate FAILED: loss {got!r} != reference {GATE_LOSS!r} (rtol {GATE_RTOL}); "
@@ -130,7 +190,7 @@ def parity_gate(model, dev, pdn):
         p.zero_grad()
     return {"loss": got, "reference_loss": GATE_LOSS, "rel_err": abs(got - GATE_LOSS) / GATE_LOSS,
             "grad_norms_checked": sum(v is not None for v in norms.values()), "worst_grad_norm_rel_err": worst,
-            "rtol": GATE_RTOL, "fused_nodes_taken": ["qkv_attention", "gate_up_swiglu", "linear_cross_entropy"]}
+            "rtol": GATE_RTOL, "fused_nodes_built": cn.counts, "kernel_launches": {k: v for k, v in launched.items() if v}}
 
 
 def _free_port():
@@ -201,8 +261,10 @@ def batch_gate(model, ids_np, tgt_np, dev, pdn, lib, rtol=1e-4, want_families=(2
 
     zero()
     lib.call("pdn_gemm_prof_enable", 1)
+    kernel_counters(lib, reset=True)
     lossB = model.loss(ids_np, tgt_np.reshape(-1))
     lossB.backward()
+    launched = kernel_counters(lib, reset=True)
     ms2, fl2, n2 = (ctypes.c_double * 5)(), (ctypes.c_double * 5)(), (ctypes.c_int64 * 5)()
     lib.call("pdn_gemm_prof_enable", 0)
     lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
@@ -211,6 +273,8 @@ def batch_gate(model, ids_np, tgt_np, dev, pdn, lib, rtol=1e-4, want_families=(2
     if missing:
         raise SystemExit(f"bench.py batch gate FAILED: GEMM kernel families {missing} were not launched at batch {B} "
                          f"(launches per family {taken})")
+    if want_families:                 # (the timed batch: every kernel the roofline block prices must have run)
+        require_path("batch gate", None, launched, LAYERS, full_size=True)
     lossB = float(lossB.item())
     with model.lm_head.weight.device:
         gB = {n: p.grad.copy() for n, p in params.items()}
@@ -249,7 +313,8 @@ def batch_gate(model, ids_np, tgt_np, dev, pdn, lib, rtol=1e-4, want_families=(2
                          f"single-sequence gradients by {worst:.2e} of its largest entry (rtol {rtol})")
     return {"batch": B, "loss": lossB, "mean_single_sequence_loss": loss1, "loss_rel_err": abs(lossB - loss1) / abs(loss1),
             "grad_tensors_checked": len(params), "worst_grad_rel_err": worst, "worst_grad": worst_name, "rtol": rtol,
-            "gemm_family_launches": dict(zip(("tiled", "tn_stream", "rowres", "outres", "outres_tn"), taken))}
+            "gemm_family_launches": dict(zip(("tiled", "tn_stream", "rowres", "outres", "outres_tn"), taken)),
+            "kernel_launches": {k: v for k, v in launched.items() if v}}
 
 
 def pmc_traffic():
@@ -277,20 +342,27 @@ def pmc_traffic():
             out["_stale"] = meta["kernel_sources_sha16"] != stamp_pmc.sources_sha()
     except Exception:
         pass
-    for fam in ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel",
-                "gemm_outres_tn_kernel", "ce_fwd_bwd_reg_kernel", "adam_multi_kernel", "gemm_rowres_kernel<EPI>",
-                "rmsnorm_bwd_kernel"):
+    def is_rowres(name):
+        return name.startswith("gemm_rowres_kernel") or name.startswith("gemm_rowtile_kernel")
+
+    def is_fused(name):                   # SwiGLU forward / backward, RoPE in the store: EPI 1 / 2 / 3
+        n = name.rstrip()
+        if name.startswith("gemm_rowres_kernel"):
+            return n.endswith((", 1>", ", 2>", ", 3>"))
+        if name.startswith("gemm_rowtile_kernel"):          # gemm_rowtile_kernel<BT, EPI, GUARD>
+            return any(f", {e}, " in n for e in (1, 2, 3))
+        return False
+
+    for fam in ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "row_resident", "gemm_outres_kernel",
+                "gemm_outres_tn_kernel", "adam_multi_kernel", "row_resident<EPI>", "rmsnorm_bwd_kernel"):
         n = tot = 0.0
         for name, r in rows.items():
-            # (the row-resident launches with a fused epilogue -- last template argument 1 / 2 / 3 -- are a family
-            #  of their own: `gemm_rowres_kernel<EPI>` below)
-            # (epilogues 4 / 5 -- the lm_head forward with row statistics -- are counted with the plain family, as
-            #  their launches are in the GEMM profile)
-            epi = name.startswith("gemm_rowres_kernel") and name.rstrip().endswith((", 1>", ", 2>", ", 3>"))
-            if fam == "gemm_rowres_kernel<EPI>":
-                match = epi
+            if fam == "row_resident":
+                match = is_rowres(name)                     # the whole template family, fused epilogues included
+            elif fam == "row_resident<EPI>":
+                match = is_rowres(name) and is_fused(name)
             else:
-                match = name.startswith(fam) and not epi
+                match = name.startswith(fam)
             if match and "FETCH_SIZE" in r and "WRITE_SIZE" in r:
                 d = r.get("dispatches", 1)
                 n += d
@@ -301,54 +373,32 @@ def pmc_traffic():
 
 
 def hbm_kernels(lib, hp, B, traffic, opt=None, nparams=0):
-    """The HBM-bound kernels of the step, timed live with HIP events on the launch stream at the step's own
-    shapes: achieved = ALGORITHMIC bytes per launch / average launch duration, against the 8 TB/s HBM3E peak."""
-    import ctypes
+    """The HBM-bound kernel of the step, timed live with HIP events on the launch stream: achieved = ALGORITHMIC bytes per
+    launch / average launch duration, against the 8 TB/s HBM3E peak.  Adam: one multi-tensor launch reading p, g, m, v and
+    writing p, m, v (28 B per parameter); 20 launches of the kernel back to back through the C entry point (the queue
+    stays full: `opt.step()` per launch left the GPU idle for ~40 us of host work between two 108 us kernels and the line
+    under-reported its own kernel).  Run AFTER the timed region (it moves the weights along the last gradient)."""
     out = {}
-    T = B * L
-    x = hp.empty((T, V), np.float32)
-    lib.call("pdn_fill", 0, 0.01, 2, (ctypes.c_int64 * 2)(T, V), x._ptr, (ctypes.c_int64 * 2)(V, 1), hp.stream())
-    tgt = hp.from_numpy(np.random.default_rng(0).integers(0, V, T))
-    row, lse, loss = hp.empty((T,)), hp.empty((T,)), hp.empty((1,))
-
-    def ce():       # the statistics pass of the fused lm_head + cross-entropy node: the logits are read once,
-        # nothing of their size is written (the gradient is formed inside the two backward products)
-        lib.call("pdn_cross_entropy_fwd_f32", x._ptr, tgt._ptr, T, V, 1, row._ptr, lse._ptr, loss._ptr,
-                 hp.err_flag_ptr(), hp.stream())
-    # (the statistics pass IS an instantiation of ce_fwd_bwd_reg_kernel -- <false, false>: no gradient store -- so the
-    #  counter rows of that kernel name in the PMC summary are its own)
-    for name, fn, nbytes in (("ce_fwd_bwd_reg_kernel", ce, 4.0 * T * V),):
-        fn(); hp.synchronize()
-        with hp.Timer() as t:
-            for _ in range(5):
-                fn()
-        us = t.ms / 5 * 1e3
-        from pydynet_amd.core import fused
-        lce = fused.linear_cross_entropy
-        split = bool(lce.deferred_norm and lib.query("pdn_linear_rowmax_supported", T, V, 288)
-                     and lib.query("pdn_linear_ce_dx_deferred_supported", T, V, 288))
-        in_gemm = bool(lce.lse_epilogue and lib.query("pdn_linear_lse_supported", T, V, 288))
-        out[name] = {"bound": "hbm", "what": "cross-entropy row statistics (read-only pass over the logits)",
-                     # at this many tokens the step takes the statistics from the two lm_head products instead
-                     # (fused.linear_cross_entropy: row maxima in the projection's store, the sum of exponentials in the
-                     # input-gradient product); the pass is timed here as the HBM-bound reference kernel it replaces
-                     "in_step": not (split or in_gemm),
-                     "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
-                     "avg_launch_us": us, "traffic": traffic.get(name)}
     if opt is not None and nparams:
-        # the optimizer: one multi-tensor launch reading p, g, m, v and writing p, m, v (28 B per parameter).  Timed on the
-        # job's own optimizer AFTER the timed region (it moves the weights five more steps along the last gradient).
-        opt.step(); hp.synchronize()
+        fast = opt._hip_params()
+        table = opt._chunk_table(fast)
+
+        def launch():
+            lib.call("pdn_adam_multi_f32", table._ptr, table.shape[0], 1e-9, opt.beta1, opt.beta2, 1 - opt.beta1,
+                     1 - opt.beta2, opt.eps, opt.weight_decay, opt.grad_scale, hp.stream())
+        for _ in range(3):
+            launch()
+        hp.synchronize()
+        N = 20
         with hp.Timer() as t:
-            for _ in range(5):
-                opt.step()
-        us = t.ms / 5 * 1e3
+            for _ in range(N):
+                launch()
+        us = t.ms / N * 1e3
         nbytes = 28.0 * nparams
         out["adam_multi_kernel"] = {"bound": "hbm", "what": "Adam over every parameter in one launch (optim/optimizer.py:160-196)",
                                     "in_step": True, "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                     "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
-                                    "avg_launch_us": us, "traffic": traffic.get("adam_multi_kernel")}
+                                    "avg_launch_us": us, "launches_timed": N, "traffic": traffic.get("adam_multi_kernel")}
     return out
 
 
@@ -415,7 +465,7 @@ def main():
     model = Llama(V, D, H, F_, 1024, 1, LAYERS, np.float32)           # (max_batch_size only sizes the unused KV caches)
     model.tok_embedding.weight.data[...] = (0.02 * np.random.randn(V, D)).astype(np.float32)
     model.to(dev)
-    gate = None if args.no_parity_gate else parity_gate(model, dev, pdn)    # refuses to go on if the path is wrong
+    gate = None if args.no_parity_gate else parity_gate(model, dev, pdn, lib)    # refuses to go on if the path is wrong
     rng = np.random.default_rng(1000 + rank)                # each rank owns its shard of the global batch
     ids_np, tgt_np = rng.integers(0, V, (B, L)), rng.integers(0, V, (B * L,))
     bgate = None
@@ -462,6 +512,7 @@ def main():
     comm_events.clear()
     if not args.no_gemm_prof:
         lib.call("pdn_gemm_prof_enable", 1)
+    kernel_counters(lib, reset=True)
     losses = []
     t0 = time.perf_counter()
     # every step's loss is read, one step behind and through an event of its own (hipnp.read_later): a blocking copy
@@ -490,37 +541,49 @@ def main():
         peak = PEAK_FP32_MFMA / 1e12
         traffic = pmc_traffic()
 
-        def family(i, name):
-            return {"achieved": tf(fl2[i], ms2[i]), "frac": tf(fl2[i], ms2[i]) / peak, "launches": n2[i],
-                    "avg_launch_us": 1e3 * ms2[i] / max(n2[i], 1), "time_share_of_step": ms2[i] * 1e-3 / dt,
-                    "algorithmic_flop_per_launch": fl2[i] / max(n2[i], 1), "traffic": traffic.get(name)}
-        # five GEMM kernels share the step; the roofline block is that of the one with the largest time share
-        # (`achieved` = algorithmic 2MNK of ITS launches / HIP-event time around them, on the launch stream),
-        # the others are reported beside it
-        names = ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "gemm_rowres_kernel", "gemm_outres_kernel",
-                 "gemm_outres_tn_kernel")
-        fams = {n: family(i, n) for i, n in enumerate(names)}
-        dom = max(names, key=lambda n: fams[n]["time_share_of_step"])
+        def fam_rec(ms, fl, n, name):
+            return {"achieved": tf(fl, ms), "frac": tf(fl, ms) / peak, "launches": n,
+                    "avg_launch_us": 1e3 * ms / max(n, 1), "time_share_of_step": ms * 1e-3 / dt,
+                    "algorithmic_flop_per_launch": fl / max(n, 1), "traffic": traffic.get(name)}
+        # Five GEMM kernel TEMPLATES share the step; the roofline block is that of the template family with the largest
+        # time share -- ALL instantiations of a template together (`achieved` = algorithmic 2MNK of its launches /
+        # HIP-event time around them, on the launch stream).  The row-resident family = gemm_rowtile_kernel (round 5;
+        # gemm_rowres_kernel below its row threshold) incl. the projections with a fused epilogue, which are ALSO shown
+        # as a sub-block with their HBM side (`fused_epilogue_gemms`); the other families are reported beside it.
+        keys = ("gemm_f32_mfma_kernel", "gemm_tn_stream_dma_kernel", "row_resident", "gemm_outres_kernel",
+                "gemm_outres_tn_kernel")
+        shown = {"row_resident": "gemm_rowtile_kernel"}
+        fams = {}
+        for i, k in enumerate(keys):
+            ms_, fl_, n_ = ms2[i], fl2[i], n2[i]
+            if k == "row_resident":
+                ms_, fl_, n_ = ms_ + fms.value, fl_ + ffl.value, n_ + fn.value
+            fams[shown.get(k, k)] = fam_rec(ms_, fl_, n_, k)
+        dom = max(fams, key=lambda n: fams[n]["time_share_of_step"])
         f0 = fams[dom]
-        roof = {"bound": "mfma", "kernel": dom, "achieved": f0["achieved"], "peak": peak,
+        roof = {"bound": "mfma", "kernel": dom,
+                "kernel_family": "all instantiations of the template; gemm_rowtile_kernel = the row-resident family "
+                                 "(plain, + SwiGLU forward / backward, + RoPE, + row maxima)",
+                "achieved": f0["achieved"], "peak": peak,
                 "unit": "TFLOP/s", "frac": f0["frac"], "traffic": f0["traffic"],
                 "launches": f0["launches"], "avg_launch_us": f0["avg_launch_us"],
                 "time_share_of_step": f0["time_share_of_step"],
                 "algorithmic_flop_per_launch": f0["algorithmic_flop_per_launch"],
-                "other_gemm_families": {n: fams[n] for n in names if n != dom},
+                "other_gemm_families": {n: fams[n] for n in fams if n != dom},
                 "fused_epilogue_gemms": None if fn.value == 0 else {
-                    "what": "gemm_rowres_kernel<EPI>: gate|up + SwiGLU forward, dh + SwiGLU backward, q|k|v + RoPE "
-                            "(the elementwise pass rides in the accumulator store; swiglu_rows_* kernels are gone)",
+                    "what": "the row-resident launches with a bandwidth pass in their store: gate|up + SwiGLU forward, "
+                            "dh + SwiGLU backward, q|k|v + RoPE (a SUBSET of the gemm_rowtile_kernel family above)",
                     "launches": fn.value, "avg_launch_us": 1e3 * fms.value / fn.value,
                     "achieved": tf(ffl.value, fms.value), "frac": tf(ffl.value, fms.value) / peak, "unit": "TFLOP/s",
                     "hbm_achieved_GBps": fby.value / (fms.value * 1e-3) / 1e9,
                     "hbm_frac": fby.value / (fms.value * 1e-3) / 8e12,
                     "algorithmic_bytes_per_launch": fby.value / fn.value,
-                    "traffic": traffic.get("gemm_rowres_kernel<EPI>"),
+                    "traffic": traffic.get("row_resident<EPI>"),
                     "time_share_of_step": fms.value * 1e-3 / dt},
                 "all_gemm": {"achieved": tf(sum(fl2) + ffl.value, sum(ms2) + fms.value),
                              "frac": tf(sum(fl2) + ffl.value, sum(ms2) + fms.value) / peak,
                              "time_share_of_step": (sum(ms2) + fms.value) * 1e-3 / dt},
+                "kernel_launches_per_step": {k: v / max(args.steps, 1) for k, v in kernel_counters(lib).items() if v},
                 "traffic_source": traffic.get("_source"), "traffic_source_sha12": traffic.get("_sha12"),
                 "traffic_stale": traffic.get("_stale")}
         roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic, opt if dp is None else None,

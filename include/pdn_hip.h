@@ -132,6 +132,16 @@ int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
 int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
+/* Launch counters per kernel: which kernel the entry points really launched since the last reset -- bench.py's parity
+ * gates and the tests assert on them (a dispatch that silently falls back to a slower kernel must not stay green).
+ * Copies min(n, 16) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
+ *   0 gemm_rowres_kernel (chunk kernel, any)      1 gemm_rowtile_kernel plain        2 ... + SwiGLU forward (gate | up)
+ *   3 ... + SwiGLU backward (dh)                  4 ... + RoPE (q | k | v)           5 ... + row maxima (lm_head forward)
+ *   6 gemm_rowres_kernel with a fused epilogue    7 attention_p forward (persistent) 8 attention_p backward (dQ + dK/dV)
+ *   9 resident attention forward                 10 resident attention backward     11 streaming attention (either direction)
+ *  12 lm_head input gradient + sum of exponentials (gemm_outres_kernel CE 2)        13 lm_head weight gradient, CE gradient inside
+ *  14 gemm_outres_kernel plain                   15 gemm_outres_tn_kernel plain */
+int pdn_kernel_counters(int64_t* out, int n, int reset);
 /* Round 5: which kernel the row-resident entry points below and above launch.  The tile-piece kernel
  * (csrc/gemm_rowtile.hip: one 32-column tile of B over the whole contraction per piece, rotating accumulator sets, stores
  * and epilogue reads drained under the next tile's MFMAs) takes a shape when every CU gets an 8-wave workgroup; the chunk

@@ -1,6 +1,7 @@
 // Library-level entry points of the pdnhip C ABI: error string, version, device queries.
 #include "common.h"
 #include <stdarg.h>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -38,5 +39,19 @@ extern "C" int pdn_device_info(int device, char* name, int cap, int* compute_uni
 
 extern "C" int pdn_stream_synchronize(void* stream) {
   PDN_HIP(hipStreamSynchronize((hipStream_t)stream));
+  return PDN_OK;
+}
+
+// Launch counters per kernel (slots: PDN_CNT_* in common.h, listed in include/pdn_hip.h).  Copies min(n, 16) counters
+// to `out` (may be null) and clears them when `reset` is non-zero.
+static std::atomic<int64_t> g_counters[PDN_CNT_SLOTS];
+void pdn_count(int slot) {
+  if (slot >= 0 && slot < PDN_CNT_SLOTS) g_counters[slot].fetch_add(1, std::memory_order_relaxed);
+}
+extern "C" int pdn_kernel_counters(int64_t* out, int n, int reset) {
+  for (int i = 0; i < PDN_CNT_SLOTS; ++i) {
+    const int64_t v = reset ? g_counters[i].exchange(0) : g_counters[i].load();
+    if (out && i < n) out[i] = v;
+  }
   return PDN_OK;
 }

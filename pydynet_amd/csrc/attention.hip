@@ -408,15 +408,19 @@ __global__ __launch_bounds__(512, 1) void attention_fwd_kernel(
     }
     mc = fmaxf(mc, __shfl_xor(mc, 32, 64));
     const float mn = fmaxf(m, mc);
+    // a query whose keys were ALL masked so far (key bias -inf over a whole leading chunk: a left-padded batch) has
+    // mn = -inf: exp2(-inf * c1 + inf) would be NaN and poison the row for good.  Its probabilities are exactly 0 against
+    // any finite reference point, so the exponent is taken against 0 until a finite score arrives.
+    const float msafe = mn == -INFINITY ? 0.f : mn;
     if (MULTI && c) {
       // online rescale of what the earlier chunks left (one per-lane scalar: a lane owns a query row of O^T)
-      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c1);
+      const float alpha = __builtin_amdgcn_exp2f((m - msafe) * c1);       // (m = -inf: 0, and nothing had been added)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
       lsum *= alpha;
     }
     m = mn;
-    const float c2 = -m * c1;
+    const float c2 = -msafe * c1;
     float lc = 0.f;
 #pragma unroll
     for (int kt = 0; kt < ATT_MAX_TILES; ++kt) {
@@ -544,6 +548,7 @@ static int att_fwd_impl(const float* q, const float* k, const float* v, float* o
   if (head_dim == 48) { if (multi) ATT_FWD(48, true); else ATT_FWD(48, false); }
   else { if (multi) ATT_FWD(64, true); else ATT_FWD(64, false); }
 #undef ATT_FWD
+  pdn_count(PDN_CNT_ATT_RES_FWD);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -939,6 +944,7 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
                      sq, causal, rope_cos, rope_sin, prerot, key_bias, kb_bs);                                            \
   PDN_LAUNCH_CHECK();
   const bool multi = L > ATT_CHUNK;
+  pdn_count(PDN_CNT_ATT_RES_BWD);
   if (head_dim == 48) { if (multi) { ATT_BWD(48, true) } else { ATT_BWD(48, false) } }
   else { if (multi) { ATT_BWD(64, true) } else { ATT_BWD(64, false) } }
 #undef ATT_BWD

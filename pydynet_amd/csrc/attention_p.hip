@@ -273,6 +273,7 @@ int pdn_attention_p_fwd(const float* q, const float* k, const float* v, float* o
   const int grid = BH < ap_num_cus() ? BH : ap_num_cus();
   hipLaunchKernelGGL((attention_p_fwd_kernel<HD>), dim3(grid), dim3(512), shm, (hipStream_t)stream, q, k, v, o, lse, BH, H, L,
                      row_stride, batch_stride, o_row_stride, o_batch_stride, sqrtf((float)head_dim), causal);
+  pdn_count(PDN_CNT_ATT_P_FWD);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
@@ -606,6 +607,7 @@ int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const fl
                      dv, BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos, rope_sin);   \
   PDN_LAUNCH_CHECK();
   if (rope_cos) { AP_BWD(true) } else { AP_BWD(false) }
+  pdn_count(PDN_CNT_ATT_P_BWD);
 #undef AP_BWD
   return PDN_OK;
 }

@@ -523,6 +523,7 @@ int pdn_attention_stream_fwd_f32(const float* q, const float* k, const float* v,
   AS_DISPATCH(head_dim, {
     auto kern = attn_fwd_stream_kernel<HD>;
     PDN_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(HD)));
+    pdn_count(PDN_CNT_ATT_STREAM);
     hipLaunchKernelGGL(kern, grid, dim3(256), stream_lds(HD), (hipStream_t)stream, q, k, v, o, lse, a);
   });
   PDN_LAUNCH_CHECK();
@@ -556,6 +557,7 @@ int pdn_attention_stream_bwd_f32(const float* q, const float* k, const float* v,
     auto kkv = attn_bwd_dkv_stream_kernel<HD>;
     PDN_HIP(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(HD)));
     PDN_HIP(hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stream_lds(HD)));
+    pdn_count(PDN_CNT_ATT_STREAM);
     hipLaunchKernelGGL(kq, dim3((Lq + 127) / 128, B * H), dim3(256), stream_lds(HD), st, q, k, v, o, d_o, lse, dq,
                        delta, a);
     hipLaunchKernelGGL(kkv, dim3((Lk + 127) / 128, B * H), dim3(256), stream_lds(HD), st, q, k, v, d_o, lse, delta,

@@ -18,6 +18,29 @@ enum {
 
 void pdn_set_error(const char* fmt, ...);
 
+// ---- kernel launch counters (include/pdn_hip.h: pdn_kernel_counters): which kernel an entry point really launched.
+// bench.py's parity gates and the tests read them -- a dispatch regression to a slower kernel must not stay green.
+enum {
+  PDN_CNT_ROWRES_CHUNK = 0,       // gemm_rowres_kernel (chunk kernel), any epilogue
+  PDN_CNT_ROWTILE_PLAIN = 1,      // gemm_rowtile_kernel<EPI 0>
+  PDN_CNT_ROWTILE_SWIGLU_FWD = 2, // EPI 1: gate | up + SwiGLU
+  PDN_CNT_ROWTILE_SWIGLU_BWD = 3, // EPI 2: dh + SwiGLU backward
+  PDN_CNT_ROWTILE_ROPE = 4,       // EPI 3: q | k | v + RoPE
+  PDN_CNT_ROWTILE_ROWMAX = 5,     // EPI 5: vocabulary projection + row maxima
+  PDN_CNT_ROWRES_CHUNK_EPI = 6,   // gemm_rowres_kernel with a fused epilogue (EPI 1 / 2 / 3 / 4 / 5)
+  PDN_CNT_ATT_P_FWD = 7,          // attention_p_fwd_kernel (persistent, DMA-staged)
+  PDN_CNT_ATT_P_BWD = 8,          // attention_p_bwd_dq / dkv kernels
+  PDN_CNT_ATT_RES_FWD = 9,        // attention_fwd_kernel (resident, chunked)
+  PDN_CNT_ATT_RES_BWD = 10,
+  PDN_CNT_ATT_STREAM = 11,        // attn_*_stream_kernel, forward or backward
+  PDN_CNT_CE_DX_DEFERRED = 12,    // gemm_outres_kernel<.., CE 2>: lm_head input gradient + sum of exponentials
+  PDN_CNT_CE_DW = 13,             // gemm_outres_tn_kernel with the cross-entropy gradient formed inside
+  PDN_CNT_OUTRES = 14,            // gemm_outres_kernel, plain
+  PDN_CNT_OUTRES_TN = 15,         // gemm_outres_tn_kernel, plain
+  PDN_CNT_SLOTS = 16
+};
+void pdn_count(int slot);
+
 #define PDN_CHECK_ARG(cond, ...)          \
   do {                                    \
     if (!(cond)) {                        \

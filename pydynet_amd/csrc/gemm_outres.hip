@@ -461,6 +461,7 @@ static int outres_launch(const float* A, const float* B, float* C, const float* 
   const int nw = nw_env ? nw_env : plan_nw;
   const int stage = stage_env >= 0 ? stage_env : 1;
   const dim3 grid((M + 32 * nw - 1) / (32 * nw), splits);
+  pdn_count(PDN_CNT_OUTRES);
 #define OR_LAUNCH(BT_, NW_, ST_, AB_) hipLaunchKernelGGL((gemm_outres_kernel<BT_, NW_, ST_, AB_>), grid, dim3(NW_ * 64), 0, st, p)
   if (ablate == 1 && b_trans) OR_LAUNCH(true, 4, 1, 1);
   else if (ablate == 2 && b_trans) OR_LAUNCH(true, 4, 1, 2);
@@ -568,6 +569,7 @@ int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const flo
   }
   const dim3 grid((M + 32 * nw - 1) / (32 * nw), splits);
   hipStream_t st = (hipStream_t)stream;
+  pdn_count(PDN_CNT_CE_DX_DEFERRED);
   if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, 2>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, 2>), grid, dim3(256), 0, st, p);
   PDN_LAUNCH_CHECK();
@@ -891,6 +893,7 @@ static int outres_tn_launch(OutResTnParams& p, int nw, bool ce, void* stream) {
   TN_EACH(TN_GO)
 #undef TN_GO
 #undef TN_EACH
+  pdn_count(ce ? PDN_CNT_CE_DW : PDN_CNT_OUTRES_TN);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -751,6 +751,8 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     RR_LAUNCH(false, 4, 0);
   }
 #undef RR_LAUNCH
+  pdn_count(PDN_CNT_ROWRES_CHUNK);
+  if (kind) pdn_count(PDN_CNT_ROWRES_CHUNK_EPI);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

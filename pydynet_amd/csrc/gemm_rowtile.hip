@@ -508,6 +508,7 @@ int pdn_rowtile_launch(const RowTileArgs& a, void* stream) {
     default: pdn_set_error("pdn_rowtile_launch: epilogue %d", a.epi); return PDN_EINVAL;
   }
 #undef RT_LAUNCH
+  pdn_count(a.epi == 0 ? PDN_CNT_ROWTILE_PLAIN : a.epi == 5 ? PDN_CNT_ROWTILE_ROWMAX : PDN_CNT_ROWTILE_PLAIN + a.epi);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
 }

@@ -204,6 +204,32 @@ class EmulatedLib:
 
     def pdn_gemm_rowtile_mode(self, mode): return 1       # (kernel selection only: results are bit-identical)
 
+    # -- launch counters per kernel (include/pdn_hip.h: pdn_kernel_counters): the emulated entry points count the kernel
+    #    the library would have launched for the same arguments (its dispatch rules restated), so the gates of bench.py
+    #    and the path assertions of the tests run without a GPU
+    def _count(self, slot):
+        self._counters = getattr(self, "_counters", [0] * 16)
+        self._counters[slot] += 1
+
+    def pdn_kernel_counters(self, out, n, reset):
+        c = getattr(self, "_counters", [0] * 16)
+        if out:
+            arr = ctypes.cast(out, ctypes.POINTER(ctypes.c_int64))
+            for i in range(min(int(n), 16)):
+                arr[i] = c[i]
+        if reset:
+            self._counters = [0] * 16
+        return 0
+
+    @staticmethod
+    def _rowtile_takes(M, pieces):
+        rb = (M + 255) // 256
+        return rb >= 192 or rb * pieces >= 256
+
+    @staticmethod
+    def _att_p(L, hd):                       # csrc/attention_p.hip: pdn_attention_p_supported
+        return hd == 48 and L % 32 == 0 and 32 <= L <= 256
+
     def pdn_gemm_rowres_supported(self, M, N, K, lda, ldb, ldc, b_trans):
         return int(K == 288 and N % 32 == 0 and N >= 96 and M >= 1 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K
                    and ldb >= (K if b_trans else N) and ldc >= N and 32 * ldc < (1 << 30))
@@ -251,6 +277,7 @@ class EmulatedLib:
         return (chunks + cpw - 1) // cpw
 
     def pdn_linear_rowmax_fwd_f32(self, x, w, bias, logits, rowmax, M, V, K, ldx, ldw, ldl, stream):
+        self._count(5 if self._rowtile_takes(M, V // 32) else 0)
         if not self.pdn_linear_rowmax_supported(M, V, K) or ldl % 4:
             return -2
         z = np.matmul(view(x, (M, K), (ldx, 1), np.float32), view(w, (K, V), (ldw, 1), np.float32))
@@ -291,6 +318,7 @@ class EmulatedLib:
         return s_ * rows * 289 * 4 if s_ > 1 else 0
 
     def pdn_linear_ce_dx_deferred_f32(self, logits, rowmax, parts, targets, gscale, W, dx, lse, rows, V, fin, ws, wsb, stream):
+        self._count(12)
         if not self.pdn_linear_ce_dx_deferred_supported(rows, V, fin):
             return -2
         if wsb < self.pdn_linear_ce_dx_deferred_workspace_bytes(rows, V, fin):
@@ -342,6 +370,7 @@ class EmulatedLib:
         return int(K == 288 and F % 96 == 0 and F >= 96 and M >= 1 and 64 * F < (1 << 29))
 
     def pdn_gateup_swiglu_fwd_f32(self, x, wg, w_stride, gu, h, M, F, K, ldx, stream):
+        self._count(2 if self._rowtile_takes(M, 2 * (F // 32)) else 6)
         if M == 0 or F == 0:
             return 0
         if not self.pdn_gateup_swiglu_supported(M, F, K) or w_stride % 4 or abs(w_stride) < K * F:
@@ -355,6 +384,7 @@ class EmulatedLib:
         return 0
 
     def pdn_swiglu_bwd_gemm_f32(self, dy, wd, gu, dgu, M, F, K, ldy, stream):
+        self._count(3 if self._rowtile_takes(M, F // 32) else 6)
         if M == 0 or F == 0:
             return 0
         if not self.pdn_gateup_swiglu_supported(M, F, K):
@@ -382,6 +412,7 @@ class EmulatedLib:
         return 0
 
     def pdn_qkv_rope_fwd_f32(self, x, wq, w_stride, qkv, rope, M, D, K, L, hd, ldx, stream):
+        self._count(4 if self._rowtile_takes(M, 3 * D // 32) else 6)
         if M == 0 or D == 0:
             return 0
         if not self.pdn_qkv_rope_supported(M, D, K, L, hd) or w_stride % 4:
@@ -661,6 +692,7 @@ class EmulatedLib:
 
     def pdn_linear_ce_backward_f32(self, x, ldx, logits, lse, targets, gscale, upstream, W, dx, dx_res, dW, dw_beta,
                                    dbias, db_beta, rows, V, fin, ws, wsb, stream):
+        self._count(13)
         if not self.pdn_linear_ce_supported(rows, V, fin):
             return -2
         a = np.array(flat(logits, rows * V).reshape(rows, V))
@@ -714,6 +746,7 @@ class EmulatedLib:
         return out
 
     def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn, stream):
+        self._count(7 if (not rc and self._att_p(L, hd)) else 9)
         if not self.pdn_attention_supported(L, hd):
             return -2
         Q, K, V = self._att_views([q, k, v], B, H, L, hd, rs, bs)
@@ -728,6 +761,7 @@ class EmulatedLib:
 
     def pdn_attention_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn,
                               ws, wsb, stream):
+        self._count(8 if (not rc and self._att_p(L, hd)) else 10)
         if not self.pdn_attention_supported(L, hd):
             return -2
         Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
@@ -750,6 +784,7 @@ class EmulatedLib:
         return view(kb, (B, 1, 1, L), (kbs, 0, 0, 1), np.float32)
 
     def pdn_attention_fwd_bias_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, ors, obs, causal, kb, kbs, stream):
+        self._count(9)
         if not self.pdn_attention_supported(L, hd):
             return -2
         Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
@@ -766,6 +801,7 @@ class EmulatedLib:
 
     def pdn_attention_bwd_bias_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, kb, kbs,
                                    ws, wsb, stream):
+        self._count(10)
         if not self.pdn_attention_supported(L, hd):
             return -2
         Q, K, V = [np.array(a) for a in self._att_views([q, k, v], B, H, L, hd, rs, bs)]
@@ -785,7 +821,8 @@ class EmulatedLib:
 
     def pdn_attention_bwd_rotated_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn,
                                       ws, wsb, stream):
-        """q, k already rotated: nothing rotated on the way in, dq / dk rotated back on the way out."""
+        """q, k already rotated: nothing rotated on the way in, dq / dk rotated back on the way out.
+        (counted by the plain backward it is stated with: rotation-free operands)"""
         if not self.pdn_attention_supported(L, hd):
             return -2
         rc2 = self.pdn_attention_bwd_f32(q, k, v, o, do, lse, dq, dk, dv, B, H, L, hd, rs, bs, ors, obs, causal, None, None,
@@ -812,6 +849,7 @@ class EmulatedLib:
 
     def pdn_attention_stream_fwd_f32(self, q, k, v, o, lse, B, H, Lq, Lk, hd, qrs, qbs, krs, kbs, causal, start,
                                      mask, sb, sh, sq, sk, rc, rsn, stream):
+        self._count(11)
         if not self.pdn_attention_stream_supported(hd) or (rc and start):
             return -2
         Q, O = [view(p, (B, H, Lq, hd), (qbs, hd, qrs, 1), np.float32) for p in (q, o)]
@@ -827,6 +865,7 @@ class EmulatedLib:
 
     def pdn_attention_stream_bwd_f32(self, q, k, v, o, do, lse, dq, dk, dv, B, H, Lq, Lk, hd, qrs, qbs, krs, kbs,
                                      causal, start, mask, sb, sh, sq, sk, rc, rsn, ws, wsb, stream):
+        self._count(11)
         if not self.pdn_attention_stream_supported(hd) or (rc and start):
             return -2
         qv = lambda p: view(p, (B, H, Lq, hd), (qbs, hd, qrs, 1), np.float32)

@@ -532,6 +532,44 @@ def test_fused_attention_key_bias(hip, B, H, L, causal, hd, shared):
         assert not got_dk[b][masked[b if not shared else 0]].any() and not got_dv[b][masked[b if not shared else 0]].any()
 
 
+@pytest.mark.parametrize("L,hd,pad", [(512, 48, 256), (768, 64, 300), (1024, 48, 520)])
+def test_fused_attention_left_padded_batch_is_finite(hip, L, hd, pad):
+    """A LEFT-padded batch: the first `pad` >= 256 keys of a row carry -inf, i.e. the whole first 256-key chunk of the
+    chunked resident kernel is masked and its running maximum is still -inf when the first finite score arrives (ADVICE
+    round 4: exp2(-inf * c + inf) = NaN poisoned the row).  The reference -- softmax over the full row,
+    nn/functional.py:43-49 with the (B, 1, 1, L) mask of examples/pydynet/transformer.py:92-96 -- is finite."""
+    from pydynet_amd import _lib
+    Lb = _lib.lib()
+    B, H = 2, 2
+    rng = np.random.default_rng(L + pad)
+    q, k, v, do = (rng.standard_normal((B, L, H, hd), dtype=np.float32) for _ in range(4))
+    kb = np.zeros((B, L), np.float32)
+    kb[0, :pad] = -np.inf                          # sequence 0: left padding over more than one chunk
+    kb[1, :7] = -np.inf                            # sequence 1: a few pad tokens only
+    Q, K, V, DO, KB = map(hip.from_numpy, (q, k, v, do, kb))
+    o, dq, dk, dv = (hip.empty((B, L, H, hd)) for _ in range(4))
+    lse = hip.empty((B, H, L))
+    Lb.call("pdn_attention_fwd_bias_f32", Q._ptr, K._ptr, V._ptr, o._ptr, lse._ptr, B, H, L, hd, H * hd, L * H * hd,
+            H * hd, L * H * hd, 0, KB._ptr, L, hip.stream())
+    q64, k64, v64, g64 = (a.astype(np.float64).transpose(0, 2, 1, 3) for a in (q, k, v, do))
+    s = q64 @ k64.swapaxes(-1, -2) / math.sqrt(hd) + kb.astype(np.float64)[:, None, None, :]
+    m = s.max(-1, keepdims=True)
+    e = np.exp(s - m)
+    p = e / e.sum(-1, keepdims=True)
+    assert np.isfinite(o.get()).all() and np.isfinite(lse.get()).all()
+    assert rel_err(o.get(), (p @ v64).transpose(0, 2, 1, 3)) < 2e-5
+    assert np.allclose(lse.get(), (m + np.log(e.sum(-1, keepdims=True)))[..., 0], rtol=1e-5, atol=1e-5)
+    ws, wsb = hip.workspace(Lb.query("pdn_attention_bwd_workspace_bytes", B, H, L))
+    Lb.call("pdn_attention_bwd_bias_f32", Q._ptr, K._ptr, V._ptr, o._ptr, DO._ptr, lse._ptr, dq._ptr, dk._ptr, dv._ptr,
+            B, H, L, hd, H * hd, L * H * hd, H * hd, L * H * hd, 0, KB._ptr, L, ws, wsb, hip.stream())
+    dp = g64 @ v64.swapaxes(-1, -2)
+    ds = p * (dp - (dp * p).sum(-1, keepdims=True)) / math.sqrt(hd)
+    for got, ref in ((dv, p.swapaxes(-1, -2) @ g64), (dq, ds @ k64), (dk, ds.swapaxes(-1, -2) @ q64)):
+        assert np.isfinite(got.get()).all()
+        assert rel_err(got.get(), ref.transpose(0, 2, 1, 3)) < 5e-5
+    assert not dk.get()[0, :pad].any() and not dv.get()[0, :pad].any()       # padded keys receive no gradient
+
+
 @pytest.mark.parametrize("B,H,L,causal,hd,with_mask,kind", [(2, 2, 50, 0, 64, False, "stream"),   # CLIP vision: 49 patches + class token
                                                             (2, 2, 77, 1, 64, False, "stream"),   # CLIP text
                                                             (3, 4, 64, 0, 48, True, "resident"),
