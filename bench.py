@@ -402,6 +402,36 @@ def hbm_kernels(lib, hp, B, traffic, opt=None, nparams=0):
     return out
 
 
+def other_configs(*release):
+    """BASELINE.json configs 2 and 3 (MLP / LeNet at the reference's batch 256 and at a chip-filling batch), the GRU of
+    examples/pydynet/ts_prediction.py and KV-cache greedy decode, each a SHORT run of `bench.py --config ...` (same code:
+    bench_other.py -- parity gate against the oracle first, then timed steps, roofline of the dominant kernel) inside the
+    default run, so that whoever runs the headline command also holds these numbers.  Not part of `value`; a failure
+    here is recorded, never raised (the headline line must still be printed)."""
+    import argparse as _ap
+    import gc
+    import bench_other
+    from pydynet_amd.core.tensor import Graph
+    del release
+    gc.collect()
+    res = {}
+    runs = (("mlp_b256", "mlp", 256, 200, 20), ("mlp_b65536", "mlp", 65536, 20, 3), ("lenet_b256", "lenet", 256, 200, 20),
+            ("lenet_b4096", "lenet", 4096, 50, 5), ("gru", "gru", 0, 100, 10), ("decode", "decode", 0, 200, 20))
+    for key, cfg, batch, steps, warmup in runs:
+        a = _ap.Namespace(config=cfg, batch=batch, steps=steps, warmup=warmup, no_graph=False, no_cpu_baseline=True, gpus=1)
+        try:
+            Graph.clear()
+            fn = {"mlp": lambda: bench_other.run_train(a, "mlp"), "lenet": lambda: bench_other.run_train(a, "lenet"),
+                  "gru": lambda: bench_other.run_gru(a), "decode": lambda: bench_other.run_decode(a)}[cfg]
+            r = fn()
+            r.pop("memory", None)
+            res[key] = r
+        except BaseException as e:                       # (SystemExit of a failed gate included)
+            res[key] = {"error": f"{type(e).__name__}: {e}"}
+        gc.collect()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -420,6 +450,9 @@ def main():
                          "the JSON line then carries parity_gate = null")
     ap.add_argument("--no-batch-gate", action="store_true",
                     help="skip the parity check of the timed batch against the single-sequence path")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE configs 2 / 3 (MLP, LeNet), the GRU and greedy decode that the "
+                         "default single-GPU line carries in `other_configs`")
     args = ap.parse_args()
 
     if args.config != "llama":
@@ -629,6 +662,8 @@ def main():
                                "the rest overlaps backward"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if rank == 0 and world == 1 and not args.no_other_configs and not force_dp:
+        out["other_configs"] = other_configs(model, opt, dp)
     # RCCL writes a version banner through C stdio (block-buffered when piped): every rank pushes its
     # own out, then all ranks meet, and only then rank 0 prints -- the JSON record stays the last line
     try:

@@ -113,6 +113,41 @@ def _gemm_roofline(lib, step, hp, n=5):
                          "ms_per_step": tot_ms / n}}
 
 
+def _launch_floor_us(hp, lib, nodes=64, replays=20):
+    """What ONE dependent kernel launch costs when there is nothing to compute: a chain of `nodes` one-element fills on the
+    compute stream, captured and replayed as a hipGraph (how the launch-bound steps here are issued).  A step of n
+    launches cannot take less than n x this, whatever its kernels do -- the roof of a latency-bound line."""
+    buf = hp.zeros((64,), np.float32)
+    shape, strides = (ctypes.c_int64 * 1)(1), (ctypes.c_int64 * 1)(1)
+
+    def chain():
+        for _ in range(nodes):
+            lib.call("pdn_fill", 0, 1.0, 1, shape, buf._ptr, strides, hp.stream())
+    chain()
+    hp.synchronize()
+    g = hp.Graph()
+    g.capture(chain)
+    g.replay()
+    hp.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        g.replay()
+    hp.synchronize()
+    us = (time.perf_counter() - t0) / (replays * nodes) * 1e6
+    g.destroy()
+    return us
+
+
+def _latency_roof(hp, lib, launches, step_us, what):
+    """Roofline block of a step that is bound by its chain of dependent launches, not by a throughput roof."""
+    floor = _launch_floor_us(hp, lib)
+    return {"bound": "latency", "what": what, "launches_per_step": launches, "per_launch_floor_us": floor,
+            "floor_us_per_step": launches * floor, "measured_us_per_step": step_us, "unit": "us",
+            "achieved": step_us, "peak": launches * floor, "frac": launches * floor / max(step_us, 1e-9), "traffic": None,
+            "note": "frac = (launches x measured cost of an empty dependent launch) / measured step: 1.0 would be a step "
+                    "whose kernels cost nothing; a throughput roof (HBM, MFMA) says nothing about these lines"}
+
+
 def _event_time_us(hp, fn, n=10):
     fn()
     hp.synchronize()
@@ -156,6 +191,10 @@ def run_train(args, which):
     roof = _gemm_roofline(lib, step, hp)
     if which == "lenet":
         roof = dict(_conv_roofline(lib, hp, B), gemm=roof)
+    if use_graph and nodes:
+        # launch-bound at this batch: the informative roof is the launch chain (the GEMM block stays beside it)
+        roof = dict(_latency_roof(hp, lib, int(nodes), 1e6 * dt / args.steps, "whole step replayed as one hipGraph"),
+                    dominant_gemm=roof)
     out = {
         "metric": f"training-step samples/sec ({'3-layer MLP 784-1024-1024-10' if which == 'mlp' else 'LeNet, 3x32x32 inputs'})",
         "value": value, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -372,10 +411,19 @@ def run_gru(args):
                                              rh._ptr, nn_._ptr, outb._ptr, T_, B, Hd, hp.stream()))
     nbytes = 4.0 * T_ * B * Hd * (3 + 5)                      # reads the hoisted projections (3 H), writes z, r, rh, n, out
     flops = 2.0 * T_ * B * Hd * 3 * Hd
-    roof = {"bound": "hbm", "kernel": "gru_seq_fwd_kernel (gru_seq.hip)", "achieved": nbytes / (us * 1e-6) / 1e9,
-            "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": nbytes / (us * 1e-6) / PEAK_HBM, "traffic": None,
-            "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
-            "note": f"a {T_}-step recurrence: latency-bound by construction ({flops / (us * 1e-6) / 1e12:.2f} TFLOP/s of recurrent MFMA work)"}
+    seq = {"kernel": "gru_seq_fwd_kernel (gru_seq.hip)", "avg_launch_us": us, "algorithmic_bytes_per_launch": nbytes,
+           "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
+           "note": f"a {T_}-step recurrence ({flops / (us * 1e-6) / 1e12:.2f} TFLOP/s of recurrent MFMA work): {T_} dependent "
+                   "steps of 48 MFMAs inside ONE launch -- neither an HBM nor an MFMA roof applies"}
+    try:
+        gcount = hp.Graph()
+        gcount.capture(step)
+        launches = int(gcount.nodes)
+        gcount.destroy()
+    except Exception:
+        launches = 0
+    roof = dict(_latency_roof(hp, lib, launches, 1e6 * dt / args.steps, "eager launches of one training step"),
+                sequence_kernel=seq)
     out = {"metric": "training-step sequences/sec (GRU 1->32, T=40, ts_prediction.py)", "value": value, "unit": "sequences/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -518,15 +566,19 @@ def run_decode(args):
                                              head.weight.data._ptr, V, V, 0, head.bias.data._ptr, None, 0, lg._ptr, V,
                                              B, D, V, 0, 0, 0, None, None, hp.stream()), n=50)
     hb = 4.0 * (D * V + V + B * D + B * V)
-    roof = {"bound": "hbm", "kernel": "decode_gemv_kernel<64, 1, 18, true> (lm_head, decode.hip)", "achieved": hb / (us * 1e-6) / 1e9,
-            "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": hb / (us * 1e-6) / PEAK_HBM, "traffic": None,
-            "avg_launch_us": us, "algorithmic_bytes_per_launch": hb,
-            "whole_step": {"algorithmic_weight_bytes_per_token": wbytes, "achieved_GBps": wbytes * value / B / 1e9,
-                           "frac_of_hbm_peak": wbytes * value / B / PEAK_HBM,
-                           "note": "the 61 MB of weights sit in the 256 MiB Infinity Cache after the first token; a "
-                                   "token is 2 launches per block + 2 = 14 dependent launches replayed as one hipGraph "
-                                   "(latency chain: DESIGN.md 4.10, profiles/*_decode_trace.txt), the next step queued "
-                                   "while the host polls the mapped mailbox slot the pick kernel stored the token into"}}
+    st = getattr(model, "_decode_st", None) or {}
+    graphs = st.get("graphs") or {}
+    per_token = max([int(g.nodes) for g in graphs.values() if g] or [0])
+    roof = dict(_latency_roof(hp, lib, per_token, 1e6 * dt / max(produced, 1),
+                              "one token = a chain of dependent launches replayed as one hipGraph"),
+                vocabulary_projection={"kernel": "decode_gemv_kernel<64, 1, 18, true> (lm_head, decode.hip)", "avg_launch_us": us,
+                                       "algorithmic_bytes_per_launch": hb, "achieved_GBps": hb / (us * 1e-6) / 1e9},
+                whole_step={"algorithmic_weight_bytes_per_token": wbytes, "achieved_GBps": wbytes * value / B / 1e9,
+                            "frac_of_hbm_peak": wbytes * value / B / PEAK_HBM,
+                            "note": "the 61 MB of weights sit in the 256 MiB Infinity Cache after the first token; a "
+                                    "token is 2 launches per block + 2 = 14 dependent launches replayed as one hipGraph "
+                                    "(latency chain: DESIGN.md 4.10, profiles/*_decode_trace.txt), the next step queued "
+                                    "while the host polls the mapped mailbox slot the pick kernel stored the token into"})
     out = {"metric": "greedy decode tokens/sec (6L Llama3, KV cache, batch 1)", "value": value, "unit": "tokens/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / produced,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
