@@ -188,7 +188,8 @@ int pdn_linear_rowmax_parts(int64_t M, int V, int K);      /* vectors of M maxim
 int pdn_linear_rowmax_fwd_f32(const float* x, const float* w, const float* bias, float* logits, float* rowmax, int M,
                               int V, int K, int64_t ldx, int64_t ldw, int64_t ldl, void* stream);
 int pdn_linear_ce_dx_deferred_supported(int64_t rows, int V, int in_features);
-int64_t pdn_linear_ce_dx_deferred_workspace_bytes(int64_t rows, int V, int in_features);
+int64_t pdn_linear_ce_dx_deferred_workspace_bytes(int64_t rows, int V, int in_features);   /* a W^T copy (V x 288: the rows W[:, target]
+                                                                                             * are read from it) + the range slabs of few-row launches */
 int pdn_linear_ce_dx_deferred_f32(const float* logits, const float* rowmax, int max_parts, const int64_t* targets,
                                   float gscale, const float* W, float* dx, float* lse, int64_t rows, int V,
                                   int in_features, void* workspace, int64_t workspace_bytes, void* stream);

@@ -57,6 +57,9 @@ struct OutResParams {
   int max_parts;                  // the row maxima come as `max_parts` vectors of M (the projection's chunk ranges)
   float* zslab;                   // K split over grid.y: split y leaves its UNNORMALISED rows in slab y and its row sums in
                                   // zslab + y * M; outres_ce2_reduce_kernel normalises
+  const float* Wt;                // CE 2: W^T (V x 288) row-major -- the rows W[:, target] of the normalising store are read as
+                                  // 1152 contiguous bytes per token (from W itself they are 288 floats 4 V bytes apart: one
+                                  // 64-byte sector each, 2.1 GB of extra HBM reads per step at the benchmark shape)
 };
 
 // gradient of the mean cross entropy w.r.t. one logit
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
     if (lh == 0 && m0 + li < p.M) p.lse_out[m0 + li] = ce_m + __logf(z);
     const int mrem2 = p.M - m0;
     float* __restrict__ Cw = p.C + (int64_t)m0 * p.ldc + li;
-    const float* __restrict__ Wc = p.B + (unsigned)li * ldb;
+    const float* __restrict__ Wc = p.Wt + li;
     const float sc = p.gscale;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
       if (rho < mrem2) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
-          const float wt = Wc[(unsigned)(32 * j) * ldb + (unsigned)tg];
+          const float wt = Wc[(unsigned)tg * (unsigned)OR_N + 32 * j];
           Cw[(unsigned)rho * (unsigned)p.ldc + 32 * j] = sc * (acc[j][r] * iz - wt);
         }
       }
@@ -567,16 +570,29 @@ __global__ __launch_bounds__(256) void outres_ce2_reduce_kernel(const float* __r
   }
   const int t = min(max((int)targets[row], 0), V - 1);
   const float iz = 1.f / z;
-  const float* __restrict__ wt = W + (int64_t)(4 * c4) * ldw + t;
+  const float4 wt = *reinterpret_cast<const float4*>(W + (int64_t)t * OR_N + 4 * c4);      // W = the transposed copy (V x 288)
   float4 o;
-  o.x = gscale * (a.x * iz - wt[0]); o.y = gscale * (a.y * iz - wt[ldw]);
-  o.z = gscale * (a.z * iz - wt[2 * ldw]); o.w = gscale * (a.w * iz - wt[3 * ldw]);
+  o.x = gscale * (a.x * iz - wt.x); o.y = gscale * (a.y * iz - wt.y);
+  o.z = gscale * (a.z * iz - wt.z); o.w = gscale * (a.w * iz - wt.w);
   *reinterpret_cast<float4*>(dx + (int64_t)row * ldc + 4 * c4) = o;
   if (c4 == 0) {
     float m = rowmax[row];
     for (int q = 1; q < max_parts; ++q) m = fmaxf(m, rowmax[(int64_t)q * M + row]);
     lse_out[row] = m + __logf(z);
   }
+}
+
+// Wt (V x 288) = W^T for W (288 x V, leading dimension ldw): 32 x 32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void outres_wt_transpose_kernel(const float* __restrict__ W, int64_t ldw, int V,
+                                                                  float* __restrict__ Wt) {
+  __shared__ float tile[32][33];
+  const int v0 = blockIdx.x * 32, k0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = (v0 + tx < V) ? W[(int64_t)(k0 + r) * ldw + v0 + tx] : 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int r = ty; r < 32; r += 8)
+    if (v0 + r < V) Wt[(int64_t)(v0 + r) * OR_N + k0 + tx] = tile[tx][r];
 }
 
 extern "C" int pdn_linear_ce_dx_deferred_supported(int64_t M, int V, int K) {
@@ -587,7 +603,8 @@ extern "C" int64_t pdn_linear_ce_dx_deferred_workspace_bytes(int64_t M, int V, i
   if (!pdn_linear_ce_dx_deferred_supported(M, V, K)) return 0;
   int nw, kps;
   const int splits = pdn_gemm_outres_plan((int)M, V, &nw, &kps);
-  return splits > 1 ? (int64_t)splits * M * (OR_N + 1) * 4 : 0;
+  // [W^T copy: V x 288] then, when the vocabulary is cut into ranges, [splits x M x 288 rows | splits x M row sums]
+  return (int64_t)V * OR_N * 4 + (splits > 1 ? (int64_t)splits * M * (OR_N + 1) * 4 : 0);
 }
 int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const float* rowmax, int max_parts,
                                      const int64_t* targets, float gscale, const float* W, int64_t ldw, float* dx,
@@ -598,16 +615,21 @@ int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const flo
   p.max_parts = max_parts;
   int nw = 8, kps = V / OR_KP;
   const int splits = pdn_gemm_outres_plan(M, V, &nw, &kps);
+  const int64_t wt_floats = (int64_t)V * OR_N;
+  PDN_CHECK_ARG(workspace && workspace_bytes >= wt_floats * 4 + (splits > 1 ? (int64_t)splits * M * (OR_N + 1) * 4 : 0) &&
+                    (((uintptr_t)workspace | (uintptr_t)dx) & 15) == 0 && (ldc & 3) == 0,
+                "pdn_linear_ce_dx_deferred_f32: workspace too small or misaligned");
+  float* Wt = (float*)workspace;
+  p.Wt = Wt;
   if (splits > 1) {
-    PDN_CHECK_ARG(workspace && workspace_bytes >= (int64_t)splits * M * (OR_N + 1) * 4 && (((uintptr_t)workspace | (uintptr_t)dx) & 15) == 0 &&
-                      (ldc & 3) == 0,
-                  "pdn_linear_ce_dx_deferred_f32: workspace too small or misaligned");
     p.kps = kps;
-    p.slab = (float*)workspace;
+    p.slab = Wt + wt_floats;
     p.zslab = p.slab + (int64_t)splits * M * OR_N;
   }
   const dim3 grid((M + 32 * nw - 1) / (32 * nw), splits);
   hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(outres_wt_transpose_kernel, dim3((V + 31) / 32, OR_N / 32), dim3(256), 0, st, W, ldw, V, Wt);
+  PDN_LAUNCH_CHECK();
   pdn_count(PDN_CNT_CE_DX_DEFERRED);
   if (nw == 8) hipLaunchKernelGGL((gemm_outres_kernel<true, 8, 1, 0, 2>), grid, dim3(512), 0, st, p);
   else hipLaunchKernelGGL((gemm_outres_kernel<true, 4, 1, 0, 2>), grid, dim3(256), 0, st, p);
@@ -615,7 +637,7 @@ int pdn_outres_ce_dx_deferred_launch(const float* logits, int64_t ldl, const flo
   if (splits > 1) {
     const int64_t n4 = (int64_t)M * (OR_N / 4);
     hipLaunchKernelGGL(outres_ce2_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p.slab, p.zslab, splits, M,
-                       rowmax, max_parts, targets, W, ldw, V, gscale, dx, ldc, lse_out);
+                       rowmax, max_parts, targets, Wt, ldw, V, gscale, dx, ldc, lse_out);
     PDN_LAUNCH_CHECK();
   }
   return PDN_OK;

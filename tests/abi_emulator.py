@@ -315,7 +315,7 @@ class EmulatedLib:
 
     def pdn_linear_ce_dx_deferred_workspace_bytes(self, rows, V, fin):
         s_ = self._outres_splits(rows, V)
-        return s_ * rows * 289 * 4 if s_ > 1 else 0
+        return V * 288 * 4 + (s_ * rows * 289 * 4 if s_ > 1 else 0)       # W^T copy, then the range slabs
 
     def pdn_linear_ce_dx_deferred_f32(self, logits, rowmax, parts, targets, gscale, W, dx, lse, rows, V, fin, ws, wsb, stream):
         self._count(12)
