@@ -132,6 +132,17 @@ int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
 int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
 int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias, const float* residual,
                         int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans, void* stream);
+/* Round 5: the two projections above with the RMSNorm IN FRONT of them folded into the A load (nn/modules/norm.py:221-248
+ * feeding llm/llama/model.py:56-58, 93-104): x = the rows before the norm; the wave that holds 32 rows of x in registers forms
+ * their rms, normalises in place, multiplies the normalised rows and leaves xn (M x K) = x / sqrt(mean(x^2) + eps) * norm_w and
+ * rms (M) for the backward -- the norm's own pass over the activation is gone.  Tile-piece kernel only: `*_norm_supported`. */
+int pdn_gateup_swiglu_norm_supported(int M, int F, int K);
+int pdn_gateup_swiglu_norm_fwd_f32(const float* x, const float* norm_w, float eps, float* xn, float* rms, const float* w_gate,
+                                   int64_t w_stride, float* gu, float* h, int M, int F, int K, int64_t ldx, void* stream);
+int pdn_qkv_rope_norm_supported(int M, int D, int K, int L, int hd);
+int pdn_qkv_rope_norm_fwd_f32(const float* x, const float* norm_w, float eps, float* xn, float* rms, const float* wq,
+                              int64_t w_stride, float* qkv, const float* rope, int M, int D, int K, int L, int hd,
+                              int64_t ldx, void* stream);
 /* Launch counters per kernel: which kernel the entry points really launched since the last reset -- bench.py's parity
  * gates and the tests assert on them (a dispatch that silently falls back to a slower kernel must not stay green).
  * Copies min(n, 16) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:

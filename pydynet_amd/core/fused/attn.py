@@ -8,6 +8,7 @@ import os
 
 import numpy as np
 
+from .norm import rms_norm
 from ..tensor import Tensor, _Operator
 from ._common import _hip, _L, _contig, _require_f32, _beside, _is_leaf_f32, _dx_of_shared_input
 
@@ -275,7 +276,6 @@ class qkv_attention(_Operator):
         hp, L = _hip(), _L()
         B, Lq, D = x.shape
         H, hd, T = self.H, D // self.H, B * Lq
-        x2 = _contig(x.data).reshape(T, D)
         qkv = hp.empty((T, 3 * D), np.float32)
         blocks = self._blocks(qkv, T, D)
         ws = [_contig(w.data) for w in (wq, wk, wv)]
@@ -288,7 +288,21 @@ class qkv_attention(_Operator):
                             and abs(stack._strides[0]) < (1 << 40)
                             and T >= qkv_attention.rope_min_rows
                             and L.query("pdn_qkv_rope_supported", T, D, D, Lq, hd))
-        if self.rotated:
+        # a still-deferred RMSNorm in front (fused.rms_norm): its rows are normalised in this projection's A load
+        self.norm_folded = bool(self.rotated and isinstance(x, rms_norm) and x._pending is not None
+                                and L.query("pdn_qkv_rope_norm_supported", T, D, D, Lq, hd))
+        if self.norm_folded:
+            raw_t, wn = x._pending
+            raw = _contig(raw_t.data)
+            xn, rms = hp.empty(x.shape, np.float32), hp.empty((T,), np.float32)
+            tab = self._rope_table(cos, sin, Lq, hd)
+            L.call("pdn_qkv_rope_norm_fwd_f32", raw._ptr, _contig(wn.data)._ptr, x.eps, xn._ptr, rms._ptr, ws[0]._ptr,
+                   (ws[1]._ptr - ws[0]._ptr) // 4, qkv._ptr, tab._ptr, T, D, D, Lq, hd, D, hp.stream())
+            x._adopt(raw, rms, xn)
+        x2 = _contig(x.data).reshape(T, D)
+        if self.norm_folded:
+            pass
+        elif self.rotated:
             tab = self._rope_table(cos, sin, Lq, hd)
             L.call("pdn_qkv_rope_fwd_f32", x2._ptr, ws[0]._ptr, (ws[1]._ptr - ws[0]._ptr) // 4, qkv._ptr, tab._ptr,
                    T, D, D, Lq, hd, D, hp.stream())

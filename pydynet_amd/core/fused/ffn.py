@@ -7,6 +7,7 @@ import os
 
 import numpy as np
 
+from .norm import rms_norm
 from ..tensor import _Operator
 from ._common import (_hip, _L, _contig, _require_f32, _foldable, _beside, _is_leaf_f32, _pack_columns, _dx_of_shared_input)
 
@@ -130,14 +131,26 @@ class ffn_swiglu(_Operator):
         _require_f32(self, x, wg, wu, wd, r)
         hp, L = _hip(), _L()
         fin, F = wg.shape
-        x2 = _contig(x.data).reshape(-1, fin)
-        T = x2.shape[0]
+        T = x.size // fin
         gu = hp.empty((T, 2 * F), np.float32)
         h = hp.empty((T, F), np.float32)
         ws = [_contig(wg.data), _contig(wu.data)]
         stack = hp.stacked_view(ws)
         self.used_epilogue = self._epilogue(T, F, fin, stack)
-        if self.used_epilogue:
+        # a still-deferred RMSNorm in front (fused.rms_norm): its rows are normalised in the gate | up projection's A load
+        self.norm_folded = bool(self.used_epilogue and isinstance(x, rms_norm) and x._pending is not None
+                                and L.query("pdn_gateup_swiglu_norm_supported", T, F, fin))
+        if self.norm_folded:
+            raw_t, wn = x._pending
+            raw = _contig(raw_t.data)
+            xn, rms = hp.empty(x.shape, np.float32), hp.empty((T,), np.float32)
+            L.call("pdn_gateup_swiglu_norm_fwd_f32", raw._ptr, _contig(wn.data)._ptr, x.eps, xn._ptr, rms._ptr, ws[0]._ptr,
+                   (ws[1]._ptr - ws[0]._ptr) // 4, gu._ptr, h._ptr, T, F, fin, fin, hp.stream())
+            x._adopt(raw, rms, xn)
+        x2 = _contig(x.data).reshape(-1, fin)
+        if self.norm_folded:
+            pass
+        elif self.used_epilogue:
             L.call("pdn_gateup_swiglu_fwd_f32", x2._ptr, ws[0]._ptr, (ws[1]._ptr - ws[0]._ptr) // 4, gu._ptr, h._ptr,
                    T, F, fin, fin, hp.stream())
         else:

@@ -4,18 +4,38 @@ from __future__ import annotations
 
 import numpy as np
 
+import os
+
+from ...autograd import is_grad_enable
 from ..tensor import _Operator
-from ._common import _hip, _L, _contig, _require_f32, _foldable, _is_leaf_f32
+from ._common import _hip, _L, _contig, _require_f32, _foldable, _is_leaf_f32, _Deferred
 
 
-class rms_norm(_Operator):
-    """y = x / sqrt(mean(x^2, -1) + eps) * w   (w 1-D over the last axis)."""
+class rms_norm(_Deferred, _Operator):
+    """y = x / sqrt(mean(x^2, -1) + eps) * w   (w 1-D over the last axis).
+
+    Round 5: on the HIP device, at the model width the row-resident projection kernels hold in registers (288) and with
+    enough rows for them, the node is DEFERRED (`_Deferred`): a `qkv_attention` / `ffn_swiglu` node that consumes it
+    normalises the rows inside its projection's A load (`pdn_*_norm_fwd_f32`) and hands this node its output and the rows'
+    rms (`_adopt`); any other consumer reads `.data`, which runs the node's own kernel then.  Backward is unchanged."""
 
     folds_existing = True
+    fold = os.environ.get("PDN_NO_NORM_FOLD", "0") != "1"        # (same-box A/B switch)
+    fold_min_rows = 4096
 
     def __init__(self, x, weight, eps=1e-6):
         self.eps = float(eps)
-        super().__init__(x, weight)
+        if (rms_norm.fold and type(self) is rms_norm and x.device.is_hip and is_grad_enable()
+                and x.dtype == np.float32 and weight.dtype == np.float32 and x.ndim >= 2 and x.shape[-1] == 288
+                and weight.shape == (288,) and x.size // 288 >= rms_norm.fold_min_rows):
+            self._init_deferred((x, weight), x.shape, np.float32)
+        else:
+            super().__init__(x, weight)
+
+    def _adopt(self, raw, rms, out):
+        """A consumer's projection kernel formed this node's output: `raw` = the contiguous input rows it read."""
+        self._x, self._rms = raw, rms
+        self.data = out                     # (no longer pending: an ordinary node from here on)
 
     def forward_(self, x, w):
         if self.xp is np:

@@ -662,6 +662,8 @@ struct RowResEpi {
   unsigned g_off = 0, u_off = 0;              // 1
   float* lse = nullptr;                       // 4, 5
   int parts = 0;                              // 5, plan only (lse == nullptr): the number of chunk ranges = vectors of maxima
+  // RMSNorm folded into the A load (kinds 1 and 3, tile-piece kernel only): norm weight, eps, outputs y (M x 288) and rms (M)
+  const float* norm_w = nullptr; float* xn = nullptr; float* rms = nullptr; int64_t ldxn = 0; float norm_eps = 0.f;
 };
 
 static int rowres_launch(const float* A, const float* B, float* C, const float* bias, const float* residual, int M,
@@ -688,8 +690,13 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
       ta.H = epi->H; ta.ldh = epi->ldh; ta.GU = epi->GU; ta.F = epi->F; ta.rope = epi->rope; ta.L = epi->L; ta.hd = epi->hd;
       ta.rope_cols = epi->rope_cols; ta.g_off = epi->g_off; ta.u_off = epi->u_off; ta.lse = epi->lse;
       ta.parts = &const_cast<RowResEpi*>(epi)->parts;
+      ta.norm_w = epi->norm_w; ta.xn = epi->xn; ta.rms = epi->rms; ta.ldxn = epi->ldxn; ta.norm_eps = epi->norm_eps;
     }
     if (pdn_rowtile_takes(ta)) return pdn_rowtile_launch(ta, stream);
+  }
+  if (epi && epi->norm_w) {
+    pdn_set_error("row-resident projection with the RMSNorm folded in: only the tile-piece kernel has it (M=%d too small)", M);
+    return PDN_EUNSUPPORTED;
   }
   RowResParams p{A, B, C, bias, residual, M, N, lda, ldb, ldc, (N + RR_NC - 1) / RR_NC, 0, 0, b_block_stride};
   p.cpb = nblocks > 1 ? nper / RR_NC : p.chunks;
@@ -781,6 +788,38 @@ extern "C" int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, in
   pdn_gemm_prof_end(tk, stream);
   return rc;
 }
+// The same with the RMSNorm in front of the projection folded into the A load (nn/modules/norm.py:221-248 feeding
+// llm/llama/model.py:56-58): x = the rows BEFORE the norm; xn (M x K) = x / sqrt(mean(x^2) + eps) * norm_w and rms (M) are left
+// for the backward (the weight gradient contracts xn, the norm's backward wants x and rms).  Tile-piece kernel only.
+static int rowtile_would_take(int M, int N, int epi, int F) {
+  RowTileArgs ta;
+  memset(&ta, 0, sizeof(ta));
+  ta.M = M; ta.N = N; ta.lda = 288; ta.ldb = N; ta.ldc = N; ta.nblocks = 1; ta.epi = epi; ta.F = F;
+  return pdn_rowtile_takes(ta);
+}
+extern "C" int pdn_gateup_swiglu_norm_supported(int M, int F, int K) {
+  return (pdn_gateup_swiglu_supported(M, F, K) && rowtile_would_take(M, 2 * F, 1, F)) ? 1 : 0;
+}
+extern "C" int pdn_gateup_swiglu_norm_fwd_f32(const float* x, const float* norm_w, float eps, float* xn, float* rms,
+                                              const float* w_gate, int64_t w_stride, float* gu, float* h, int M, int F,
+                                              int K, int64_t ldx, void* stream) {
+  if (M == 0 || F == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && norm_w && xn && rms && w_gate && gu && h, "pdn_gateup_swiglu_norm_fwd_f32: null operand");
+  const int64_t ws = w_stride < 0 ? -w_stride : w_stride;
+  if (!pdn_gateup_swiglu_norm_supported(M, F, K) || ws % 4 != 0 || ws < (int64_t)K * F || ws + (int64_t)K * F >= (1ll << 30)) {
+    pdn_set_error("pdn_gateup_swiglu_norm_fwd_f32: unsupported shape M=%d F=%d K=%d", M, F, K);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{1, h, F, nullptr, F, nullptr, 1, 1, 0};
+  e.g_off = w_stride < 0 ? (unsigned)ws : 0u;
+  e.u_off = w_stride < 0 ? 0u : (unsigned)ws;
+  e.norm_w = norm_w; e.xn = xn; e.rms = rms; e.ldxn = K; e.norm_eps = eps;
+  const float* wbase = w_stride < 0 ? w_gate + w_stride : w_gate;
+  const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (2.0 * F) * K, 4.0 * (2.0 * M * K + 2.0 * K * F + 3.0 * M * F), stream);
+  const int rc = rowres_launch(x, wbase, gu, nullptr, nullptr, M, 2 * F, K, ldx, F, 2 * F, 0, 2, ws, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
 // dgu (M x 2F) = SwiGLU'(gu) applied to dh = dy (M x 288) W_down^T, W_down (F x 288) row-major; dh is never written.
 extern "C" int pdn_swiglu_bwd_gemm_f32(const float* dy, const float* w_down, const float* gu, float* dgu, int M, int F, int K,
                                        int64_t ldy, void* stream) {
@@ -811,6 +850,28 @@ extern "C" int pdn_qkv_rope_fwd_f32(const float* x, const float* wq, int64_t w_s
   }
   RowResEpi e{3, nullptr, 0, nullptr, 0, rope, L, hd, 2 * D};
   const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (3.0 * D) * K, 4.0 * ((double)M * K + 3.0 * K * D + 3.0 * M * D), stream);
+  const int rc = rowres_launch(x, wq, qkv, nullptr, nullptr, M, 3 * D, K, ldx, D, 3 * D, 0, 3, w_stride, stream, &e);
+  pdn_gemm_prof_end(tk, stream);
+  return rc;
+}
+
+// q | k | v + RoPE with the RMSNorm in front folded into the A load (see pdn_gateup_swiglu_norm_fwd_f32)
+extern "C" int pdn_qkv_rope_norm_supported(int M, int D, int K, int L, int hd) {
+  return (pdn_qkv_rope_supported(M, D, K, L, hd) && rowtile_would_take(M, 3 * D, 3, 0)) ? 1 : 0;
+}
+extern "C" int pdn_qkv_rope_norm_fwd_f32(const float* x, const float* norm_w, float eps, float* xn, float* rms, const float* wq,
+                                         int64_t w_stride, float* qkv, const float* rope, int M, int D, int K, int L, int hd,
+                                         int64_t ldx, void* stream) {
+  if (M == 0 || D == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && norm_w && xn && rms && wq && qkv && rope && (((uintptr_t)rope & 7) == 0),
+                "pdn_qkv_rope_norm_fwd_f32: null / misaligned operand");
+  if (!pdn_qkv_rope_norm_supported(M, D, K, L, hd) || w_stride % 4 != 0) {
+    pdn_set_error("pdn_qkv_rope_norm_fwd_f32: unsupported shape M=%d D=%d K=%d L=%d hd=%d", M, D, K, L, hd);
+    return PDN_EUNSUPPORTED;
+  }
+  RowResEpi e{3, nullptr, 0, nullptr, 0, rope, L, hd, 2 * D};
+  e.norm_w = norm_w; e.xn = xn; e.rms = rms; e.ldxn = K; e.norm_eps = eps;
+  const int tk = pdn_gemm_prof_begin(5, 2.0 * M * (3.0 * D) * K, 4.0 * (2.0 * M * K + 3.0 * K * D + 3.0 * M * D), stream);
   const int rc = rowres_launch(x, wq, qkv, nullptr, nullptr, M, 3 * D, K, ldx, D, 3 * D, 0, 3, w_stride, stream, &e);
   pdn_gemm_prof_end(tk, stream);
   return rc;

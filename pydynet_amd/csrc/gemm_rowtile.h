@@ -22,6 +22,8 @@ struct RowTileArgs {
   unsigned g_off, u_off;          // EPI 1
   float* lse;                     // EPI 5 (null: plan only -> *parts)
   int* parts;                     // EPI 5: number of column ranges = vectors of maxima
+  // RMSNorm in front of the projection (EPI 1 / 3): A = the rows before the norm, norm_w (288), y -> xn (M x 288, ldxn), rms (M)
+  const float* norm_w; float* xn; float* rms; int64_t ldxn; float norm_eps;
 };
 
 // 1 when the tile-piece kernel takes this shape (K = 288, N a multiple of 32, enough rows to give every CU one 8-wave

@@ -56,6 +56,13 @@ struct RowTileParams {
   int F, L, hd, rope_tiles;
   unsigned g_off, u_off;
   float* lse;
+  // NORM: A holds the rows BEFORE an RMSNorm (nn/modules/norm.py:221-248); the wave normalises its rows in registers
+  // (y = x / sqrt(mean(x^2) + eps) * w), multiplies THOSE, and leaves y and the rows' rms for the backward
+  const float* norm_w;
+  float* xn;
+  float* rms;
+  int64_t ldxn;
+  float norm_eps;
   int ablate;                     // timing experiments (PDN_ROWTILE_ABLATE; 0 in the library): 1 = no barriers after the first
 };
 
@@ -76,7 +83,8 @@ __device__ __forceinline__ void rt_barrier() {      // bare: __syncthreads() wou
 
 // BT: B is the row-major (N x 288) matrix whose transpose is meant.  EPI: 0 bias, 1 SwiGLU forward (NN), 2 SwiGLU
 // backward (NT), 3 RoPE (NN), 5 row maxima (NN).  GUARD: M is not a multiple of 256 (row tests in every drain step).
-template <bool BT, int EPI, bool GUARD>
+// NORM: the RMSNorm in front of the projection is applied to the A rows in registers (its own pass over x is gone).
+template <bool BT, int EPI, bool GUARD, bool NORM = false>
 __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   static_assert(EPI != 1 || !BT, "SwiGLU forward: NN form");
   static_assert(EPI != 2 || BT, "SwiGLU backward: NT form");
@@ -172,6 +180,35 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
     park_v(0, q, t5[q]);
+  }
+  if (NORM) {
+    // a lane holds half of row m0 + li (k = 8 t + 4 lh .. + 3): sum of squares in-lane, the other half one shuffle away
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < RT_KG; ++t) ss += (a[t].x * a[t].x + a[t].y * a[t].y) + (a[t].z * a[t].z + a[t].w * a[t].w);
+    ss += __shfl_xor(ss, 32, 64);
+    const float r = sqrtf(ss / 288.f + p.norm_eps);
+    const float inv = 1.f / r;
+    const bool row_ok = !GUARD || m0 + li < p.M;
+    if (lh == 0 && row_ok) p.rms[m0 + li] = r;
+    const float* wrow = p.norm_w + 4 * lh;
+    float* xrow = p.xn + (int64_t)min(m0 + li, p.M - 1) * p.ldxn + 4 * lh;
+#pragma unroll
+    for (int t0 = 0; t0 < RT_KG; t0 += 6) {         // the norm weights six k-groups at a time (register budget)
+      float4 w6[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const float4 v = *reinterpret_cast<const float4*>(wrow + 8 * (t0 + e));
+        w6[e].x = v.x; w6[e].y = v.y; w6[e].z = v.z; w6[e].w = v.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 6; ++e) {
+        const int t = t0 + e;
+        a[t].x = a[t].x * inv * w6[e].x; a[t].y = a[t].y * inv * w6[e].y;
+        a[t].z = a[t].z * inv * w6[e].z; a[t].w = a[t].w * inv * w6[e].w;
+        if (row_ok) *reinterpret_cast<float4*>(xrow + 8 * t) = a[t];
+      }
+    }
   }
 
   f32x16 acc[NSET];
@@ -493,21 +530,29 @@ int pdn_rowtile_launch(const RowTileArgs& a, void* stream) {
   p.F = a.F; p.L = a.L > 0 ? a.L : 1; p.hd = a.hd > 0 ? a.hd : 32; p.rope_tiles = a.rope_cols / 32;
   p.g_off = a.g_off; p.u_off = a.u_off; p.lse = a.lse;
   p.ablate = getenv("PDN_ROWTILE_ABLATE") ? atoi(getenv("PDN_ROWTILE_ABLATE")) : 0;
+  p.norm_w = a.norm_w; p.xn = a.xn; p.rms = a.rms; p.ldxn = a.ldxn; p.norm_eps = a.norm_eps;
+  const bool norm = a.norm_w != nullptr;
+  if (norm && !(a.epi == 1 || a.epi == 3)) { pdn_set_error("pdn_rowtile_launch: the RMSNorm fold exists for the gate | up and q | k | v projections"); return PDN_EINVAL; }
+  if (norm && !(a.xn && a.rms && (a.ldxn & 3) == 0 && (((uintptr_t)a.xn | (uintptr_t)a.norm_w) & 15) == 0)) { pdn_set_error("pdn_rowtile_launch: RMSNorm fold needs xn / rms outputs, 16-byte aligned"); return PDN_EINVAL; }
   const dim3 grid((a.M + 255) / 256, nsplit), block(512);
   hipStream_t st = (hipStream_t)stream;
   const bool guard = a.M % 256 != 0;
 #define RT_LAUNCH(BT_, EPI_)                                                                          \
   if (guard) hipLaunchKernelGGL((gemm_rowtile_kernel<BT_, EPI_, true>), grid, block, 0, st, p);        \
   else hipLaunchKernelGGL((gemm_rowtile_kernel<BT_, EPI_, false>), grid, block, 0, st, p)
+#define RT_LAUNCH_N(BT_, EPI_)                                                                        \
+  if (guard) hipLaunchKernelGGL((gemm_rowtile_kernel<BT_, EPI_, true, true>), grid, block, 0, st, p);  \
+  else hipLaunchKernelGGL((gemm_rowtile_kernel<BT_, EPI_, false, true>), grid, block, 0, st, p)
   switch (a.epi) {
     case 0: if (a.b_trans) { RT_LAUNCH(true, 0); } else { RT_LAUNCH(false, 0); } break;
-    case 1: RT_LAUNCH(false, 1); break;
+    case 1: if (norm) { RT_LAUNCH_N(false, 1); } else { RT_LAUNCH(false, 1); } break;
     case 2: RT_LAUNCH(true, 2); break;
-    case 3: RT_LAUNCH(false, 3); break;
+    case 3: if (norm) { RT_LAUNCH_N(false, 3); } else { RT_LAUNCH(false, 3); } break;
     case 5: RT_LAUNCH(false, 5); break;
     default: pdn_set_error("pdn_rowtile_launch: epilogue %d", a.epi); return PDN_EINVAL;
   }
 #undef RT_LAUNCH
+#undef RT_LAUNCH_N
   pdn_count(a.epi == 0 ? PDN_CNT_ROWTILE_PLAIN : a.epi == 5 ? PDN_CNT_ROWTILE_ROWMAX : PDN_CNT_ROWTILE_PLAIN + a.epi);
   PDN_LAUNCH_CHECK();
   return PDN_OK;

@@ -383,6 +383,36 @@ class EmulatedLib:
         flat(h, M * F).reshape(M, F)[...] = g / (1 + np.exp(-g)) * u
         return 0
 
+    # -- the same projections with the RMSNorm in front folded into the A load (round 5, csrc/gemm_rowtile.hip NORM) ----
+    def _norm_rows(self, x, norm_w, eps, xn, rms, M, K, ldx):
+        xv = view(x, (M, K), (ldx, 1), np.float32)
+        r = np.sqrt((xv * xv).mean(-1, dtype=np.float32) + np.float32(eps)).astype(np.float32)
+        y = (xv / r[:, None] * flat(norm_w, K)).astype(np.float32)
+        view(xn, (M, K), (K, 1), np.float32)[...] = y
+        flat(rms, M)[...] = r
+
+    def pdn_gateup_swiglu_norm_supported(self, M, F, K):
+        return 1 if (self.pdn_gateup_swiglu_supported(M, F, K) and self._rowtile_takes(M, 2 * (F // 32))) else 0
+
+    def pdn_gateup_swiglu_norm_fwd_f32(self, x, norm_w, eps, xn, rms, wg, w_stride, gu, h, M, F, K, ldx, stream):
+        if M == 0 or F == 0:
+            return 0
+        if not self.pdn_gateup_swiglu_norm_supported(M, F, K):
+            return -2
+        self._norm_rows(x, norm_w, eps, xn, rms, M, K, ldx)
+        return self.pdn_gateup_swiglu_fwd_f32(xn, wg, w_stride, gu, h, M, F, K, K, stream)
+
+    def pdn_qkv_rope_norm_supported(self, M, D, K, L, hd):
+        return 1 if (self.pdn_qkv_rope_supported(M, D, K, L, hd) and self._rowtile_takes(M, 3 * D // 32)) else 0
+
+    def pdn_qkv_rope_norm_fwd_f32(self, x, norm_w, eps, xn, rms, wq, w_stride, qkv, rope, M, D, K, L, hd, ldx, stream):
+        if M == 0 or D == 0:
+            return 0
+        if not self.pdn_qkv_rope_norm_supported(M, D, K, L, hd):
+            return -2
+        self._norm_rows(x, norm_w, eps, xn, rms, M, K, ldx)
+        return self.pdn_qkv_rope_fwd_f32(xn, wq, w_stride, qkv, rope, M, D, K, L, hd, K, stream)
+
     def pdn_swiglu_bwd_gemm_f32(self, dy, wd, gu, dgu, M, F, K, ldy, stream):
         self._count(3 if self._rowtile_takes(M, F // 32) else 6)
         if M == 0 or F == 0:

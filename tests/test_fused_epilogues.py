@@ -309,10 +309,120 @@ def check_llama_block_epilogues_vs_separate_kernels(dev):
         close(g1[n], g0[n], f"grad {n}")
 
 
+# ---- RMSNorm folded into the projections' A load (round 5: csrc/gemm_rowtile.hip NORM, fused.rms_norm deferred) -------
+def _norm_fold_case(M, Lq, seed):
+    """`pdn_{qkv_rope,gateup_swiglu}_norm_fwd_f32` on raw rows vs the standalone RMSNorm kernel followed by the plain entry
+    points (nn/modules/norm.py:245-248 then llm/llama/model.py:93-104 / 56-58), and vs float64."""
+    L, hp = _lib_hp()
+    K = D = 288
+    F, hd, eps = 768, 48, 1e-6
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((M, K)) * rng.uniform(0.2, 3.0, (M, 1))).astype(np.float32)
+    wn = rng.uniform(0.5, 1.5, K).astype(np.float32)
+    assert L.query("pdn_qkv_rope_norm_supported", M, D, K, Lq, hd) and L.query("pdn_gateup_swiglu_norm_supported", M, F, K)
+    xd, wnd = hp.from_numpy(x), hp.from_numpy(wn)
+    # the separate path
+    xn0, rms0 = hp.empty((M, K), np.float32), hp.empty((M,), np.float32)
+    L.call("pdn_rmsnorm_fwd_f32", xd._ptr, wnd._ptr, xn0._ptr, rms0._ptr, M, K, eps, hp.stream())
+    x64 = x.astype(np.float64)
+    r64 = np.sqrt((x64 * x64).mean(-1) + eps)
+    xn64 = x64 / r64[:, None] * wn
+    close(xn0, xn64, "standalone rmsnorm")
+    # q | k | v + RoPE
+    wsq = [(0.08 * rng.standard_normal((K, D))).astype(np.float32) for _ in range(3)]
+    buf, views, stride = _stack(hp, wsq)
+    cos, sin = _tables(Lq, hd)
+    tab = hp.empty((Lq, hd, 2), np.float32)
+    cd, sd = hp.from_numpy(cos), hp.from_numpy(sin)
+    L.call("pdn_rope_table_f32", cd._ptr, sd._ptr, tab._ptr, Lq, hd, hp.stream())
+    q0, q1 = hp.empty((M, 3 * D), np.float32), hp.empty((M, 3 * D), np.float32)
+    xn1, rms1 = hp.empty((M, K), np.float32), hp.empty((M,), np.float32)
+    L.call("pdn_qkv_rope_fwd_f32", xn0._ptr, views[0]._ptr, stride, q0._ptr, tab._ptr, M, D, K, Lq, hd, K, hp.stream())
+    L.call("pdn_qkv_rope_norm_fwd_f32", xd._ptr, wnd._ptr, eps, xn1._ptr, rms1._ptr, views[0]._ptr, stride, q1._ptr,
+           tab._ptr, M, D, K, Lq, hd, K, hp.stream())
+    close(xn1, xn64, "normalised rows left by the q|k|v projection", 2e-6)
+    close(rms1, r64, "rms left by the q|k|v projection", 2e-6)
+    close(q1, q0.get(), "q|k|v: folded vs separate norm", 5e-6)
+    c64, s64 = cos.astype(np.float64), sin.astype(np.float64)
+    close(q1.get()[:, :D], _rope_ref(xn64 @ wsq[0], c64, s64, Lq, hd), "rotated q vs float64")
+    close(q1.get()[:, 2 * D:], xn64 @ wsq[2], "v vs float64")
+    # gate | up + SwiGLU
+    wg = (0.08 * rng.standard_normal((K, F))).astype(np.float32)
+    wu = (0.08 * rng.standard_normal((K, F))).astype(np.float32)
+    bufg, (dg, du), gstride = _stack(hp, [wg, wu])
+    gu0, h0, gu1, h1 = (hp.empty((M, n), np.float32) for n in (2 * F, F, 2 * F, F))
+    xn2, rms2 = hp.empty((M, K), np.float32), hp.empty((M,), np.float32)
+    L.call("pdn_gateup_swiglu_fwd_f32", xn0._ptr, dg._ptr, gstride, gu0._ptr, h0._ptr, M, F, K, K, hp.stream())
+    L.call("pdn_gateup_swiglu_norm_fwd_f32", xd._ptr, wnd._ptr, eps, xn2._ptr, rms2._ptr, dg._ptr, gstride, gu1._ptr, h1._ptr,
+           M, F, K, K, hp.stream())
+    close(xn2, xn64, "normalised rows left by the gate|up projection", 2e-6)
+    close(rms2, r64, "rms left by the gate|up projection", 2e-6)
+    close(gu1, gu0.get(), "gate|up: folded vs separate norm", 5e-6)
+    close(h1, h0.get(), "h: folded vs separate norm", 5e-6)
+    g64, u64 = xn64 @ wg, xn64 @ wu
+    close(h1, _silu(g64) * u64, "h vs float64")
+
+
+def check_norm_fold_full_row_blocks(dev):
+    _norm_fold_case(2560, 64, 11)
+
+
+def check_norm_fold_ragged_rows(dev):
+    _norm_fold_case(2592, 32, 12)          # 2592 = 10 x 256 + 32: the GUARD instantiations
+
+
+def _norm_fold_step(dev, fold):
+    from pydynet_amd.llm.llama import Llama
+    saved = (fused.rms_norm.fold, fused.rms_norm.fold_min_rows, fused.ffn_swiglu.epilogue_min_rows,
+             fused.qkv_attention.rope_min_rows)
+    fused.rms_norm.fold, fused.rms_norm.fold_min_rows = fold, 32
+    fused.ffn_swiglu.epilogue_min_rows = fused.qkv_attention.rope_min_rows = 32
+    adopted = {"n": 0}
+    orig = fused.rms_norm._adopt
+
+    def spy(self, *a):
+        adopted["n"] += 1
+        return orig(self, *a)
+    fused.rms_norm._adopt = spy
+    try:
+        Graph.clear()
+        np.random.seed(8)
+        V, D, H, F, Lq, B = 64, 288, 6, 768, 64, 40        # 2560 tokens: the tile-piece projections take them
+        model = Llama(V, D, H, F, Lq, B, 2, np.float32)
+        rng = np.random.default_rng(9)
+        model.tok_embedding.weight.data[...] = (0.5 * rng.standard_normal((V, D))).astype(np.float32)
+        for n, p_ in model.named_parameters():
+            if n.endswith("norm.weight"):                   # (ones by default: make the weight gradient path non-trivial)
+                p_.data[...] = rng.uniform(0.5, 1.5, p_.shape).astype(np.float32)
+        model.to(dev)
+        ids, tgt = rng.integers(0, V, (B, Lq)), rng.integers(0, V, (B, Lq))
+        loss = model.loss(ids, tgt)
+        loss.backward()
+        grads = {n: host(p_.grad) for n, p_ in model.named_parameters() if p_.requires_grad and p_.grad is not None}
+        return float(host(loss)), grads, adopted["n"]
+    finally:
+        fused.rms_norm._adopt = orig
+        (fused.rms_norm.fold, fused.rms_norm.fold_min_rows, fused.ffn_swiglu.epilogue_min_rows,
+         fused.qkv_attention.rope_min_rows) = saved
+
+
+def check_llama_block_norm_fold_vs_separate_norm(dev):
+    """Two Llama blocks, one step: the four block norms ride in the q|k|v / gate|up projections (the final norm in front
+    of lm_head keeps its own kernel); loss and every gradient -- the norm weights' included -- equal the unfolded step."""
+    l1, g1, n1 = _norm_fold_step(dev, True)
+    l0, g0, n0 = _norm_fold_step(dev, False)
+    assert n1 == 4 and n0 == 0, (n1, n0)
+    assert abs(l1 - l0) <= 1e-5 * abs(l0), (l1, l0)
+    assert g1.keys() == g0.keys() and len(g1) >= 20
+    for n in g0:
+        close(g1[n], g0[n], f"grad {n}", 2e-5)
+
+
 for _fn in [check_gateup_swiglu_full_blocks, check_gateup_swiglu_ragged_rows_ffn768,
             check_gateup_swiglu_up_matrix_first_in_memory, check_qkv_rope_hd48,
             check_qkv_rope_hd96_ragged_tail, check_attention_bwd_rotated_equals_plain,
             check_dx_over_qkv_weight_blocks, check_dx_over_gate_up_weight_blocks_reversed,
             check_linear_lse_tail_chunk_and_ragged_rows, check_linear_lse_single_tile_tail,
-            check_llama_block_epilogues_vs_separate_kernels]:
+            check_llama_block_epilogues_vs_separate_kernels, check_norm_fold_full_row_blocks,
+            check_norm_fold_ragged_rows, check_llama_block_norm_fold_vs_separate_norm]:
     device_variants(globals(), _fn)
