@@ -1148,6 +1148,7 @@ extern "C" int pdn_gemm_outres_f32(const float* A, const float* B, float* C, con
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
                                    int64_t ldc, int b_trans, void* stream);
 extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans);
+int pdn_rowtile_plain_ok(int M, int N, int b_trans);
 extern "C" int pdn_gemm_rowres_f32(const float* A, const float* B, float* C, const float* bias,
                                    const float* residual, int M, int N, int K, int64_t lda, int64_t ldb,
                                    int64_t ldc, int b_trans, void* stream);
@@ -1272,8 +1273,14 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     const bool blocks = nbatch > 1 && one_dim && a_bs == 0 && c_bs == N && ldc >= (int64_t)nbatch * N && !bias &&
                         N % 96 == 0 && (b_bs & 3) == 0;
     const int64_t n_all = (int64_t)N * (blocks ? nbatch : 1);
-    if ((nbatch == 1 || blocks) && K == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum && !residual &&
-        n_all >= 768 && n_all < (1 << 30) && M >= 8192 && al16(A) && al16(B) && !getenv("PDN_GEMM_NO_ROWRES")) {
+    // (round 5: the tile-piece kernel also takes what the chunk kernel lost to the tiled one -- outputs narrower than 768
+    //  columns, i.e. the 288 x 288 products of the attention output projection, and a residual added in the store)
+    const int bt0 = (b_rs == 1 && b_cs != 1) ? 1 : 0;
+    const bool tilepiece = nbatch == 1 && K == 288 && n_all >= 96 && n_all % 32 == 0 && M >= 8192 &&
+                           pdn_rowtile_plain_ok(M, (int)n_all, bt0);
+    if ((nbatch == 1 || blocks) && K == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum &&
+        (tilepiece || (!residual && n_all >= 768)) && n_all < (1 << 30) && M >= 8192 && al16(A) && al16(B) &&
+        (!residual || al16(residual)) && !getenv("PDN_GEMM_NO_ROWRES")) {
       const int bt = (b_rs == 1 && b_cs != 1) ? 1 : 0;
       const int64_t ldb = bt ? b_cs : b_rs;
       if ((bt || b_cs == 1) && pdn_gemm_rowres_supported(M, N, K, a_rs, ldb, ldc, bt)) {
@@ -1294,7 +1301,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
           fprintf(stderr, "pdn_gemm_f32 M=%d N=%lld K=%d -> row-resident (%s, %d block%s)\n", M, (long long)n_all, K,
                   bt ? "NT" : "NN", blocks ? nbatch : 1, blocks ? "s" : "");
         const int rc = blocks ? pdn_gemm_rowres_blocks(A, B, C, M, (int)n_all, K, a_rs, ldb, ldc, bt, nbatch, b_bs, stream)
-                              : pdn_gemm_rowres_f32(A, B, C, bias, nullptr, M, N, K, a_rs, ldb, ldc, bt, stream);
+                              : pdn_gemm_rowres_f32(A, B, C, bias, residual, M, N, K, a_rs, ldb, ldc, bt, stream);
         if (rc) return rc;
         if (prof) {
           PDN_HIP(hipEventRecord(rec.e1, st));

@@ -643,6 +643,14 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_rowres_kernel(R
 
 // K = 288 (the model width of the benchmarked Llama), N a multiple of 32 and >= 96, A rows contiguous,
 // B rows contiguous (either orientation), 16-byte aligned rows.
+// 1 when the tile-piece kernel would take a plain (M x N) projection (pdn_gemm_f32 then also sends it the 288-wide
+// products and the ones with a residual, which the chunk kernel loses to the tiled kernel)
+int pdn_rowtile_plain_ok(int M, int N, int b_trans) {
+  RowTileArgs ta;
+  memset(&ta, 0, sizeof(ta));
+  ta.M = M; ta.N = N; ta.lda = 288; ta.ldb = b_trans ? 288 : N; ta.ldc = N; ta.b_trans = b_trans; ta.nblocks = 1;
+  return pdn_rowtile_takes(ta);
+}
 extern "C" int pdn_gemm_rowres_supported(int M, int N, int K, int64_t lda, int64_t ldb, int64_t ldc, int b_trans) {
   return K == 288 && N % 32 == 0 && N >= RR_NC && M >= 1 && lda % 4 == 0 && ldb % 4 == 0 && lda >= K &&
          ldb >= (b_trans ? K : N) && ldc >= N && (int64_t)32 * ldc < (1ll << 30);
@@ -681,10 +689,13 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_rowres_f32: 16-byte alignment required");
   // round 5: the tile-piece kernel (csrc/gemm_rowtile.hip) takes every shape that gives each CU an 8-wave workgroup --
   // its stores and epilogue reads leave under the next tile's MFMAs instead of in a store phase of their own
-  if (!residual) {
+  // (a residual that ALIASES C stays on the chunk kernel: the tile-piece kernel's first, dummy drain writes the place of the
+  //  workgroup's last tile before that tile's residual rows have been read)
+  const bool res_alias = residual && (const float*)C < residual + (int64_t)M * ldc && residual < (const float*)C + (int64_t)M * ldc;
+  if ((!residual || !epi) && !res_alias) {
     RowTileArgs ta;
     memset(&ta, 0, sizeof(ta));
-    ta.A = A; ta.B = B; ta.C = C; ta.bias = bias; ta.M = M; ta.N = N; ta.lda = lda; ta.ldb = ldb; ta.ldc = ldc;
+    ta.A = A; ta.B = B; ta.C = C; ta.bias = bias; ta.residual = residual; ta.M = M; ta.N = N; ta.lda = lda; ta.ldb = ldb; ta.ldc = ldc;
     ta.b_trans = b_trans; ta.nblocks = nblocks; ta.b_block_stride = b_block_stride; ta.epi = epi ? epi->kind : 0;
     if (epi) {
       ta.H = epi->H; ta.ldh = epi->ldh; ta.GU = epi->GU; ta.F = epi->F; ta.rope = epi->rope; ta.L = epi->L; ta.hd = epi->hd;

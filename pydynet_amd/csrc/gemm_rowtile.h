@@ -9,6 +9,7 @@ struct RowTileArgs {
   const float* B;                 // NN: (288 x N) row-major; NT: (N x 288) row-major (its transpose is meant)
   float* C;                       // (M x N) (EPI 1 / 2: M x 2F, the packed [gate | up] layout)
   const float* bias;              // EPI 0 / 5, may be null
+  const float* residual;          // EPI 0, may be null: (M x N, leading dimension ldc) added to the product
   int M, N;
   int64_t lda, ldb, ldc;
   int b_trans;

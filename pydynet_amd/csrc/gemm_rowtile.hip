@@ -42,6 +42,7 @@ struct RowTileParams {
   const float* B;
   float* C;
   const float* bias;              // always a readable address (B when there is no bias: has_bias = 0)
+  const float* residual;          // EPI 6: (M x N), leading dimension ldc, added in the drain
   int M, N;
   int64_t lda, ldb, ldc;
   int pieces, ppw;                // pieces in total / per workgroup (grid.y)
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   static_assert(EPI != 1 || !BT, "SwiGLU forward: NN form");
   static_assert(EPI != 2 || BT, "SwiGLU backward: NT form");
   static_assert((EPI != 3 && EPI != 5) || !BT, "RoPE / row maxima: NN form");
+  // (EPI 6 = EPI 0 + a residual read eight row steps ahead of its add, like the saved gate / up rows of EPI 2)
   constexpr int NSET = EPI == 1 ? 3 : 2;
   __shared__ __attribute__((aligned(16))) float smem[2 * RT_PIECE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -257,6 +259,14 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
       ring1[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Gd) + o + 4u * (unsigned)p.F);
     }
   }
+  if (EPI == 6 && wave_on) {
+    const float* Rd = p.residual + (int64_t)m0 * p.ldc + 32 * (P_end - 1);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const unsigned o = (unsigned)(GUARD ? min(row_of(r), p.M - 1 - m0) : row_of(r)) * (4u * ldc) + 4u * li;
+      ring0[r] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Rd) + o);
+    }
+  }
   if (EPI == 3 && wave_on) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -292,6 +302,15 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
       const float v = x + bvd;
       if (EPI == 5) mx[r] = fmaxf(mx[r], v);
       if (ok) stf(Cd, od, v);
+    } else if (EPI == 6) {
+      if (ok) stf(Cd, od, (x + bvd) + ring0[r & 7]);
+      if (r < 8 || !LAST) {
+        const float* G = r < 8 ? Gd : Gn;           // (Gd / Gn: the residual rows of the leaving / the next tile)
+        unsigned o;
+        if (GUARD) o = (unsigned)min(row_of(r < 8 ? r + 8 : r - 8), p.M - 1 - m0) * ldcb + 4u * li;
+        else o = r < 8 ? od + 16u * ldcb : od - 16u * ldcb;
+        ring0[r & 7] = ldf(G, o);
+      }
     } else if (EPI == 1) {
       if (MODE == 0) {
         if (ok) stf(Cd, od, x);
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
       const int Pd = first ? P_end - 1 : P - 1;
       Cd = p.C + (int64_t)m0 * p.ldc + 32 * Pd;
       if (EPI == 2) { Gd = p.GU + (int64_t)m0 * p.ldc + 32 * Pd; Gn = p.GU + (int64_t)m0 * p.ldc + 32 * P; }
+      if (EPI == 6) { Gd = p.residual + (int64_t)m0 * p.ldc + 32 * Pd; Gn = p.residual + (int64_t)m0 * p.ldc + 32 * P; }
       if (EPI == 3) rot_d = Pd < p.rope_tiles;
     }
     unsigned od = (unsigned)(4 * lh) * ldcb + 4u * li, oh = (unsigned)(4 * lh) * ldhb + 4u * li;
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
       if (g == 16) { park_one(BUF ^ 1, 0); park_one(BUF ^ 1, 1); park_one(BUF ^ 1, 2); }
       if (g == 17 || g == 18) issue_one(nb, g - 14);   // second half: requested in 17, 18, parked in 34
       if (g == 34) { park_one(BUF ^ 1, 3); park_one(BUF ^ 1, 4); }
-      if ((EPI == 0 || EPI == 5) && g == 20) {      // bias of THIS tile's column (it leaves during the next piece)
+      if ((EPI == 0 || EPI == 5 || EPI == 6) && g == 20) {      // bias of THIS tile's column (it leaves during the next piece)
         const float b = ldf(p.bias + 32 * P, 4u * li);
         bvn = p.has_bias ? b : 0.f;
       }
@@ -424,6 +444,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
     } else {
       Cd = p.C + (int64_t)m0 * p.ldc + 32 * (P_end - 1);
       if (EPI == 2) Gd = p.GU + (int64_t)m0 * p.ldc + 32 * (P_end - 1);
+      if (EPI == 6) Gd = p.residual + (int64_t)m0 * p.ldc + 32 * (P_end - 1);
       if (EPI == 3) rot_d = P_end - 1 < p.rope_tiles;
     }
     unsigned od = (unsigned)(4 * lh) * ldcb + 4u * li, oh = (unsigned)(4 * lh) * ldhb + 4u * li;
@@ -505,6 +526,7 @@ int pdn_rowtile_takes(const RowTileArgs& a) {
   if (a.epi == 2 && !a.b_trans) return 0;
   if ((a.epi == 3 || a.epi == 5) && a.b_trans) return 0;
   if (a.epi == 4) return 0;
+  if (a.residual && a.epi != 0) return 0;
   const int np = a.epi == 1 ? 2 * (a.F / 32) : a.N / 32;
   const int row_blocks = (a.M + 255) / 256;
   // one 8-wave workgroup per CU must have work (rows, or rows x column ranges); below that the 4-wave chunk kernel runs
@@ -521,6 +543,7 @@ int pdn_rowtile_launch(const RowTileArgs& a, void* stream) {
   memset(&p, 0, sizeof(p));
   p.A = a.A; p.B = a.B; p.C = a.C;
   p.bias = a.bias ? a.bias : a.B; p.has_bias = a.bias ? 1 : 0;
+  p.residual = a.residual;
   p.M = a.M; p.N = a.N; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
   p.pieces = pieces; p.ppw = ppw;
   p.tpb = a.epi == 1 ? pieces : (a.N / a.nblocks) / 32;
@@ -544,7 +567,10 @@ int pdn_rowtile_launch(const RowTileArgs& a, void* stream) {
   if (guard) hipLaunchKernelGGL((gemm_rowtile_kernel<BT_, EPI_, true, true>), grid, block, 0, st, p);  \
   else hipLaunchKernelGGL((gemm_rowtile_kernel<BT_, EPI_, false, true>), grid, block, 0, st, p)
   switch (a.epi) {
-    case 0: if (a.b_trans) { RT_LAUNCH(true, 0); } else { RT_LAUNCH(false, 0); } break;
+    case 0:
+      if (a.residual) { if (a.b_trans) { RT_LAUNCH(true, 6); } else { RT_LAUNCH(false, 6); } }
+      else if (a.b_trans) { RT_LAUNCH(true, 0); } else { RT_LAUNCH(false, 0); }
+      break;
     case 1: if (norm) { RT_LAUNCH_N(false, 1); } else { RT_LAUNCH(false, 1); } break;
     case 2: RT_LAUNCH(true, 2); break;
     case 3: if (norm) { RT_LAUNCH_N(false, 3); } else { RT_LAUNCH(false, 3); } break;

@@ -77,6 +77,59 @@ def test_plain_projection_bit_identical(hip, M, N, bt, bias):
     _close(new[0], ref, "x @ W")
 
 
+@pytest.mark.parametrize("M,N,bt,bias", [(256, 288, 0, False), (300, 288, 1, True), (2048, 864, 0, True), (1000, 96, 1, False)])
+def test_projection_with_residual_bit_identical(hip, M, N, bt, bias):
+    """C = x @ W (+ bias) + residual: the residual rows ride in the drain of the tile-piece kernel (EPI 6), eight row
+    steps ahead of their add -- the transformer's `x + sublayer(x)` (llm/llama/model.py:140-150) and the engine's
+    "add to the gradient this input already holds" (tensor.py:371)."""
+    L, hp = _lib_hp()
+    rng = np.random.default_rng(M + N + 1)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (0.1 * rng.standard_normal((N, K) if bt else (K, N))).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    xd, wd, bd, rd = hp.from_numpy(x), hp.from_numpy(w), hp.from_numpy(b), hp.from_numpy(res)
+
+    def run():
+        c = hp.empty((M, N), np.float32)
+        c[...] = 7.0
+        L.call("pdn_gemm_rowres_f32", xd._ptr, wd._ptr, c._ptr, bd._ptr if bias else None, rd._ptr, M, N, K, K, K if bt else N, N,
+               bt, hp.stream())
+        return [c]
+
+    old, new = _both(run)
+    _same(old, new, ["C"])
+    ref = x.astype(np.float64) @ (w.T if bt else w).astype(np.float64) + (b if bias else 0.0) + res
+    _close(new[0], ref, "x @ W + residual")
+
+
+def test_attention_output_projection_takes_the_tile_piece_kernel(hip):
+    """The 288 x 288 products of a block (ctx Wo + x, dz Wo^T: llm/llama/model.py:121, tensor.py:670) through pdn_gemm_f32 at
+    the benchmark row count: routed to the tile-piece kernel (counter), equal to the tiled kernel's result."""
+    import ctypes
+    L, hp = _lib_hp()
+    M = 16384
+    rng = np.random.default_rng(3)
+    x = hp.from_numpy(rng.standard_normal((M, K), dtype=np.float32))
+    w = hp.from_numpy((0.1 * rng.standard_normal((K, K))).astype(np.float32))
+    res = hp.from_numpy(rng.standard_normal((M, K), dtype=np.float32))
+    outs = []
+    for mode in (0, 1):
+        prev = L.query("pdn_gemm_rowtile_mode", mode)
+        try:
+            L.call("pdn_kernel_counters", None, 0, 1)
+            y, dx = hp.empty((M, K)), hp.empty((M, K))
+            hp.gemm(x, w, y, residual=res)
+            hp.gemm(x, w.T, dx)
+            buf = (ctypes.c_int64 * 16)()
+            L.call("pdn_kernel_counters", buf, 16, 1)
+            outs.append((y.get(), dx.get(), int(buf[1])))
+        finally:
+            L.query("pdn_gemm_rowtile_mode", prev)
+    assert outs[0][2] == 0 and outs[1][2] == 2, (outs[0][2], outs[1][2])
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_blocks_projection_bit_identical(hip):
     """x [W0 | W1 | W2] with the three matrices equally spaced (the packed q | k | v projection), ragged rows."""
     L, hp = _lib_hp()
