@@ -67,6 +67,13 @@ __device__ __forceinline__ float ce_grad(float logit, float lse, bool is_target,
   return (__expf(logit - lse) - (is_target ? 1.f : 0.f)) * sc;
 }
 
+// the same without the scale and with the row's  -lse * log2(e)  prepared: one fma, one exp2, one select-subtract per logit;
+// the weight-gradient kernel applies the scale to its 144 accumulators (and the column sums) once, at the end
+__device__ __forceinline__ float ce_unscaled(float logit, float neg_lse_l2e, bool is_target) {
+  const float e = __builtin_amdgcn_exp2f(fmaf(logit, 1.4426950408889634f, neg_lse_l2e));
+  return is_target ? e - 1.f : e;
+}
+
 __device__ __forceinline__ void or_glds16(const float* g, float* l) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -97,18 +104,33 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
   // DMA instruction I (0..35) of a piece covers its 16-byte units 64 I .. 64 I + 63 (LDS side linear in the lane).
   // NN: unit u = row k = u / 72, column unit u % 72.   NT: unit u = row n = u / 8, k unit (u % 8) ^ ((n >> 1) & 7).
   // (the lane offset is recomputed per instruction, in the shadow of the MFMAs, instead of occupying registers)
-  auto piece_src = [&](int piece, int q, int& I) -> const float* {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    I = min(q * NW + wave, 35);
-    const int u = 64 * I + ln;
-    unsigned o;
+  // (STAGE: the NQ lane offsets live in registers -- recomputed per instruction they were ~8 VALU operations each, 40 of
+  //  the ~110 non-MFMA vector instructions a wave issued per 144 MFMAs (PMC, round 4); the LDS-DMA form keeps recomputing:
+  //  its 4-wave instantiations have no registers to spare)
+  constexpr bool PSO = STAGE && NW == 8;           // (the 4-wave forms carry NQ = 9 offsets: they spill)
+  unsigned pso[PSO ? NQ : 1];
+  auto lane_off = [&](int q, int ln) -> unsigned {
+    const int u = 64 * min(q * NW + wave, 35) + ln;
     if (BT) {
       const int n = u >> 3, cu = (u & 7) ^ ((n >> 1) & 7);
-      o = (unsigned)n * ldb + 4u * (unsigned)cu;
+      return (unsigned)n * ldb + 4u * (unsigned)cu;
+    }
+    const int k = u / 72, n4 = u - 72 * k;
+    return (unsigned)k * ldb + 4u * (unsigned)n4;
+  };
+  if (PSO) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) pso[q] = lane_off(q, lane);
+  }
+  auto piece_src = [&](int piece, int q, int& I) -> const float* {
+    I = min(q * NW + wave, 35);
+    unsigned o;
+    if (PSO) {
+      o = pso[q];
     } else {
-      const int k = u / 72, n4 = u - 72 * k;
-      o = (unsigned)k * ldb + 4u * (unsigned)n4;
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      o = lane_off(q, ln);
     }
     const float* src;
     if (BT && p.ppb) {
@@ -715,12 +737,14 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
   float csum = 0.f;
 
   float4 rb[NQ], rg[4];
+  unsigned xo[NQ];                                  // lane offsets of the X staging, once (they were ~10 VALU operations per fetch)
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int u = 64 * min(q * NW + wave, 35) + lane, k = u / 72, n4 = u - 72 * k;
+    xo[q] = (unsigned)k * ldx + 4u * (unsigned)n4;
+  }
   auto fetch = [&](int piece, int q) {
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-    const int I = min(q * NW + wave, 35);
-    const int u = 64 * I + ln, k = u / 72, n4 = u - 72 * k;
-    const float4 v = *reinterpret_cast<const float4*>(Xk + (int64_t)piece * OR_KP * p.ldx + (unsigned)k * ldx + 4u * (unsigned)n4);
+    const float4 v = *reinterpret_cast<const float4*>(Xk + (int64_t)piece * OR_KP * p.ldx + xo[q]);
     rb[q].x = v.x; rb[q].y = v.y; rb[q].z = v.z; rb[q].w = v.w;
   };
   // G piece: instruction e covers rows 8e .. 8e + 7, eight lanes (128 bytes) per row; LDS image [32 k][32 n] linear
@@ -736,7 +760,7 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
   auto fetch_rows = [&](int piece) {                // CE: the piece's 32 tokens
     if (CE && wave == 0) {
       const int t = k_begin + piece * OR_KP + li;
-      ce_row = lh == 0 ? p.lse[t] : __int_as_float((int)p.targets[t]);
+      ce_row = lh == 0 ? -1.4426950408889634f * p.lse[t] : __int_as_float((int)p.targets[t]);   // (-lse log2 e: one fma + exp2 per logit)
     }
   };
   auto park = [&](int buf) {
@@ -795,10 +819,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
           const float4 l4 = *reinterpret_cast<const float4*>(Ls + (s & 1) * 32 + 8 * g + 4 * lh);
           const float4 t4 = *reinterpret_cast<const float4*>(Ls + (2 + (s & 1)) * 32 + 8 * g + 4 * lh);
           const int col = n0 + li;
-          gv[0] = ce_grad(gv[0], l4.x, __float_as_int(t4.x) == col, ce_sc);
-          gv[1] = ce_grad(gv[1], l4.y, __float_as_int(t4.y) == col, ce_sc);
-          gv[2] = ce_grad(gv[2], l4.z, __float_as_int(t4.z) == col, ce_sc);
-          gv[3] = ce_grad(gv[3], l4.w, __float_as_int(t4.w) == col, ce_sc);
+          gv[0] = ce_unscaled(gv[0], l4.x, __float_as_int(t4.x) == col);
+          gv[1] = ce_unscaled(gv[1], l4.y, __float_as_int(t4.y) == col);
+          gv[2] = ce_unscaled(gv[2], l4.z, __float_as_int(t4.z) == col);
+          gv[3] = ce_unscaled(gv[3], l4.w, __float_as_int(t4.w) == col);
           csum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
         }
         if (g + 1 < 4) {
@@ -859,10 +883,10 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
         const float4 l4 = *reinterpret_cast<const float4*>(Ls + (s & 1) * 32 + 8 * g + 4 * lh);
         const float4 t4 = *reinterpret_cast<const float4*>(Ls + (2 + (s & 1)) * 32 + 8 * g + 4 * lh);
         const int col = n0 + li;
-        gv[0] = ce_grad(gv[0], l4.x, __float_as_int(t4.x) == col, ce_sc);
-        gv[1] = ce_grad(gv[1], l4.y, __float_as_int(t4.y) == col, ce_sc);
-        gv[2] = ce_grad(gv[2], l4.z, __float_as_int(t4.z) == col, ce_sc);
-        gv[3] = ce_grad(gv[3], l4.w, __float_as_int(t4.w) == col, ce_sc);
+        gv[0] = ce_unscaled(gv[0], l4.x, __float_as_int(t4.x) == col);
+        gv[1] = ce_unscaled(gv[1], l4.y, __float_as_int(t4.y) == col);
+        gv[2] = ce_unscaled(gv[2], l4.z, __float_as_int(t4.z) == col);
+        gv[3] = ce_unscaled(gv[3], l4.w, __float_as_int(t4.w) == col);
         csum += (gv[0] + gv[1]) + (gv[2] + gv[3]);
       }
       if (g + 1 < 4) {
@@ -889,6 +913,13 @@ __global__ __launch_bounds__(NW * 64, 1) void gemm_outres_tn_kernel(OutResTnPara
     park((s + 1) & 1);
   }
   if (!active) return;
+  if (CE) {                                         // the operand was formed without its scale (ce_unscaled)
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] *= ce_sc;
+    csum *= ce_sc;
+  }
   if (CE && p.colsum) {                             // both half-waves saw disjoint token rows
     csum += __shfl_xor(csum, 32, 64);
     if (lh == 0) p.colsum[(int64_t)by * p.N + n0 + li] = csum;
