@@ -238,7 +238,13 @@ class linear_cross_entropy(_Operator):
     logits GEMM and one read-only pass for the row statistics (log-sum-exp, loss).  Backward: the two products
     `dlogits @ W^T` and `x^T @ dlogits` (and the column sums for the bias) form
     dlogits = (softmax - onehot) * scale from the saved logits as they consume it (`pdn_linear_ce_backward_f32`).
-    Versus linear + cross_entropy nodes: one (rows x V) write and none of its re-reads less."""
+    Versus linear + cross_entropy nodes: one (rows x V) write and none of its re-reads less.
+    Deferred form (training step): the input-gradient product runs in the FORWARD pass (it is where the sum of exponentials
+    comes from), so (i) a forward under grad mode that is never followed by `backward()` still pays that product -- wrap
+    validation losses in `no_grad()` -- and (ii) dx is formed from the weights as they are at forward time: updating the
+    weight IN PLACE between forward and backward leaves dx consistent with the forward pass (as the reference's tape is)
+    but not with a dW computed from the new weights; `backward_all` asserts that the weight buffer is still the one
+    forward read."""
 
     folds_existing = True
     enabled = True
@@ -302,6 +308,7 @@ class linear_cross_entropy(_Operator):
             L.call("pdn_linear_rowmax_fwd_f32", x2._ptr, wd._ptr, bp, logits._ptr, rowmax._ptr, n, V, fin, x2._strides[0],
                    V, V, hp.stream())
             self._dxu = hp.empty((n, fin), np.float32)
+            self._w_ptr = wd._ptr                          # (backward checks that the weight was not re-homed meanwhile)
             ws, wsb = hp.workspace(L.query("pdn_linear_ce_dx_deferred_workspace_bytes", n, V, fin))
             L.call("pdn_linear_ce_dx_deferred_f32", logits._ptr, rowmax._ptr, parts, self._t._ptr,
                    1.0 / n if mean else 1.0, wd._ptr, self._dxu._ptr, lse._ptr, n, V, fin, ws, wsb, hp.stream())
@@ -333,6 +340,9 @@ class linear_cross_entropy(_Operator):
         grads = [None] * len(self.last)
         dx = ex = None
         dxu, self._dxu = self._dxu, None
+        if dxu is not None and getattr(self, "_w_ptr", None) not in (None, w.data._ptr):
+            raise RuntimeError("linear_cross_entropy: the weight's buffer was replaced between forward and backward; the "
+                               "input gradient of the deferred form was formed from the forward pass's weights")
         if x.requires_grad and dxu is not None:
             dxu *= g.reshape(())                           # formed in the forward pass, up to the upstream scalar
             grads[0] = dxu.reshape(x.shape)

@@ -56,9 +56,18 @@ class RcclComm:
         # gradient exchange of a step (97.8 MB, ring all-reduce: 2 (N - 1) / N x that per GPU = 171 MB at N = 8) needs
         # ~0.5 ms of the seven xGMI links spread over a 57 ms backward, so a handful of channels is plenty: 8 (one per
         # link + one) unless the launcher says otherwise (NCCL_MAX_NCHANNELS / PDN_RCCL_MAX_CHANNELS; 0 = RCCL's default).
+        # The variable is read by RCCL at ITS first initialisation in the process (a communicator created earlier by another
+        # package has already fixed it: logged below) and is put back right after ncclCommInitRank, so child processes and
+        # other NCCL users of this process do not inherit the cap.
         ch = os.environ.get("PDN_RCCL_MAX_CHANNELS", "8")
-        if ch != "0":
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", ch)
+        self._nch_prev, self._nch_set = os.environ.get("NCCL_MAX_NCHANNELS"), False
+        if ch != "0" and self._nch_prev is None:
+            os.environ["NCCL_MAX_NCHANNELS"] = ch
+            self._nch_set = True
+        if self.rank == 0 and os.environ.get("PDN_DP_QUIET") != "1":
+            import sys
+            print(f"[pydynet_amd.distributed] RCCL channels: NCCL_MAX_NCHANNELS={os.environ.get('NCCL_MAX_NCHANNELS', 'unset (RCCL default)')}"
+                  f"{' (set here; PDN_RCCL_MAX_CHANNELS=0 leaves the default)' if self._nch_set else ''}", file=sys.stderr)
         uid = None
         if self.rank == 0:
             buf = ctypes.create_string_buffer(128)
@@ -68,6 +77,8 @@ class RcclComm:
         h = ctypes.c_void_p()
         L.call("pdn_comm_init", ctypes.byref(h), self.rank, self.world, uid)
         self._comm = h.value
+        if self._nch_set:                               # the cap was for THIS communicator's initialisation only
+            os.environ.pop("NCCL_MAX_NCHANNELS", None)
         s = ctypes.c_void_p()
         # NORMAL priority on purpose: while a high-priority queue holds a barrier packet waiting for an
         # event, every kernel of the compute queue runs 10-60 us longer (one-GPU probe, B = 256:
@@ -251,7 +262,7 @@ class DataParallel:
             # a parameter that fills a bucket by itself (the embedding table: 36.9 MB, and the LAST gradient of
             # backward) reduces alone: what was collected before it -- layer 0's 2.6 MB -- goes out now instead of
             # waiting for it (anything under 1/8 of a bucket rides along: not worth a message of its own)
-            if n >= cap and off - start >= cap // 8:
+            if n >= cap and off > start and off - start >= cap // 8:        # (off > start: never an EMPTY bucket, tiny caps)
                 self.buckets.append((start, off, first, i))
                 start, first = off, i
             end = off + (n + 3) // 4 * 4

@@ -100,169 +100,6 @@ def synchronize():
     _lib.lib().call("pdn_stream_synchronize", stream())
 
 
-_side = {}        # device -> (side stream, fork event, join event)
-
-
-class side_stream:
-    """Run the launches of the `with` body on a second stream of the current device, concurrently with
-    whatever the compute stream is given next; `join()` makes the compute stream wait for them.
-
-        with hipnp.side_stream() as s:      # side stream waits for everything enqueued so far
-            hipnp.gemm(x.T, g, dw)          # ... runs beside ...
-        hipnp.gemm(g, w.T, dx)              # ... this one
-        s.join()                            # later compute-stream work sees both results
-
-    Lifetime rule (the allocator orders reuse on the compute stream only): join before any buffer the
-    body touched can be released, i.e. before the enclosing operator returns.  Workspaces are per stream."""
-
-    def __enter__(self):
-        L = _lib.lib()
-        dev = _state["device"]
-        ent = _side.get(dev)
-        if ent is None:
-            st, e0, e1 = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
-            L.call("pdn_stream_create", ctypes.byref(st), 0)
-            L.call("pdn_event_create", ctypes.byref(e0), 0)
-            L.call("pdn_event_create", ctypes.byref(e1), 0)
-            ent = _side[dev] = (st.value, e0, e1)
-        self._main = stream()
-        self._side, self._e0, self._e1 = ent
-        L.call("pdn_event_record", self._e0, self._main)
-        L.call("pdn_stream_wait_event", self._side, self._e0)
-        _state["stream"] = self._side
-        return self
-
-    def __exit__(self, *exc):
-        _state["stream"] = self._main
-        _lib.lib().call("pdn_event_record", self._e1, self._side)
-        return False
-
-    def join(self):
-        _lib.lib().call("pdn_stream_wait_event", self._main, self._e1)
-
-
-class Timer:
-    """HIP-event stopwatch on the compute stream: `with Timer() as t: ...; t.ms`."""
-
-    def __enter__(self):
-        L = _lib.lib()
-        self._e = [ctypes.c_void_p(), ctypes.c_void_p()]
-        for e in self._e:
-            L.call("pdn_event_create", ctypes.byref(e), 1)
-        L.call("pdn_event_record", self._e[0], stream())
-        return self
-
-    def __exit__(self, *exc):
-        L = _lib.lib()
-        L.call("pdn_event_record", self._e[1], stream())
-        L.call("pdn_event_synchronize", self._e[1])
-        ms = ctypes.c_float()
-        L.call("pdn_event_elapsed_ms", self._e[0], self._e[1], ctypes.byref(ms))
-        self.ms = ms.value
-        for e in self._e:
-            L.call("pdn_event_destroy", e)
-        return False
-
-
-_capture = {"graph": None}
-
-
-def capturing():
-    """The Graph being captured right now (or warmed up inside its private pool), else None."""
-    return _capture["graph"]
-
-
-class Graph:
-    """A whole step captured once and replayed as ONE hipGraph launch: the reference pays a Python object
-    and at least one kernel launch per scalar-level operator, which bounds small-batch steps
-    by launch latency; a replay costs one launch and no Python work.
-
-        g = hipnp.Graph()
-        loss = g.capture(step)          # runs `step` twice: once to fill the private pool, once captured
-        for _ in range(n):
-            ids.data[...] = next_batch  # refresh the static input buffers in place (optional)
-            g.replay()                  # `loss` (and anything else `step` returned) is overwritten in place
-
-    Rules for `step`: everything on the device (no `.item()`, no host arrays turned into device tensors,
-    no dropout drawing host random numbers); tensors it allocates live in a pool private to the graph,
-    so the arrays it returns stay valid -- and are rewritten -- across replays.  Optimizers that keep a
-    host-side step counter (Adam) switch to a device-side counter while capturing."""
-
-    def __init__(self):
-        self._exec, self._pool, self.nodes, self._hooks, self._keep = None, None, 0, [], None
-        self._ws, self._pinned = {}, []          # scratch buffers / side tables the captured launches point into
-
-    def pin(self, obj):
-        """Keep `obj` (an array whose raw pointer a captured launch holds: a scratch workspace, an optimizer's
-        chunk table) alive until destroy(): a replay writes through the pointers baked in at capture time, so
-        nothing they address may go back to the allocator while the graph can still be launched."""
-        self._pinned.append(obj)
-        return obj
-
-    def on_replay(self, fn):
-        """Host bookkeeping to run at every replay (e.g. an optimizer's step counter)."""
-        self._hooks.append(fn)
-
-    def capture(self, step):
-        import gc
-        L = _lib.lib()
-        if _capture["graph"] is not None:
-            raise RuntimeError("a Graph is already being captured")
-        st = stream()
-        pool = ctypes.c_int()
-        L.call("pdn_pool_create", ctypes.byref(pool))
-        self._pool = pool.value
-        _capture["graph"] = self
-        self._warm = True
-        try:
-            L.call("pdn_pool_activate", self._pool)
-            out = step()                                   # fills the pool (driver allocations happen here)
-            L.call("pdn_stream_synchronize", st)
-            del out
-            gc.collect()
-            self._warm = False
-            self._hooks = []
-            L.call("pdn_graph_begin_capture", st)
-            try:
-                out = step()
-            finally:
-                h, n = ctypes.c_void_p(), ctypes.c_int()
-                L.call("pdn_graph_end_capture", st, ctypes.byref(h), ctypes.byref(n))
-            self._exec, self.nodes = h.value, n.value
-        finally:
-            L.call("pdn_pool_activate", 0)
-            _capture["graph"] = None
-        self._keep = out
-        self.replay()                                      # the captured run itself executed nothing
-        return out
-
-    @property
-    def warming(self):
-        return getattr(self, "_warm", False)
-
-    def replay(self):
-        for fn in self._hooks:
-            fn()
-        _lib.lib().call("pdn_graph_launch", self._exec, stream())
-
-    def pool_stats(self):
-        vals = [ctypes.c_int64() for _ in range(3)]
-        _lib.lib().call("pdn_pool_stats", self._pool, *[ctypes.byref(v) for v in vals])
-        return dict(zip(("in_use", "reserved", "device_allocs"), (v.value for v in vals)))
-
-    def destroy(self):
-        L = _lib.lib()
-        if self._exec:
-            L.call("pdn_stream_synchronize", stream())
-            L.call("pdn_graph_destroy", self._exec)
-            self._exec = None
-        self._keep = None
-        self._ws, self._pinned = {}, []
-        if self._pool:
-            L.call("pdn_pool_destroy", self._pool)
-            self._pool = None
-
-
 def memory_stats(device=None):
     """Allocator counters of a device: bytes in use / reserved / peak, driver allocations, requests, hits."""
     vals = [ctypes.c_int64() for _ in range(6)]
@@ -308,7 +145,7 @@ def workspace(nbytes: int):
     if nbytes <= 0:
         return 0, 0
     key = (_state["device"], _state["stream"])
-    g = _capture["graph"]
+    g = capturing()
     if g is not None:
         # a step being captured gets scratch of its OWN (from the graph's private pool, alive as long as the
         # graph): the process-wide buffer below may be replaced by a bigger one by any later eager op, and the
@@ -616,167 +453,6 @@ def full(shape, value, dtype=None):
 
 def zeros_like(a, dtype=None): return zeros(a.shape, dtype or a.dtype)
 def ones_like(a, dtype=None): return ones(a.shape, dtype or a.dtype)
-class readback_array(ndarray):
-    """A device array whose HOST value arrives by itself: its producer leaves it in host-visible memory
-    (`Mailbox.slot`: a kernel stores straight into mapped host memory); `get()` / `item()` wait for THAT value only
-    instead of synchronising the compute stream -- which may already be running later work (the next decode step,
-    llm/llama.py).  Basic-index views (`a[0]`) keep the property.  Writing into the array drops the host value: it is
-    an ordinary device array from then on."""
-
-    __slots__ = ("_rb", "_host")
-
-    def _settle(self):
-        """Host value (NumPy) of the array, or None if it was invalidated."""
-        rb = self._rb
-        if rb is not None:
-            self._rb = None
-            rb._finish(self)
-        return self._host
-
-    def get(self):
-        h = self._settle()
-        return np.array(h) if h is not None else ndarray.get(self)
-
-    def __getitem__(self, key):
-        out = ndarray.__getitem__(self, key)
-        if type(out) is ndarray and out._buf is self._buf:
-            h = self._settle()
-            if h is not None:
-                v = readback_array(out._buf, out._ptr, out.shape, out._strides, out.dtype)
-                v._rb, v._host = None, h[key]
-                return v
-        return out
-
-    def _dirty(self):
-        self._settle()
-        self._host = None
-
-    def __setitem__(self, key, value):
-        self._dirty(); ndarray.__setitem__(self, key, value)
-
-    def fill(self, value):
-        self._dirty(); return ndarray.fill(self, value)
-
-    def __iadd__(self, o): self._dirty(); return ndarray.__iadd__(self, o)
-    def __isub__(self, o): self._dirty(); return ndarray.__isub__(self, o)
-    def __imul__(self, o): self._dirty(); return ndarray.__imul__(self, o)
-    def __itruediv__(self, o): self._dirty(); return ndarray.__itruediv__(self, o)
-
-
-class _MappedHost:
-    """Owner of a block of coherent pinned host memory mapped into the device (pdn_host_alloc_mapped)."""
-
-    __slots__ = ("host", "ptr", "nbytes", "device", "__weakref__")
-
-    def __init__(self, nbytes):
-        h, d = ctypes.c_void_p(), ctypes.c_void_p()
-        _lib.lib().call("pdn_host_alloc_mapped", ctypes.byref(h), ctypes.byref(d), int(nbytes))
-        self.host, self.ptr, self.nbytes, self.device = h.value, d.value, int(nbytes), _state["device"]
-
-    def __del__(self):
-        h, self.host = self.host, 0
-        if h:
-            try:
-                _lib.lib().call("pdn_host_free", h)
-            except Exception:                      # interpreter shutdown
-                pass
-
-
-class read_later:
-    """Host value of a device array WITHOUT synchronising the compute stream: the copy into pinned host memory is queued
-    behind the array's producers and an event behind the copy; `get()` / `item()` wait for that event only.  A training
-    loop that reads step i's loss after queueing step i + 1 never lets the GPU run dry (`ndarray.get()` -- a blocking
-    copy on the compute stream -- waits for everything queued so far, i.e. also for the step just launched: measured
-    0.25 ms of idle GPU per 53 ms step in bench.py).  Pinned slots and events are recycled: allocating pinned memory
-    waits for the device (0.45 ms when it was done per call)."""
-
-    __slots__ = ("_slot", "_shape", "_dtype", "_nbytes", "_value")
-    _free = {}                                    # device -> [(mapped host block, event), ...]
-
-    def __init__(self, a: "ndarray"):
-        a = a if a.is_contiguous() else a.copy()
-        L = _lib.lib()
-        self._shape, self._dtype, self._value = a.shape, a.dtype, None
-        self._nbytes = a.size * a.dtype.itemsize
-        pool = read_later._free.setdefault(_state["device"], [])
-        slot = next((x for x in pool if x[0].nbytes >= self._nbytes), None)
-        if slot is not None:
-            pool.remove(slot)
-        else:
-            ev = ctypes.c_void_p()
-            L.call("pdn_event_create", ctypes.byref(ev), 0)
-            slot = (_MappedHost(_bi.max(self._nbytes, 256)), ev.value)
-        self._slot = slot
-        if self._nbytes:
-            L.call("pdn_memcpy_d2h_async", slot[0].host, a._ptr, self._nbytes, stream())
-        L.call("pdn_event_record", slot[1], stream())
-
-    def get(self) -> np.ndarray:
-        if self._value is None:
-            mem, ev = self._slot
-            _lib.lib().call("pdn_event_synchronize", ev)
-            buf = (ctypes.c_char * mem.nbytes).from_address(mem.host)
-            n = int(np.prod(self._shape, dtype=np.int64))
-            self._value = np.frombuffer(buf, dtype=self._dtype, count=n).reshape(self._shape).copy()
-            read_later._free.setdefault(mem.device, []).append(self._slot)
-            self._slot = None
-        return self._value
-
-    def item(self):
-        return self.get().item()
-
-    def __del__(self):
-        slot = getattr(self, "_slot", None)            # dropped unread: the slot goes back once its copy is through
-        if slot is not None:
-            try:
-                _lib.lib().call("pdn_event_synchronize", slot[1])
-                read_later._free.setdefault(slot[0].device, []).append(slot)
-            except Exception:                          # interpreter shutdown
-                pass
-
-
-class Mailbox:
-    """(n, *shape) int64 slots in host memory the GPU writes directly: a kernel stores slot i (system scope), the host
-    reads it by polling -- no copy command, no event, nothing queued between two graph replays.  Slots start at -1
-    (the kernels store non-negative values: token ids); `slot(i)` is slot i as a device array (its address is the
-    mapped one: kernels may read it) whose `get()` / `item()` wait until the GPU has filled it."""
-
-    def __init__(self, n, shape):
-        self.shape = tuple(int(s) for s in shape)
-        self.n, self.per = int(n), int(math.prod(self.shape))
-        self._mem = _MappedHost(8 * self.n * self.per)
-        buf = (ctypes.c_char * self._mem.nbytes).from_address(self._mem.host)
-        self.host = np.frombuffer(buf, dtype=np.int64).reshape((self.n,) + self.shape)
-        self.host[...] = -1
-        self._ptr = self._mem.ptr
-
-    def slot(self, i):
-        strides, acc = [], 1
-        for d in reversed(self.shape):
-            strides.append(acc); acc *= d
-        out = readback_array(self._mem, self._ptr + 8 * self.per * int(i), self.shape, tuple(reversed(strides)), np.int64)
-        out._host = None
-        out._rb = _Polled(self.host[int(i)])
-        return out
-
-
-class _Polled:
-    __slots__ = ("view",)
-
-    def __init__(self, view):
-        self.view = view
-
-    def _finish(self, arr):
-        v, spins = self.view, 0
-        while (v < 0).any():                       # the GPU's store has not landed yet
-            spins += 1
-            if spins == 200000:                    # far beyond any decode step: make sure the stream is still alive
-                synchronize()
-            elif spins > 400000:
-                raise RuntimeError("Mailbox slot was never written by the GPU")
-        arr._host = v.copy()
-
-
 def stacked_view(arrays):
     """A (n, *shape) view over `arrays` when they are contiguous, alike and equally spaced in memory
     (e.g. consecutive parameters of a flat buffer), else None.  Lets n GEMMs that share an operand
@@ -1334,3 +1010,8 @@ class _Random:
 
 
 random = _Random()
+
+
+# ---- parts of this module that live in files of their own (round 5) -- imported LAST: they build on the names above ----
+from ._hipnp_streams import side_stream, Timer, capturing, Graph                       # noqa: E402,F401
+from ._hipnp_host import readback_array, _MappedHost, read_later, Mailbox, _Polled     # noqa: E402,F401

@@ -256,7 +256,7 @@ class Llama(nn.Module):
                                             f.gate.weight, f.up.weight, f.down.weight, layer.input_norm.weight,
                                             layer.post_attn_norm.weight)]
         key = (B, hp._state["device"], int(Llama.fused_decode or 0), os.environ.get("PDN_DECODE_SPLITS", ""),
-               self.layers[0].attention.cache_k.shape[1], hash(tuple(ptrs)))
+               self.layers[0].attention.cache_k.shape[1], tuple(ptrs))      # (the addresses themselves: no hash to collide)
         if st is not None and st["key"] == key:
             return st if st["ok"] else None
         if st is not None:
