@@ -57,6 +57,7 @@ struct OutResParams {
   int max_parts;                  // the row maxima come as `max_parts` vectors of M (the projection's chunk ranges)
   float* zslab;                   // K split over grid.y: split y leaves its UNNORMALISED rows in slab y and its row sums in
                                   // zslab + y * M; outres_ce2_reduce_kernel normalises
+  int ablate_rt;                  // timing experiments (PDN_OUTRES_RT_ABLATE; 0 in the library): 1 = no epilogue (nothing stored)
   const float* Wt;                // CE 2: W^T (V x 288) row-major -- the rows W[:, target] of the normalising store are read as
                                   // 1152 contiguous bytes per token (from W itself they are 288 floats 4 V bytes apart: one
                                   // 64-byte sector each, 2.1 GB of extra HBM reads per step at the benchmark shape)
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void gemm_outres_kernel(O
   const unsigned ldc = to_slab ? (unsigned)OR_N : (unsigned)p.ldc;
   const int mrem = p.M - m0 - 4 * lh;               // rows rr < mrem exist
   const bool full = m0 + 32 <= p.M;
+  if (p.ablate_rt & 1) return;
   if (full) {
     // Whole row blocks (every wave of the benchmarked shapes).  The nine tiles used to leave one after the other, each
     // behind a wait for its own residual loads AND for the stores before them (vmcnt(0): nine serialised round trips while
@@ -504,6 +506,7 @@ static int outres_launch(const float* A, const float* B, float* C, const float* 
   }
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_outres_f32: 16-byte alignment required");
   OutResParams p{A, B, C, bias, residual, M, K, lda, ldb, ldc, nullptr, nullptr, nullptr, 0.f, K / OR_KP, nullptr};
+  p.ablate_rt = getenv("PDN_OUTRES_RT_ABLATE") ? atoi(getenv("PDN_OUTRES_RT_ABLATE")) : 0;
   if (kb > 0) {
     p.ppb = kb / OR_KP;
     p.ppb_magic = (unsigned)(((1ull << 32) + (unsigned)p.ppb - 1) / (unsigned)p.ppb);
