@@ -1,6 +1,6 @@
 #!/bin/bash
 # gpurun_out/$ROUND (scratch, written by tools/round_evidence.sh on the GPU box) -> profiles/ (tracked)
-ROUND=${ROUND:-r04}; S=gpurun_out/$ROUND; D=profiles
+ROUND=${ROUND:-r05}; S=gpurun_out/$ROUND; D=profiles
 cp $S/bench_default.json $D/${ROUND}_bench_default.json
 tail -1 $S/bench_force_dp.json > $D/${ROUND}_bench_force_dp.json
 for b in 128 64; do cp $S/bench_b$b.json $D/${ROUND}_bench_b$b.json; done
@@ -18,6 +18,7 @@ cp $S/decode_trace.txt $D/${ROUND}_decode_trace.txt
 cp $S/epilogue_probe.txt $D/${ROUND}_epilogue_probe.txt
 cp $S/lmhead_probe.txt $D/${ROUND}_lmhead_probe.txt
 cp $S/attn_masked_probe.txt $D/${ROUND}_attn_masked_probe.txt
+for f in rowtile_probe lmhead_gap_probe outres_fixed_probe; do cp $S/$f.txt $D/${ROUND}_$f.txt; done
 cp $S/step_gaps.txt $D/${ROUND}_step_gaps.txt
 cp $S/pmc_lenet_b4096.json $D/${ROUND}_pmc_lenet_b4096.json
 { grep -E "passed|failed|error" $S/pytest_gpu.log | tail -2; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt

@@ -4,24 +4,24 @@
 #   rocprofv3 kernel stats of the bench command, PMC passes (SQ / LDS / L2 / FETCH / WRITE) of the same command
 #   -- regenerated EVERY time (the summary records a hash of the kernel sources it was measured on; bench.py flags
 #   `traffic_stale` when the sources have changed since) -- the LeNet profile, attention / GEMM probes.
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 R=$PWD; O=$R/gpurun_out/$ROUND; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # counters first: bench.py reads the summary it finds under profiles/ (copied there right away on this box)
-bash tools/pmc_cmd.sh ${ROUND}_bench kernel python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate > $O/bench_pmc.txt 2>&1
+bash tools/pmc_cmd.sh ${ROUND}_bench kernel python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs > $O/bench_pmc.txt 2>&1
 python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_bench/summary.json $O/pmc_bench_b256.json && cp $O/pmc_bench_b256.json profiles/${ROUND}_pmc_bench_b256.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
-PDN_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline > $O/bench_force_dp.json 2>> $O/bench_default.err
-python bench.py --no-cpu-baseline --batch 128 > $O/bench_b128.json 2>> $O/bench_default.err
-python bench.py --no-cpu-baseline --batch 64 > $O/bench_b64.json 2>> $O/bench_default.err
+PDN_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline --no-other-configs > $O/bench_force_dp.json 2>> $O/bench_default.err
+python bench.py --no-cpu-baseline --no-other-configs --batch 128 > $O/bench_b128.json 2>> $O/bench_default.err
+python bench.py --no-cpu-baseline --no-other-configs --batch 64 > $O/bench_b64.json 2>> $O/bench_default.err
 for c in mlp lenet gru decode; do python bench.py --config $c --steps 200 --warmup 20 > $O/bench_$c.json 2>> $O/bench_default.err; done
 # (the LeNet line reads the counter summary of its own kernels: collected and stamped first)
 bash tools/pmc_cmd.sh ${ROUND}_lenet conv python tools/bench_configs.py 3 lenet:4096 > $O/lenet_pmc.txt 2>&1
 python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_lenet/summary.json $O/pmc_lenet_b4096.json && cp $O/pmc_lenet_b4096.json profiles/${ROUND}_pmc_lenet_b4096.json
 python bench.py --config lenet --batch 4096 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_lenet_b4096.json 2>> $O/bench_default.err
 python bench.py --config mlp --batch 65536 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_mlp_b65536.json 2>> $O/bench_default.err
-bash tools/prof_cmd.sh ${ROUND}_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate > $O/bench_kernel_stats.txt 2>&1
+bash tools/prof_cmd.sh ${ROUND}_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs > $O/bench_kernel_stats.txt 2>&1
 cp gpurun_out/prof_${ROUND}_bench/p_kernel_stats.csv $O/bench_b256_kernel_stats.csv 2>/dev/null
 bash tools/prof_cmd.sh ${ROUND}_lenet python tools/bench_configs.py 10 lenet:4096 > $O/lenet_kernel_stats.txt 2>&1
 bash tools/prof_cmd.sh ${ROUND}_decode python tools/bench_decode.py 256 8 > $O/decode_kernel_stats.txt 2>&1
@@ -38,5 +38,8 @@ bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
 python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
 python tools/lmhead_probe.py > $O/lmhead_probe.txt 2>&1
 python tools/attn_masked_probe.py > $O/attn_masked_probe.txt 2>&1
+python tools/rowtile_probe.py > $O/rowtile_probe.txt 2>&1
+python tools/lmhead_gap_probe.py > $O/lmhead_gap_probe.txt 2>&1
+python tools/outres_fixed_probe.py > $O/outres_fixed_probe.txt 2>&1
 bash tools/step_gaps.sh > $O/step_gaps.txt 2>&1
 ls -la $O
