@@ -1,7 +1,7 @@
 #!/bin/bash
 # idle time between consecutive kernels of one training step (rocprofv3 kernel trace of bench.py): bash tools/step_gaps.sh
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/ht; rocprofv3 --kernel-trace --output-format csv -d /tmp/ht -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate "$@" > /tmp/ht.log 2>&1
+rm -rf /tmp/ht; rocprofv3 --kernel-trace --output-format csv -d /tmp/ht -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs "$@" > /tmp/ht.log 2>&1
 f=$(find /tmp/ht -name "*kernel_trace.csv" | head -1)
 python - <<PY
 import csv, collections
