@@ -317,7 +317,7 @@ def batch_gate(model, ids_np, tgt_np, dev, pdn, lib, rtol=1e-4, want_families=(2
             "kernel_launches": {k: v for k, v in launched.items() if v}}
 
 
-def pmc_traffic():
+def pmc_traffic(batch=256):
     """HBM bytes per launch from the committed rocprofv3 PMC summary of this same command (FETCH_SIZE x 2 -- the
     gfx950 correction of MI355X_MICROARCH.md -- plus WRITE_SIZE, separate --pmc passes; tools/round_evidence.sh
     regenerates it with tools/pmc_cmd.sh + tools/stamp_pmc.py).  Counters cannot be read from inside the timed run,
@@ -325,13 +325,21 @@ def pmc_traffic():
     `_stale` says whether the kernel sources have changed since it was collected."""
     import glob
     import hashlib
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_b256.json")))
-    if not files:
+    # (counter summaries are per launch: only one collected at THIS per-GPU batch describes this run's launches;
+    #  `_meta.per_gpu_batch`, 256 for the files of rounds 1-4)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_b256.json")) +
+                   glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_bench_default.json")),
+                   key=lambda f: os.path.basename(f)[:3])
+    path = raw = rows = meta = None
+    for cand in reversed(files):
+        raw = open(cand, "rb").read()
+        rows = json.loads(raw)
+        meta = rows.pop("_meta", {})
+        if int(meta.get("per_gpu_batch", 256)) == int(batch):
+            path = cand
+            break
+    if path is None:
         return {}
-    path = files[-1]
-    raw = open(path, "rb").read()
-    rows = json.loads(raw)
-    meta = rows.pop("_meta", {})
     rel = os.path.relpath(path, ROOT)
     out = {"_source": f"{rel} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same command)",
            "_sha12": hashlib.sha256(raw).hexdigest()[:12], "_stale": None}
@@ -441,7 +449,7 @@ def main():
                     help="llama = the headline line (BASELINE.json configs 4 / 5); mlp / lenet = configs 2 / 3; gru = "
                          "examples/pydynet/ts_prediction.py; decode = KV-cache greedy generation (bench_other.py)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "0")),
-                    help="per-GPU batch (default: 256 for llama / mlp / lenet, 1568 for gru, 1 for decode)")
+                    help="per-GPU batch (default: 512 for llama (256 in rounds 1-4), 256 for mlp / lenet, 1568 for gru, 1 for decode)")
     ap.add_argument("--no-graph", action="store_true", help="mlp / lenet: time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-prof", action="store_true")
@@ -458,7 +466,10 @@ def main():
     if args.config != "llama":
         import bench_other
         return bench_other.run(args)
-    args.batch = args.batch or 256
+    # per-GPU batch: 512 sequences = 131072 token rows = two row blocks per CU for the row- / output-resident kernels (their
+    # per-launch costs -- the burst of A rows, the first piece, the last drain -- are paid once per 2 x the work: 81.5 % of the
+    # fp32-MFMA peak against 80.0 % at 256, rounds 1-4's default; 1024: 82.0 %); 32 GB of the 288 GB of HBM in use
+    args.batch = args.batch or 512
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # no launcher: this process becomes one (the ranks re-enter main() with RANK / WORLD_SIZE set)
         if os.environ.get("PDN_BENCH_SPAWN_PROBE") != "1":
@@ -572,7 +583,7 @@ def main():
         lib.call("pdn_gemm_prof_collect_families", ms2, fl2, n2)
         tf = lambda f, m: f / (m * 1e-3) / 1e12 if m > 0 else 0.0
         peak = PEAK_FP32_MFMA / 1e12
-        traffic = pmc_traffic()
+        traffic = pmc_traffic(B)
 
         def fam_rec(ms, fl, n, name):
             return {"achieved": tf(fl, ms), "frac": tf(fl, ms) / peak, "launches": n,

@@ -64,7 +64,8 @@ struct RowTileParams {
   float* rms;
   int64_t ldxn;
   float norm_eps;
-  int ablate;                     // timing experiments (PDN_ROWTILE_ABLATE; 0 in the library): 1 = no barriers after the first
+  int ablate;                     // timing experiments (PDN_ROWTILE_ABLATE; 0 in the library): 1 = no barriers after the first,
+                                  // 2 = the A rows are loaded from ONE cache line per lane (no 75 MB burst), 4 = no final drain
 };
 
 template <int V> using rt_ic = std::integral_constant<int, V>;
@@ -172,9 +173,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   {
     const int arow_i = min(m0 + li, p.M - 1);
     const float* arow = p.A + (int64_t)arow_i * p.lda + 4 * lh;
+    const int astep = (p.ablate & 2) ? 0 : 8;
 #pragma unroll
     for (int t = 0; t < RT_KG; ++t) {
-      const float4 v = *reinterpret_cast<const float4*>(arow + 8 * t);
+      const float4 v = *reinterpret_cast<const float4*>(arow + astep * t);
       a[t].x = v.x; a[t].y = v.y; a[t].z = v.z; a[t].w = v.w;
     }
   }
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
   // the last tile (EPI 1: up + h of the last pair) leaves with nothing to hide behind
   auto final_drain = [&](auto sc) __attribute__((always_inline)) {
     constexpr int SD = decltype(sc)::value;         // the set of the last piece (EPI 1: unused)
-    if (!wave_on) return;
+    if (!wave_on || (p.ablate & 4)) return;
     float* Cd; float* Hd = nullptr; const float* Gd = nullptr;
     bool rot_d = false;
     if (EPI == 1) {

@@ -3,12 +3,12 @@
 ROUND=${ROUND:-r05}; S=gpurun_out/$ROUND; D=profiles
 cp $S/bench_default.json $D/${ROUND}_bench_default.json
 tail -1 $S/bench_force_dp.json > $D/${ROUND}_bench_force_dp.json
-for b in 128 64; do cp $S/bench_b$b.json $D/${ROUND}_bench_b$b.json; done
+for b in 1024 256 128 64; do cp $S/bench_b$b.json $D/${ROUND}_bench_b$b.json; done
 for c in mlp lenet gru decode lenet_b4096 mlp_b65536; do cp $S/bench_$c.json $D/${ROUND}_bench_$c.json; done
-cp $S/bench_b256_kernel_stats.csv $D/${ROUND}_bench_b256_kernel_stats.csv
-cp $S/bench_kernel_stats.txt $D/${ROUND}_bench_b256_kernel_stats.txt
-cp $S/pmc_bench_b256.json $D/${ROUND}_pmc_bench_b256.json
-cp $S/bench_pmc.txt $D/${ROUND}_pmc_bench_b256.txt
+cp $S/bench_default_kernel_stats.csv $D/${ROUND}_bench_default_kernel_stats.csv
+cp $S/bench_kernel_stats.txt $D/${ROUND}_bench_default_kernel_stats.txt
+cp $S/pmc_bench_default.json $D/${ROUND}_pmc_bench_default.json
+cp $S/bench_pmc.txt $D/${ROUND}_pmc_bench_default.txt
 cp $S/lenet_kernel_stats.txt $D/${ROUND}_lenet_b4096_kernel_stats.txt
 cp $S/lenet_pmc.txt $D/${ROUND}_lenet_b4096_pmc.txt
 cp $S/decode_kernel_stats.txt $D/${ROUND}_decode_kernel_stats.txt

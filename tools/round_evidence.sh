@@ -10,9 +10,11 @@ timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
 # counters first: bench.py reads the summary it finds under profiles/ (copied there right away on this box)
 bash tools/pmc_cmd.sh ${ROUND}_bench kernel python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs > $O/bench_pmc.txt 2>&1
-python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_bench/summary.json $O/pmc_bench_b256.json && cp $O/pmc_bench_b256.json profiles/${ROUND}_pmc_bench_b256.json
+python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_bench/summary.json $O/pmc_bench_default.json 512 && cp $O/pmc_bench_default.json profiles/${ROUND}_pmc_bench_default.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
 PDN_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline --no-other-configs > $O/bench_force_dp.json 2>> $O/bench_default.err
+python bench.py --no-cpu-baseline --no-other-configs --batch 256 > $O/bench_b256.json 2>> $O/bench_default.err
+python bench.py --no-cpu-baseline --no-other-configs --batch 1024 --steps 5 > $O/bench_b1024.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --no-other-configs --batch 128 > $O/bench_b128.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --no-other-configs --batch 64 > $O/bench_b64.json 2>> $O/bench_default.err
 for c in mlp lenet gru decode; do python bench.py --config $c --steps 200 --warmup 20 > $O/bench_$c.json 2>> $O/bench_default.err; done
@@ -22,7 +24,7 @@ python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_lenet/summary.json $O/pmc_lene
 python bench.py --config lenet --batch 4096 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_lenet_b4096.json 2>> $O/bench_default.err
 python bench.py --config mlp --batch 65536 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_mlp_b65536.json 2>> $O/bench_default.err
 bash tools/prof_cmd.sh ${ROUND}_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs > $O/bench_kernel_stats.txt 2>&1
-cp gpurun_out/prof_${ROUND}_bench/p_kernel_stats.csv $O/bench_b256_kernel_stats.csv 2>/dev/null
+cp gpurun_out/prof_${ROUND}_bench/p_kernel_stats.csv $O/bench_default_kernel_stats.csv 2>/dev/null
 bash tools/prof_cmd.sh ${ROUND}_lenet python tools/bench_configs.py 10 lenet:4096 > $O/lenet_kernel_stats.txt 2>&1
 bash tools/prof_cmd.sh ${ROUND}_decode python tools/bench_decode.py 256 8 > $O/decode_kernel_stats.txt 2>&1
 bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 256 48 > $O/attn_pmc.txt 2>&1

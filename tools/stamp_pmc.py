@@ -20,6 +20,7 @@ def sources_sha():
 if __name__ == "__main__":
     rows = json.load(open(sys.argv[1]))
     rows["_meta"] = {"kernel_sources_sha16": sources_sha(),
+                     "per_gpu_batch": int(sys.argv[3]) if len(sys.argv) > 3 else 256,
                      "collected_with": "tools/pmc_cmd.sh (rocprofv3 --kernel-trace --pmc, five separate passes)"}
     json.dump(rows, open(sys.argv[2], "w"), indent=1)
     print("stamped", sys.argv[2], rows["_meta"]["kernel_sources_sha16"])
