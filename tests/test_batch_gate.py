@@ -23,7 +23,7 @@ def _fullsize(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B", [224, 256])
+@pytest.mark.parametrize("B", [224, 256, 512])     # 512 = bench.py's default per-GPU batch (round 5), 256 = rounds 1-4's
 def test_benchmarked_batch_equals_mean_of_single_sequence_steps_gpu(hip, B):
     import bench
     import pydynet_amd as pdn
