@@ -1,4 +1,6 @@
-"""Row-resident projections with their stores switched off (PDN_ROWRES_EPI_ABLATE=4, timing only): what the store phases cost.
+"""Row-resident projections ON THE CHUNK KERNEL (csrc/gemm_rowres.hip: `pdn_gemm_rowtile_mode(0)`) with their stores switched off
+(PDN_ROWRES_EPI_ABLATE=4, timing only): what the store phases cost -- the measurement the tile-piece kernel of round 5 was
+designed from.
 usage: python tools/rowres_ablate.py [tokens=65536]"""
 import os
 import sys
@@ -9,6 +11,7 @@ from pydynet_amd import hipnp as hp, _lib
 
 hp.set_device(0)
 L = _lib.lib()
+L.query("pdn_gemm_rowtile_mode", 0)
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 K = 288
 rng = np.random.default_rng(0)
