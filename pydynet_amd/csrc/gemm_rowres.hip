@@ -692,7 +692,15 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
   // (a residual that ALIASES C stays on the chunk kernel: the tile-piece kernel's first, dummy drain writes the place of the
   //  workgroup's last tile before that tile's residual rows have been read)
   const bool res_alias = residual && (const float*)C < residual + (int64_t)M * ldc && residual < (const float*)C + (int64_t)M * ldc;
-  if ((!residual || !epi) && !res_alias) {
+  // (the same for a SwiGLU backward run IN PLACE, d[gate | up] over the saved [gate | up]: the chunk kernel reads a
+  //  position before it writes it; the tile-piece kernel's dummy first drain would not)
+  const bool gu_alias = epi && epi->kind == 2 && epi->GU && (const float*)C < epi->GU + (int64_t)M * ldc &&
+                        epi->GU < (const float*)C + (int64_t)M * ldc;
+  if (epi && epi->norm_w && epi->xn && A < epi->xn + (int64_t)M * epi->ldxn && epi->xn < A + (int64_t)M * lda) {
+    pdn_set_error("row-resident projection with the RMSNorm folded in: xn must not overlap x (other workgroups read the same rows)");
+    return PDN_EINVAL;
+  }
+  if ((!residual || !epi) && !res_alias && !gu_alias) {
     RowTileArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.A = A; ta.B = B; ta.C = C; ta.bias = bias; ta.residual = residual; ta.M = M; ta.N = N; ta.lda = lda; ta.ldb = ldb; ta.ldc = ldc;

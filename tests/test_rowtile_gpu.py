@@ -259,3 +259,19 @@ def test_rowmax_projection_bit_identical(hip, M, V, bias):
     _same(old, new, ["logits", "row maxima"])
     assert np.array_equal(new[1], new[0].max(1))
     _close(new[0], x.astype(np.float64) @ w.astype(np.float64) + (b if bias else 0.0), "logits")
+
+
+def test_swiglu_backward_in_place_stays_correct(hip):
+    """d[gate | up] written OVER the saved [gate | up] (an in-place caller): the entry point must not take the tile-piece
+    kernel, whose first (dummy) drain writes a tile before its gate / up rows were read; results equal the out-of-place call."""
+    L, hp = _lib_hp()
+    M, F = 2560, 768
+    rng = np.random.default_rng(77)
+    dy = hp.from_numpy(rng.standard_normal((M, K)).astype(np.float32))
+    wdn = hp.from_numpy((0.08 * rng.standard_normal((F, K))).astype(np.float32))
+    gu_h = rng.standard_normal((M, 2 * F)).astype(np.float32)
+    gu, out = hp.from_numpy(gu_h), hp.empty((M, 2 * F), np.float32)
+    L.call("pdn_swiglu_bwd_gemm_f32", dy._ptr, wdn._ptr, gu._ptr, out._ptr, M, F, K, K, hp.stream())
+    inplace = hp.from_numpy(gu_h)
+    L.call("pdn_swiglu_bwd_gemm_f32", dy._ptr, wdn._ptr, inplace._ptr, inplace._ptr, M, F, K, K, hp.stream())
+    assert np.array_equal(out.get(), inplace.get())
