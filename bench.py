@@ -83,14 +83,15 @@ GATE_RTOL = 1e-4
 
 COUNTER_SLOTS = ("rowres_chunk", "rowtile_plain", "rowtile_swiglu_fwd", "rowtile_swiglu_bwd", "rowtile_rope", "rowtile_rowmax",
                  "rowres_chunk_epilogue", "attention_p_fwd", "attention_p_bwd", "attention_resident_fwd",
-                 "attention_resident_bwd", "attention_stream", "lm_head_dx_sumexp", "lm_head_dw_ce", "outres", "outres_tn")
+                 "attention_resident_bwd", "attention_stream", "lm_head_dx_sumexp", "lm_head_dw_ce", "outres", "outres_tn",
+                 "linear_relu_fwd", "linear_dx_masked", "ce_small")
 
 
 def kernel_counters(lib, reset=False):
     """Launches per kernel since the last reset, from the library's own counters (include/pdn_hip.h: pdn_kernel_counters)."""
     import ctypes
-    buf = (ctypes.c_int64 * 16)()
-    lib.call("pdn_kernel_counters", buf, 16, 1 if reset else 0)
+    buf = (ctypes.c_int64 * len(COUNTER_SLOTS))()
+    lib.call("pdn_kernel_counters", buf, len(COUNTER_SLOTS), 1 if reset else 0)
     return dict(zip(COUNTER_SLOTS, (int(v) for v in buf)))
 
 

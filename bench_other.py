@@ -238,6 +238,9 @@ def _train_gate(which, net, X, y, step, rtol=1e-4):
     popt = Adam(net.parameters(), lr=1e-4)
     ropt = onn.Adam(ref.parameters(), lr=1e-4)
     worst = 0.0
+    from bench import kernel_counters
+    from pydynet_amd import _lib
+    kernel_counters(_lib.lib(), reset=True)
     for _ in range(3):
         loss = F.cross_entropy_loss(net(Xs), Ys)
         popt.zero_grad(); loss.backward(); popt.step()
@@ -249,7 +252,13 @@ def _train_gate(which, net, X, y, step, rtol=1e-4):
     for n, p in mine.items():                                # timing starts from the initial weights again
         p.data[...] = keep[n]
     otape.reset_tape()
-    return {"steps": 3, "batch": nb, "worst_loss_rel_err": worst, "rtol": rtol, "against": "oracle (NumPy port of the reference)"}
+    launched = {k: v for k, v in kernel_counters(_lib.lib(), reset=True).items() if v}
+    if which == "mlp" and (launched.get("linear_relu_fwd", 0) < 6 or launched.get("linear_dx_masked", 0) < 6):
+        # Linear -> ReLU as one product, the relu gradient applied in the consumer's input-gradient product: a dispatch
+        # that falls back to separate relu passes would keep the losses right and only show as a slower number
+        raise SystemExit(f"bench.py --config mlp: the fused Linear + ReLU products were not launched ({launched})")
+    return {"steps": 3, "batch": nb, "worst_loss_rel_err": worst, "rtol": rtol, "against": "oracle (NumPy port of the reference)",
+            "kernel_launches": launched}
 
 
 def _cpu_train(which, budget=12.0):

@@ -124,6 +124,22 @@ int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
                  float* b_colsum, int colsum_accumulate, void* workspace, int64_t workspace_bytes,
                  void* stream);
 int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
+/* `relu(linear(x))` as one product, and its backward without an elementwise pass (examples/pydynet/mnist.py:70-78:
+ * Linear -> ReLU -> Linear -> ReLU -> Linear; nn/functional.py:31-32 relu = maximum(0., x); tensor.py:808-814: its
+ * gradient passes where out == x, i.e. where the pre-activation is >= 0).
+ *  - pdn_linear_relu_fwd_f32: h (M x N, ldh) = max(0, x W + b), and mask: ONE BIT per element, set where x W + b >= 0;
+ *    bit c of word [row * (N / 32) + col / 32] is column 32 * (col / 32) + c.  x rows x_rs apart (unit stride inside),
+ *    W (K x N) with strides (w_rs, w_cs).  The pre-activation is never stored.
+ *  - pdn_linear_dx_masked_f32: dx (M x fin, ld) = mask o (g (M x fout) W^T + existing), W (fin x fout): the consumer of h
+ *    hands this layer the gradient of the PRE-activation straight from its input-gradient product.
+ *  - pdn_relu_mask_bwd_f32: dz = mask o g over a contiguous (rows x cols) array (any other consumer of h).
+ * N / fin / cols must be multiples of 32 (pdn_relu_mask_supported). */
+int pdn_relu_mask_supported(int64_t rows, int cols);
+int pdn_linear_relu_fwd_f32(const float* x, int64_t x_rs, const float* W, int64_t w_rs, int64_t w_cs, const float* bias,
+                            float* h, int64_t ldh, uint32_t* mask, int M, int N, int K, void* stream);
+int pdn_linear_dx_masked_f32(const float* g, int64_t g_rs, const float* W, int64_t w_rs, int64_t w_cs, float* dx, int64_t ld,
+                             const float* existing, const uint32_t* mask, int M, int fin, int fout, void* stream);
+int pdn_relu_mask_bwd_f32(const float* g, const uint32_t* mask, float* dz, int64_t rows, int cols, void* stream);
 /* Row-resident product for the layer projections (tall A with contiguous rows, contraction of a few
  * hundred): C (M x N) = A (M x K) * B + bias[N] + residual[M x N]; B is (K x N) row-major, or with
  * `b_trans` the (N x K) row-major matrix whose transpose is meant (`grad @ W^T`, tensor.py:670).
@@ -145,13 +161,14 @@ int pdn_qkv_rope_norm_fwd_f32(const float* x, const float* norm_w, float eps, fl
                               int64_t ldx, void* stream);
 /* Launch counters per kernel: which kernel the entry points really launched since the last reset -- bench.py's parity
  * gates and the tests assert on them (a dispatch that silently falls back to a slower kernel must not stay green).
- * Copies min(n, 16) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
+ * Copies min(n, 19) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
  *   0 gemm_rowres_kernel (chunk kernel, any)      1 gemm_rowtile_kernel plain        2 ... + SwiGLU forward (gate | up)
  *   3 ... + SwiGLU backward (dh)                  4 ... + RoPE (q | k | v)           5 ... + row maxima (lm_head forward)
  *   6 gemm_rowres_kernel with a fused epilogue    7 attention_p forward (persistent) 8 attention_p backward (dQ + dK/dV)
  *   9 resident attention forward                 10 resident attention backward     11 streaming attention (either direction)
  *  12 lm_head input gradient + sum of exponentials (gemm_outres_kernel CE 2)        13 lm_head weight gradient, CE gradient inside
- *  14 gemm_outres_kernel plain                   15 gemm_outres_tn_kernel plain */
+ *  14 gemm_outres_kernel plain                   15 gemm_outres_tn_kernel plain
+ *  16 pdn_linear_relu_fwd_f32                    17 pdn_linear_dx_masked_f32        18 cross entropy over <= 32 classes */
 int pdn_kernel_counters(int64_t* out, int n, int reset);
 /* Round 5: which kernel the row-resident entry points below and above launch.  The tile-piece kernel
  * (csrc/gemm_rowtile.hip: one 32-column tile of B over the whole contraction per piece, rotating accumulator sets, stores

@@ -6,6 +6,8 @@ kernel (or GEMM) on a GPU device; on "cpu" the same node evaluates the equivalen
 expression.  Reference chains replaced:
 
     linear          nn/functional.py:7-11           (matmul + broadcast add; dW summed by the engine)
+    linear_relu     nn/functional.py:7-11, 31-32    (Linear -> ReLU of examples/pydynet/mnist.py:70-78: relu and one gradient bit
+                                                     per element in the product's store; the consumer's dX product applies the bits)
     rms_norm        nn/modules/norm.py:245-248      (6 nodes)
     silu / swiglu   nn/functional.py:39-40, llm/llama/model.py:56-58
     relu            nn/functional.py:31-32          (maximum(0., x); gradient 1 at x == 0)
@@ -16,7 +18,7 @@ expression.  Reference chains replaced:
     cross_entropy   nn/functional.py:364-381        (7 nodes, integer targets)
 """
 from ._common import (_hip, _L, _contig, hip_f32, _require_f32, _foldable, two_stream, _beside, _is_leaf_f32, _Deferred, _pack_columns, _dx_of_shared_input, _gemm_raw)
-from .dense import linear, embedding, cross_entropy, linear_cross_entropy
+from .dense import linear, linear_relu, embedding, cross_entropy, linear_cross_entropy
 from .pointwise import gated_sigmoid, swiglu, silu, softmax, rope
 from .norm import rms_norm, layer_norm, col_norm
 from .attn import _attn_layout, _attn_mask_args, _attn_kernel, attention, qkv_attention

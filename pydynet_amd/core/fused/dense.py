@@ -9,21 +9,29 @@ import numpy as np
 
 from ...autograd import is_grad_enable
 from ..tensor import Tensor, _Operator
-from ._common import _hip, _L, _contig, _require_f32, _foldable, _beside, _is_leaf_f32
+from ._common import _hip, _L, _contig, _require_f32, _foldable, _beside, _is_leaf_f32, _Deferred, hip_f32
 
 
-class linear(_Operator):
+class linear(_Deferred, _Operator):
     """y = x @ W (+ b) (+ residual) over the last axis of x; W is (in, out).
 
     `residual` (shape of y) folds the `z = x + sublayer(x)` add of a transformer block into the
-    GEMM epilogue; its gradient is the upstream gradient itself."""
+    GEMM epilogue; its gradient is the upstream gradient itself.
+
+    A projection `relu` could take over (float32 on the device, out features a multiple of 32, no residual) is
+    created without running anything (`_Deferred`): `F.relu` of it becomes ONE `linear_relu` node, any other consumer
+    reads `.data`, which runs the product then."""
 
     folds_existing = True      # backward adds the gradient x already holds inside the dX GEMM
+    defer = True               # class switch: False runs every product at construction (no linear + relu fusion)
 
     def __init__(self, x, weight, bias=None, residual=None):
         self.has_bias, self.has_res = bias is not None, residual is not None
         ins = [x, weight] + ([bias] if self.has_bias else []) + ([residual] if self.has_res else [])
-        super().__init__(*ins)
+        if type(self) is linear and self.defer and linear_relu.applicable(x, weight, bias, residual):
+            self._init_deferred(ins, tuple(x.shape[:-1]) + (weight.shape[1],), np.float32)
+        else:
+            super().__init__(*ins)
 
     def _split(self, ins):
         b = ins[2] if self.has_bias else None
@@ -50,6 +58,16 @@ class linear(_Operator):
     def _dx(self, hp, g2, x, w, fin):
         dx = hp.empty(x.shape, np.float32)
         ex = _foldable(self, 0, x)
+        mask = getattr(x, "_relu_bits", None) if type(x) is linear_relu else None
+        if mask is not None and g2._strides[-1] == 1 and (ex is None or ex.is_contiguous()):
+            # x = relu(pre-activation) of a linear_relu node: its bits applied in this product's store, so that node
+            # receives the gradient of its PRE-activation (relu'(z) o (g W^T + what x already holds)) -- no relu pass
+            wd = w.data
+            _L().call("pdn_linear_dx_masked_f32", g2._ptr, g2._strides[0], wd._ptr, wd._strides[0], wd._strides[1],
+                      dx._ptr, fin, ex._ptr if ex is not None else None, mask._ptr, g2.shape[0], fin, wd.shape[1],
+                      hp.stream())
+            dx._aux = ("relu_masked", mask)
+            return dx
         hp.gemm(g2, w.data.T, dx.reshape(-1, fin),                         # NT
                 residual=ex.reshape(-1, fin) if ex is not None else None)
         return dx
@@ -105,6 +123,52 @@ class linear(_Operator):
         if need_db and not fuse_db:
             grads[2] = g2.sum(0).reshape(b.shape)
         return grads
+
+
+class linear_relu(linear):
+    """relu(x @ W + b) as ONE node (examples/pydynet/mnist.py:70-78: Linear -> ReLU; nn/functional.py:31-32 relu =
+    maximum(0., x), tensor.py:808-814: its gradient passes where out == x, i.e. pre-activation >= 0).
+
+    Forward: the product stores max(0, x W + b) and one bit per element (pre-activation >= 0) -- the pre-activation
+    never exists in HBM (`pdn_linear_relu_fwd_f32`).  Backward: a `linear` consumer applies the bits inside its
+    input-gradient product (`linear._dx`), so the gradient arrives as that of the pre-activation; a gradient from any
+    other consumer (or an accumulated one) gets the bits applied here (`pdn_relu_mask_bwd_f32`; applying them twice
+    changes nothing)."""
+
+    min_rows = 1
+
+    @staticmethod
+    def applicable(x, weight, bias, residual=None):
+        if (residual is not None or x.ndim < 1 or weight.ndim != 2 or not x.device.is_hip
+                or not hip_f32(x, weight, bias)):
+            return False
+        rows = int(np.prod(x.shape[:-1], dtype=np.int64))
+        return (rows >= linear_relu.min_rows and weight.shape[1] % 32 == 0 and x.shape[-1] == weight.shape[0]
+                and (bias is None or bias.size == weight.shape[1]))
+
+    def forward_(self, *ins):
+        x, w, b, _ = self._split(ins)
+        hp, L = _hip(), _L()
+        fin, fout = w.shape
+        x2 = _contig(x.data).reshape(-1, fin)
+        out = hp.empty(x.shape[:-1] + (fout,), np.float32)
+        self._relu_bits = hp.empty((x2.shape[0], fout // 32), np.float32)      # opaque 32-bit words
+        wd = w.data
+        L.call("pdn_linear_relu_fwd_f32", x2._ptr, x2._strides[0], wd._ptr, wd._strides[0], wd._strides[1],
+               _contig(b.data).reshape(-1)._ptr if b is not None else None, out._ptr, fout, self._relu_bits._ptr,
+               x2.shape[0], fout, fin, hp.stream())
+        return out
+
+    def backward_all(self, g):
+        aux = getattr(g, "_aux", None)
+        if not (aux is not None and aux[0] == "relu_masked" and aux[1] is self._relu_bits):
+            hp = _hip()
+            g = _contig(g)
+            dz = hp.empty(g.shape, np.float32)
+            _L().call("pdn_relu_mask_bwd_f32", g._ptr, self._relu_bits._ptr, dz._ptr, g.size // g.shape[-1], g.shape[-1],
+                      hp.stream())
+            g = dz
+        return super().backward_all(g)
 
 
 class embedding(_Operator):

@@ -318,6 +318,8 @@ def _accumulate(t, add_grad, xp):
         t._grad_owned = fresh
     elif t._grad_owned:
         t.grad += add_grad
+        if getattr(t.grad, "_aux", None) is not None:
+            t.grad._aux = None           # a producer's note about the array (column sums, relu bits applied) no longer holds
     else:                                # adopted array may alias another node's grad
         t.grad = t.grad + add_grad
         t._grad_owned = True

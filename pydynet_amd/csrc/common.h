@@ -37,7 +37,10 @@ enum {
   PDN_CNT_CE_DW = 13,             // gemm_outres_tn_kernel with the cross-entropy gradient formed inside
   PDN_CNT_OUTRES = 14,            // gemm_outres_kernel, plain
   PDN_CNT_OUTRES_TN = 15,         // gemm_outres_tn_kernel, plain
-  PDN_CNT_SLOTS = 16
+  PDN_CNT_LINEAR_RELU_FWD = 16,   // tiled kernel with the relu + bit-mask store (pdn_linear_relu_fwd_f32)
+  PDN_CNT_LINEAR_DX_MASKED = 17,  // tiled kernel with the bit mask applied in the store (pdn_linear_dx_masked_f32)
+  PDN_CNT_CE_SMALL = 18,          // ce_small_kernel: cross entropy over <= 32 classes, one thread per row
+  PDN_CNT_SLOTS = 19
 };
 void pdn_count(int slot);
 

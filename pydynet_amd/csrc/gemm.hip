@@ -50,6 +50,10 @@ struct GemmParams {
   const float* residual;   // optional, same indexing as C: C += residual
   float* colsum;           // optional, length N: column sums of B (bias gradient of x^T @ g)
   int colsum_acc;
+  // tiled kernel only, one batch, no k-split, N a multiple of 32: one bit per output element, bit c of word
+  // [row * (N / 32) + col / 32] <-> column 32 * (col / 32) + c
+  uint32_t* relu_mask;       // store max(0, result) and set the bit where result >= 0 (relu gradient passes, functional.py:31-32)
+  const uint32_t* grad_mask; // store result where the bit is set, 0 elsewhere
   float* ws;
   int M, N, K;
   int64_t a_rs, a_cs, b_rs, b_cs, ldc;
@@ -59,6 +63,15 @@ struct GemmParams {
   int splits, k_per_split;
   int tiles_m, tiles_n;
 };
+
+// relu epilogue helpers: max(0, v) that keeps a NaN (numpy.maximum propagates it) and turns -0 into +0; bit j of an 8-bit
+// value moved to bit 4j
+__device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v + 0.f; }
+__device__ __forceinline__ uint32_t spread_bits8(uint32_t x) {
+  x = (x | (x << 12)) & 0x000F000Fu;
+  x = (x | (x << 6)) & 0x03030303u;
+  return (x | (x << 3)) & 0x11111111u;
+}
 
 // ---- global -> register -> LDS staging -------------------------------------------------------
 // Tile of an operand: MN rows (m or n index) x BK contraction columns.
@@ -272,7 +285,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
 #undef GEMM_LOAD
 }
 
-template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM>
+// MASKS: the instantiations behind pdn_linear_relu_fwd_f32 / pdn_linear_dx_masked_f32 (GemmParams::relu_mask / grad_mask)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM, bool MASKS = false>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ? 3 : 2) void gemm_f32_mfma_kernel(GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -394,6 +408,20 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
             const float4 o = *reinterpret_cast<const float4*>(dst);
             v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
           }
+          if (MASKS && p.grad_mask) {             // (8 lanes = one 32-column word of this row)
+            const uint32_t w = p.grad_mask[(int64_t)(row0 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] >> (4 * (c4 & 7));
+            v.x = (w & 1u) ? v.x : 0.f; v.y = (w & 2u) ? v.y : 0.f; v.z = (w & 4u) ? v.z : 0.f; v.w = (w & 8u) ? v.w : 0.f;
+          }
+          if (MASKS && p.relu_mask) {
+            // bit j of a lane group's byte of each ballot = lane 8g + j = columns 4j .. 4j + 3 of the word
+            const int sh = lane & 56;
+            const uint32_t word = spread_bits8((uint32_t)(__ballot(v.x >= 0.f) >> sh) & 0xffu) |
+                                  spread_bits8((uint32_t)(__ballot(v.y >= 0.f) >> sh) & 0xffu) << 1 |
+                                  spread_bits8((uint32_t)(__ballot(v.z >= 0.f) >> sh) & 0xffu) << 2 |
+                                  spread_bits8((uint32_t)(__ballot(v.w >= 0.f) >> sh) & 0xffu) << 3;
+            v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); v.z = relu_keep_nan(v.z); v.w = relu_keep_nan(v.w);
+            if ((lane & 7) == 0) p.relu_mask[(int64_t)(row0 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] = word;
+          }
           *reinterpret_cast<float4*>(dst) = v;
         }
       }
@@ -421,7 +449,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
-          if (row < p.M) C[(int64_t)row * ldc + col] = p.alpha * acc[i][j][r] + bv + old[r];
+          float v = p.alpha * acc[i][j][r] + bv + old[r];
+          // (masks: N is a multiple of 32, so `col < N` holds for whole waves; a 32-lane half shares its row)
+          if (MASKS && p.grad_mask && row < p.M) v = ((p.grad_mask[(int64_t)row * (p.N >> 5) + (col >> 5)] >> li) & 1u) ? v : 0.f;
+          if (MASKS && p.relu_mask) {
+            const uint64_t b = __ballot(v >= 0.f);
+            v = relu_keep_nan(v);
+            if (li == 0 && row < p.M) p.relu_mask[(int64_t)row * (p.N >> 5) + (col >> 5)] = (uint32_t)(b >> (32 * lh));
+          }
+          if (row < p.M) C[(int64_t)row * ldc + col] = v;
         }
       }
     }
@@ -1023,19 +1059,19 @@ static const TileCfg kCfgs[] = {
 static const int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 static const int kScalarCfg = 5;
 
-template <int WMV, int WNV, int WM, int WN, int BK, bool VEC>
+template <int WMV, int WNV, int WM, int WN, int BK, bool VEC, bool MASKS = false>
 static void launch_layout(const GemmParams& p, bool a_kin, bool b_kin, dim3 grid, hipStream_t st) {
   constexpr int NT = WMV * WNV * 64;
   if (a_kin && b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, true, VEC, false>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, true, VEC, false, MASKS>), grid, dim3(NT), 0, st, p);
   else if (a_kin && !b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, false, VEC, false>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, true, false, VEC, false, MASKS>), grid, dim3(NT), 0, st, p);
   else if (!a_kin && b_kin)
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, true, VEC, false>), grid, dim3(NT), 0, st, p);
-  else if (p.colsum && VEC)   // x^T @ g with the bias gradient (column sums of g) fused in
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC, VEC>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, true, VEC, false, MASKS>), grid, dim3(NT), 0, st, p);
+  else if (!MASKS && p.colsum && VEC)   // x^T @ g with the bias gradient (column sums of g) fused in
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC, VEC && !MASKS, false>), grid, dim3(NT), 0, st, p);
   else
-    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC, false>), grid, dim3(NT), 0, st, p);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<WMV, WNV, WM, WN, BK, false, false, VEC, false, MASKS>), grid, dim3(NT), 0, st, p);
 }
 
 // ---- optional per-launch timing of the dominant kernel (bench.py roofline) ------------
@@ -1161,13 +1197,30 @@ extern "C" int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch)
   return (int64_t)64 * M * N * (int64_t)nbatch * 4;
 }
 
-extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
-                            int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta,
-                            float* C, int64_t ldc, const float* bias, int nb1, int nb2,
-                            int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
-                            int64_t c_bs1, int64_t c_bs2, const float* residual,
-                            float* b_colsum, int colsum_accumulate, void* workspace,
-                            int64_t workspace_bytes, void* stream) {
+// csrc/gemm_narrow.hip: products with at most 16 output columns on the vector ALUs (bandwidth kernels)
+bool pdn_gemm_narrow_nn_ok(int M, int N, int K, int64_t a_rs, int64_t a_cs, const void* A);
+int pdn_gemm_narrow_nn_launch(const float* A, int64_t lda, const float* B, int64_t b_rs, int64_t b_cs, const float* bias,
+                              float* C, int64_t ldc, int M, int N, int K, void* stream);
+bool pdn_gemm_narrow_k_ok(int M, int N, int K, int64_t a_cs, int64_t ldc, const void* C, const void* existing);
+int pdn_gemm_narrow_k_launch(const float* G, int64_t g_rs, const float* W, int64_t w_rs, int64_t w_cs, const float* existing,
+                             const uint32_t* bits, float* C, int64_t ldc, int M, int N, int K, void* stream);
+int pdn_gemm_narrow_tn_plan(int Mc, int N, int K, int64_t a_rs, int64_t a_cs, int64_t b_cs, const void* A, int64_t ws_cap_floats,
+                            int* kps);
+int pdn_gemm_narrow_tn_launch(const float* A, int64_t a_cs, const float* B, int64_t b_rs, float* slabs, int Mc, int N, int K,
+                              int kps, int splits, void* stream);
+
+// pdn_gemm_f32 proper.  `relu_mask` / `grad_mask` (GemmParams) are the one-bit-per-element epilogues of
+// pdn_linear_relu_fwd_f32 / pdn_linear_dx_masked_f32: with either, the product goes to the tiled kernel unsplit.
+static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
+                         int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta,
+                         float* C, int64_t ldc, const float* bias, int nb1, int nb2,
+                         int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
+                         int64_t c_bs1, int64_t c_bs2, const float* residual,
+                         float* b_colsum, int colsum_accumulate, void* workspace,
+                         int64_t workspace_bytes, void* stream, uint32_t* relu_mask, const uint32_t* grad_mask) {
+  const bool ext_on = relu_mask || grad_mask;
+  PDN_CHECK_ARG(!ext_on || (nb1 == 1 && nb2 == 1 && N % 32 == 0 && !b_colsum),
+                "pdn_gemm_f32: the mask epilogues need one batch and N a multiple of 32 (N = %d)", N);
   PDN_CHECK_ARG(M >= 0 && N >= 0 && K >= 0 && nb1 >= 0 && nb2 >= 0, "pdn_gemm_f32: negative extent");
   if (M == 0 || N == 0 || nb1 == 0 || nb2 == 0) return PDN_OK;
   PDN_CHECK_ARG(A && B && C, "pdn_gemm_f32: null operand");
@@ -1178,6 +1231,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = (float*)workspace;
   p.residual = residual; p.colsum = b_colsum; p.colsum_acc = colsum_accumulate;
+  p.relu_mask = relu_mask; p.grad_mask = grad_mask;
   p.M = M; p.N = N; p.K = K;
   p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
   p.nb2 = nb2;
@@ -1208,7 +1262,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   // ---- one to four output rows (decode): stream the weight matrix once ----------------------
   // (a workgroup walks ALL of K for its 128 columns: right when the weight matrix is wide, wrong for a
   //  long-K / narrow-N product such as the input-weight gradient of an RNN with one input feature)
-  if (M <= 4 && nbatch == 1 && !b_colsum && b_cs == 1 && a_cs == 1 && m4(N) && m4(b_rs) && m4(ldc) &&
+  if (M <= 4 && !ext_on && nbatch == 1 && !b_colsum && b_cs == 1 && a_cs == 1 && m4(N) && m4(b_rs) && m4(ldc) &&
       al16(B) && al16(C) && (!bias || al16(bias)) && (!residual || al16(residual)) && K > 0 &&
       (K <= 4096 || (int64_t)K <= 4ll * N)) {
     const dim3 g((N + 127) / 128);
@@ -1221,13 +1275,41 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     PDN_LAUNCH_CHECK();
     return PDN_OK;
   }
+  // ---- a contraction of at most 16 into a wide output (the input gradient below a classifier head): write-bound ----
+  if (nbatch == 1 && !relu_mask && alpha == 1.f && beta == 0.f && !bias && !b_colsum && pdn_gemm_narrow_k_ok(M, N, K, a_cs, ldc, C, residual) &&
+      (!grad_mask || N % 32 == 0) && !getenv("PDN_GEMM_NO_NARROW")) {
+    if (getenv("PDN_GEMM_DEBUG")) fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> narrow K\n", M, N, K);
+    return pdn_gemm_narrow_k_launch(A, a_rs, B, b_rs, b_cs, residual, grad_mask, C, ldc, M, N, K, stream);
+  }
+  // ---- a handful of output columns (a classifier head): bandwidth kernels on the vector ALUs (gemm_narrow.hip) ----
+  if (nbatch == 1 && !ext_on && N <= 16 && alpha == 1.f && !residual && !b_colsum && !getenv("PDN_GEMM_NO_NARROW")) {
+    if (beta == 0.f && pdn_gemm_narrow_nn_ok(M, N, K, a_rs, a_cs, A)) {
+      if (getenv("PDN_GEMM_DEBUG")) fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> narrow NN\n", M, N, K);
+      return pdn_gemm_narrow_nn_launch(A, a_rs, B, b_rs, b_cs, bias, C, ldc, M, N, K, stream);
+    }
+    int kps = 0;
+    const int64_t cap = (workspace && workspace_bytes > 0 && al16(workspace)) ? workspace_bytes / 4 : 0;
+    const int sp = !bias ? pdn_gemm_narrow_tn_plan(M, N, K, a_rs, a_cs, b_cs, A, cap, &kps) : 0;
+    if (sp > 0) {
+      if (getenv("PDN_GEMM_DEBUG")) fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> narrow TN (%d slabs)\n", M, N, K, sp);
+      const int rc = pdn_gemm_narrow_tn_launch(A, a_cs, B, b_rs, (float*)workspace, M, N, K, kps, sp, stream);
+      if (rc) return rc;
+      p.splits = sp;
+      const int64_t total = (int64_t)M * N;
+      const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+      const int rvec = (N % 4 == 0) && (ldc % 4 == 0) && al16(C);
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p, 1, rvec);
+      PDN_LAUNCH_CHECK();
+      return PDN_OK;
+    }
+  }
   // ---- tall A, contraction 288, wide-enough output: rows of A resident in registers (gemm_rowres.hip) ----
   // measured against the tiled kernel at 65536 rows: N 864 +19 %, 1536 +14 %, 768 (either B orientation)
   // +11..14 %, 32000 +4 %; N 288 equal (left to the tiled kernel); with a residual the tiled epilogue wins
   // ---- tall A, output exactly the model width (288), longer contraction: outputs resident in accumulators
   // (gemm_outres.hip).  Measured against the tiled kernel at 65536 rows: K 768 +6 %, 864 +17 %, 1536 +20 %,
   // 32000 +15 % (91.7 % of the matrix peak); at 32768 rows (4-wave workgroups, one wave per SIMD) K >= 1536 only.
-  if (nbatch == 1 && N == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum && K >= 768 &&
+  if (nbatch == 1 && !ext_on && N == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum && K >= 768 &&
       al16(A) && al16(B) && !getenv("PDN_GEMM_NO_OUTRES")) {
     const int bt = (b_rs == 1 && b_cs != 1) ? 1 : 0;
     const int64_t ldb = bt ? b_cs : b_rs;
@@ -1278,7 +1360,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     const int bt0 = (b_rs == 1 && b_cs != 1) ? 1 : 0;
     const bool tilepiece = nbatch == 1 && K == 288 && n_all >= 96 && n_all % 32 == 0 && M >= 8192 &&
                            pdn_rowtile_plain_ok(M, (int)n_all, bt0);
-    if ((nbatch == 1 || blocks) && K == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum &&
+    if ((nbatch == 1 || blocks) && !ext_on && K == 288 && a_cs == 1 && alpha == 1.f && beta == 0.f && !b_colsum &&
         (tilepiece || (!residual && n_all >= 768)) && n_all < (1 << 30) && M >= 8192 && al16(A) && al16(B) &&
         (!residual || al16(residual)) && !getenv("PDN_GEMM_NO_ROWRES")) {
       const int bt = (b_rs == 1 && b_cs != 1) ? 1 : 0;
@@ -1316,7 +1398,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   // ---- weight gradient of a wide layer out of the model width: C (288 x N) = x^T (288 x K) g (K x N), K = tokens --
   // (the lm_head: N = 32000).  Output-resident over the 288 rows, g read once straight into MFMA operands
   // (gemm_outres_tn_kernel); K split so that the grid fills the chip once, slabs combined (with beta) below.
-  if (nbatch == 1 && M == 288 && a_rs == 1 && a_cs >= 288 && b_cs == 1 && alpha == 1.f && !b_colsum && !bias && !residual &&
+  if (nbatch == 1 && !ext_on && M == 288 && a_rs == 1 && a_cs >= 288 && b_cs == 1 && alpha == 1.f && !b_colsum && !bias && !residual &&
       N >= 8192 && N % 32 == 0 && K % 32 == 0 && K >= 4096 && m4(a_cs) && m4(b_rs) && al16(A) && al16(B) &&
       (int64_t)288 * ldc < (1ll << 30) && (int64_t)32 * b_rs < (1ll << 30) && !getenv("PDN_GEMM_NO_OUTRES")) {
     int nw = 8, kps = K;
@@ -1408,9 +1490,27 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   // ---- weight-gradient form (small output, long K): wave-streaming kernel --------------------
   constexpr int SNW = 8;                                  // waves per streaming workgroup
   bool use_stream = false;
-  if (!a_kin && !b_kin && a_rs == 1 && b_cs == 1 && !b_colsum && K >= 2048 &&
+  int sshape = 0;
+  if (!ext_on && !a_kin && !b_kin && a_rs == 1 && b_cs == 1 && !b_colsum && K >= 2048 &&
       (int64_t)M * N * nbatch <= (1 << 20) && nbatch <= 64 && !getenv("PDN_GEMM_NO_STREAM")) {
-    const int tm = (int)cdiv64(M, 96), tn = (int)cdiv64(N, 96), tiles = tm * tn * nbatch;
+    // tile shape of the LDS-staged kernel (in 32-row / 32-column MFMA tiles): 3 x 3 unless another one pads the output
+    // less (784 x 1024: 9 x 11 tiles of 96 x 96 = 912 K accumulators, 5 x 16 of 160 x 64 = 819 K)
+    static const int kShapes[5][2] = {{3, 3}, {5, 2}, {2, 5}, {4, 2}, {2, 4}};
+    // time per accumulator of the padded output relative to 3 x 3 (tools/mlp_dw_probe.py, 65536 tokens: 784 x 1024,
+    // 1024 x 1024, 768 x 768, 512 x 2048); an exact 3 x 3 tiling takes the DMA-staged kernel
+    static const double kShapeCost[5] = {1.0, 1.05, 1.08, 1.07, 1.02};
+    sshape = 0;
+    if (vec) {
+      double best_area = (double)cdiv64(M, 96) * cdiv64(N, 96) * 96 * 96 * ((M % 96 == 0 && N % 96 == 0) ? 0.975 : 1.0);
+      for (int c = 1; c < 5; ++c) {
+        const int th = kShapes[c][0] * 32, tw = kShapes[c][1] * 32;
+        const double area = (double)cdiv64(M, th) * cdiv64(N, tw) * th * tw * kShapeCost[c];
+        if (area < best_area) { best_area = area; sshape = c; }
+      }
+      if (const char* e = getenv("PDN_GEMM_STREAM_SHAPE")) { const int c = atoi(e); if (c >= 0 && c < 5) sshape = c; }
+    }
+    const int sth = kShapes[sshape][0] * 32, stw = kShapes[sshape][1] * 32;
+    const int tm = (int)cdiv64(M, sth), tn = (int)cdiv64(N, stw), tiles = tm * tn * nbatch;
     if (tiles <= 256) {
       // one 8-wave workgroup per CU (2 waves / SIMD): rounds of 256 blocks; each extra slab costs a
       // write + read of the output in the reduce pass (~1.7 KB/clk), plus its launch
@@ -1422,7 +1522,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
         const int kw = (int)cdiv64(cdiv64(K, (int64_t)s * SNW), 8) * 8;
         const int kps = kw * SNW, sp = (int)cdiv64(K, kps);
         const double rounds = (double)cdiv64((int64_t)tiles * sp, 256);
-        double cost = rounds * (kw * 0.5 * 9 * 64 * (SNW / 4.0) + 6000.0);
+        double cost = rounds * (kw * 0.5 * (kShapes[sshape][0] * kShapes[sshape][1]) * 64 * (SNW / 4.0) + 6000.0);
         if (sp > 1) cost += (double)sp * M * N * nbatch * 8.0 / 1700.0 + 5000.0;
         if (cost < best_cost) { best_cost = cost; best_kps = kps; best_sp = sp; }
       }
@@ -1447,6 +1547,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   static const bool no_fixed = getenv("PDN_GEMM_NO_FIXED") != nullptr;      // A/B switch for the residency-round term
   for (int c = 0; c < kNumCfgs && !use_stream; ++c) {
     if (!vec && c != kScalarCfg) continue;  // scalar staging: 64x64 only
+    if (ext_on && !(c == 0 || c == 3 || c == 8 || c == kScalarCfg)) continue;   // the tile shapes built with MASKS
     if (c == 7 && N < 2048) continue;
     if (c == 8 && N < 768) continue;        // 256-row tiles lose on narrow outputs (one block per CU)
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
@@ -1457,7 +1558,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     if (c == 12 && !(tiles > 512 && tiles <= 768 && K <= 1024 && a_kin && !b_kin)) continue;
     const int ktiles = (int)cdiv64(K > 0 ? K : 1, bk);
     for (int s = 1; s <= 64; s *= 2) {
-      if (s > 1 && b_colsum) break;
+      if (s > 1 && (b_colsum || ext_on)) break;
       if (s > 1) {
         if (ktiles * bk / s < 128) break;
         if ((int64_t)s * M * N * nbatch > ws_cap) break;
@@ -1488,7 +1589,7 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     }
   }
   PDN_CHECK_ARG(best >= 0 || use_stream, "pdn_gemm_f32: no tile configuration");
-  if (!use_stream && best_splits == 1 && !b_colsum && K >= 8192) {
+  if (!use_stream && best_splits == 1 && !b_colsum && !ext_on && K >= 8192) {
     // 2-4 very long blocks per CU: the last one of each CU runs without a co-resident partner to
     // hide its barriers behind; halving the blocks evens that out (measured -3..4 % on the
     // 32768 x 288 x 32000 and 288 x 32000 x 32768 products, slab pass included)
@@ -1499,9 +1600,10 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   if (use_stream) best = 0;
   else if (const char* e = getenv("PDN_GEMM_CFG")) {            // tuning override: "<cfg>[,<splits>]"
     int c = -1, sp = 0;
-    if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec) {
+    if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec &&
+        (!ext_on || c == 0 || c == 3 || c == 8 || c == kScalarCfg)) {
       best = c;
-      if (sp >= 1 && (sp == 1 || ((int64_t)sp * M * N * nbatch <= ws_cap && !b_colsum))) best_splits = sp;
+      if (sp >= 1 && (sp == 1 || ((int64_t)sp * M * N * nbatch <= ws_cap && !b_colsum && !ext_on))) best_splits = sp;
     }
   }
   if (getenv("PDN_GEMM_DEBUG"))
@@ -1538,7 +1640,14 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
   if (use_stream) {
     const dim3 sgrid(p.tiles_m * p.tiles_n * p.splits, nbatch);
     const bool exact = M % 96 == 0 && N % 96 == 0;
-    if (vec && !getenv("PDN_GEMM_STREAM_DIRECT")) {      // 16-byte loads staged through LDS
+    if (vec && sshape != 0) {                            // (set for aligned operands only)
+      switch (sshape) {
+        case 1: hipLaunchKernelGGL((gemm_tn_stream_lds_kernel<5, 2, SNW, true>), sgrid, dim3(SNW * 64), 0, st, p); break;
+        case 2: hipLaunchKernelGGL((gemm_tn_stream_lds_kernel<2, 5, SNW, true>), sgrid, dim3(SNW * 64), 0, st, p); break;
+        case 3: hipLaunchKernelGGL((gemm_tn_stream_lds_kernel<4, 2, SNW, true>), sgrid, dim3(SNW * 64), 0, st, p); break;
+        default: hipLaunchKernelGGL((gemm_tn_stream_lds_kernel<2, 4, SNW, true>), sgrid, dim3(SNW * 64), 0, st, p); break;
+      }
+    } else if (vec && !getenv("PDN_GEMM_STREAM_DIRECT")) {      // 16-byte loads staged through LDS
       if (exact && !getenv("PDN_GEMM_STREAM_NODMA"))
         hipLaunchKernelGGL((gemm_tn_stream_dma_kernel<3, 3, SNW>), sgrid, dim3(SNW * 64), 0, st, p);
       else if (exact) hipLaunchKernelGGL((gemm_tn_stream_lds_kernel<3, 3, SNW, false>), sgrid, dim3(SNW * 64), 0, st, p);
@@ -1546,6 +1655,14 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     } else {                                             // unaligned operands: dword loads, no LDS
       if (exact) hipLaunchKernelGGL((gemm_tn_stream_kernel<3, 3, SNW, false>), sgrid, dim3(SNW * 64), 0, st, p);
       else hipLaunchKernelGGL((gemm_tn_stream_kernel<3, 3, SNW, true>), sgrid, dim3(SNW * 64), 0, st, p);
+    }
+  } else if (ext_on) {
+    if (!vec) launch_layout<2, 2, 1, 1, 32, false, true>(p, a_kin, b_kin, grid, st);
+    else switch (best) {
+      case 0: launch_layout<2, 2, 2, 2, 32, true, true>(p, a_kin, b_kin, grid, st); break;
+      case 3: launch_layout<4, 1, 1, 2, 32, true, true>(p, a_kin, b_kin, grid, st); break;
+      case 8: launch_layout<4, 1, 2, 3, 16, true, true>(p, a_kin, b_kin, grid, st); break;
+      default: launch_layout<2, 2, 1, 1, 32, true, true>(p, a_kin, b_kin, grid, st); break;
     }
   } else if (vec) {
     switch (best) {
@@ -1580,6 +1697,68 @@ extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, in
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(rec);
   }
+  return PDN_OK;
+}
+
+extern "C" int pdn_gemm_f32(int M, int N, int K, float alpha, const float* A, int64_t a_rs,
+                            int64_t a_cs, const float* B, int64_t b_rs, int64_t b_cs, float beta,
+                            float* C, int64_t ldc, const float* bias, int nb1, int nb2,
+                            int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
+                            int64_t c_bs1, int64_t c_bs2, const float* residual,
+                            float* b_colsum, int colsum_accumulate, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+  return gemm_f32_impl(M, N, K, alpha, A, a_rs, a_cs, B, b_rs, b_cs, beta, C, ldc, bias, nb1, nb2, a_bs1, a_bs2, b_bs1, b_bs2,
+                       c_bs1, c_bs2, residual, b_colsum, colsum_accumulate, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+// ======================================================================================
+// `relu(linear(x))` as one product and its backward without an elementwise pass (examples/pydynet/mnist.py:70-78:
+// Linear -> ReLU -> Linear -> ReLU -> Linear; nn/functional.py:31-32 relu = maximum(0., x), tensor.py:808-814 its gradient
+// passes where out == x, i.e. x >= 0).  The forward stores h = max(0, x W + b) and ONE BIT per element (x W + b >= 0);
+// the consumer's input-gradient product applies those bits in its store (pdn_linear_dx_masked_f32), so the gradient
+// with respect to the pre-activation is what reaches this layer; anything else uses pdn_relu_mask_bwd_f32.
+extern "C" int pdn_relu_mask_supported(int64_t rows, int cols) { return rows > 0 && cols > 0 && cols % 32 == 0; }
+
+extern "C" int pdn_linear_relu_fwd_f32(const float* x, int64_t x_rs, const float* W, int64_t w_rs, int64_t w_cs,
+                                       const float* bias, float* h, int64_t ldh, uint32_t* mask, int M, int N, int K,
+                                       void* stream) {
+  PDN_CHECK_ARG(x && W && h && mask, "pdn_linear_relu_fwd_f32: null operand");
+  PDN_CHECK_ARG(pdn_relu_mask_supported(M, N), "pdn_linear_relu_fwd_f32: out features must be a multiple of 32 (N = %d)", N);
+  pdn_count(PDN_CNT_LINEAR_RELU_FWD);
+  return gemm_f32_impl(M, N, K, 1.f, x, x_rs, 1, W, w_rs, w_cs, 0.f, h, ldh, bias, 1, 1, 0, 0, 0, 0, 0, 0, nullptr, nullptr, 0,
+                       nullptr, 0, stream, mask, nullptr);
+}
+
+// dx (M x fin) = mask o (g (M x fout) W^T + existing);  W is (fin x fout) with strides (w_rs, w_cs)
+extern "C" int pdn_linear_dx_masked_f32(const float* g, int64_t g_rs, const float* W, int64_t w_rs, int64_t w_cs,
+                                        float* dx, int64_t ld, const float* existing, const uint32_t* mask, int M,
+                                        int fin, int fout, void* stream) {
+  PDN_CHECK_ARG(g && W && dx && mask, "pdn_linear_dx_masked_f32: null operand");
+  PDN_CHECK_ARG(pdn_relu_mask_supported(M, fin), "pdn_linear_dx_masked_f32: in features must be a multiple of 32 (%d)", fin);
+  pdn_count(PDN_CNT_LINEAR_DX_MASKED);
+  return gemm_f32_impl(M, fin, fout, 1.f, g, g_rs, 1, W, w_cs, w_rs, 0.f, dx, ld, nullptr, 1, 1, 0, 0, 0, 0, 0, 0, existing,
+                       nullptr, 0, nullptr, 0, stream, nullptr, mask);
+}
+
+__global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float4* __restrict__ g, const uint32_t* __restrict__ mask,
+                                                            float4* __restrict__ dz, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const uint32_t w = mask[i >> 3] >> (4 * (i & 7));
+    float4 v = g[i];
+    v.x = (w & 1u) ? v.x : 0.f; v.y = (w & 2u) ? v.y : 0.f; v.z = (w & 4u) ? v.z : 0.f; v.w = (w & 8u) ? v.w : 0.f;
+    dz[i] = v;
+  }
+}
+
+// dz = mask o g over a contiguous (rows x cols) array, cols a multiple of 32 (g == dz allowed)
+extern "C" int pdn_relu_mask_bwd_f32(const float* g, const uint32_t* mask, float* dz, int64_t rows, int cols, void* stream) {
+  PDN_CHECK_ARG(g && mask && dz, "pdn_relu_mask_bwd_f32: null operand");
+  PDN_CHECK_ARG(pdn_relu_mask_supported(rows, cols) && (((uintptr_t)g | (uintptr_t)dz) & 15) == 0,
+                "pdn_relu_mask_bwd_f32: cols must be a multiple of 32 and the arrays 16-byte aligned");
+  const int64_t n4 = rows * cols / 4;
+  const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 8192);
+  hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)g, mask, (float4*)dz, n4);
+  PDN_LAUNCH_CHECK();
   return PDN_OK;
 }
 

@@ -31,7 +31,12 @@ def embedding(x, weight, padding_idx):
 
 def sigmoid(x): return tensor.sigmoid(x)
 def tanh(x): return tensor.tanh(x)
-def relu(x): return fused.relu(x)          # (generic kernels inside for non-float32 HIP operands)
+def relu(x):
+    if type(x) is fused.linear and x._pending is not None:
+        # relu(linear(...)) with the product still deferred: ONE node, relu and its gradient bits in the GEMM stores
+        ins = x._pending
+        return fused.linear_relu(ins[0], ins[1], ins[2] if x.has_bias else None)
+    return fused.relu(x)                    # (generic kernels inside for non-float32 HIP operands)
 def leaky_relu(x, alpha: float): return tensor.maximum(x, alpha * x)
 
 

@@ -202,23 +202,55 @@ class EmulatedLib:
         c[...] = r
         return 0
 
+    # -- relu(linear) with one bit per element for the gradient (csrc/gemm.hip: bit c of word [row * (N / 32) + col / 32])
+    def pdn_relu_mask_supported(self, rows, cols): return int(rows > 0 and cols > 0 and cols % 32 == 0)
+
+    @staticmethod
+    def _bits(ptr, rows, cols):
+        return np.unpackbits(view(ptr, (rows, cols // 8), (cols // 8, 1), np.uint8), axis=1, bitorder="little").astype(bool)
+
+    def pdn_linear_relu_fwd_f32(self, x, x_rs, W, w_rs, w_cs, bias, h, ldh, mask, M, N, K, stream):
+        assert N % 32 == 0
+        z = view(x, (M, K), (x_rs, 1), np.float32) @ view(W, (K, N), (w_rs, w_cs), np.float32)
+        if bias:
+            z = z + flat(bias, N)
+        view(h, (M, N), (ldh, 1), np.float32)[...] = np.maximum(np.float32(0), z)
+        view(mask, (M, N // 8), (N // 8, 1), np.uint8)[...] = np.packbits(z >= 0, axis=1, bitorder="little")
+        self._count(16)
+        return 0
+
+    def pdn_linear_dx_masked_f32(self, g, g_rs, W, w_rs, w_cs, dx, ld, existing, mask, M, fin, fout, stream):
+        assert fin % 32 == 0
+        r = view(g, (M, fout), (g_rs, 1), np.float32) @ view(W, (fin, fout), (w_rs, w_cs), np.float32).T
+        if existing:
+            r = r + view(existing, (M, fin), (ld, 1), np.float32)
+        view(dx, (M, fin), (ld, 1), np.float32)[...] = np.where(self._bits(mask, M, fin), r, np.float32(0))
+        self._count(17)
+        return 0
+
+    def pdn_relu_mask_bwd_f32(self, g, mask, dz, rows, cols, stream):
+        assert cols % 32 == 0
+        gv = np.array(view(g, (rows, cols), (cols, 1), np.float32))
+        view(dz, (rows, cols), (cols, 1), np.float32)[...] = np.where(self._bits(mask, rows, cols), gv, np.float32(0))
+        return 0
+
     def pdn_gemm_rowtile_mode(self, mode): return 1       # (kernel selection only: results are bit-identical)
 
     # -- launch counters per kernel (include/pdn_hip.h: pdn_kernel_counters): the emulated entry points count the kernel
     #    the library would have launched for the same arguments (its dispatch rules restated), so the gates of bench.py
     #    and the path assertions of the tests run without a GPU
     def _count(self, slot):
-        self._counters = getattr(self, "_counters", [0] * 16)
+        self._counters = getattr(self, "_counters", [0] * 19)
         self._counters[slot] += 1
 
     def pdn_kernel_counters(self, out, n, reset):
-        c = getattr(self, "_counters", [0] * 16)
+        c = getattr(self, "_counters", [0] * 19)
         if out:
             arr = ctypes.cast(out, ctypes.POINTER(ctypes.c_int64))
-            for i in range(min(int(n), 16)):
+            for i in range(min(int(n), 19)):
                 arr[i] = c[i]
         if reset:
-            self._counters = [0] * 16
+            self._counters = [0] * 19
         return 0
 
     @staticmethod
@@ -1159,6 +1191,8 @@ class EmulatedLib:
                                       loss_out, dlogits, colsum, ws, wsb, err, stream):
         self.pdn_cross_entropy_fwd_f32(logits, targets, rows, V, mean, loss_row, lse_row, loss_out, err, stream)
         rc = self.pdn_cross_entropy_bwd_f32(logits, targets, lse_row, None, gscale, dlogits, rows, V, stream)
+        if V <= 32 and rows >= 1024 and not colsum:
+            self._count(18)                     # ce_small_kernel: one thread per row
         if colsum:
             flat(colsum, V)[...] = flat(dlogits, rows * V).reshape(rows, V).sum(0)
         return rc
