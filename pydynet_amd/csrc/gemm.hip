@@ -379,8 +379,23 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
     constexpr int C4 = WN * 8;                   // float4 per row of the wave block
     constexpr int UNITS = 32 * C4;
     const int col0 = n0 + wave_n * WN * 32;
+    constexpr int NU = (UNITS + 63) / 64;
+    // MASKS: the gradient-bit words of every band are requested before the first store of this epilogue (a load inside
+    // the store loop waits behind the stores before it: +33 us on a 1.09 ms product), and the words a relu store
+    // produces leave after the band's loop (one predicated region per band instead of one per 16-byte store)
+    uint32_t gm[MASKS ? WM : 1][NU];
+    if (MASKS && p.grad_mask) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui) {
+          const int u = 64 * ui + lane, r = u / C4, c4 = u % C4;
+          gm[i][ui] = p.grad_mask[(int64_t)(m0 + (wave_m * WM + i) * 32 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] >> (4 * (c4 & 7));
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
+      uint32_t wd[NU];
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -409,7 +424,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
             v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
           }
           if (MASKS && p.grad_mask) {             // (8 lanes = one 32-column word of this row)
-            const uint32_t w = p.grad_mask[(int64_t)(row0 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] >> (4 * (c4 & 7));
+            const uint32_t w = gm[MASKS ? i : 0][u0 / 64];
             v.x = (w & 1u) ? v.x : 0.f; v.y = (w & 2u) ? v.y : 0.f; v.z = (w & 4u) ? v.z : 0.f; v.w = (w & 8u) ? v.w : 0.f;
           }
           if (MASKS && p.relu_mask) {
@@ -420,9 +435,16 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
                                   spread_bits8((uint32_t)(__ballot(v.z >= 0.f) >> sh) & 0xffu) << 2 |
                                   spread_bits8((uint32_t)(__ballot(v.w >= 0.f) >> sh) & 0xffu) << 3;
             v.x = relu_keep_nan(v.x); v.y = relu_keep_nan(v.y); v.z = relu_keep_nan(v.z); v.w = relu_keep_nan(v.w);
-            if ((lane & 7) == 0) p.relu_mask[(int64_t)(row0 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] = word;
+            wd[u0 / 64] = word;
           }
           *reinterpret_cast<float4*>(dst) = v;
+        }
+      }
+      if (MASKS && p.relu_mask && (lane & 7) == 0) {
+#pragma unroll
+        for (int ui = 0; ui < NU; ++ui) {
+          const int u = 64 * ui + lane, r = u / C4, c4 = u % C4;
+          if (UNITS % 64 == 0 || u < UNITS) p.relu_mask[(int64_t)(row0 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] = wd[ui];
         }
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);        // band reads done before the next band overwrites
@@ -1197,13 +1219,10 @@ extern "C" int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch)
   return (int64_t)64 * M * N * (int64_t)nbatch * 4;
 }
 
-// csrc/gemm_narrow.hip: products with at most 16 output columns on the vector ALUs (bandwidth kernels)
+// csrc/gemm_narrow.hip: products with at most 16 output columns (bandwidth kernels)
 bool pdn_gemm_narrow_nn_ok(int M, int N, int K, int64_t a_rs, int64_t a_cs, const void* A);
 int pdn_gemm_narrow_nn_launch(const float* A, int64_t lda, const float* B, int64_t b_rs, int64_t b_cs, const float* bias,
                               float* C, int64_t ldc, int M, int N, int K, void* stream);
-bool pdn_gemm_narrow_k_ok(int M, int N, int K, int64_t a_cs, int64_t ldc, const void* C, const void* existing);
-int pdn_gemm_narrow_k_launch(const float* G, int64_t g_rs, const float* W, int64_t w_rs, int64_t w_cs, const float* existing,
-                             const uint32_t* bits, float* C, int64_t ldc, int M, int N, int K, void* stream);
 int pdn_gemm_narrow_tn_plan(int Mc, int N, int K, int64_t a_rs, int64_t a_cs, int64_t b_cs, const void* A, int64_t ws_cap_floats,
                             int* kps);
 int pdn_gemm_narrow_tn_launch(const float* A, int64_t a_cs, const float* B, int64_t b_rs, float* slabs, int Mc, int N, int K,
@@ -1275,13 +1294,7 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
     PDN_LAUNCH_CHECK();
     return PDN_OK;
   }
-  // ---- a contraction of at most 16 into a wide output (the input gradient below a classifier head): write-bound ----
-  if (nbatch == 1 && !relu_mask && alpha == 1.f && beta == 0.f && !bias && !b_colsum && pdn_gemm_narrow_k_ok(M, N, K, a_cs, ldc, C, residual) &&
-      (!grad_mask || N % 32 == 0) && !getenv("PDN_GEMM_NO_NARROW")) {
-    if (getenv("PDN_GEMM_DEBUG")) fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> narrow K\n", M, N, K);
-    return pdn_gemm_narrow_k_launch(A, a_rs, B, b_rs, b_cs, residual, grad_mask, C, ldc, M, N, K, stream);
-  }
-  // ---- a handful of output columns (a classifier head): bandwidth kernels on the vector ALUs (gemm_narrow.hip) ----
+  // ---- a handful of output columns (a classifier head): bandwidth kernels (gemm_narrow.hip) ----
   if (nbatch == 1 && !ext_on && N <= 16 && alpha == 1.f && !residual && !b_colsum && !getenv("PDN_GEMM_NO_NARROW")) {
     if (beta == 0.f && pdn_gemm_narrow_nn_ok(M, N, K, a_rs, a_cs, A)) {
       if (getenv("PDN_GEMM_DEBUG")) fprintf(stderr, "pdn_gemm_f32 M=%d N=%d K=%d -> narrow NN\n", M, N, K);

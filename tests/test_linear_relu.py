@@ -138,6 +138,7 @@ class _MLP(nn.Module):
 
 def _mlp_step(device, sizes, batch, fuse, seed=0, twice_consumed=False):
     fused.linear.defer = fuse
+    saved_rows, fused.linear_relu.min_rows = fused.linear_relu.min_rows, 1      # (small test batches take the fused node too)
     try:
         np.random.seed(seed)
         model = _MLP(sizes).to(device)
@@ -158,6 +159,7 @@ def _mlp_step(device, sizes, batch, fuse, seed=0, twice_consumed=False):
         return float(loss.item()), grads, kinds
     finally:
         fused.linear.defer = True
+        fused.linear_relu.min_rows = saved_rows
 
 
 def check_mlp_chain_fused_equals_unfused(device):
@@ -195,7 +197,12 @@ def check_deferred_linear_is_an_ordinary_node_for_other_consumers(device):
     np.random.seed(0)
     lin = nn.Linear(64, 96, dtype=np.float32).to(device)
     x = pdn.Tensor(np.random.randn(33, 64).astype(np.float32), device=device)
-    z = lin(x)
+    assert type(lin(x)) is fused.linear and lin(x)._pending is None, "below linear_relu.min_rows the product runs at construction"
+    saved_rows, fused.linear_relu.min_rows = fused.linear_relu.min_rows, 1
+    try:
+        z = lin(x)
+    finally:
+        fused.linear_relu.min_rows = saved_rows
     assert type(z) is fused.linear and z._pending is not None and z.shape == (33, 96) and z.dtype == np.float32
     y = (z * z).sum()
     assert z._pending is None
