@@ -131,14 +131,17 @@ int64_t pdn_gemm_f32_workspace_bytes(int M, int N, int K, int nbatch);
  *    bit c of word [row * (N / 32) + col / 32] is column 32 * (col / 32) + c.  x rows x_rs apart (unit stride inside),
  *    W (K x N) with strides (w_rs, w_cs).  The pre-activation is never stored.
  *  - pdn_linear_dx_masked_f32: dx (M x fin, ld) = mask o (g (M x fout) W^T + existing), W (fin x fout): the consumer of h
- *    hands this layer the gradient of the PRE-activation straight from its input-gradient product.
+ *    hands this layer the gradient of the PRE-activation straight from its input-gradient product.  `colsum_partials`
+ *    (may be null; ceil(M / 32) x fin floats, 16-byte aligned): row b receives the column sums of dx over rows 32 b ..
+ *    32 b + 31 -- summed over b they are the bias gradient of the layer below (tensor.py:360-370), without a pass over dx.
  *  - pdn_relu_mask_bwd_f32: dz = mask o g over a contiguous (rows x cols) array (any other consumer of h).
  * N / fin / cols must be multiples of 32 (pdn_relu_mask_supported). */
 int pdn_relu_mask_supported(int64_t rows, int cols);
 int pdn_linear_relu_fwd_f32(const float* x, int64_t x_rs, const float* W, int64_t w_rs, int64_t w_cs, const float* bias,
                             float* h, int64_t ldh, uint32_t* mask, int M, int N, int K, void* stream);
 int pdn_linear_dx_masked_f32(const float* g, int64_t g_rs, const float* W, int64_t w_rs, int64_t w_cs, float* dx, int64_t ld,
-                             const float* existing, const uint32_t* mask, int M, int fin, int fout, void* stream);
+                             const float* existing, const uint32_t* mask, float* colsum_partials, int M, int fin, int fout,
+                             void* stream);
 int pdn_relu_mask_bwd_f32(const float* g, const uint32_t* mask, float* dz, int64_t rows, int cols, void* stream);
 /* Row-resident product for the layer projections (tall A with contiguous rows, contraction of a few
  * hundred): C (M x N) = A (M x K) * B + bias[N] + residual[M x N]; B is (K x N) row-major, or with

@@ -63,10 +63,14 @@ class linear(_Deferred, _Operator):
             # x = relu(pre-activation) of a linear_relu node: its bits applied in this product's store, so that node
             # receives the gradient of its PRE-activation (relu'(z) o (g W^T + what x already holds)) -- no relu pass
             wd = w.data
+            # ... and the column sums of that gradient (the bias gradient of the layer below) leave the same store as one
+            # partial row per 32 rows: no pass over dx for them
+            xb = x.last[2] if (x.has_bias and len(x.last) > 2) else None
+            parts = hp.empty(((g2.shape[0] + 31) // 32, fin), np.float32) if (xb is not None and xb.requires_grad) else None
             _L().call("pdn_linear_dx_masked_f32", g2._ptr, g2._strides[0], wd._ptr, wd._strides[0], wd._strides[1],
-                      dx._ptr, fin, ex._ptr if ex is not None else None, mask._ptr, g2.shape[0], fin, wd.shape[1],
-                      hp.stream())
-            dx._aux = ("relu_masked", mask)
+                      dx._ptr, fin, ex._ptr if ex is not None else None, mask._ptr,
+                      parts._ptr if parts is not None else None, g2.shape[0], fin, wd.shape[1], hp.stream())
+            dx._aux = ("relu_masked", mask, parts.sum(0) if parts is not None else None)
             return dx
         hp.gemm(g2, w.data.T, dx.reshape(-1, fin),                         # NT
                 residual=ex.reshape(-1, fin) if ex is not None else None)
@@ -170,6 +174,8 @@ class linear_relu(linear):
             _L().call("pdn_relu_mask_bwd_f32", g._ptr, self._relu_bits._ptr, dz._ptr, g.size // g.shape[-1], g.shape[-1],
                       hp.stream())
             g = dz
+        elif len(aux) > 2 and aux[2] is not None:
+            g._aux = ("colsum", aux[2])          # the producer summed the columns of this very array (see linear._dx)
         return super().backward_all(g)
 
 

@@ -54,6 +54,7 @@ struct GemmParams {
   // [row * (N / 32) + col / 32] <-> column 32 * (col / 32) + c
   uint32_t* relu_mask;       // store max(0, result) and set the bit where result >= 0 (relu gradient passes, functional.py:31-32)
   const uint32_t* grad_mask; // store result where the bit is set, 0 elsewhere
+  float* mask_colsum;        // with grad_mask: (ceil(M / 32) x N) partial column sums of what is stored, one row per 32-row band
   float* ws;
   int M, N, K;
   int64_t a_rs, a_cs, b_rs, b_cs, ldc;
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
       uint32_t wd[NU];
+      float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // MASKS + mask_colsum: this lane's columns summed over the band's rows
 #pragma unroll
       for (int j = 0; j < WN; ++j)
 #pragma unroll
@@ -426,6 +428,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
           if (MASKS && p.grad_mask) {             // (8 lanes = one 32-column word of this row)
             const uint32_t w = gm[MASKS ? i : 0][u0 / 64];
             v.x = (w & 1u) ? v.x : 0.f; v.y = (w & 2u) ? v.y : 0.f; v.z = (w & 4u) ? v.z : 0.f; v.w = (w & 8u) ? v.w : 0.f;
+            cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
           }
           if (MASKS && p.relu_mask) {
             // bit j of a lane group's byte of each ballot = lane 8g + j = columns 4j .. 4j + 3 of the word
@@ -439,6 +442,15 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
           }
           *reinterpret_cast<float4*>(dst) = v;
         }
+      }
+      if (MASKS && 64 % C4 == 0 && p.mask_colsum) {
+        // a lane keeps its float4 column over the band (64 is a multiple of the C4 lanes of a row): combine the 64 / C4
+        // lanes that share it, one partial row per band
+#pragma unroll
+        for (int sft = C4; sft < 64; sft <<= 1) {
+          cs.x += __shfl_xor(cs.x, sft); cs.y += __shfl_xor(cs.y, sft); cs.z += __shfl_xor(cs.z, sft); cs.w += __shfl_xor(cs.w, sft);
+        }
+        if (lane < C4) *reinterpret_cast<float4*>(p.mask_colsum + (int64_t)(row0 >> 5) * p.N + col0 + 4 * lane) = cs;
       }
       if (MASKS && p.relu_mask && (lane & 7) == 0) {
 #pragma unroll
@@ -462,6 +474,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
       if (col < p.N) {
         const float bv = bias ? bias[col] : 0.f;
         float old[16];
+        float csum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -474,12 +487,18 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
           float v = p.alpha * acc[i][j][r] + bv + old[r];
           // (masks: N is a multiple of 32, so `col < N` holds for whole waves; a 32-lane half shares its row)
           if (MASKS && p.grad_mask && row < p.M) v = ((p.grad_mask[(int64_t)row * (p.N >> 5) + (col >> 5)] >> li) & 1u) ? v : 0.f;
+          if (MASKS && p.mask_colsum && row < p.M) csum += v;
           if (MASKS && p.relu_mask) {
             const uint64_t b = __ballot(v >= 0.f);
             v = relu_keep_nan(v);
             if (li == 0 && row < p.M) p.relu_mask[(int64_t)row * (p.N >> 5) + (col >> 5)] = (uint32_t)(b >> (32 * lh));
           }
           if (row < p.M) C[(int64_t)row * ldc + col] = v;
+        }
+        if (MASKS && p.mask_colsum) {
+          csum += __shfl_xor(csum, 32);
+          const int band_row = m0 + (wave_m * WM + i) * 32;
+          if (lh == 0 && band_row < p.M) p.mask_colsum[(int64_t)(band_row >> 5) * p.N + col] = csum;
         }
       }
     }
@@ -1236,7 +1255,8 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
                          int64_t a_bs1, int64_t a_bs2, int64_t b_bs1, int64_t b_bs2,
                          int64_t c_bs1, int64_t c_bs2, const float* residual,
                          float* b_colsum, int colsum_accumulate, void* workspace,
-                         int64_t workspace_bytes, void* stream, uint32_t* relu_mask, const uint32_t* grad_mask) {
+                         int64_t workspace_bytes, void* stream, uint32_t* relu_mask, const uint32_t* grad_mask,
+                         float* mask_colsum = nullptr) {
   const bool ext_on = relu_mask || grad_mask;
   PDN_CHECK_ARG(!ext_on || (nb1 == 1 && nb2 == 1 && N % 32 == 0 && !b_colsum),
                 "pdn_gemm_f32: the mask epilogues need one batch and N a multiple of 32 (N = %d)", N);
@@ -1250,7 +1270,7 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   GemmParams p;
   p.A = A; p.B = B; p.C = C; p.bias = bias; p.ws = (float*)workspace;
   p.residual = residual; p.colsum = b_colsum; p.colsum_acc = colsum_accumulate;
-  p.relu_mask = relu_mask; p.grad_mask = grad_mask;
+  p.relu_mask = relu_mask; p.grad_mask = grad_mask; p.mask_colsum = grad_mask ? mask_colsum : nullptr;
   p.M = M; p.N = N; p.K = K;
   p.a_rs = a_rs; p.a_cs = a_cs; p.b_rs = b_rs; p.b_cs = b_cs; p.ldc = ldc;
   p.nb2 = nb2;
@@ -1561,6 +1581,7 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   for (int c = 0; c < kNumCfgs && !use_stream; ++c) {
     if (!vec && c != kScalarCfg) continue;  // scalar staging: 64x64 only
     if (ext_on && !(c == 0 || c == 3 || c == 8 || c == kScalarCfg)) continue;   // the tile shapes built with MASKS
+    if (mask_colsum && c == 8) continue;    // (a lane keeps its columns over a band only when 64 % (8 WN) == 0)
     if (c == 7 && N < 2048) continue;
     if (c == 8 && N < 768) continue;        // 256-row tiles lose on narrow outputs (one block per CU)
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
@@ -1614,7 +1635,7 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   else if (const char* e = getenv("PDN_GEMM_CFG")) {            // tuning override: "<cfg>[,<splits>]"
     int c = -1, sp = 0;
     if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec &&
-        (!ext_on || c == 0 || c == 3 || c == 8 || c == kScalarCfg)) {
+        (!ext_on || c == 0 || c == 3 || (c == 8 && !mask_colsum) || c == kScalarCfg)) {
       best = c;
       if (sp >= 1 && (sp == 1 || ((int64_t)sp * M * N * nbatch <= ws_cap && !b_colsum && !ext_on))) best_splits = sp;
     }
@@ -1742,15 +1763,18 @@ extern "C" int pdn_linear_relu_fwd_f32(const float* x, int64_t x_rs, const float
                        nullptr, 0, stream, mask, nullptr);
 }
 
-// dx (M x fin) = mask o (g (M x fout) W^T + existing);  W is (fin x fout) with strides (w_rs, w_cs)
+// dx (M x fin) = mask o (g (M x fout) W^T + existing);  W is (fin x fout) with strides (w_rs, w_cs).
+// colsum_partials (may be null): (ceil(M / 32) x fin) floats, row b = the column sums of dx over rows 32 b .. 32 b + 31 --
+// the bias gradient of the layer below is their sum over b (no pass over dx for it).
 extern "C" int pdn_linear_dx_masked_f32(const float* g, int64_t g_rs, const float* W, int64_t w_rs, int64_t w_cs,
-                                        float* dx, int64_t ld, const float* existing, const uint32_t* mask, int M,
-                                        int fin, int fout, void* stream) {
+                                        float* dx, int64_t ld, const float* existing, const uint32_t* mask,
+                                        float* colsum_partials, int M, int fin, int fout, void* stream) {
   PDN_CHECK_ARG(g && W && dx && mask, "pdn_linear_dx_masked_f32: null operand");
   PDN_CHECK_ARG(pdn_relu_mask_supported(M, fin), "pdn_linear_dx_masked_f32: in features must be a multiple of 32 (%d)", fin);
+  PDN_CHECK_ARG(!colsum_partials || ((uintptr_t)colsum_partials & 15) == 0, "pdn_linear_dx_masked_f32: unaligned partials");
   pdn_count(PDN_CNT_LINEAR_DX_MASKED);
   return gemm_f32_impl(M, fin, fout, 1.f, g, g_rs, 1, W, w_cs, w_rs, 0.f, dx, ld, nullptr, 1, 1, 0, 0, 0, 0, 0, 0, existing,
-                       nullptr, 0, nullptr, 0, stream, nullptr, mask);
+                       nullptr, 0, nullptr, 0, stream, nullptr, mask, colsum_partials);
 }
 
 __global__ __launch_bounds__(256) void relu_mask_bwd_kernel(const float4* __restrict__ g, const uint32_t* __restrict__ mask,

@@ -219,12 +219,18 @@ class EmulatedLib:
         self._count(16)
         return 0
 
-    def pdn_linear_dx_masked_f32(self, g, g_rs, W, w_rs, w_cs, dx, ld, existing, mask, M, fin, fout, stream):
+    def pdn_linear_dx_masked_f32(self, g, g_rs, W, w_rs, w_cs, dx, ld, existing, mask, partials, M, fin, fout, stream):
         assert fin % 32 == 0
         r = view(g, (M, fout), (g_rs, 1), np.float32) @ view(W, (fin, fout), (w_rs, w_cs), np.float32).T
         if existing:
             r = r + view(existing, (M, fin), (ld, 1), np.float32)
-        view(dx, (M, fin), (ld, 1), np.float32)[...] = np.where(self._bits(mask, M, fin), r, np.float32(0))
+        r = np.where(self._bits(mask, M, fin), r, np.float32(0)).astype(np.float32)
+        view(dx, (M, fin), (ld, 1), np.float32)[...] = r
+        if partials:
+            nb = (M + 31) // 32
+            pad = np.zeros((nb * 32, fin), np.float32)
+            pad[:M] = r
+            view(partials, (nb, fin), (fin, 1), np.float32)[...] = pad.reshape(nb, 32, fin).sum(1)
         self._count(17)
         return 0
 

@@ -97,7 +97,7 @@ device_variants(globals(), check_linear_relu_forward_tiles)
 
 def check_linear_dx_masked_and_mask_bwd(device):
     for (M, fin, fout, seed, existing) in ((256, 128, 64, 0, False), (1000, 96, 10, 1, True), (300, 1024, 10, 2, False),
-                                           (129, 32, 200, 3, True)):
+                                           (129, 32, 200, 3, True), (4096, 1024, 1024, 4, False), (8200, 256, 512, 5, True)):
         L, hp = _lib_hp()
         rng = np.random.default_rng(seed)
         g = rng.standard_normal((M, fout)).astype(np.float32)
@@ -108,13 +108,23 @@ def check_linear_dx_masked_and_mask_bwd(device):
         gd, wd, md = hp.from_numpy(g), hp.from_numpy(w), hp.from_numpy(np.ascontiguousarray(words))
         exd = hp.from_numpy(ex) if ex is not None else None
         dx = hp.empty((M, fin), np.float32)
+        nb = (M + 31) // 32
+        parts = hp.empty((nb, fin), np.float32)
         _counters(L)
         L.call("pdn_linear_dx_masked_f32", gd._ptr, fout, wd._ptr, wd._strides[0], wd._strides[1], dx._ptr, fin,
-               exd._ptr if exd is not None else None, md._ptr, M, fin, fout, hp.stream())
+               exd._ptr if exd is not None else None, md._ptr, parts._ptr, M, fin, fout, hp.stream())
         assert _counters(L)[17] == 1
         want = g.astype(np.float64) @ w.astype(np.float64).T + (ex.astype(np.float64) if ex is not None else 0.0)
-        close(dx, np.where(keep, want, 0.0), "mask o (g W^T + existing)")
+        want = np.where(keep, want, 0.0)
+        close(dx, want, "mask o (g W^T + existing)")
         assert not np.any(host(dx)[~keep] != 0)
+        pad = np.zeros((nb * 32, fin))
+        pad[:M] = want
+        close(parts, pad.reshape(nb, 32, fin).sum(1), "column sums per 32-row band", rt=2e-5)
+        dx2 = hp.empty((M, fin), np.float32)             # without partials: the same stores
+        L.call("pdn_linear_dx_masked_f32", gd._ptr, fout, wd._ptr, wd._strides[0], wd._strides[1], dx2._ptr, fin,
+               exd._ptr if exd is not None else None, md._ptr, None, M, fin, fout, hp.stream())
+        assert np.array_equal(host(dx2), host(dx))
         dz = hp.empty((M, fin), np.float32)
         src = hp.from_numpy(want.astype(np.float32))
         L.call("pdn_relu_mask_bwd_f32", src._ptr, md._ptr, dz._ptr, M, fin, hp.stream())
