@@ -164,14 +164,15 @@ int pdn_qkv_rope_norm_fwd_f32(const float* x, const float* norm_w, float eps, fl
                               int64_t ldx, void* stream);
 /* Launch counters per kernel: which kernel the entry points really launched since the last reset -- bench.py's parity
  * gates and the tests assert on them (a dispatch that silently falls back to a slower kernel must not stay green).
- * Copies min(n, 19) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
+ * Copies min(n, 21) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
  *   0 gemm_rowres_kernel (chunk kernel, any)      1 gemm_rowtile_kernel plain        2 ... + SwiGLU forward (gate | up)
  *   3 ... + SwiGLU backward (dh)                  4 ... + RoPE (q | k | v)           5 ... + row maxima (lm_head forward)
  *   6 gemm_rowres_kernel with a fused epilogue    7 attention_p forward (persistent) 8 attention_p backward (dQ + dK/dV)
  *   9 resident attention forward                 10 resident attention backward     11 streaming attention (either direction)
  *  12 lm_head input gradient + sum of exponentials (gemm_outres_kernel CE 2)        13 lm_head weight gradient, CE gradient inside
  *  14 gemm_outres_kernel plain                   15 gemm_outres_tn_kernel plain
- *  16 pdn_linear_relu_fwd_f32                    17 pdn_linear_dx_masked_f32        18 cross entropy over <= 32 classes */
+ *  16 pdn_linear_relu_fwd_f32                    17 pdn_linear_dx_masked_f32        18 cross entropy over <= 32 classes
+ *  19 pdn_gateup_swiglu_tiled_fwd_f32            20 pdn_swiglu_bwd_tiled_f32 */
 int pdn_kernel_counters(int64_t* out, int n, int reset);
 /* Round 5: which kernel the row-resident entry points below and above launch.  The tile-piece kernel
  * (csrc/gemm_rowtile.hip: one 32-column tile of B over the whole contraction per piece, rotating accumulator sets, stores
@@ -229,6 +230,17 @@ int pdn_gateup_swiglu_fwd_f32(const float* x, const float* w_gate, int64_t w_str
                               int F, int K, int64_t ldx, void* stream);
 int pdn_swiglu_bwd_gemm_f32(const float* dy, const float* w_down, const float* gu, float* dgu, int M, int F, int K,
                             int64_t ldy, void* stream);
+/* The same two epilogues for the model widths the row-resident kernels do not take (contraction other than 288), in the
+ * stores of the tiled kernel (csrc/gemm.hip): [Wg | Wu] is packed once per call into `workspace`
+ * (pdn_gateup_swiglu_tiled_workspace_bytes) with alternating groups of 32 gate / 32 up columns, so a wave's accumulators
+ * hold a gate group beside its up group.  M a multiple of 128, F a multiple of 32 (backward: 4), 16-byte aligned operands. */
+int pdn_gateup_swiglu_tiled_supported(int M, int F, int K);
+int64_t pdn_gateup_swiglu_tiled_workspace_bytes(int F, int K);
+int pdn_gateup_swiglu_tiled_fwd_f32(const float* x, int64_t ldx, const float* w_gate, int64_t w_stride, float* gu, float* h,
+                                    int M, int F, int K, void* workspace, int64_t workspace_bytes, void* stream);
+int pdn_swiglu_bwd_tiled_supported(int M, int F, int K);
+int pdn_swiglu_bwd_tiled_f32(const float* dy, int64_t ldy, const float* w_down, const float* gu, float* dgu, int M, int F,
+                             int K, void* stream);
 int pdn_qkv_rope_supported(int M, int D, int K, int L, int hd);
 int pdn_qkv_rope_fwd_f32(const float* x, const float* wq, int64_t w_stride, float* qkv, const float* rope, int M,
                          int D, int K, int L, int hd, int64_t ldx, void* stream);

@@ -137,6 +137,10 @@ class ffn_swiglu(_Operator):
         ws = [_contig(wg.data), _contig(wu.data)]
         stack = hp.stacked_view(ws)
         self.used_epilogue = self._epilogue(T, F, fin, stack)
+        # other model widths: the same two epilogues in the stores of the tiled kernel (csrc/gemm.hip SWI)
+        self.tiled_epilogue = bool(not self.used_epilogue and ffn_swiglu.epilogues and stack is not None
+                                   and T >= ffn_swiglu.epilogue_min_rows and x.size == T * fin
+                                   and L.query("pdn_gateup_swiglu_tiled_supported", T, F, fin))
         # a still-deferred RMSNorm in front (fused.rms_norm): its rows are normalised in the gate | up projection's A load
         self.norm_folded = bool(self.used_epilogue and isinstance(x, rms_norm) and x._pending is not None
                                 and L.query("pdn_gateup_swiglu_norm_supported", T, F, fin))
@@ -153,6 +157,10 @@ class ffn_swiglu(_Operator):
         elif self.used_epilogue:
             L.call("pdn_gateup_swiglu_fwd_f32", x2._ptr, ws[0]._ptr, (ws[1]._ptr - ws[0]._ptr) // 4, gu._ptr, h._ptr,
                    T, F, fin, fin, hp.stream())
+        elif self.tiled_epilogue:
+            wsp, wsb = hp.workspace(L.query("pdn_gateup_swiglu_tiled_workspace_bytes", F, fin))
+            L.call("pdn_gateup_swiglu_tiled_fwd_f32", x2._ptr, x2._strides[0], ws[0]._ptr, (ws[1]._ptr - ws[0]._ptr) // 4,
+                   gu._ptr, h._ptr, T, F, fin, wsp, wsb, hp.stream())
         else:
             halves = gate_up_swiglu._halves(gu, T, F)
             if stack is not None:
@@ -191,6 +199,8 @@ class ffn_swiglu(_Operator):
         wdd = _contig(wd.data)
         if self.used_epilogue:
             L.call("pdn_swiglu_bwd_gemm_f32", g2._ptr, wdd._ptr, gu._ptr, dgu._ptr, T, F, fin, fin, hp.stream())
+        elif self.tiled_epilogue and L.query("pdn_swiglu_bwd_tiled_supported", T, F, fin):
+            L.call("pdn_swiglu_bwd_tiled_f32", g2._ptr, g2._strides[0], wdd._ptr, gu._ptr, dgu._ptr, T, F, fin, hp.stream())
         else:
             dh = hp.empty((T, F), np.float32)
             hp.gemm(g2, wdd.T, dh)

@@ -40,7 +40,9 @@ enum {
   PDN_CNT_LINEAR_RELU_FWD = 16,   // tiled kernel with the relu + bit-mask store (pdn_linear_relu_fwd_f32)
   PDN_CNT_LINEAR_DX_MASKED = 17,  // tiled kernel with the bit mask applied in the store (pdn_linear_dx_masked_f32)
   PDN_CNT_CE_SMALL = 18,          // ce_small_kernel: cross entropy over <= 32 classes, one thread per row
-  PDN_CNT_SLOTS = 19
+  PDN_CNT_TILED_SWIGLU_FWD = 19,  // tiled kernel with SwiGLU in the store (pdn_gateup_swiglu_tiled_fwd_f32)
+  PDN_CNT_TILED_SWIGLU_BWD = 20,  // ... with the SwiGLU backward in the store (pdn_swiglu_bwd_tiled_f32)
+  PDN_CNT_SLOTS = 21
 };
 void pdn_count(int slot);
 

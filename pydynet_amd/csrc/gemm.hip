@@ -55,6 +55,14 @@ struct GemmParams {
   uint32_t* relu_mask;       // store max(0, result) and set the bit where result >= 0 (relu gradient passes, functional.py:31-32)
   const uint32_t* grad_mask; // store result where the bit is set, 0 elsewhere
   float* mask_colsum;        // with grad_mask: (ceil(M / 32) x N) partial column sums of what is stored, one row per 32-row band
+  // SwiGLU in the store (SWI instantiations, pdn_gateup_swiglu_tiled_fwd_f32 / pdn_swiglu_bwd_tiled_f32):
+  //  1: the product's columns alternate 32 gate / 32 up columns (weights packed that way); C = [gate | up] (M x 2 F, ldc),
+  //     swi_h (M x F, swi_ldh) = silu(gate) * up
+  //  2: the product is dh (M x F); C = d[gate | up] (M x 2 F, ldc) from dh and the saved swi_gu (M x 2 F, ldc)
+  float* swi_h;
+  const float* swi_gu;
+  int64_t swi_ldh;
+  int swi_F;
   float* ws;
   int M, N, K;
   int64_t a_rs, a_cs, b_rs, b_cs, ldc;
@@ -68,6 +76,11 @@ struct GemmParams {
 // relu epilogue helpers: max(0, v) that keeps a NaN (numpy.maximum propagates it) and turns -0 into +0; bit j of an 8-bit
 // value moved to bit 4j
 __device__ __forceinline__ float relu_keep_nan(float v) { return v < 0.f ? 0.f : v + 0.f; }
+__device__ __forceinline__ float gemm_silu(float g) { return g / (1.f + expf(-g)); }          // (as csrc/fused.hip: silu_f / dsilu_f)
+__device__ __forceinline__ float gemm_dsilu(float g) {
+  const float sg = 1.f / (1.f + expf(-g));
+  return sg * (1.f + g * (1.f - sg));
+}
 __device__ __forceinline__ uint32_t spread_bits8(uint32_t x) {
   x = (x | (x << 12)) & 0x000F000Fu;
   x = (x | (x << 6)) & 0x03030303u;
@@ -287,7 +300,8 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
 }
 
 // MASKS: the instantiations behind pdn_linear_relu_fwd_f32 / pdn_linear_dx_masked_f32 (GemmParams::relu_mask / grad_mask)
-template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM, bool MASKS = false>
+// SWI: SwiGLU in the store (GemmParams::swi_*), whole row tiles only (the launcher guarantees M % BM == 0 and aligned operands)
+template <int WAVES_M, int WAVES_N, int WM, int WN, int BK, bool A_KIN, bool B_KIN, bool VEC, bool COLSUM, bool MASKS = false, int SWI = 0>
 __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ? 3 : 2) void gemm_f32_mfma_kernel(GemmParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;
   constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
@@ -370,9 +384,9 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
   const float* __restrict__ R = (partial || !p.residual) ? nullptr : p.residual + b1 * p.c_bs1 + b2 * p.c_bs2;
   const float beta = partial ? 0.f : p.beta;
 
-  const bool wide = (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((ldc & 3) == 0) &&
-                    (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
-                    (!R || ((uintptr_t)R & 15) == 0);
+  const bool wide = SWI != 0 || ((m0 + BM <= p.M) && (n0 + BN <= p.N) && ((ldc & 3) == 0) &&
+                                 (((uintptr_t)C & 15) == 0) && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                                 (!R || ((uintptr_t)R & 15) == 0));
   if (wide) {
     // The main loop's last barrier has retired every read of the staging buffers, and each wave
     // only touches its own band region, so wave-level ordering is all that is needed from here.
@@ -406,6 +420,47 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
       __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): own LDS writes landed
       __builtin_amdgcn_wave_barrier();
       const int row0 = m0 + (wave_m * WM + i) * 32;
+      if constexpr (SWI == 1) {
+        // the wave's columns are 32 gate | 32 up | 32 gate | ...: a lane takes a gate float4 and the up float4 32 columns on
+        static_assert(SWI != 1 || WN % 2 == 0, "gate / up column groups come in pairs");
+        constexpr int PC4 = C4 / 2, PUNITS = 32 * PC4;
+#pragma unroll
+        for (int u0 = 0; u0 < PUNITS; u0 += 64) {
+          const int u = u0 + lane;
+          if (PUNITS % 64 == 0 || u < PUNITS) {
+            const int r = u / PC4, pc = u % PC4, grp = pc >> 3, w4 = pc & 7;
+            const float4 g = *reinterpret_cast<const float4*>(ws + r * EW + 64 * grp + 4 * w4);
+            const float4 up = *reinterpret_cast<const float4*>(ws + r * EW + 64 * grp + 32 + 4 * w4);
+            const int gcol = (col0 >> 1) + 32 * grp + 4 * w4;
+            if (gcol < p.swi_F) {
+              float* grow = C + (int64_t)(row0 + r) * ldc + gcol;
+              *reinterpret_cast<float4*>(grow) = g;
+              *reinterpret_cast<float4*>(grow + p.swi_F) = up;
+              *reinterpret_cast<float4*>(p.swi_h + (int64_t)(row0 + r) * p.swi_ldh + gcol) =
+                  make_float4(gemm_silu(g.x) * up.x, gemm_silu(g.y) * up.y, gemm_silu(g.z) * up.z, gemm_silu(g.w) * up.w);
+            }
+          }
+        }
+      } else if constexpr (SWI == 2) {
+#pragma unroll
+        for (int u0 = 0; u0 < UNITS; u0 += 64) {
+          const int u = u0 + lane;
+          if (UNITS % 64 == 0 || u < UNITS) {
+            const int r = u / C4, c4 = u % C4;
+            const int col = col0 + 4 * c4;
+            if (col < p.N) {
+              const float4 d = *reinterpret_cast<const float4*>(ws + r * EW + 4 * c4);
+              const float* srow = p.swi_gu + (int64_t)(row0 + r) * ldc + col;
+              const float4 a = *reinterpret_cast<const float4*>(srow), b = *reinterpret_cast<const float4*>(srow + p.swi_F);
+              float* drow = C + (int64_t)(row0 + r) * ldc + col;
+              *reinterpret_cast<float4*>(drow) = make_float4(d.x * b.x * gemm_dsilu(a.x), d.y * b.y * gemm_dsilu(a.y),
+                                                             d.z * b.z * gemm_dsilu(a.z), d.w * b.w * gemm_dsilu(a.w));
+              *reinterpret_cast<float4*>(drow + p.swi_F) = make_float4(d.x * gemm_silu(a.x), d.y * gemm_silu(a.y),
+                                                                       d.z * gemm_silu(a.z), d.w * gemm_silu(a.w));
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int u0 = 0; u0 < UNITS; u0 += 64) {
         const int u = u0 + lane;
@@ -442,6 +497,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
           }
           *reinterpret_cast<float4*>(dst) = v;
         }
+      }
       }
       if (MASKS && 64 % C4 == 0 && p.mask_colsum) {
         // a lane keeps its float4 column over the band (64 is a multiple of the C4 lanes of a row): combine the 64 / C4
@@ -1796,6 +1852,98 @@ extern "C" int pdn_relu_mask_bwd_f32(const float* g, const uint32_t* mask, float
   const int blocks = (int)std::min<int64_t>((n4 + 255) / 256, 8192);
   hipLaunchKernelGGL(relu_mask_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4*)g, mask, (float4*)dz, n4);
   PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
+// ======================================================================================
+// SwiGLU in the stores of the tiled kernel, for the model widths the row-resident kernels (csrc/gemm_rowres.hip,
+// contraction 288) do not take -- llm/llama/model.py:56-58 forward, its backward through `dh = dy W_down^T`
+// (tensor.py:670).  Forward: [Wg | Wu] is packed once per call with its columns in alternating groups of 32 gate / 32 up
+// columns (zero-padded to whole 256-column tiles), so a wave's accumulator block holds a gate group and ITS up group side
+// by side; the store writes gate, up (the saved [gate | up] layout) and h = silu(gate) * up.  Backward: the store of
+// dy W_down^T reads the saved gate / up and writes d[gate | up]; dh never exists.
+__global__ __launch_bounds__(256) void swiglu_pack_weights_kernel(const float* __restrict__ wg, int64_t w_stride, float* __restrict__ out,
+                                                                  int K, int F, int Np) {
+  const int64_t total = (int64_t)K * (Np / 4);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i / (Np / 4)), c = (int)(i - (int64_t)k * (Np / 4)) * 4;       // packed column c .. c + 3
+    const int grp = c >> 6, up = (c >> 5) & 1, col = 32 * grp + (c & 31);             // source column in Wg / Wu
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (col < F) v = *reinterpret_cast<const float4*>(wg + (up ? w_stride : 0) + (int64_t)k * F + col);
+    *reinterpret_cast<float4*>(out + (int64_t)k * Np + c) = v;
+  }
+}
+
+static int swiglu_packed_cols(int F) { return (2 * F + 255) / 256 * 256; }
+
+extern "C" int pdn_gateup_swiglu_tiled_supported(int M, int F, int K) {
+  return M >= 4096 && M % 128 == 0 && F >= 256 && F % 32 == 0 && K >= 64 && K % 4 == 0 && !getenv("PDN_NO_TILED_SWIGLU");
+}
+extern "C" int64_t pdn_gateup_swiglu_tiled_workspace_bytes(int F, int K) { return (int64_t)K * swiglu_packed_cols(F) * 4; }
+
+static void swiglu_params(GemmParams& p, int M, int N, int K, int BM, int BN, int BK) {
+  p.bias = nullptr; p.residual = nullptr; p.colsum = nullptr; p.colsum_acc = 0;
+  p.relu_mask = nullptr; p.grad_mask = nullptr; p.mask_colsum = nullptr; p.ws = nullptr;
+  p.M = M; p.N = N; p.K = K; p.nb2 = 1;
+  p.a_bs1 = p.a_bs2 = p.b_bs1 = p.b_bs2 = p.c_bs1 = p.c_bs2 = 0;
+  p.alpha = 1.f; p.beta = 0.f; p.splits = 1;
+  p.k_per_split = (K + BK - 1) / BK * BK;
+  p.tiles_m = (M + BM - 1) / BM; p.tiles_n = (N + BN - 1) / BN;
+}
+
+// gu (M x 2 F) = x [Wg | Wu], h (M x F) = silu(gate) * up;  Wg, Wu (K x F) row-major, w_stride floats apart
+extern "C" int pdn_gateup_swiglu_tiled_fwd_f32(const float* x, int64_t ldx, const float* w_gate, int64_t w_stride, float* gu,
+                                               float* h, int M, int F, int K, void* workspace, int64_t workspace_bytes,
+                                               void* stream) {
+  PDN_CHECK_ARG(x && w_gate && gu && h && workspace, "pdn_gateup_swiglu_tiled_fwd_f32: null operand");
+  PDN_CHECK_ARG(pdn_gateup_swiglu_tiled_supported(M, F, K) && ldx % 4 == 0 && w_stride % 4 == 0 &&
+                    ((((uintptr_t)x | (uintptr_t)w_gate | (uintptr_t)gu | (uintptr_t)h | (uintptr_t)workspace) & 15) == 0),
+                "pdn_gateup_swiglu_tiled_fwd_f32: unsupported shape or alignment (M %d, F %d, K %d)", M, F, K);
+  const int Np = swiglu_packed_cols(F);
+  if (workspace_bytes < (int64_t)K * Np * 4) { pdn_set_error("pdn_gateup_swiglu_tiled_fwd_f32: workspace too small"); return PDN_EWORKSPACE; }
+  hipStream_t st = (hipStream_t)stream;
+  float* packed = (float*)workspace;
+  hipLaunchKernelGGL(swiglu_pack_weights_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)K * (Np / 4) + 255) / 256, 2048)), dim3(256), 0, st,
+                     w_gate, w_stride, packed, K, F, Np);
+  PDN_LAUNCH_CHECK();
+  GemmParams p;
+  p.A = x; p.B = packed; p.C = gu; p.a_rs = ldx; p.a_cs = 1; p.b_rs = Np; p.b_cs = 1; p.ldc = 2 * (int64_t)F;
+  p.swi_h = h; p.swi_gu = nullptr; p.swi_ldh = F; p.swi_F = F;
+  int tok = pdn_gemm_prof_begin(0, 2.0 * M * 2.0 * F * K, 0.0, stream);
+  if (Np >= 2048) {                                            // 128 x 256 tiles
+    swiglu_params(p, M, Np, K, 128, 256, 16);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, 2, 4, 16, true, false, true, false, false, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  } else {                                                     // 128 x 128
+    swiglu_params(p, M, Np, K, 128, 128, 32);
+    hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, 2, 2, 32, true, false, true, false, false, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  }
+  PDN_LAUNCH_CHECK();
+  pdn_gemm_prof_end(tok, stream);
+  pdn_count(PDN_CNT_TILED_SWIGLU_FWD);
+  return PDN_OK;
+}
+
+extern "C" int pdn_swiglu_bwd_tiled_supported(int M, int F, int K) {
+  return M >= 4096 && M % 128 == 0 && F >= 256 && F % 4 == 0 && K >= 64 && K % 4 == 0 && !getenv("PDN_NO_TILED_SWIGLU");
+}
+
+// dgu (M x 2 F) = d[gate | up] from dh = dy (M x K) W_down^T, W_down (F x K) row-major, and the saved gu (M x 2 F)
+extern "C" int pdn_swiglu_bwd_tiled_f32(const float* dy, int64_t ldy, const float* w_down, const float* gu, float* dgu, int M,
+                                        int F, int K, void* stream) {
+  PDN_CHECK_ARG(dy && w_down && gu && dgu, "pdn_swiglu_bwd_tiled_f32: null operand");
+  PDN_CHECK_ARG(pdn_swiglu_bwd_tiled_supported(M, F, K) && ldy % 4 == 0 &&
+                    ((((uintptr_t)dy | (uintptr_t)w_down | (uintptr_t)gu | (uintptr_t)dgu) & 15) == 0),
+                "pdn_swiglu_bwd_tiled_f32: unsupported shape or alignment (M %d, F %d, K %d)", M, F, K);
+  hipStream_t st = (hipStream_t)stream;
+  GemmParams p;
+  p.A = dy; p.B = w_down; p.C = dgu; p.a_rs = ldy; p.a_cs = 1; p.b_rs = 1; p.b_cs = K; p.ldc = 2 * (int64_t)F;
+  p.swi_h = nullptr; p.swi_gu = gu; p.swi_ldh = 0; p.swi_F = F;
+  int tok = pdn_gemm_prof_begin(0, 2.0 * M * (double)F * K, 0.0, stream);
+  swiglu_params(p, M, F, K, 128, 128, 32);
+  hipLaunchKernelGGL((gemm_f32_mfma_kernel<2, 2, 2, 2, 32, true, true, true, false, false, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, st, p);
+  PDN_LAUNCH_CHECK();
+  pdn_gemm_prof_end(tok, stream);
+  pdn_count(PDN_CNT_TILED_SWIGLU_BWD);
   return PDN_OK;
 }
 

@@ -246,17 +246,17 @@ class EmulatedLib:
     #    the library would have launched for the same arguments (its dispatch rules restated), so the gates of bench.py
     #    and the path assertions of the tests run without a GPU
     def _count(self, slot):
-        self._counters = getattr(self, "_counters", [0] * 19)
+        self._counters = getattr(self, "_counters", [0] * 21)
         self._counters[slot] += 1
 
     def pdn_kernel_counters(self, out, n, reset):
-        c = getattr(self, "_counters", [0] * 19)
+        c = getattr(self, "_counters", [0] * 21)
         if out:
             arr = ctypes.cast(out, ctypes.POINTER(ctypes.c_int64))
-            for i in range(min(int(n), 19)):
+            for i in range(min(int(n), 21)):
                 arr[i] = c[i]
         if reset:
-            self._counters = [0] * 19
+            self._counters = [0] * 21
         return 0
 
     @staticmethod
@@ -464,6 +464,42 @@ class EmulatedLib:
         out = flat(dgu, M * 2 * F).reshape(M, 2 * F)
         out[:, :F] = d * u * sg * (1 + g * (1 - sg))
         out[:, F:] = d * g * sg
+        return 0
+
+    # -- the same two epilogues in the stores of the tiled kernel (other model widths; csrc/gemm.hip SWI) -----------------
+    def pdn_gateup_swiglu_tiled_supported(self, M, F, K):
+        return int(M >= 4096 and M % 128 == 0 and F >= 256 and F % 32 == 0 and K >= 64 and K % 4 == 0)
+
+    def pdn_gateup_swiglu_tiled_workspace_bytes(self, F, K): return K * ((2 * F + 255) // 256 * 256) * 4
+
+    def pdn_gateup_swiglu_tiled_fwd_f32(self, x, ldx, wg, w_stride, gu, h, M, F, K, ws, wsb, stream):
+        if not self.pdn_gateup_swiglu_tiled_supported(M, F, K) or w_stride % 4:
+            return -1
+        if wsb < self.pdn_gateup_swiglu_tiled_workspace_bytes(F, K):
+            return -3
+        a = view(x, (M, K), (ldx, 1), np.float32)
+        g = np.matmul(a, view(wg, (K, F), (F, 1), np.float32))
+        u = np.matmul(a, view(int(wg) + 4 * w_stride, (K, F), (F, 1), np.float32))
+        out = flat(gu, M * 2 * F).reshape(M, 2 * F)
+        out[:, :F], out[:, F:] = g, u
+        flat(h, M * F).reshape(M, F)[...] = g / (1 + np.exp(-g)) * u
+        self._count(19)
+        return 0
+
+    def pdn_swiglu_bwd_tiled_supported(self, M, F, K):
+        return int(M >= 4096 and M % 128 == 0 and F >= 256 and F % 4 == 0 and K >= 64 and K % 4 == 0)
+
+    def pdn_swiglu_bwd_tiled_f32(self, dy, ldy, wd, gu, dgu, M, F, K, stream):
+        if not self.pdn_swiglu_bwd_tiled_supported(M, F, K):
+            return -1
+        d = np.matmul(view(dy, (M, K), (ldy, 1), np.float32), flat(wd, F * K).reshape(F, K).T)
+        a = np.array(flat(gu, M * 2 * F).reshape(M, 2 * F))
+        g, u = a[:, :F], a[:, F:]
+        sg = 1 / (1 + np.exp(-g))
+        out = flat(dgu, M * 2 * F).reshape(M, 2 * F)
+        out[:, :F] = d * u * sg * (1 + g * (1 - sg))
+        out[:, F:] = d * g * sg
+        self._count(20)
         return 0
 
     def pdn_qkv_rope_supported(self, M, D, K, L, hd):
