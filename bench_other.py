@@ -172,6 +172,7 @@ def run_train(args, which):
     np.random.seed(42)
     net = (MLP if which == "mlp" else LeNet)().to("hip:0")
     opt = Adam(net.parameters(), lr=1e-4)
+    opt.flatten_grads()                                       # one flat gradient buffer: zero_grad is a single fill (as bench.py)
     shape = (1, 28, 28) if which == "mlp" else (3, 32, 32)
     X = pdn.Tensor(np.random.rand(B, *shape).astype(np.float32), device="hip:0")
     y = pdn.Tensor(np.random.randint(0, 10, B), dtype=np.int64, device="hip:0")
