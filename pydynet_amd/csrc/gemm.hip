@@ -217,7 +217,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   const int li = lane & 31, lh = lane >> 5;
   // interior tiles: lift the bounds so every `<` test folds to true
   const int m_end = INTERIOR ? 0x7fffffff : p.M, n_end = INTERIOR ? 0x7fffffff : p.N;
-  const int kk_end = k_end;
+  const int kk_end = INTERIOR ? 0x7fffffff : k_end;
 
   // Two register sets: while tile t is multiplied, tile t+1 waits in one set (it is written to
   // LDS in the middle of tile t's MFMA stream) and tile t+2 is in flight into the other.  The
@@ -232,10 +232,11 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams& p, const float* 
   }
   // contraction stride of each operand in the staged layout (1 for K-contiguous operands)
   const int64_t ka = p.a_cs, kb = p.b_rs;
-  // (an interior tile whose contraction range ends inside a k-tile -- K = 500, 784 with BK 32 -- takes the guarded loads
-  //  for that last k-tile only, with the row / column bounds lifted: before round 5 it took them for every k-tile)
+  // (tried in round 5: interior tiles with a trailing partial k-tile -- K = 500, 784 with BK 32 -- taking the guarded loads
+  //  for that last k-tile only.  The run-time test puts BOTH load paths into the interior instantiation: the dim-512 Llama
+  //  step lost 3 % (74.4 -> 72.0 % at model level) and the K = 500 products it was meant for gained nothing; removed)
 #define GEMM_LOAD(RA, RB, K0)                                                        \
-  if (INTERIOR && (K0) + BK <= k_end) {                                              \
+  if (INTERIOR) {                                                                    \
     LA::load_fast(RA, A + (int64_t)(K0) * ka, offa);                                 \
     LB::load_fast(RB, B + (int64_t)(K0) * kb, offb);                                 \
   } else {                                                                           \
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
   const int k_begin = split * p.k_per_split;
   const int k_end = min(p.K, k_begin + p.k_per_split);
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  const bool interior = VEC && (m0 + BM <= p.M) && (n0 + BN <= p.N) && ((k_end - k_begin) % BK == 0);
 
   f32x16 acc[WM][WN];
 #pragma unroll

@@ -4,7 +4,7 @@ ROUND=${ROUND:-r05}; S=gpurun_out/$ROUND; D=profiles
 cp $S/bench_default.json $D/${ROUND}_bench_default.json
 tail -1 $S/bench_force_dp.json > $D/${ROUND}_bench_force_dp.json
 for b in 1024 256 128 64; do cp $S/bench_b$b.json $D/${ROUND}_bench_b$b.json; done
-for c in mlp lenet gru decode lenet_b4096 mlp_b65536; do cp $S/bench_$c.json $D/${ROUND}_bench_$c.json; done
+for c in mlp lenet gru decode lenet_b4096 mlp_b65536 mlp_b8192; do cp $S/bench_$c.json $D/${ROUND}_bench_$c.json; done
 cp $S/bench_default_kernel_stats.csv $D/${ROUND}_bench_default_kernel_stats.csv
 cp $S/bench_kernel_stats.txt $D/${ROUND}_bench_default_kernel_stats.txt
 cp $S/pmc_bench_default.json $D/${ROUND}_pmc_bench_default.json
@@ -20,6 +20,8 @@ cp $S/lmhead_probe.txt $D/${ROUND}_lmhead_probe.txt
 cp $S/attn_masked_probe.txt $D/${ROUND}_attn_masked_probe.txt
 for f in rowtile_probe lmhead_gap_probe outres_fixed_probe; do cp $S/$f.txt $D/${ROUND}_$f.txt; done
 cp $S/step_gaps.txt $D/${ROUND}_step_gaps.txt
+cp $S/mlp_b65536_kernel_stats.txt $D/${ROUND}_mlp_b65536_kernel_stats.txt
+cp $S/mlp_dw_probe.txt $D/${ROUND}_mlp_dw_probe.txt
 cp $S/pmc_lenet_b4096.json $D/${ROUND}_pmc_lenet_b4096.json
 { grep -E "passed|failed|error" $S/pytest_gpu.log | tail -2; tail -1 $S/smoke.log; } > $D/${ROUND}_gpu_tests.txt
 ls -la $D | grep ${ROUND}_

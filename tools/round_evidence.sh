@@ -23,6 +23,9 @@ bash tools/pmc_cmd.sh ${ROUND}_lenet conv python tools/bench_configs.py 3 lenet:
 python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_lenet/summary.json $O/pmc_lenet_b4096.json && cp $O/pmc_lenet_b4096.json profiles/${ROUND}_pmc_lenet_b4096.json
 python bench.py --config lenet --batch 4096 --steps 50 --warmup 5 --no-cpu-baseline > $O/bench_lenet_b4096.json 2>> $O/bench_default.err
 python bench.py --config mlp --batch 65536 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_mlp_b65536.json 2>> $O/bench_default.err
+python bench.py --config mlp --batch 8192 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_mlp_b8192.json 2>> $O/bench_default.err
+bash tools/prof_cmd.sh ${ROUND}_mlp python bench.py --config mlp --batch 65536 --steps 10 --warmup 3 --no-cpu-baseline > $O/mlp_b65536_kernel_stats.txt 2>&1
+python tools/mlp_dw_probe.py > $O/mlp_dw_probe.txt 2>&1
 bash tools/prof_cmd.sh ${ROUND}_bench python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs > $O/bench_kernel_stats.txt 2>&1
 cp gpurun_out/prof_${ROUND}_bench/p_kernel_stats.csv $O/bench_default_kernel_stats.csv 2>/dev/null
 bash tools/prof_cmd.sh ${ROUND}_lenet python tools/bench_configs.py 10 lenet:4096 > $O/lenet_kernel_stats.txt 2>&1
