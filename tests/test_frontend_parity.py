@@ -379,6 +379,47 @@ def check_mlp_lenet_three_steps(dev):
         close(np.array(losses), d[f"{name}_losses"], RT, 0)
 
 
+def check_mlp_three_steps_linear_relu_node(dev):
+    """The MLP golden (vectors generated from the real reference, tools/gen_golden.py) through the ONE-product Linear + ReLU
+    node: relu and its gradient bits in the GEMM stores, the relu and bias gradients taken in the consumer's
+    input-gradient store (core/fused/dense.py: linear_relu).  The node's row threshold is lowered for the fixture's batch;
+    the library's launch counters say the fused products really ran."""
+    import ctypes
+    from pydynet_amd.core import fused
+    from pydynet_amd import _lib
+    d = load("mlp_lenet.npz")
+    L = _lib.lib()
+    Graph.clear()
+    np.random.seed(42)
+    net = _MLP().to(dev)
+    X, y = T(d["mlp_X"], dev), pdn.Tensor(d["mlp_y"], dtype=np.int64, device=dev)
+    opt = Adam(net.parameters(), lr=1e-4)
+    saved, fused.linear_relu.min_rows = fused.linear_relu.min_rows, 1
+    buf = (ctypes.c_int64 * 21)()
+    L.call("pdn_kernel_counters", buf, 21, 1)
+    losses = []
+    try:
+        for s in range(3):
+            loss = F.cross_entropy_loss(net(X), y)
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(loss.item())
+            if s == 0:
+                for n, p in net.named_parameters():
+                    g = float(np.linalg.norm(host(p.grad).astype(np.float64)))
+                    ref = float(d[f"mlp_gnorm/{n}"])
+                    assert abs(g - ref) <= RT * ref + 1e-9, (n, g, ref)
+                    if f"mlp_grad1/{n}" in d.files:
+                        close(p.grad, d[f"mlp_grad1/{n}"], RT, 1e-7)
+    finally:
+        fused.linear_relu.min_rows = saved
+    L.call("pdn_kernel_counters", buf, 21, 1)
+    assert buf[16] == 6 and buf[17] == 6, ("Linear + ReLU products / masked input gradients launched", buf[16], buf[17])
+    close(np.array(losses), d["mlp_losses"], RT, 0)
+
+
+device_variants(globals(), check_mlp_three_steps_linear_relu_node)
+
+
 def test_autograd2d_cpu_config():
     """BASELINE.json configs[0]: examples/pydynet/autograd2d.py on the NumPy device."""
     ref = json.load(open(os.path.join(G, "autograd2d.json")))["trajectory"]
