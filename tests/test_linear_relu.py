@@ -286,3 +286,23 @@ def test_narrow_products_gpu(hip):
         dw = hp.from_numpy(dw0)
         hp.gemm(hp.from_numpy(x).T, hp.from_numpy(g), dw, beta=1.0)
         close(dw, dw0 + x.astype(np.float64).T @ g.astype(np.float64), f"narrow weight gradient {T} tokens {Mc} x {N}", rt=2e-5)
+
+
+@pytest.mark.gpu
+def test_mlp_full_batch_fused_equals_unfused_gpu(hip):
+    """BASELINE config 2 at the benchmarked batch (65536 x 784 -> 1024 -> 1024 -> 10): one step through the Linear + ReLU
+    node, the masked input gradients with their column-sum partials, the 10-column products of gemm_narrow.hip and the
+    few-class cross entropy, against the same step with Linear and ReLU as the two nodes the reference builds (plain
+    products, relu passes, column-sum reductions).  Loss and every parameter gradient within 1e-4 of its largest entry;
+    the launch counters say which kernels each step took."""
+    L, _ = _lib_hp()
+    _counters(L)
+    l1, g1, k1 = _mlp_step("hip:0", (784, 1024, 1024, 10), 65536, True)
+    c = _counters(L)
+    assert k1 == ["linear_relu", "linear_relu"] and c[16] == 2 and c[17] == 2 and c[18] == 1, (k1, c[16:19])
+    l0, g0, k0 = _mlp_step("hip:0", (784, 1024, 1024, 10), 65536, False)
+    c = _counters(L)
+    assert k0 == ["relu", "relu"] and c[16] == 0 and c[17] == 0, (k0, c[16:18])
+    assert abs(l1 - l0) <= RT * abs(l0)
+    for a, b in zip(g1, g0):
+        close(a, b, "parameter gradient at batch 65536, fused vs two nodes")
