@@ -492,6 +492,15 @@ int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const fl
                         int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
                         const float* rope_cos, const float* rope_sin, float* delta, void* stream);
 
+// csrc/attention_blocks.hip: 512 / 768 / 1024 positions as 256-row block pairs on the persistent kernels
+int pdn_attention_blocks_ok(int L, int head_dim);
+int pdn_attention_blocks_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L,
+                             int hd, int64_t rs, int64_t bs, int64_t o_rs, int64_t o_bs, int causal, void* stream);
+int pdn_attention_blocks_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                             float* dq, float* dk, float* dv, int B, int H, int L, int hd, int64_t rs, int64_t bs, int64_t o_rs,
+                             int64_t o_bs, int causal, const float* rope_cos, const float* rope_sin, float* workspace,
+                             void* stream);
+
 static bool att_shape_ok(int L, int head_dim) {
   return (head_dim == 48 || head_dim == 64) && L % 32 == 0 && L >= 32 && L <= ATT_MAX_L;
 }
@@ -530,6 +539,10 @@ static int att_fwd_impl(const float* q, const float* k, const float* v, float* o
   if (!rope_cos && !key_bias && pdn_attention_p_supported(L, head_dim))
     return pdn_attention_p_fwd(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride,
                                causal, stream);
+  // ... and longer sequences as 256-row block pairs on the same kernels (csrc/attention_blocks.hip)
+  if (!rope_cos && !key_bias && pdn_attention_blocks_ok(L, head_dim) && (int64_t)L * row_stride < (1ll << 31))
+    return pdn_attention_blocks_fwd(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride,
+                                    causal, stream);
   const size_t shm = (size_t)pdn_attention_lds_bytes(L, head_dim);
   static bool attr_set = false;
   if (!attr_set) {
@@ -921,6 +934,9 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
   if ((prerot || !rope_cos) && !key_bias && pdn_attention_p_supported(L, head_dim))
     return pdn_attention_p_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
                                o_batch_stride, causal, rope_cos, rope_sin, delta, stream);
+  if ((prerot || !rope_cos) && !key_bias && pdn_attention_blocks_ok(L, head_dim) && (int64_t)L * row_stride < (1ll << 31))
+    return pdn_attention_blocks_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
+                                    o_batch_stride, causal, rope_cos, rope_sin, delta, stream);
   static bool attr_set = false;
   if (!attr_set) {
 #define ATT_ATTR(K_) PDN_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))

@@ -579,10 +579,14 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
 
 int64_t pdn_attention_p_bwd_workspace_bytes(int B, int H, int L) { return (int64_t)B * H * L * 4; }
 
-int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
-                        float* dq, float* dk, float* dv, int B, int H, int L, int head_dim, int64_t row_stride,
-                        int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
-                        const float* rope_cos, const float* rope_sin, float* delta, void* stream) {
+// (rope tables of the QUERY rows for dq and of the KEY rows for dk: the same pointers for a whole sequence, different
+//  row offsets when q and k are different 256-row blocks of one -- csrc/attention_blocks.hip)
+int pdn_attention_p_bwd_tables(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                               float* dq, float* dk, float* dv, int B, int H, int L, int head_dim, int64_t row_stride,
+                               int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
+                               const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k,
+                               float* delta, void* stream) {
+  const float* rope_cos = rope_cos_q;
   constexpr int HD = 48;
   const size_t shm_dq = (size_t)(3 * AP_ROWS * HD) * 4 + 64, shm_dkv = (size_t)(3 * AP_ROWS * HD + 1024) * 4 + 64;
   static bool attr_set = false;
@@ -601,13 +605,21 @@ int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const fl
   hipStream_t st = (hipStream_t)stream;
 #define AP_BWD(R_)                                                                                                          \
   hipLaunchKernelGGL((attention_p_bwd_dq_kernel<HD, R_>), dim3(grid), dim3(512), shm_dq, st, q, k, v, o, d_o, lse, dq, delta, \
-                     BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos, rope_sin);       \
+                     BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos_q, rope_sin_q);   \
   PDN_LAUNCH_CHECK();                                                                                                         \
   hipLaunchKernelGGL((attention_p_bwd_dkv_kernel<HD, R_>), dim3(grid), dim3(512), shm_dkv, st, q, k, v, d_o, lse, delta, dk,  \
-                     dv, BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos, rope_sin);   \
+                     dv, BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos_k, rope_sin_k); \
   PDN_LAUNCH_CHECK();
   if (rope_cos) { AP_BWD(true) } else { AP_BWD(false) }
   pdn_count(PDN_CNT_ATT_P_BWD);
 #undef AP_BWD
   return PDN_OK;
+}
+
+int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                        float* dq, float* dk, float* dv, int B, int H, int L, int head_dim, int64_t row_stride,
+                        int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
+                        const float* rope_cos, const float* rope_sin, float* delta, void* stream) {
+  return pdn_attention_p_bwd_tables(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
+                                    o_batch_stride, causal, rope_cos, rope_sin, rope_cos, rope_sin, delta, stream);
 }

@@ -265,8 +265,9 @@ class EmulatedLib:
         return rb >= 192 or rb * pieces >= 256
 
     @staticmethod
-    def _att_p(L, hd):                       # csrc/attention_p.hip: pdn_attention_p_supported
-        return hd == 48 and L % 32 == 0 and 32 <= L <= 256
+    def _att_p(L, hd):                       # csrc/attention_p.hip: pdn_attention_p_supported (+ attention_blocks.hip:
+        # 512 / 768 / 1024 positions as 256-row block pairs on the same kernels; counted once per call here)
+        return hd == 48 and L % 32 == 0 and (32 <= L <= 256 or (L % 256 == 0 and L <= 1024))
 
     def pdn_gemm_rowres_supported(self, M, N, K, lda, ldb, ldc, b_trans):
         return int(K == 288 and N % 32 == 0 and N >= 96 and M >= 1 and lda % 4 == 0 and ldb % 4 == 0 and lda >= K

@@ -1,4 +1,5 @@
-"""A Llama of ANOTHER width than the benchmarked 288 (the reference's constructor is general: llm/llama/model.py:153-197)
+"""(Also, at the end: the benchmarked width at 512 positions, `long288_llama.npz`.)
+A Llama of ANOTHER width than the benchmarked 288 (the reference's constructor is general: llm/llama/model.py:153-197)
 against the REAL reference: `tests/golden/wide_llama.npz` holds the loss, the norm and a strided sample of every gradient
 of one training step of a one-layer model of width 512 (head dim 64, ffn 1376) over 4096 tokens, produced by
 `tools/gen_golden_r2.py wide_llama` importing /root/reference.  At this width the row-resident kernels do not apply: the
@@ -17,10 +18,10 @@ from tests.conftest import device_variants
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASE = dict(V=256, D=512, H=8, F=1376, L=256, B=16, seed=11)          # = tools/gen_golden_r2.py WIDE_CASE
+LONG288 = dict(V=64, D=288, H=6, F=768, L=512, B=8, seed=12)          # = tools/gen_golden_r2.py LONG288_CASE
 
 
-def _step(dev):
-    c = CASE
+def _step(dev, c=CASE):
     Graph.clear()
     np.random.seed(c["seed"])
     m = Llama(c["V"], c["D"], c["H"], c["F"], c["L"], c["B"], 1, np.float32)
@@ -34,16 +35,19 @@ def _step(dev):
     return float(loss.item()), {n: p.grad.get() if hasattr(p.grad, "get") else np.array(p.grad) for n, p in m.named_parameters()}
 
 
-def _check(dev):
-    ref = np.load(os.path.join(G, "wide_llama.npz"))
+def _check(dev, fixture="wide_llama.npz", case=CASE, want=None):
+    ref = np.load(os.path.join(G, fixture))
     if dev != "cpu":
         from pydynet_amd import _lib
         buf = (ctypes.c_int64 * 21)()
         _lib.lib().call("pdn_kernel_counters", buf, 21, 1)
-    loss, grads = _step(dev)
+    loss, grads = _step(dev, case)
     if dev != "cpu":
         _lib.lib().call("pdn_kernel_counters", buf, 21, 1)
-        assert buf[19] == 1 and buf[20] == 1, ("SwiGLU in the tiled kernel's stores (forward, backward)", buf[19], buf[20])
+        if want is None:
+            assert buf[19] == 1 and buf[20] == 1, ("SwiGLU in the tiled kernel's stores (forward, backward)", buf[19], buf[20])
+        else:
+            want(list(buf))
     ref_loss = float(ref["loss"])
     assert abs(loss - ref_loss) <= 1e-4 * abs(ref_loss), (loss, ref_loss)
     names = [k[6:] for k in ref.files if k.startswith("gnorm/")]
@@ -65,3 +69,24 @@ device_variants(globals(), check_wide_llama_step)
 
 def test_wide_llama_step_cpu():
     _check("cpu")
+
+
+# ---- width 288 at 512 positions: RoPE in the projection's store, attention as 256-row block pairs (round 5) ------------
+def _long288_kernels(c):
+    # one layer: the persistent attention kernels once per (query block, key block <= query block) pair on the GPU (the
+    # emulator counts a call once), no resident / streaming attention launch; the rotated projection
+    assert c[7] in (1, 3) and c[8] in (1, 3) and c[9] == 0 and c[10] == 0 and c[11] == 0, ("attention launches", c[7:12])
+    assert c[4] + c[6] >= 1, ("q | k | v projection with RoPE in its store", c[4], c[6])
+
+
+def check_long288_llama_step(dev):
+    """`tests/golden/long288_llama.npz` (tools/gen_golden_r2.py long288_llama, the real reference): one step of a one-layer
+    Llama of width 288 / head dim 48 at 512 positions over 4096 tokens."""
+    _check(dev, "long288_llama.npz", LONG288, _long288_kernels)
+
+
+device_variants(globals(), check_long288_llama_step)
+
+
+def test_long288_llama_step_cpu():
+    _check("cpu", "long288_llama.npz", LONG288)

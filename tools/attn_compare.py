@@ -40,7 +40,8 @@ r_b = timed(lambda: L_.call("pdn_attention_bwd_f32", q, k, v, o._ptr, do._ptr, l
 s_f = timed(lambda: L_.call("pdn_attention_stream_fwd_f32", qd._ptr, k, v, o._ptr, lse._ptr, B, H, L, L, hd, D, L * D, 3 * D, L * 3 * D, 1, 0, None, 0, 0, 0, 0, C._ptr, S._ptr, st))
 s_b = timed(lambda: L_.call("pdn_attention_stream_bwd_f32", qd._ptr, k, v, o._ptr, do._ptr, lse._ptr, dqd._ptr, dk, dv, B, H, L, L, hd, D, L * D, 3 * D, L * 3 * D, 1, 0, None, 0, 0, 0, 0, C._ptr, S._ptr, ws, wsb, st))
 rows = [("resident", r_f, r_b), ("stream", s_f, s_b)]
-if hd == 48 and L <= 256:
+if hd == 48 and (L <= 256 or (L % 256 == 0 and L <= 1024)):
+    # (round 5: 512 / 768 / 1024 positions run as 256-row block pairs on the same kernels, csrc/attention_blocks.hip)
     # round 4: q, k rotated by the projection's epilogue -> the persistent, DMA-staged kernels (csrc/attention_p.hip)
     p_f = timed(lambda: L_.call("pdn_attention_fwd_f32", q, k, v, o._ptr, lse._ptr, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1, None, None, st))
     p_b = timed(lambda: L_.call("pdn_attention_bwd_rotated_f32", q, k, v, o._ptr, do._ptr, lse._ptr, dq, dk, dv, B, H, L, hd, 3 * D, L * 3 * D, D, L * D, 1, C._ptr, S._ptr, ws, wsb, st))

@@ -19,6 +19,8 @@ reference's source.  Fixtures written here:
                       every step's logits row (model.py:254-269)
     wide_llama.npz    one training step of a one-layer Llama of width 512 / head dim 64 / ffn 1376 over 4096 tokens: loss, norm
                       and a strided sample of every gradient -> pins the SwiGLU epilogues of the tiled kernel (round 5)
+    long288_llama.npz the same for width 288 / head dim 48 at 512 positions (4096 tokens) -> pins RoPE in the projection's
+                      store + the attention as 256-row block pairs on the persistent kernels (round 5)
     masked_attention.npz   the attention chain of examples/pydynet/transformer.py:84-101 (matmul, / sqrt(hd), + (B, 1, 1, L)
                       padding mask with -inf, softmax, matmul) on the reference's own operators at head dim 48 / 64 and
                       whole 32-row tiles, non-causal: output and the three input gradients
@@ -352,6 +354,37 @@ def gen_wide_llama():
     print("wide llama loss", float(loss.item()), len([k for k in d if k.startswith("gnorm/")]), "gradients")
 
 
+LONG288_CASE = dict(V=64, D=288, H=6, F=768, L=512, B=8, seed=12)    # tests/test_wide_llama.py builds the same model
+
+
+def gen_long288_llama():
+    """One training step of a one-layer Llama of the BENCHMARKED width (288, head dim 48) at 512 positions over 4096 tokens
+    on the REAL reference: loss, norm and a strided sample of every gradient.  At this width RoPE rides in the projection's
+    store and the attention runs as 256-row block pairs on the persistent kernels (round 5, csrc/attention_blocks.hip):
+    this fixture pins that path to llm/llama/model.py:23-44, 95-121."""
+    from llm.llama.model import Llama
+    c = LONG288_CASE
+    fresh()
+    np.random.seed(c["seed"])
+    m = Llama(c["V"], c["D"], c["H"], c["F"], c["L"], c["B"], 1, np.float32)
+    m.tok_embedding.weight.data[...] = (0.05 * np.random.randn(c["V"], c["D"])).astype(np.float32)
+    rng = np.random.default_rng(c["seed"])
+    ids, tgt = rng.integers(0, c["V"], (c["B"], c["L"])), rng.integers(0, c["V"], (c["B"], c["L"]))
+    m.train(True)
+    logits = m.forward_logits(ids)
+    loss = F.cross_entropy_loss(logits.reshape(c["B"] * c["L"], c["V"]), pdn.Tensor(tgt.reshape(-1), dtype=np.int64))
+    loss.backward()
+    d = {"loss": np.array(float(loss.item()))}
+    for n, p in m._parameters.items():
+        if p.requires_grad:
+            g = np.asarray(p.grad, np.float64).reshape(-1)
+            d["gnorm/" + n] = np.array(float(np.linalg.norm(g)))
+            d["gmax/" + n] = np.array(float(np.abs(g).max()))
+            d["gsample/" + n] = g[::61][:4096].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "long288_llama.npz"), **d)
+    print("long288 llama loss", float(loss.item()), len([k for k in d if k.startswith("gnorm/")]), "gradients")
+
+
 GEN_FULL = dict(V=32000, D=288, H=6, F=768, layers=6, max_seq=128, seed=0, prompt_len=8, total=72)
 
 
@@ -421,7 +454,7 @@ def gen_masked_attention():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["fused_llama", "generate", "llama_io", "clip_blocks", "ops_r2", "long_attention", "generate_full", "wide_llama",
+    which = sys.argv[1:] or ["fused_llama", "generate", "llama_io", "clip_blocks", "ops_r2", "long_attention", "generate_full", "wide_llama", "long288_llama",
                              "masked_attention"]
     for w in which:
         globals()["gen_" + w]()
