@@ -9,9 +9,9 @@
 // pairs of a query block are combined the way the key loop of a flash kernel combines its tiles:
 //   forward   O_i = sum_j exp(lse_ij - lse_i) O_ij,  lse_i = log sum_j exp(lse_ij)        (att_merge_kernel)
 //   backward  every pair recomputes P from the GLOBAL lse_i and delta_i = rowsum(dO_i o O_i) (both exact for a key subset),
-//             dQ_i = sum_j dQ_ij, dK_j = sum_i dK_ij, dV_j = sum_i dV_ij                       (att_add_rows_kernel)
+//             dQ_i = sum_j dQ_ij, dK_j = sum_i dK_ij, dV_j = sum_i dV_ij      (added in the kernels' own stores: ACC)
 // No tile pair is computed twice and none that the mask removes; what is added is one pass over O per extra key block
-// forward and one pass over a gradient block per extra contribution backward.
+// forward, and backward a read of the gradient rows a pair adds to.
 #include "common.h"
 #include <stdint.h>
 #include <stdlib.h>
@@ -25,7 +25,7 @@ int pdn_attention_p_bwd_tables(const float* q, const float* k, const float* v, c
                                float* dq, float* dk, float* dv, int B, int H, int L, int head_dim, int64_t row_stride,
                                int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
                                const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k,
-                               float* delta, void* stream);
+                               float* delta, void* stream, int acc_q, int acc_kv);
 extern "C" int pdn_malloc(void** ptr, int64_t bytes);
 extern "C" int pdn_free(void* ptr);
 
@@ -65,23 +65,6 @@ __global__ __launch_bounds__(256) void att_lse_move_kernel(float* __restrict__ f
     const int p = (int)(i - bh * AB_ROWS);
     if (to_full) full[bh * L + pos0 + p] = compact[i];
     else compact[i] = full[bh * L + pos0 + p];
-  }
-}
-
-// dst (B x 256 rows of `row` floats, strided) += src (the same rows with strides of its own)
-__global__ __launch_bounds__(256) void att_add_rows_kernel(float* __restrict__ dst, int64_t d_rs, int64_t d_bs,
-                                                           const float* __restrict__ src, int64_t s_rs, int64_t s_bs, int B,
-                                                           int row4) {
-  const int64_t total = (int64_t)B * AB_ROWS * row4;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int c4 = (int)(i % row4);
-    const int64_t t = i / row4;
-    const int p = (int)(t % AB_ROWS), b = (int)(t / AB_ROWS);
-    float4* d = reinterpret_cast<float4*>(dst + (int64_t)b * d_bs + (int64_t)p * d_rs) + c4;
-    const float4 s = reinterpret_cast<const float4*>(src + (int64_t)b * s_bs + (int64_t)p * s_rs)[c4];
-    float4 v = *d;
-    v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-    *d = v;
   }
 }
 
@@ -147,17 +130,11 @@ int pdn_attention_blocks_bwd(const float* q, const float* k, const float* v, con
   const int64_t BH = (int64_t)B * H, lse_n = BH * AB_ROWS;
   float* delta = workspace;
   float* lc = workspace + lse_n;
-  // The gradients of a pair that is not the first contribution to its block go to scratch and are added.  The kernels
-  // have ONE set of strides for q, k, v and their gradients, so the scratch arrays repeat the layout of the gradients
-  // (B batches `bs` apart: the same offsets address a block in either).
-  const int64_t span = (int64_t)(B - 1) * bs + (int64_t)(L - 1) * rs + (int64_t)H * hd;
-  AbTemp tq, tk, tv;
-  int rc;
-  if ((rc = tq.get(span * 4)) || (rc = tk.get(span * 4)) || (rc = tv.get(span * 4))) return rc;
+  // The first pair that contributes to a gradient block writes it, every further one ADDS in its store (the ACC
+  // instantiations of the backward kernels): no scratch, no extra pass.  (First form: scratch arrays + one add pass per
+  // further contribution -- 3 passes at L = 512, 18 at 1024.)
   hipStream_t st = (hipStream_t)stream;
-  const int row4 = H * hd / 4;
   const int64_t tab = (int64_t)AB_ROWS * (hd / 2);             // floats of the (L, hd / 2) cos / sin tables per block
-  const int grid = ab_grid((int64_t)B * AB_ROWS * row4);
   bool k_seen[8] = {false, false, false, false, false, false, false, false};
   for (int i = 0; i < nb; ++i) {
     hipLaunchKernelGGL(att_lse_move_kernel, dim3(ab_grid(lse_n)), dim3(256), 0, st, const_cast<float*>(lse), lc, BH, L, i * AB_ROWS, 0);
@@ -166,25 +143,12 @@ int pdn_attention_blocks_bwd(const float* q, const float* k, const float* v, con
     const int jn = causal ? i + 1 : nb;
     for (int j = 0; j < jn; ++j) {
       const int64_t ko = (int64_t)j * AB_ROWS * rs;
-      const bool q_first = j == 0, k_first = !k_seen[j];
-      float* dqp = (q_first ? dq : (float*)tq.p) + qo;
-      float* dkp = (k_first ? dk : (float*)tk.p) + ko;
-      float* dvp = (k_first ? dv : (float*)tv.p) + ko;
-      rc = pdn_attention_p_bwd_tables(q + qo, k + ko, v + ko, o + oo, d_o + oo, lc, dqp, dkp, dvp, B, H, AB_ROWS, hd, rs, bs,
-                                      o_rs, o_bs, causal && j == i, rope_cos ? rope_cos + i * tab : nullptr,
-                                      rope_sin ? rope_sin + i * tab : nullptr, rope_cos ? rope_cos + j * tab : nullptr,
-                                      rope_sin ? rope_sin + j * tab : nullptr, delta, stream);
+      const int rc = pdn_attention_p_bwd_tables(q + qo, k + ko, v + ko, o + oo, d_o + oo, lc, dq + qo, dk + ko, dv + ko, B, H,
+                                                AB_ROWS, hd, rs, bs, o_rs, o_bs, causal && j == i,
+                                                rope_cos ? rope_cos + i * tab : nullptr, rope_sin ? rope_sin + i * tab : nullptr,
+                                                rope_cos ? rope_cos + j * tab : nullptr, rope_sin ? rope_sin + j * tab : nullptr,
+                                                delta, stream, j > 0, k_seen[j]);
       if (rc) return rc;
-      if (!q_first) {
-        hipLaunchKernelGGL(att_add_rows_kernel, dim3(grid), dim3(256), 0, st, dq + qo, rs, bs, dqp, rs, bs, B, row4);
-        PDN_LAUNCH_CHECK();
-      }
-      if (!k_first) {
-        hipLaunchKernelGGL(att_add_rows_kernel, dim3(grid), dim3(256), 0, st, dk + ko, rs, bs, dkp, rs, bs, B, row4);
-        PDN_LAUNCH_CHECK();
-        hipLaunchKernelGGL(att_add_rows_kernel, dim3(grid), dim3(256), 0, st, dv + ko, rs, bs, dvp, rs, bs, B, row4);
-        PDN_LAUNCH_CHECK();
-      }
       k_seen[j] = true;
     }
   }

@@ -308,18 +308,29 @@ struct ApRope {                       // (cos, sin) of the pairs a lane's output
 
 // X^T tiles t0 / t1 (lane = row, register r = head-dim index (r & 3) + 8 (r >> 2) + 4 h) -> the lane's own row:
 // 16-byte pieces straight from the accumulators; `rowp` = first element of the lane's row + 4 h.
-template <bool ROT>
+// ACC: the row already holds the contributions of other (query block, key block) pairs of a longer sequence
+// (csrc/attention_blocks.hip): its six pieces are read first and the new values added.
+template <bool ROT, bool ACC = false>
 __device__ __forceinline__ void ap_store_rows(const f32x16& t0, const f32x16& t1, float* __restrict__ rowp, float scale,
                                               const ApRope& rr) {
+  float4 old[6];
+  if (ACC) {
+#pragma unroll
+    for (int g = 0; g < 6; ++g) old[g] = *reinterpret_cast<const float4*>(rowp + 8 * g);
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
-    const float4 v = make_float4(t0[4 * g] * scale, t0[4 * g + 1] * scale, t0[4 * g + 2] * scale, t0[4 * g + 3] * scale);
-    *reinterpret_cast<float4*>(rowp + 8 * g) = ROT ? rr.back(v, g) : v;
+    float4 v = make_float4(t0[4 * g] * scale, t0[4 * g + 1] * scale, t0[4 * g + 2] * scale, t0[4 * g + 3] * scale);
+    if (ROT) v = rr.back(v, g);
+    if (ACC) { v.x += old[g].x; v.y += old[g].y; v.z += old[g].z; v.w += old[g].w; }
+    *reinterpret_cast<float4*>(rowp + 8 * g) = v;
   }
 #pragma unroll
   for (int g = 0; g < 2; ++g) {
-    const float4 v = make_float4(t1[4 * g] * scale, t1[4 * g + 1] * scale, t1[4 * g + 2] * scale, t1[4 * g + 3] * scale);
-    *reinterpret_cast<float4*>(rowp + 32 + 8 * g) = ROT ? rr.back(v, 4 + g) : v;
+    float4 v = make_float4(t1[4 * g] * scale, t1[4 * g + 1] * scale, t1[4 * g + 2] * scale, t1[4 * g + 3] * scale);
+    if (ROT) v = rr.back(v, 4 + g);
+    if (ACC) { v.x += old[4 + g].x; v.y += old[4 + g].y; v.z += old[4 + g].z; v.w += old[4 + g].w; }
+    *reinterpret_cast<float4*>(rowp + 32 + 8 * g) = v;
   }
 }
 
@@ -329,7 +340,7 @@ __device__ __forceinline__ void ap_store_rows(const f32x16& t0, const f32x16& t1
 // registers, V halves of the next head issued at two barriers inside the head -- nothing exposed, but three barriers per
 // head whose causal skew -- SIMD s hosts tiles s and 7 - s: equal totals, unequal per phase -- cost more: 225 vs 197 us
 // at 1536 heads, same box.)
-template <int HD, bool ROT>
+template <int HD, bool ROT, bool ACC = false>
 __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ O,
     const float* __restrict__ dO, const float* __restrict__ LSE, float* __restrict__ dQ, float* __restrict__ Delta, int BH,
@@ -435,11 +446,11 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dq_kernel(
     if (nxt < BH) load_rows(nxt);                   // (qf / gf / of_ of this head are dead)
     ap_landed();                                    // next K (a head old), rope factors, next rows: before the stores
     if (active && lh == 0) Delta[(int64_t)bh * L + qpos] = delta_q;
-    if (active) ap_store_rows<ROT>(dq0, dq1, dQ + head_base(bh) + (int64_t)qpos * row_stride + 4 * lh, inv_sqrt, rr);
+    if (active) ap_store_rows<ROT, ACC>(dq0, dq1, dQ + head_base(bh) + (int64_t)qpos * row_stride + 4 * lh, inv_sqrt, rr);
   }
 }
 
-template <int HD, bool ROT>
+template <int HD, bool ROT, bool ACC = false>
 __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
     const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V, const float* __restrict__ dO,
     const float* __restrict__ LSE, const float* __restrict__ Delta, float* __restrict__ dK, float* __restrict__ dV, int BH,
@@ -569,8 +580,8 @@ __global__ __launch_bounds__(512, 1) void attention_p_bwd_dkv_kernel(
     }
     if (active) {
       const int64_t base = head_base(bh);
-      ap_store_rows<ROT>(dk0, dk1, dK + base + (int64_t)kpos * row_stride + 4 * lh, inv_sqrt, rr);
-      ap_store_rows<false>(dv0, dv1, dV + base + (int64_t)kpos * row_stride + 4 * lh, 1.f, rr);
+      ap_store_rows<ROT, ACC>(dk0, dk1, dK + base + (int64_t)kpos * row_stride + 4 * lh, inv_sqrt, rr);
+      ap_store_rows<false, ACC>(dv0, dv1, dV + base + (int64_t)kpos * row_stride + 4 * lh, 1.f, rr);
     }
 #pragma unroll
     for (int t = 0; t < NT8; ++t) { kf[t] = kn[t]; vf[t] = vn[t]; }
@@ -585,7 +596,7 @@ int pdn_attention_p_bwd_tables(const float* q, const float* k, const float* v, c
                                float* dq, float* dk, float* dv, int B, int H, int L, int head_dim, int64_t row_stride,
                                int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
                                const float* rope_cos_q, const float* rope_sin_q, const float* rope_cos_k, const float* rope_sin_k,
-                               float* delta, void* stream) {
+                               float* delta, void* stream, int acc_q, int acc_kv) {
   const float* rope_cos = rope_cos_q;
   constexpr int HD = 48;
   const size_t shm_dq = (size_t)(3 * AP_ROWS * HD) * 4 + 64, shm_dkv = (size_t)(3 * AP_ROWS * HD + 1024) * 4 + 64;
@@ -594,6 +605,8 @@ int pdn_attention_p_bwd_tables(const float* q, const float* k, const float* v, c
 #define AP_ATTR(K_) PDN_HIP(hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
     AP_ATTR((attention_p_bwd_dq_kernel<48, true>)); AP_ATTR((attention_p_bwd_dq_kernel<48, false>));
     AP_ATTR((attention_p_bwd_dkv_kernel<48, true>)); AP_ATTR((attention_p_bwd_dkv_kernel<48, false>));
+    AP_ATTR((attention_p_bwd_dq_kernel<48, true, true>)); AP_ATTR((attention_p_bwd_dq_kernel<48, false, true>));
+    AP_ATTR((attention_p_bwd_dkv_kernel<48, true, true>)); AP_ATTR((attention_p_bwd_dkv_kernel<48, false, true>));
 #undef AP_ATTR
     attr_set = true;
   }
@@ -603,16 +616,21 @@ int pdn_attention_p_bwd_tables(const float* q, const float* k, const float* v, c
   const int grid = BH < ap_num_cus() ? BH : ap_num_cus();
   const float sq = sqrtf((float)head_dim);
   hipStream_t st = (hipStream_t)stream;
-#define AP_BWD(R_)                                                                                                          \
-  hipLaunchKernelGGL((attention_p_bwd_dq_kernel<HD, R_>), dim3(grid), dim3(512), shm_dq, st, q, k, v, o, d_o, lse, dq, delta, \
-                     BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos_q, rope_sin_q);   \
-  PDN_LAUNCH_CHECK();                                                                                                         \
-  hipLaunchKernelGGL((attention_p_bwd_dkv_kernel<HD, R_>), dim3(grid), dim3(512), shm_dkv, st, q, k, v, d_o, lse, delta, dk,  \
-                     dv, BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos_k, rope_sin_k); \
+#define AP_DQ(R_, A_)                                                                                                       \
+  hipLaunchKernelGGL((attention_p_bwd_dq_kernel<HD, R_, A_>), dim3(grid), dim3(512), shm_dq, st, q, k, v, o, d_o, lse, dq, delta, \
+                     BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos_q, rope_sin_q)
+#define AP_DKV(R_, A_)                                                                                                      \
+  hipLaunchKernelGGL((attention_p_bwd_dkv_kernel<HD, R_, A_>), dim3(grid), dim3(512), shm_dkv, st, q, k, v, d_o, lse, delta, dk,  \
+                     dv, BH, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, sq, causal, rope_cos_k, rope_sin_k)
+  if (rope_cos) { if (acc_q) AP_DQ(true, true); else AP_DQ(true, false); }
+  else { if (acc_q) AP_DQ(false, true); else AP_DQ(false, false); }
   PDN_LAUNCH_CHECK();
-  if (rope_cos) { AP_BWD(true) } else { AP_BWD(false) }
+  if (rope_cos) { if (acc_kv) AP_DKV(true, true); else AP_DKV(true, false); }
+  else { if (acc_kv) AP_DKV(false, true); else AP_DKV(false, false); }
+  PDN_LAUNCH_CHECK();
+#undef AP_DQ
+#undef AP_DKV
   pdn_count(PDN_CNT_ATT_P_BWD);
-#undef AP_BWD
   return PDN_OK;
 }
 
@@ -621,5 +639,5 @@ int pdn_attention_p_bwd(const float* q, const float* k, const float* v, const fl
                         int64_t batch_stride, int64_t o_row_stride, int64_t o_batch_stride, int causal,
                         const float* rope_cos, const float* rope_sin, float* delta, void* stream) {
   return pdn_attention_p_bwd_tables(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, head_dim, row_stride, batch_stride, o_row_stride,
-                                    o_batch_stride, causal, rope_cos, rope_sin, rope_cos, rope_sin, delta, stream);
+                                    o_batch_stride, causal, rope_cos, rope_sin, rope_cos, rope_sin, delta, stream, 0, 0);
 }
