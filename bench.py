@@ -415,8 +415,9 @@ def other_configs(*release):
     """BASELINE.json configs 2 and 3 (MLP / LeNet at the reference's batch 256 and at a chip-filling batch), the GRU of
     examples/pydynet/ts_prediction.py and KV-cache greedy decode, each a SHORT run of `bench.py --config ...` (same code:
     bench_other.py -- parity gate against the oracle first, then timed steps, roofline of the dominant kernel) inside the
-    default run, so that whoever runs the headline command also holds these numbers -- and a short run of the same Llama
-    step at another model width (`llama_dim512`: tiled kernel + SwiGLU in its stores).  Not part of `value`; a failure
+    default run, so that whoever runs the headline command also holds these numbers -- and short runs of the same Llama
+    step at another model width (`llama_dim512`: tiled kernel + SwiGLU in its stores) and at 512 positions (`llama_seq512`:
+    attention as 256-row block pairs on the persistent kernels).  Not part of `value`; a failure
     here is recorded, never raised (the headline line must still be printed)."""
     import argparse as _ap
     import gc
@@ -432,6 +433,12 @@ def other_configs(*release):
         res["llama_dim512"] = llama_other_width(512, 8, 1536)
     except BaseException as e:
         res["llama_dim512"] = {"error": f"{type(e).__name__}: {e}"}
+    gc.collect()
+    try:                                                     # the benchmarked width at 512 positions: attention as 256-row
+        Graph.clear()                                        # block pairs on the persistent kernels (csrc/attention_blocks.hip)
+        res["llama_seq512"] = llama_other_width(288, 6, 768, batch=128, seq=512)
+    except BaseException as e:
+        res["llama_seq512"] = {"error": f"{type(e).__name__}: {e}"}
     gc.collect()
     for key, cfg, batch, steps, warmup in runs:
         a = _ap.Namespace(config=cfg, batch=batch, steps=steps, warmup=warmup, no_graph=False, no_cpu_baseline=True, gpus=1)
@@ -483,13 +490,14 @@ def llama_other_width(dim, heads, ffn, batch=256, seq=256, layers=6, vocab=32000
     dt = (time.perf_counter() - t0) / steps
     launched = {k: v / steps for k, v in kernel_counters(lib, reset=True).items() if v}
     flop = 3 * seq * (layers * (4 * 2 * dim * dim + 3 * 2 * dim * ffn + 2 * 2 * seq * dim) + 2 * dim * vocab)
-    return {"metric": "training-step samples/sec (6L Llama3 of another width)", "value": batch / dt, "unit": "samples/s",
+    return {"metric": "training-step samples/sec (6L Llama3 of another width / sequence length)", "value": batch / dt, "unit": "samples/s",
             "ms_per_step": 1e3 * dt, "steps": steps, "warmup": warmup, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"llm/llama 6-layer Llama3, dim {dim}, {heads} heads (hd {dim // heads}), ffn {ffn}, vocab {vocab}, "
                                    f"seq {seq}, fwd+bwd+Adam", "per_gpu_batch": batch, "parallelism": "dp1"},
             "model_flops_frac_of_fp32_mfma_peak": flop * batch / dt / PEAK_FP32_MFMA, "loss": float(loss.item()),
             "kernel_launches_per_step": launched,
-            "parity": "tests/test_wide_llama.py: one step of a width-512 model against vectors generated from the real reference"}
+            "parity": "tests/test_wide_llama.py: one step of a width-512 model and one of a width-288 model at 512 positions "
+                      "against vectors generated from the real reference"}
 
 
 def main():
