@@ -357,6 +357,10 @@ int pdn_relu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void
  * backward != 0 rotates by -theta (the gradient).  In-place (y == x) is allowed. */
 int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* y, int64_t rows,
                  int L, int heads, int head_dim, int backward, void* stream);
+/* the same on rows `x_row_stride` / `y_row_stride` floats apart (in place allowed): the q | k column blocks of a packed
+ * q | k | v projection, rotated before the persistent attention kernels read them */
+int pdn_rope_rows_f32(const float* x, const float* cos_t, const float* sin_t, float* y, int64_t rows, int L, int heads,
+                      int head_dim, int64_t x_row_stride, int64_t y_row_stride, int backward, void* stream);
 
 /* ---- fused causal self-attention of the training path (llm/llama/model.py:112-121):
  * softmax(q k^T / sqrt(hd) + causal_mask) v per (batch, head), scores kept in registers.
@@ -369,6 +373,9 @@ int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* 
  * dq and dk back as it stores them, so the caller keeps (and differentiates) UN-rotated q, k.
  * q, k, v, dq, dk, dv share (row_stride, batch_stride) -- e.g. the three column blocks of ONE packed
  * (B*L, 3*H*hd) projection buffer; o and d_o have (o_row_stride, o_batch_stride). */
+/* 1 when rotation-free operands of this shape run on the persistent, DMA-staged kernels (csrc/attention_p.hip: head dim 48,
+ * L <= 256; csrc/attention_blocks.hip: 512 / 768 / 1024 positions as 256-row block pairs on them) */
+int pdn_attention_persistent_supported(int L, int head_dim);
 int pdn_attention_fwd_f32(const float* q, const float* k, const float* v, float* o, float* lse, int B,
                           int H, int L, int head_dim, int64_t row_stride, int64_t batch_stride,
                           int64_t o_row_stride, int64_t o_batch_stride,

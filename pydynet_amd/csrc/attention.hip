@@ -509,6 +509,10 @@ static int att_crows(int L) { return L < ATT_CHUNK ? L : ATT_CHUNK; }
 
 /* 1 when the resident kernels take (L, head_dim): head_dim 48 / 64, L a multiple of 32 up to 1024 */
 extern "C" int pdn_attention_supported(int L, int head_dim) { return att_shape_ok(L, head_dim) ? 1 : 0; }
+// 1 when rotation-free operands of this shape run on the persistent kernels (directly, or as 256-row block pairs)
+extern "C" int pdn_attention_persistent_supported(int L, int head_dim) {
+  return att_shape_ok(L, head_dim) && (pdn_attention_p_supported(L, head_dim) || pdn_attention_blocks_ok(L, head_dim)) ? 1 : 0;
+}
 
 extern "C" int64_t pdn_attention_lds_bytes(int L, int head_dim) {
   return (int64_t)att_crows(L) * (ATT_LD(head_dim) + ATT_LDV) * 4;

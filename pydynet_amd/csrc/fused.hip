@@ -558,6 +558,38 @@ __global__ void rope_kernel(const float* __restrict__ x, const float* __restrict
     reinterpret_cast<float2*>(y)[i] = o;
   }
 }
+// the same on rows that are `x_rs` / `y_rs` floats apart (the q | k column blocks of a packed q | k | v projection,
+// rotated in place before the persistent attention kernels read them: core/fused/attn.py)
+__global__ void rope_rows_kernel(const float* __restrict__ x, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                 float* __restrict__ y, int64_t rows, int L, int heads, int half, int64_t x_rs, int64_t y_rs,
+                                 float sign) {
+  const int64_t pairs_per_row = (int64_t)heads * half;
+  const int64_t total = rows * pairs_per_row;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t row = i / pairs_per_row;
+    const int pr = (int)(i - row * pairs_per_row), j = pr % half;
+    const int pos = (int)(row % L);
+    const float c = cosT[(int64_t)pos * half + j], s = sign * sinT[(int64_t)pos * half + j];
+    const float2 v = *reinterpret_cast<const float2*>(x + row * x_rs + 2 * pr);
+    *reinterpret_cast<float2*>(y + row * y_rs + 2 * pr) = make_float2(v.x * c - v.y * s, v.x * s + v.y * c);
+  }
+}
+extern "C" int pdn_rope_rows_f32(const float* x, const float* cos_t, const float* sin_t, float* y, int64_t rows, int L,
+                                 int heads, int head_dim, int64_t x_row_stride, int64_t y_row_stride, int backward,
+                                 void* stream) {
+  if (rows == 0) return PDN_OK;
+  PDN_CHECK_ARG(x && cos_t && sin_t && y, "pdn_rope_rows_f32: null operand");
+  PDN_CHECK_ARG(L > 0 && heads > 0 && head_dim > 0 && head_dim % 2 == 0 && x_row_stride % 2 == 0 && y_row_stride % 2 == 0,
+                "pdn_rope_rows_f32: bad dims");
+  PDN_CHECK_ARG((((uintptr_t)x | (uintptr_t)y) & 7) == 0, "pdn_rope_rows_f32: 8B alignment");
+  const int64_t total = rows * heads * (head_dim / 2);
+  hipLaunchKernelGGL(rope_rows_kernel, dim3(stream_grid(total / 2 + 1)), dim3(256), 0, (hipStream_t)stream, x, cos_t, sin_t, y,
+                     rows, L, heads, head_dim / 2, x_row_stride, y_row_stride, backward ? -1.f : 1.f);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
 extern "C" int pdn_rope_f32(const float* x, const float* cos_t, const float* sin_t, float* y,
                             int64_t rows, int L, int heads, int head_dim, int backward,
                             void* stream) {

@@ -850,6 +850,18 @@ class EmulatedLib:
         out[..., 1::2] = a[..., 0::2] * s + a[..., 1::2] * c
         return out
 
+    def pdn_attention_persistent_supported(self, L, hd): return int(bool(self.pdn_attention_supported(L, hd)) and self._att_p(L, hd))
+
+    def pdn_rope_rows_f32(self, x, cos, sin, y, rows, L, heads, hd, x_rs, y_rs, backward, stream):
+        xv = np.array(view(x, (rows, heads, hd), (x_rs, hd, 1), np.float32))
+        c = flat(cos, L * hd // 2).reshape(L, hd // 2)[np.arange(rows) % L][:, None, :]
+        s = flat(sin, L * hd // 2).reshape(L, hd // 2)[np.arange(rows) % L][:, None, :] * (-1.0 if backward else 1.0)
+        out = np.empty_like(xv)
+        out[..., 0::2] = xv[..., 0::2] * c - xv[..., 1::2] * s
+        out[..., 1::2] = xv[..., 0::2] * s + xv[..., 1::2] * c
+        view(y, (rows, heads, hd), (y_rs, hd, 1), np.float32)[...] = out
+        return 0
+
     def pdn_attention_fwd_f32(self, q, k, v, o, lse, B, H, L, hd, rs, bs, ors, obs, causal, rc, rsn, stream):
         self._count(7 if (not rc and self._att_p(L, hd)) else 9)
         if not self.pdn_attention_supported(L, hd):

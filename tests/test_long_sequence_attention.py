@@ -84,5 +84,24 @@ def test_llama_step_seq352_hd64_cpu():
     _check("cpu", "seq352_hd64")
 
 
-for _f in (check_llama_step_seq512_hd48, check_llama_step_seq352_hd64):
+def check_llama_step_seq512_hd48_prerotated(dev):
+    """The same reference step (`long_attention.npz`, width 96: no RoPE store in the projection) with q | k rotated in
+    place in the packed projection and the attention as 256-row block pairs on the PERSISTENT kernels (round 5:
+    core/fused/attn.py `prerotated`, csrc/attention_blocks.hip).  The node's row threshold is lowered for the fixture's
+    1024 tokens; the library's counters say which kernels ran."""
+    import ctypes
+    from pydynet_amd.core import fused
+    from pydynet_amd import _lib
+    saved, fused.qkv_attention.rope_min_rows = fused.qkv_attention.rope_min_rows, 32
+    buf = (ctypes.c_int64 * 21)()
+    try:
+        _lib.lib().call("pdn_kernel_counters", buf, 21, 1)
+        _check(dev, "seq512_hd48")
+        _lib.lib().call("pdn_kernel_counters", buf, 21, 1)
+    finally:
+        fused.qkv_attention.rope_min_rows = saved
+    assert buf[7] >= 1 and buf[8] >= 1 and buf[9] == 0 and buf[10] == 0, ("persistent / resident attention launches", list(buf[7:11]))
+
+
+for _f in (check_llama_step_seq512_hd48, check_llama_step_seq352_hd64, check_llama_step_seq512_hd48_prerotated):
     device_variants(globals(), _f)
