@@ -7,7 +7,8 @@
 
 One step = zero_grad -> forward -> cross entropy -> backward -> (bucketed RCCL all-reduce,
 overlapped) -> Adam, on synthetic token ids resident in HBM, random-init weights, fp32.
-Per-GPU batch is fixed (weak scaling).  Prints ONE JSON line on rank 0.  The launcher only has to
+Per-GPU batch is fixed (weak scaling).  Prints ONE compact JSON line (< 4 KB) on rank 0 and writes the
+full record (per-family GEMM tables, the other configs, memory) to bench_detail.json, which the line names.  The launcher only has to
 provide RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; this script itself uses no
 PyTorch -- device memory, streams, events and RCCL all come from libpdnhip.so.
 """
@@ -25,6 +26,9 @@ sys.path.insert(0, ROOT)
 V, D, H, F_, L, LAYERS = 32000, 288, 6, 768, 256, 6
 FLOP_PER_SAMPLE = 3 * L * (LAYERS * (4 * 2 * D * D + 3 * 2 * D * F_ + 2 * 2 * L * D) + 2 * D * V)   # 24.688e9
 PEAK_FP32_MFMA = 157.3e12
+# causal attention on 32-row x 32-key tiles: (L/32)(L/32 + 1)/2 of the (L/32)^2 score tiles hold an unmasked entry
+_T = L // 32
+EXECUTED_FLOP_PER_SAMPLE = FLOP_PER_SAMPLE - 3 * L * LAYERS * (2 * 2 * L * D) * (1.0 - (_T + 1) / (2.0 * _T))
 
 
 def cpu_baseline(seconds_budget=25.0):
@@ -381,33 +385,20 @@ def pmc_traffic(batch=256):
     return out
 
 
-def hbm_kernels(lib, hp, B, traffic, opt=None, nparams=0):
-    """The HBM-bound kernel of the step, timed live with HIP events on the launch stream: achieved = ALGORITHMIC bytes per
-    launch / average launch duration, against the 8 TB/s HBM3E peak.  Adam: one multi-tensor launch reading p, g, m, v and
-    writing p, m, v (28 B per parameter); 20 launches of the kernel back to back through the C entry point (the queue
-    stays full: `opt.step()` per launch left the GPU idle for ~40 us of host work between two 108 us kernels and the line
-    under-reported its own kernel).  Run AFTER the timed region (it moves the weights along the last gradient)."""
+def hbm_kernels(adam_events, traffic, nparams=0):
+    """The HBM-bound kernel of the step, timed live with HIP events on the launch stream INSIDE the timed steps: achieved =
+    ALGORITHMIC bytes per launch / average launch duration, against the 8 TB/s HBM3E peak.  Adam: one multi-tensor launch
+    reading p, g, m, v and writing p, m, v (28 B per parameter); the event pair brackets `opt.step()` = that one launch
+    (rounds 3-5 timed 20 launches back to back after the step and read 126 us where rocprof shows 108 us in the step)."""
     out = {}
-    if opt is not None and nparams:
-        fast = opt._hip_params()
-        table = opt._chunk_table(fast)
-
-        def launch():
-            lib.call("pdn_adam_multi_f32", table._ptr, table.shape[0], 1e-9, opt.beta1, opt.beta2, 1 - opt.beta1,
-                     1 - opt.beta2, opt.eps, opt.weight_decay, opt.grad_scale, hp.stream())
-        for _ in range(3):
-            launch()
-        hp.synchronize()
-        N = 20
-        with hp.Timer() as t:
-            for _ in range(N):
-                launch()
-        us = t.ms / N * 1e3
+    if adam_events and nparams:
+        us = 1e3 * sum(a.elapsed_ms(b) for a, b in adam_events) / len(adam_events)
         nbytes = 28.0 * nparams
         out["adam_multi_kernel"] = {"bound": "hbm", "what": "Adam over every parameter in one launch (optim/optimizer.py:160-196)",
                                     "in_step": True, "achieved": nbytes / (us * 1e-6) / 1e9, "peak": 8000.0, "unit": "GB/s",
                                     "frac": nbytes / (us * 1e-6) / 8e12, "algorithmic_bytes_per_launch": nbytes,
-                                    "avg_launch_us": us, "launches_timed": N, "traffic": traffic.get("adam_multi_kernel")}
+                                    "avg_launch_us": us, "launches_timed": len(adam_events),
+                                    "traffic": traffic.get("adam_multi_kernel")}
     return out
 
 
@@ -439,6 +430,12 @@ def other_configs(*release):
         res["llama_seq512"] = llama_other_width(288, 6, 768, batch=128, seq=512)
     except BaseException as e:
         res["llama_seq512"] = {"error": f"{type(e).__name__}: {e}"}
+    gc.collect()
+    try:                                                     # rounds 1-4 quoted the headline at per-GPU batch 256: kept comparable
+        Graph.clear()
+        res["llama_b256"] = llama_other_width(288, 6, 768, batch=256, seq=256, steps=10, warmup=3)
+    except BaseException as e:
+        res["llama_b256"] = {"error": f"{type(e).__name__}: {e}"}
     gc.collect()
     for key, cfg, batch, steps, warmup in runs:
         a = _ap.Namespace(config=cfg, batch=batch, steps=steps, warmup=warmup, no_graph=False, no_cpu_baseline=True, gpus=1)
@@ -498,6 +495,86 @@ def llama_other_width(dim, heads, ffn, batch=256, seq=256, layers=6, vocab=32000
             "kernel_launches_per_step": launched,
             "parity": "tests/test_wide_llama.py: one step of a width-512 model and one of a width-288 model at 512 positions "
                       "against vectors generated from the real reference"}
+
+
+DETAIL_FILE = "bench_detail.json"
+COMPACT_LIMIT = 4096
+
+
+def write_detail(full):
+    """The full record next to the script (`PDN_BENCH_DETAIL` overrides the path; also under gpurun_out/ when that scratch
+    directory exists, so that a gpurun call brings it back).  Returns the path the compact line names."""
+    path = os.environ.get("PDN_BENCH_DETAIL") or os.path.join(ROOT, DETAIL_FILE)
+    written = None
+    for p in (path, os.path.join(ROOT, "gpurun_out", DETAIL_FILE)):
+        if p != path and not os.path.isdir(os.path.dirname(p)):
+            continue
+        try:
+            with open(p, "w") as f:
+                json.dump(full, f, indent=1)
+            written = written or p
+        except OSError:
+            pass
+    return os.path.relpath(written, ROOT) if written else None
+
+
+def _pick(d, keys):
+    return None if d is None else {k: d.get(k) for k in keys if k in d}
+
+
+def compact_line(full, detail_path=None):
+    """The ONE stdout line: the contract's keys, the dominant kernel's roofline, the CPU baseline and the two gates as
+    scalars, one number per other config.  Everything else lives in `detail` (write_detail)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "model_flops_frac_of_fp32_mfma_peak", "executed_flops_frac",
+            "per_rank_samples_per_s", "final_loss")
+    out = {k: full[k] for k in keep if k in full}
+    roof = full.get("roofline")
+    if roof is not None:
+        r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_us",
+                         "time_share_of_step", "algorithmic_flop_per_launch", "traffic_source", "traffic_stale"))
+        if isinstance(r.get("traffic_source"), str):
+            r["traffic_source"] = r["traffic_source"].split(" ")[0]
+        if roof.get("all_gemm"):
+            r["all_gemm_frac"] = roof["all_gemm"]["frac"]
+            r["all_gemm_time_share"] = roof["all_gemm"]["time_share_of_step"]
+        fams = roof.get("other_gemm_families") or {}
+        r["other_families_frac"] = {k: round(v["frac"], 4) for k, v in fams.items() if v.get("launches")}
+        adam = (roof.get("hbm_bound_kernels") or {}).get("adam_multi_kernel")
+        if adam:
+            r["adam_hbm"] = _pick(adam, ("achieved", "peak", "unit", "frac", "avg_launch_us", "traffic"))
+        out["roofline"] = r
+    else:
+        out["roofline"] = None
+    cb = full.get("cpu_baseline")
+    out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample")) if cb else None
+    g = full.get("parity_gate")
+    out["parity_gate"] = None if g is None else {"rel_err": g["rel_err"], "worst_grad": g["worst_grad_norm_rel_err"],
+                                                 "rtol": g["rtol"], "reference_loss": g["reference_loss"]}
+    b = full.get("batch_gate")
+    out["batch_gate"] = None if b is None else {"batch": b["batch"], "loss_rel_err": b["loss_rel_err"],
+                                                "worst_grad_rel_err": b["worst_grad_rel_err"],
+                                                "grad_tensors_checked": b["grad_tensors_checked"], "rtol": b["rtol"]}
+    if "comm" in full:
+        out["comm"] = full["comm"]
+    oc = full.get("other_configs")
+    if oc:
+        brief = {}
+        for k, v in oc.items():
+            if "error" in v:
+                brief[k] = {"error": str(v["error"])[:80]}
+            else:
+                brief[k] = {"value": round(v["value"], 1), "unit": v.get("unit"), "ms": round(v.get("ms_per_step", 0.0), 4)}
+                if "model_flops_frac_of_fp32_mfma_peak" in v:
+                    brief[k]["mfma_frac"] = round(v["model_flops_frac_of_fp32_mfma_peak"], 4)
+        out["other_configs"] = brief
+    out["detail"] = detail_path
+    line = json.dumps(out)
+    if len(line) >= COMPACT_LIMIT:                          # never let an addition push the headline out of the tail
+        for k in ("other_configs", "comm", "per_rank_samples_per_s"):
+            if k in out and len(json.dumps(out)) >= COMPACT_LIMIT:
+                out[k] = f"see {detail_path}"
+    return out
 
 
 def main():
@@ -586,6 +663,7 @@ def main():
     model.train(True)
 
     comm_events = []
+    adam_events = None
 
     def step():
         opt.zero_grad()
@@ -598,7 +676,16 @@ def main():
             dp.finish()
             lib.call("pdn_event_record", e1, hipnp.stream())
             comm_events.append((e0, e1))
-        opt.step()
+        if adam_events is not None:
+            # the optimizer's ONE launch timed where it runs: events on its stream inside the timed step (a loop of
+            # back-to-back Adam launches reads 17 % slower than the same kernel behind the backward pass, rocprof agrees)
+            e0, e1 = hipnp.Event(), hipnp.Event()
+            e0.record()
+            opt.step()
+            e1.record()
+            adam_events.append((e0, e1))
+        else:
+            opt.step()
         return loss
 
     def fence():
@@ -616,6 +703,7 @@ def main():
     comm_events.clear()
     if not args.no_gemm_prof:
         lib.call("pdn_gemm_prof_enable", 1)
+        adam_events = []
     kernel_counters(lib, reset=True)
     losses = []
     t0 = time.perf_counter()
@@ -690,7 +778,7 @@ def main():
                 "kernel_launches_per_step": {k: v / max(args.steps, 1) for k, v in kernel_counters(lib).items() if v},
                 "traffic_source": traffic.get("_source"), "traffic_source_sha12": traffic.get("_sha12"),
                 "traffic_stale": traffic.get("_stale")}
-        roof["hbm_bound_kernels"] = hbm_kernels(lib, hipnp, B, traffic, opt if dp is None else None,
+        roof["hbm_bound_kernels"] = hbm_kernels(adam_events, traffic,
                                                 sum(int(p.size) for p in model.parameters())) if rank == 0 else None
     per_rank = [B * args.steps / dt]
     if world > 1:
@@ -709,6 +797,9 @@ def main():
         "config": {"workload": "llm/llama 6-layer Llama3 (dim 288, 6 heads, ffn 768, vocab 32000) fwd+bwd+Adam, random init",
                    "seq_len": L, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
         "model_flops_frac_of_fp32_mfma_peak": FLOP_PER_SAMPLE * value / world / PEAK_FP32_MFMA,
+        # SURVEY 8d counts the full L x L scores as the reference computes them; the kernels skip the 28 of 64 32 x 32
+        # score tiles that are entirely masked: the same rate priced on the FLOPs actually executed
+        "executed_flops_frac": EXECUTED_FLOP_PER_SAMPLE * value / world / PEAK_FP32_MFMA,
         "per_rank_samples_per_s": per_rank,
         "final_loss": losses[-1],
         "parity_gate": gate,
@@ -749,7 +840,9 @@ def main():
         group.barrier()
     if rank == 0:
         out["memory"] = hipnp.memory_stats()
-        print(json.dumps(out), flush=True)
+        # the FULL record (per-family GEMM tables, fused-epilogue and HBM-bound kernels, the other configs, memory) goes
+        # to a side file; stdout carries ONE compact line (< 4 KB: the driver keeps an 8 KB tail of stdout)
+        print(json.dumps(compact_line(out, write_detail(out))), flush=True)
     if group is not None:
         if world > 1:
             group.barrier()

@@ -52,6 +52,34 @@ class side_stream:
         _lib.lib().call("pdn_stream_wait_event", self._main, self._e1)
 
 
+class Event:
+    """One timing event of the library (pdn_event_*): `record()` on the launch stream, `a.elapsed_ms(b)` once both have
+    completed (synchronises on `b`).  Destroyed with the object."""
+
+    def __init__(self):
+        self._e = ctypes.c_void_p()
+        _lib.lib().call("pdn_event_create", ctypes.byref(self._e), 1)
+
+    def record(self, on=None):
+        _lib.lib().call("pdn_event_record", self._e, stream() if on is None else on)
+        return self
+
+    def elapsed_ms(self, later: "Event") -> float:
+        L = _lib.lib()
+        L.call("pdn_event_synchronize", later._e)
+        ms = ctypes.c_float()
+        L.call("pdn_event_elapsed_ms", self._e, later._e, ctypes.byref(ms))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self._e:
+                _lib.lib().call("pdn_event_destroy", self._e)
+                self._e = None
+        except Exception:
+            pass
+
+
 class Timer:
     """HIP-event stopwatch on the compute stream: `with Timer() as t: ...; t.ms`."""
 

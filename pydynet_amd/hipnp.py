@@ -1013,5 +1013,5 @@ random = _Random()
 
 
 # ---- parts of this module that live in files of their own (round 5) -- imported LAST: they build on the names above ----
-from ._hipnp_streams import side_stream, Timer, capturing, Graph                       # noqa: E402,F401
+from ._hipnp_streams import side_stream, Event, Timer, capturing, Graph                       # noqa: E402,F401
 from ._hipnp_host import readback_array, _MappedHost, read_later, Mailbox, _Polled     # noqa: E402,F401

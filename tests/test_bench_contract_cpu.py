@@ -93,3 +93,67 @@ def test_launcher_propagates_a_failing_rank():
     finally:
         bench.__file__ = real
         os.remove(path)
+
+
+COMPACT_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity_gate", "batch_gate", "detail"}
+ROOFLINE_KEYS = {"bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us",
+                 "algorithmic_flop_per_launch", "traffic_source"}
+
+
+def test_compact_line_of_the_round5_record_fits_the_driver_tail():
+    """Round 5's full record (20 KB; the driver's 8 KB stdout tail lost its head) through compact_line: < 4 KB, the
+    contract's keys, the same headline numbers."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    assert len(json.dumps(full)) > 16000
+    c = bench.compact_line(full, "bench_detail.json")
+    line = json.dumps(c)
+    assert len(line) < bench.COMPACT_LIMIT == 4096, len(line)
+    assert COMPACT_KEYS <= set(c) and ROOFLINE_KEYS <= set(c["roofline"])
+    assert {"workload", "seq_len", "per_gpu_batch", "global_batch", "parallelism"} <= set(c["config"])
+    assert {"value", "unit", "cores", "kind"} <= set(c["cpu_baseline"])
+    assert c["value"] == full["value"] and c["ms_per_step"] == full["ms_per_step"]
+    assert c["roofline"]["frac"] == full["roofline"]["frac"] and c["roofline"]["kernel"] == full["roofline"]["kernel"]
+    assert set(c["other_configs"]) == set(full["other_configs"])
+    assert c["other_configs"]["lenet_b4096"]["ms"] == round(full["other_configs"]["lenet_b4096"]["ms_per_step"], 4)
+    assert c["batch_gate"]["worst_grad_rel_err"] == full["batch_gate"]["worst_grad_rel_err"]
+    # an over-long addition is dropped in favour of the headline, never the other way round
+    full["other_configs"] = {f"cfg{i}": {"value": 1.0, "unit": "x" * 200, "ms_per_step": 1.0} for i in range(40)}
+    c = bench.compact_line(full, "bench_detail.json")
+    assert len(json.dumps(c)) < 4096 and isinstance(c["other_configs"], str) and c["value"] == full["value"]
+
+
+def test_whole_bench_main_prints_one_compact_line_and_a_detail_file(emulated_hip, monkeypatch, tmp_path, capsys):
+    """`bench.main()` at world 1 on the emulated ABI (model shrunk through the module constants; the CPU baseline and the
+    other configs answered by canned records of REAL size): stdout is exactly one line, < 4 KB, with the key set the
+    driver parses; the full record -- family tables, other configs, memory -- is in the side file the line names."""
+    import json
+    import bench
+    full5 = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_default.json")))
+    for k, v in dict(V=192, D=96, H=2, F_=128, L=32, LAYERS=2).items():
+        monkeypatch.setattr(bench, k, v)
+    monkeypatch.setattr(bench, "cpu_baseline", lambda *a, **k: full5["cpu_baseline"])
+    monkeypatch.setattr(bench, "other_configs", lambda *a, **k: full5["other_configs"])
+    detail = tmp_path / "detail.json"
+    monkeypatch.setenv("PDN_BENCH_DETAIL", str(detail))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-parity-gate"])
+    bench.main()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(lines) == 1
+    assert len(lines[0]) < 4096, len(lines[0])
+    c = json.loads(lines[0])
+    assert COMPACT_KEYS <= set(c) and ROOFLINE_KEYS <= set(c["roofline"])
+    assert c["n_gpus"] == 1 and c["steps"] == 2 and c["warmup"] == 1 and c["config"]["per_gpu_batch"] == 2
+    assert c["value"] > 0 and abs(c["value"] - 2 / (c["ms_per_step"] * 1e-3)) <= 1e-6 * c["value"]
+    assert 0 < c["executed_flops_frac"] <= c["model_flops_frac_of_fp32_mfma_peak"]
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] > 0
+    assert c["roofline"]["adam_hbm"]["avg_launch_us"] >= 0.0          # timed inside the steps (one event pair per step)
+    assert set(c["other_configs"]) == set(full5["other_configs"])
+    d = json.load(open(detail))
+    assert d["value"] == c["value"] and "other_gemm_families" in d["roofline"] and "memory" in d
+    assert d["roofline"]["hbm_bound_kernels"]["adam_multi_kernel"]["launches_timed"] == 2
+    assert d["other_configs"]["lenet_b4096"]["roofline"]
