@@ -787,7 +787,7 @@ def main():
         every = hipnp.from_numpy(mine)
         group.all_reduce(every, pdist.SUM)                       # every rank's own wall time, one slot each
         group.wait()
-        per_rank = [B * args.steps / float(t) for t in every.get()]
+        per_rank = [B * args.steps / float(t) for t in every.get() if t > 0]      # one entry per rank that answered
         dt = group.all_reduce_scalar(dt, pdist.MAX)              # slowest rank's wall time
     value = world * B * args.steps / dt
     out = {
@@ -817,7 +817,9 @@ def main():
         comm_events.clear()
         if world > 1:
             exposed = group.all_reduce_scalar(exposed, pdist.MAX)
-        out["comm"] = {"collective": "all-reduce(sum) of flat fp32 gradient buckets, RCCL", "buckets": len(dp.buckets),
+        cap = getattr(group, "channels_cap", None)
+        out["comm"] = {"collective": "all-reduce(sum) of flat fp32 gradient buckets, RCCL", "backend": group.backend,
+                       "ranks": len(per_rank), "max_channels": int(cap) if cap else None, "buckets": len(dp.buckets),
                        "bucket_MB": [round((hi - lo) * 4 / 1e6, 2) for lo, hi, _, _ in dp.buckets],
                        "payload_MB_per_step": dp.flat.size * 4 / 1e6, "exposed_ms_per_step": exposed,
                        "note": "exposed = compute-stream time blocked in DataParallel.finish() (max over ranks); "

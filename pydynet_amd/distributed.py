@@ -64,6 +64,8 @@ class RcclComm:
         if ch != "0" and self._nch_prev is None:
             os.environ["NCCL_MAX_NCHANNELS"] = ch
             self._nch_set = True
+        # what this communicator was initialised under (bench.py's `comm` block quotes it): None = RCCL's default
+        self.channels_cap = os.environ.get("NCCL_MAX_NCHANNELS")
         if self.rank == 0 and os.environ.get("PDN_DP_QUIET") != "1":
             import sys
             print(f"[pydynet_amd.distributed] RCCL channels: NCCL_MAX_NCHANNELS={os.environ.get('NCCL_MAX_NCHANNELS', 'unset (RCCL default)')}"

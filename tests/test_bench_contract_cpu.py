@@ -157,3 +157,15 @@ def test_whole_bench_main_prints_one_compact_line_and_a_detail_file(emulated_hip
     assert d["value"] == c["value"] and "other_gemm_families" in d["roofline"] and "memory" in d
     assert d["roofline"]["hbm_bound_kernels"]["adam_multi_kernel"]["launches_timed"] == 2
     assert d["other_configs"]["lenet_b4096"]["roofline"]
+
+
+def test_gpus_n_beyond_the_visible_devices_fails_fast():
+    """`bench.py --gpus 8` on a box with fewer GPUs: refused before any rank is started (no RCCL peer left hanging)."""
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "PDN_BENCH_SPAWN_PROBE")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and time.monotonic() - t0 < 10
+    assert "--gpus 64 but only" in r.stderr and r.stdout.strip() == ""

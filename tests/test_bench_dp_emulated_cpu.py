@@ -61,18 +61,25 @@ def _worker(rank, world, port, out_dir):
     json.dump([[int(v) for v in b] for b in model_box["dp"].buckets], open(os.path.join(out_dir, f"buckets{rank}.json"), "w"))
 
 
-def test_whole_bench_main_two_ranks_emulated(tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_whole_bench_main_n_ranks_emulated(tmp_path, world, monkeypatch):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    monkeypatch.setenv("PDN_BENCH_DETAIL", str(tmp_path / "detail.json"))
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     out0 = [l for l in open(tmp_path / "stdout0.txt").read().splitlines() if l.strip()]
-    out1 = [l for l in open(tmp_path / "stdout1.txt").read().splitlines() if l.strip()]
-    assert out1 == [], out1                                # only rank 0 speaks
+    for r in range(1, world):
+        outr = [l for l in open(tmp_path / f"stdout{r}.txt").read().splitlines() if l.strip()]
+        assert outr == [], outr                            # only rank 0 speaks
     assert len(out0) == 1, out0                            # ... exactly one line
+    assert len(out0[0]) < 4096, len(out0[0])               # ... that fits the driver's stdout tail
     d = json.loads(out0[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
-    assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
-    assert len(d["per_rank_samples_per_s"]) == 2 and all(v > 0 for v in d["per_rank_samples_per_s"])
-    assert d["value"] > 0 and abs(d["value"] - 2 * 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    assert d["n_gpus"] == world and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["per_gpu_batch"] == 2 and d["config"]["global_batch"] == 2 * world
+    assert d["config"]["parallelism"] == f"dp{world}"
+    assert len(d["per_rank_samples_per_s"]) == world and all(v > 0 for v in d["per_rank_samples_per_s"])
+    # whole-job rate over the slowest rank's time (all_reduce_scalar(MAX) of the per-rank times)
+    assert d["value"] > 0 and abs(d["value"] - world * 2 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    assert d["ms_per_step"] * 2e-3 >= max(2 * 2 / v for v in d["per_rank_samples_per_s"]) * (1 - 1e-4)
     # the whole job is as fast as its slowest rank: value <= sum of the per-rank rates
     assert d["value"] <= sum(d["per_rank_samples_per_s"]) * (1 + 1e-6)
     comm = d["comm"]
@@ -84,10 +91,15 @@ def test_whole_bench_main_two_ranks_emulated(tmp_path):
     lo, hi, plo, phi = buckets[-1]
     assert phi - plo == 1 and hi - lo == 192 * 96
     assert np.isfinite(d["final_loss"])
-    p0, p1 = np.load(tmp_path / "params0.npz"), np.load(tmp_path / "params1.npz")
-    assert sorted(p0.files) == sorted(p1.files) and len(p0.files) > 10
-    for n in p0.files:
-        assert np.array_equal(p0[n], p1[n]), n             # same reduced gradients -> same Adam step on both ranks
+    assert comm["ranks"] == world and comm["backend"] == "rccl"
+    p0 = np.load(tmp_path / "params0.npz")
+    for r in range(1, world):
+        p1 = np.load(tmp_path / f"params{r}.npz")
+        assert sorted(p0.files) == sorted(p1.files) and len(p0.files) > 10
+        for n in p0.files:
+            assert np.array_equal(p0[n], p1[n]), n         # same reduced gradients -> same Adam step on every rank
+    full = json.load(open(tmp_path / "detail.json"))
+    assert full["value"] == d["value"] and full["comm"]["bucket_MB"] == comm["bucket_MB"]
 
 
 def test_rendezvous_bind_host(monkeypatch):

@@ -1,4 +1,4 @@
-"""Data-parallel layer on CPU with the gloo backend, world_size 2 (the N>1 path of bench.py).
+"""Data-parallel layer on CPU with the gloo backend, world sizes 2, 4 and 8 (the N>1 path of bench.py).
 
 Contract: an N-rank step on N shards == a 1-rank step on the concatenated batch.
 The embedding gradient is a scatter-ASSIGN in the reference; the wrapper keeps that across ranks
@@ -29,19 +29,21 @@ def _build(seed=1234):
     return m
 
 
-def _data(dups=False):
+def _data(dups=False, nseq=2):
     rng = np.random.default_rng(5)
     ids = rng.permutation(64)[:32].reshape(2, 16)
+    if nseq > 2:                                   # (more tokens than ids: some repeat even without `dups`)
+        ids = np.stack([rng.permutation(64)[:16] for _ in range(nseq)])
     if dups:
         # token ids repeated inside a shard AND across shards: the embedding gradient is a scatter-ASSIGN
         # (last occurrence of the concatenated batch wins, tensor.py:937-940), which a plain sum of
-        # per-rank gradients would get wrong
-        ids = rng.integers(0, 12, (2, 16))
-    tgt = rng.integers(0, 64, (2, 16))
+        # per-rank gradients would get wrong.  With 8 sequences every id below 12 is held by ~ 6 ranks.
+        ids = rng.integers(0, 12, (nseq, 16))
+    tgt = rng.integers(0, 64, (nseq, 16))
     return ids, tgt
 
 
-def _worker(rank, world, port, out_dir, bucket_mb, dups=False):
+def _worker(rank, world, port, out_dir, bucket_mb, dups=False, nseq=2):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from pydynet_amd.optim import Adam
@@ -53,8 +55,8 @@ def _worker(rank, world, port, out_dir, bucket_mb, dups=False):
     m = _build(seed=1234 + 7 * rank)          # ranks start DIFFERENT: the wrapper must broadcast rank 0's weights
     opt = Adam(m.parameters(), lr=1e-3)
     dp = DataParallel(m, opt, bucket_mb=bucket_mb)
-    ids, tgt = _data(dups)
-    lo, hi = shard_batch(2, rank, world)
+    ids, tgt = _data(dups, nseq)
+    lo, hi = shard_batch(nseq, rank, world)
     losses = []
     for _ in range(2):
         m.train(True)
@@ -74,18 +76,38 @@ def _worker(rank, world, port, out_dir, bucket_mb, dups=False):
     pdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("bucket_mb,dups", [(0.02, False), (25.0, False), (0.02, True)])
-def test_two_rank_step_equals_single_process_step(tmp_path, bucket_mb, dups):
+def _owners_of_duplicates(ids, world):
+    """How many ranks hold the most widely shared token id (the owner vote's fan-in)."""
+    per = ids.shape[0] // world
+    holders = {}
+    for r in range(world):
+        for t in np.unique(ids[r * per:(r + 1) * per]):
+            holders[int(t)] = holders.get(int(t), 0) + 1
+    return max(holders.values())
+
+
+# world 2 as before; world 4 (two sequences per rank) and world 8 (one per rank, the node BASELINE config 5 names) on
+# a global batch of 8: bucket cut over more ranks, owner vote with up to 8 contributors per token id
+@pytest.mark.parametrize("world,nseq,bucket_mb,dups", [(2, 2, 0.02, False), (2, 2, 25.0, False), (2, 2, 0.02, True),
+                                                       (4, 8, 0.02, True), (8, 8, 0.02, False), (8, 8, 0.02, True)])
+def test_n_rank_step_equals_single_process_step(tmp_path, world, nseq, bucket_mb, dups):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path), bucket_mb, dups), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    if dups and world > 2:
+        assert _owners_of_duplicates(_data(dups, nseq)[0], world) >= 3      # duplicate ids across >= 3 ranks
+    mp.spawn(_worker, args=(world, port, str(tmp_path), bucket_mb, dups, nseq), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    r0, r1 = ranks[0], ranks[-1]
+    for r in ranks[1:-1]:
+        for k in r0.files:
+            if k != "losses":
+                assert np.array_equal(r0[k], r[k]), k
     # single process on the concatenated batch
     from pydynet_amd.optim import Adam
     from pydynet_amd.core.tensor import Graph
     Graph.clear()
     m = _build()
     opt = Adam(m.parameters(), lr=1e-3)
-    ids, tgt = _data(dups)
+    ids, tgt = _data(dups, nseq)
     ref_losses = []
     for s in range(2):
         m.train(True)
@@ -107,7 +129,7 @@ def test_two_rank_step_equals_single_process_step(tmp_path, bucket_mb, dups):
         err = np.abs(r0["p/" + n] - p.data)
         bad = err > 1e-7 + 1e-5 * np.abs(p.data)
         assert bad.sum() <= max(1, p.size // 500) and err.max() <= 2 * 1e-3 * 2, (n, int(bad.sum()), float(err.max()))
-    assert abs((r0["losses"][0] + r1["losses"][0]) / 2 - ref_losses[0]) < 1e-6
+    assert abs(np.mean([r["losses"][0] for r in ranks]) - ref_losses[0]) < 1e-6
 
 
 def test_shard_batch_rules():
@@ -132,12 +154,14 @@ def _build_hip(seed=77):
     return m
 
 
-def _data_hip(dups=False):
+def _data_hip(dups=False, nseq=2):
     rng = np.random.default_rng(9)
     ids = rng.permutation(128)[:64].reshape(2, 32)
+    if nseq > 2:
+        ids = np.stack([rng.permutation(128)[:32] for _ in range(nseq)])
     if dups:
-        ids = rng.integers(0, 20, (2, 32))
-    tgt = rng.integers(0, 128, (2, 32))
+        ids = rng.integers(0, 20, (nseq, 32))
+    tgt = rng.integers(0, 128, (nseq, 32))
     return ids, tgt
 
 
@@ -159,7 +183,7 @@ def _hip_step_loop(m, dp, ids, tgt, world, steps=2):
     return losses, grads
 
 
-def _worker_hip(rank, world, port, out_dir, dups=False):
+def _worker_hip(rank, world, port, out_dir, dups=False, nseq=2):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from tests import abi_emulator
@@ -176,8 +200,8 @@ def _worker_hip(rank, world, port, out_dir, dups=False):
     opt = Adam(m.parameters(), lr=1e-3)
     dp = DataParallel(m, opt, bucket_mb=0.05)
     assert len(dp.buckets) > 2
-    ids, tgt = _data_hip(dups)
-    lo, hi = shard_batch(2, rank, world)
+    ids, tgt = _data_hip(dups, nseq)
+    lo, hi = shard_batch(nseq, rank, world)
     from pydynet_amd import _lib
     losses, grads = _hip_step_loop(m, {"opt": opt, "dp": dp}, ids[lo:hi], tgt[lo:hi].reshape(-1), world)
     assert "pdn_attention_fwd_f32" in _lib.lib().calls and "pdn_adam_multi_f32" in _lib.lib().calls
@@ -189,17 +213,22 @@ def _worker_hip(rank, world, port, out_dir, dups=False):
     pdist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dups", [False, True])
-def test_two_rank_step_on_emulated_hip_device(tmp_path, emulated_hip, dups):
+@pytest.mark.parametrize("world,nseq,dups", [(2, 2, False), (2, 2, True), (4, 8, True), (8, 8, True)])
+def test_n_rank_step_on_emulated_hip_device(tmp_path, emulated_hip, world, nseq, dups):
     port = _free_port()
-    mp.spawn(_worker_hip, args=(2, port, str(tmp_path), dups), nprocs=2, join=True)
-    r0, r1 = np.load(tmp_path / "hrank0.npz"), np.load(tmp_path / "hrank1.npz")
+    mp.spawn(_worker_hip, args=(world, port, str(tmp_path), dups, nseq), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / f"hrank{r}.npz") for r in range(world)]
+    r0, r1 = ranks[0], ranks[-1]
+    for r in ranks[1:-1]:
+        for k in r0.files:
+            if k != "losses":
+                assert np.array_equal(r0[k], r[k]), k
     from pydynet_amd.optim import Adam
     from pydynet_amd.core.tensor import Graph
     Graph.clear()
     m = _build_hip().to("hip:0")
     opt = Adam(m.parameters(), lr=1e-3)
-    ids, tgt = _data_hip(dups)
+    ids, tgt = _data_hip(dups, nseq)
     ref_losses, ref_g = _hip_step_loop(m, {"opt": opt, "dp": None}, ids, tgt.reshape(-1), 1)
     for n, p in m.named_parameters():
         g = r0["g/" + n]
@@ -207,4 +236,4 @@ def test_two_rank_step_on_emulated_hip_device(tmp_path, emulated_hip, dups):
         scale = max(np.abs(ref_g[n]).max(), 1e-12)
         assert np.abs(g - ref_g[n]).max() <= 2e-5 * scale + 1e-9, n
         assert np.array_equal(r0["p/" + n], r1["p/" + n]), n
-    assert abs((r0["losses"][0] + r1["losses"][0]) / 2 - ref_losses[0]) < 2e-6
+    assert abs(np.mean([r["losses"][0] for r in ranks]) - ref_losses[0]) < 2e-6
