@@ -30,6 +30,7 @@
 //                                column offset; contraction over positions; deterministic two-stage
 //                                reduction (partials in a workspace, fixed combine order)
 #include "common.h"
+#include "conv_quad.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -1291,6 +1292,9 @@ int pdn_conv2d_relu_pool_fwd_f32(const float* x, const float* w, const float* bi
     pdn_set_error("pdn_conv2d_relu_pool_fwd_f32: shape outside the fused kernel");
     return PDN_EUNSUPPORTED;
   }
+  // the LeNet shapes: channel-innermost LDS image, four k-steps per ds_read_b128 (csrc/conv_quad.hip)
+  if (conv_quad_fwd_supported(C, H, W, O, k, stride, pad))
+    return conv_quad_relu_pool_fwd(x, w, bias, pooled, mask, N, C, H, W, O, stream);
   return launch_direct(x, w, bias, pooled, g, (hipStream_t)stream, 1, 0, mask);
 }
 
@@ -1303,6 +1307,9 @@ int pdn_conv2d_relu_pool_bwd_data_f32(const float* dpooled, const unsigned* mask
     pdn_set_error("pdn_conv2d_relu_pool_bwd_data_f32: shape outside the fused kernel");
     return PDN_EUNSUPPORTED;
   }
+  // LeNet's second layer: col2im-style product, accumulators scattered with ds_add_f32 (csrc/conv_quad.hip)
+  if (conv_quad_dgrad_supported(C, H, W, O, k, stride, pad))
+    return conv_quad_relu_pool_bwd_data(dpooled, mask, w, dx, N, C, H, W, O, stream);
   const int OH = H + 2 * pad - k + 1, OW = W + 2 * pad - k + 1;
   ConvGeom g;
   fwd_geom(g, N, O, OH, OW, C, k, 1, k - 1 - pad, 1, C, O);

@@ -19,6 +19,7 @@ from tests.conftest import device_variants
 CASES = [   # N, C, H, W, O     (k = 3, stride 1, pad 1)
     (5, 3, 32, 32, 20),       # LeNet conv1 (OW = 32: the window's rows are two chunks of one wave)
     (4, 20, 16, 16, 50),      # LeNet conv2 (OW = 16: a chunk holds two rows), two channel tiles
+    (7, 20, 16, 16, 50),      # ... an odd batch: conv_quad.hip pairs images in a tile, the last one is alone
     (3, 6, 8, 8, 12),         # OW = 8: four rows per chunk
     (2, 4, 16, 32, 7),        # rectangular, odd channel count
 ]
@@ -92,7 +93,12 @@ def check_fused_chain_matches_float64_and_unfused(dev):
             assert kind == "conv2d_relu_pool", (case, kind)
             kind0, out0, dx0, dw0, db0 = _run(dev, x, w, b, gp, defer=False)
             assert kind0 == "pool2d"
-            assert np.array_equal(out, out0), case                      # same accumulation order: bit-identical
+            # the LeNet shapes run the fused forward on csrc/conv_quad.hip, whose contraction order differs from the plain
+            # kernel's: identical where the arithmetic is exact (integers), fp32 round-off otherwise
+            if integer:
+                assert np.array_equal(out, out0), case
+            else:
+                _close(out, out0.astype(np.float64), (case, "vs unfused", "pooled"), 2e-6)
             ref = _ref(x, w, b, gp)
             tol = 1e-6 if integer else 2e-5
             for got, want, name in zip((out, dx, dw, db), ref, ("pooled", "dx", "dw", "db")):
