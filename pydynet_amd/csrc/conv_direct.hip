@@ -1322,6 +1322,10 @@ int pdn_conv2d_relu_pool_bwd_weight_f32(const float* x, const float* dpooled, co
                                         int pad, void* workspace, int64_t workspace_bytes, void* stream) {
   if (N == 0) return PDN_OK;
   PDN_CHECK_ARG(x && dpooled && mask && (dw || db), "pdn_conv2d_relu_pool_bwd_weight_f32: null operand");
+  // LeNet's second layer: shifted image copies in LDS, dy expanded in registers (csrc/conv_quad.hip)
+  if (conv_quad_wgrad_supported(C, H, W, O, k, stride, pad))
+    return conv_quad_relu_pool_bwd_weight(x, dpooled, mask, dw, db, accumulate, N, C, H, W, O, workspace, workspace_bytes,
+                                          stream);
   return launch_wgrad(x, dpooled, mask, dw, db, accumulate, N, C, H, W, O, k, stride, pad, workspace, workspace_bytes,
                       stream, "pdn_conv2d_relu_pool_bwd_weight_f32");
 }

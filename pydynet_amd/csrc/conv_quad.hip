@@ -44,6 +44,9 @@ struct QuadGeom {
   static constexpr int F4 = IPT * C * H * W / 4;               // 16-byte pieces of one tile group
   static constexpr int NV = (F4 + 511) / 512;
   static constexpr int LDS_FLOATS = OT * 32 * WS + OT * 32 + 2 * IPT * IMGS;
+  // workgroups per CU: a second one fills the barrier / epilogue gaps of the first where LDS and registers (one channel
+  // tile: 32 accumulators) allow it
+  static constexpr int WGS = (OT == 1 && LDS_FLOATS * 4 * 2 <= 160 * 1024) ? 2 : 1;
   static_assert(W == 16 || W == 32, "a 32-lane tile is one row of 32 positions or one row of two images");
   static_assert((H & 1) == 0 && (W & 3) == 0, "2 x 2 pooling, float4 rows");
   // frame offset (floats) of unit u relative to a lane's pixel
@@ -68,7 +71,7 @@ __device__ __forceinline__ float dpp_row_shr1(float v) {
 }
 
 template <class G>
-__global__ __launch_bounds__(512, 1) void conv_quad_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(512, G::WGS) void conv_quad_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                const float* __restrict__ bias, float* __restrict__ pooled,
                                                                unsigned* __restrict__ mask, int N) {
   constexpr int C = G::C, H = G::H, W = G::W, O = G::O, CQ = G::CQ, CP = G::CP, PW = G::PW, NP = G::NP, OT = G::OT,
@@ -136,13 +139,11 @@ __global__ __launch_bounds__(512, 1) void conv_quad_fwd_kernel(const float* __re
       const int rp = pass * 8 + wave;
       if (rp >= G::RP) break;
       const float* lb = frame + iml * IMGS + ((2 * rp) * PW + xl) * CP;          // padded (y0 + kh, x + kw) from here
-      f32x16 acc[OT][2];
+      f32x16 acc[OT][2];                  // start from the bias: the epilogue adds nothing
 #pragma unroll
       for (int o = 0; o < OT; ++o)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[o][c][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[o][0][r] = acc[o][1][r] = bs[o * 32 + qacc_row(r, half)];
       f32x4 a[2][OT], b[2][2];
       auto load = [&](int p, f32x4 (&aa)[OT], f32x4 (&bb)[2]) {
         const int o0 = G::unit_off(p), o1 = p + NP < UNITS ? G::unit_off(p + NP) : o0;
@@ -178,13 +179,12 @@ __global__ __launch_bounds__(512, 1) void conv_quad_fwd_kernel(const float* __re
         unsigned w0 = 0, w1 = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+          // hit <=> v == m: m = max(0, window) >= 0, so equality already implies relu'(v) = [v >= 0] (and -0 == +0)
           const int oc = o * 32 + qacc_row(r, half);
-          const float bb = bs[oc];
-          const float v0 = acc[o][0][r] + bb, v1 = acc[o][1][r] + bb;
-          const float r0 = fmaxf(v0, 0.f), r1 = fmaxf(v1, 0.f);
-          const float mv = fmaxf(r0, r1);
+          const float v0 = acc[o][0][r], v1 = acc[o][1][r];
+          const float mv = fmaxf(fmaxf(v0, v1), 0.f);
           const float m = fmaxf(mv, dpp_xor1(mv));
-          const unsigned long long h0 = __ballot(r0 == m && v0 >= 0.f), h1 = __ballot(r1 == m && v1 >= 0.f);
+          const unsigned long long h0 = __ballot(v0 == m), h1 = __ballot(v1 == m);
           if ((l31 & 15) == r) {
             if (W == 16) {            // a 32-position word = rows y0, y0 + 1 of ONE image: 16 bits of each ballot
               const int sh = 32 * half + 16 * iml;
@@ -396,6 +396,271 @@ int launch_dgrad(const float* dp, const unsigned* hit, const float* w, float* dx
   return PDN_OK;
 }
 
+
+// ---- weight gradient -----------------------------------------------------------------------------------------------
+// dW[o][(c, tap)] = sum over images and positions of dy[o][pos] x_pad[c][pos + tap]  (+ db[o] = the column of ones): the
+// contraction runs over POSITIONS, so "four k-steps per read" means four consecutive x of one image row.
+//   * B (x): three copies of the zero-haloed image, SHIFTED by kw = 0, 1, 2 columns, so that the four positions a lane
+//     needs for its column (c, kh, kw) are one ALIGNED ds_read_b128 at copy kw, plane c, row y + kh; lane base + compile-
+//     time constant, one read per 32-column tile and group of 8 positions (lanes 0-31: x quad 2 g, lanes 32-63: 2 g + 1).
+//     The column order inside the tiles is chosen on the host so that the 16 lanes of every ds_read_b128 service group
+//     fall into 16 different 16-byte slots (planes padded by one slot: every slot residue holds <= 12 of the 180
+//     columns = one per group); the reduce kernel undoes the permutation.  Bias column and padding lanes read a plane of ones.
+//   * A (dy) never touches LDS: lane = output channel, its four positions are two floats of the pooled gradient +
+//     four bits of the hit word, loaded one image ahead straight into registers and expanded with a few VALU
+//     instructions per 8 positions.
+//   * a wave owns ONE 32-row tile of output channels, ALL column tiles and a quarter (OT = 2) / an eighth of the image
+//     rows; accumulators stay in registers over all images of the workgroup, are summed over the waves through LDS at
+//     the end and leave as one slab per workgroup (fixed-order reduction: bit-reproducible).
+struct QuadWgradPerm {
+  unsigned short col[6 * 32];    // tile lane -> weight column c * 9 + tap, K = bias, 0xFFFF = padding
+  unsigned short slot[6 * 32];   // ... and the 16-byte slot of its operand in the shifted-copy frame
+};
+
+template <int C_, int H_, int W_, int O_>
+struct QuadWgradGeom {
+  static constexpr int C = C_, H = H_, W = W_, O = O_;
+  static constexpr int K = C * 9, CT = (K + 1 + 31) / 32, OT = (O + 31) / 32, OPAD = OT * 32, KCOLS = CT * 32;
+  static constexpr int PQ = 8 / OT, RW = H / PQ;                       // position splits; image rows per wave
+  static constexpr int SC = (H + 2) * W + 4, SK = C * SC;              // plane (+ one slot), copy
+  static constexpr int BUF = 3 * SK;                                   // one image: three shifted copies
+  static constexpr int ONES = 2 * BUF;                                 // plane of ones behind the two buffers
+  static constexpr int LDS_FLOATS = 2 * BUF + H * W + 16;
+  static constexpr int F4 = C * H * W / 4, NV = (F4 + 511) / 512;
+  static constexpr int GPR = W / 8;                                    // groups of 8 positions per image row
+  static constexpr int NPR = RW / 2, NW = (W == 16 ? NPR : RW);        // pooled rows / hit words per wave and image
+  static_assert(OT == 1 || OT == 2, "one or two 32-row tiles of output channels");
+  static_assert(CT <= 6 && (W == 16 || W == 32) && RW >= 2 && (RW & 1) == 0, "shape outside the kernel");
+  static_assert(8 * 16 * 64 <= 2 * BUF, "reduction scratch fits the image buffers");
+};
+
+template <class G>
+__global__ __launch_bounds__(512, 1) void conv_quad_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dp,
+                                                                 const unsigned* __restrict__ hit, float* __restrict__ partial,
+                                                                 QuadWgradPerm perm, int N) {
+  constexpr int C = G::C, H = G::H, W = G::W, O = G::O, CT = G::CT, OT = G::OT, PQ = G::PQ, RW = G::RW, SC = G::SC,
+                SK = G::SK, BUF = G::BUF, NV = G::NV, GPR = G::GPR, NPR = G::NPR, NW = G::NW;
+  constexpr int PM = (H / 2) * (W / 2), MW = H * W / 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+  const int ot = wave % OT, q = wave / OT, row0 = q * RW;
+  for (int e = tid; e < 2 * BUF; e += 512) lds[e] = 0.f;
+  for (int e = tid; e < H * W + 16; e += 512) lds[G::ONES + e] = 1.f;
+  // x staging plan: piece f = (c, y, x quad) in memory order; copy kw holds x_pad[..][x' + kw], x_pad[..][x''] = x[x'' - 1]
+  int dst1[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int f = tid + i * 512, xq = f % (W / 4), t1 = f / (W / 4), y = t1 % H, c = t1 / H;
+    dst1[i] = f < G::F4 ? SK + c * SC + (y + 1) * W + 4 * xq : -1;            // copy 1: aligned
+  }
+  float4 pv[NV];
+  auto issue_x = [&](int n) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      pv[i] = *reinterpret_cast<const float4*>(x + (int64_t)n * (C * H * W) + 4 * (dst1[i] >= 0 ? tid + i * 512 : 0));
+  };
+  auto commit_x = [&](float* b) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (dst1[i] >= 0) {
+        float* d1 = b + dst1[i];
+        *reinterpret_cast<float4*>(d1) = pv[i];
+        const int xq = (tid + i * 512) % (W / 4);
+        float* d0 = d1 - SK + 1;                       // copy 0: one column to the right (x' = xx + 1)
+        d0[0] = pv[i].x; d0[1] = pv[i].y; d0[2] = pv[i].z;
+        if (xq != W / 4 - 1) d0[3] = pv[i].w;
+        float* d2 = d1 + SK - 1;                       // copy 2: one column to the left (x' = xx - 1)
+        if (xq != 0) d2[0] = pv[i].x;
+        d2[1] = pv[i].y; d2[2] = pv[i].z; d2[3] = pv[i].w;
+      }
+  };
+  // dy operands of one image: pooled pairs and hit words of this lane's channel, rows row0 .. row0 + RW - 1
+  const int oc = ot * 32 + l31, ocl = oc < O ? oc : O - 1;
+  float2 dv[NPR][GPR];
+  unsigned dm[NW];
+  auto issue_dy = [&](int n) {
+    const float* dpb = dp + ((int64_t)n * O + ocl) * PM + (row0 >> 1) * (W / 2) + 2 * half;
+    const unsigned* hb = hit + ((int64_t)n * O + ocl) * MW + (row0 * W >> 5);
+#pragma unroll
+    for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+      for (int g = 0; g < GPR; ++g) dv[pr][g] = *reinterpret_cast<const float2*>(dpb + pr * (W / 2) + 4 * g);
+#pragma unroll
+    for (int i = 0; i < NW; ++i) dm[i] = oc < O ? hb[i] : 0u;
+  };
+  // B operand bases of this lane's columns (floats, buffer 0)
+  int bb[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t) bb[t] = 4 * perm.slot[t * 32 + l31] + row0 * W + 4 * half;
+
+  f32x16 acc[CT];
+#pragma unroll
+  for (int t = 0; t < CT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  __syncthreads();
+  int n = blockIdx.x;
+  if (n < N) { issue_x(n); issue_dy(n); commit_x(lds); }
+  __syncthreads();
+  int buf = 0;
+  for (; n < N; n += gridDim.x) {
+    // operands of THIS image leave their prefetch registers first, then the next image's loads are issued
+    float2 cv[NPR][GPR];
+    unsigned cm[NW];
+#pragma unroll
+    for (int pr = 0; pr < NPR; ++pr)
+#pragma unroll
+      for (int g = 0; g < GPR; ++g) cv[pr][g] = dv[pr][g];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) cm[i] = dm[i];
+    __builtin_amdgcn_sched_barrier(0);
+    const int nn = n + gridDim.x < N ? n + gridDim.x : n;          // (always issued: see the data-gradient kernel)
+    issue_x(nn);
+    issue_dy(nn);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* fb = lds + buf * BUF;
+    // step i = (row yy, position group g, column tile t); the B fragment of step i + 1 is in flight while step i multiplies
+    constexpr int NS = RW * GPR * CT;
+    f32x4 b[2];
+    auto load_b = [&](int i, f32x4& bf) {
+      const int t = i % CT, kg = i / CT, g = kg % GPR, yy = kg / GPR;
+      bf = *reinterpret_cast<const f32x4*>(fb + bb[t] + yy * W + 8 * g);
+    };
+    load_b(0, b[0]);
+    float a[4];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      // the next fragment's read is issued HERE, in front of this step's MFMAs (hipcc otherwise sinks it behind them
+      // into the registers they just freed and waits for it at once: a full LDS round trip per group of four)
+      if (i + 1 < NS) load_b(i + 1, b[(i + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      const int t = i % CT, kg = i / CT, g = kg % GPR, yy = kg / GPR;
+      if (t == 0) {
+        // the lane's four positions (row0 + yy, 4 (2 g + half) + j): bits of the hit word, pooled pair cv[yy / 2][g]
+        const unsigned wd = cm[W == 16 ? yy / 2 : yy] >> ((W == 16 ? (yy & 1) * 16 : 0) + 8 * g);
+        const unsigned bits = half ? wd >> 4 : wd;
+        const float2 p = cv[yy / 2][g];
+        a[0] = bits & 1u ? p.x : 0.f; a[1] = bits & 2u ? p.x : 0.f; a[2] = bits & 4u ? p.y : 0.f; a[3] = bits & 8u ? p.y : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[i & 1][j], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (n + (int)gridDim.x < N) commit_x(lds + (buf ^ 1) * BUF);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // sum over the PQ waves of an output-channel tile, one column tile per round, through LDS; one slab per workgroup
+  float* red = lds;                                    // [8 waves][16][64]
+  float* slab = partial + (int64_t)blockIdx.x * G::OPAD * G::KCOLS;
+#pragma unroll                                       // (unrolled: a runtime index would put the accumulators in scratch)
+  for (int t = 0; t < CT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = acc[t][r];
+    __syncthreads();
+    for (int e = tid; e < OT * 16 * 64; e += 512) {
+      const int ln = e & 63, r = (e >> 6) & 15, o2 = e >> 10;
+      float sum = 0.f;
+#pragma unroll
+      for (int qq = 0; qq < PQ; ++qq) sum += red[((qq * OT + o2) * 16 + r) * 64 + ln];
+      slab[(int64_t)(o2 * 32 + qacc_row(r, ln >> 5)) * G::KCOLS + t * 32 + (ln & 31)] = sum;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_quad_wgrad_reduce_kernel(const float* __restrict__ partial, int slabs, int OPAD,
+                                                                     int KCOLS, int O, int K, QuadWgradPerm perm,
+                                                                     float* __restrict__ dw, float* __restrict__ db,
+                                                                     int accumulate) {
+  __shared__ float red[8][32];
+  const int total = O * KCOLS;
+  const int e = blockIdx.x * 32 + (threadIdx.x & 31), grp = threadIdx.x >> 5;
+  float s = 0.f;
+  int o = 0, j = 0xFFFF;
+  if (e < total) {
+    o = e / KCOLS;
+    const int pcol = e - o * KCOLS;
+    j = perm.col[pcol];
+    if (j <= K) {
+      const float* p = partial + (int64_t)o * KCOLS + pcol;
+      const int64_t stride = (int64_t)OPAD * KCOLS;
+      for (int b = grp; b < slabs; b += 8) s += p[b * stride];
+    }
+  }
+  red[grp][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (grp == 0 && e < total && j <= K) {
+    float t = 0.f;
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) t += red[qq][threadIdx.x];
+    if (j < K) {
+      if (dw) dw[(int64_t)o * K + j] = accumulate ? dw[(int64_t)o * K + j] + t : t;
+    } else if (db) {
+      db[o] = accumulate ? db[o] + t : t;
+    }
+  }
+}
+
+// Column order: weight column (c, kh, kw) reads slot (kw SK + c SC + kh W) / 4 (+ a position term common to all lanes);
+// every ds_read_b128 service group (MI355X_MICROARCH.md, LDS: lanes {0-3, 12-15, 20-27} and {4-11, 16-19, 28-31} of each
+// half-wave) gets columns of 16 different slot residues where the class sizes allow it.
+template <class G>
+void build_wgrad_perm(QuadWgradPerm& pm) {
+  static const int grp_lanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+                                       {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+  constexpr int NG = 2 * G::CT;
+  int fill[NG] = {0};
+  unsigned used[NG] = {0};
+  for (int i = 0; i < 6 * 32; ++i) { pm.col[i] = 0xFFFF; pm.slot[i] = (unsigned short)(G::ONES / 4); }
+  auto slot_of = [](int j) { const int c = j / 9, tap = j % 9; return ((tap % 3) * G::SK + c * G::SC + (tap / 3) * G::W) / 4; };
+  auto place = [&](int g, int j, int slot) {
+    const int ln = grp_lanes[g & 1][fill[g]++];
+    pm.col[(g >> 1) * 32 + ln] = (unsigned short)j;
+    pm.slot[(g >> 1) * 32 + ln] = (unsigned short)slot;
+    used[g] |= 1u << (slot & 15);
+  };
+  bool placed[G::K + 1] = {false};
+  for (int pass = 0; pass < 2; ++pass)              // conflict-free placements first, the rest where there is room
+    for (int j = 0; j < G::K; ++j) {
+      if (placed[j]) continue;
+      const int slot = slot_of(j);
+      int best = -1;
+      for (int g = 0; g < NG; ++g)
+        if (fill[g] < 16 && (pass == 1 || !(used[g] >> (slot & 15) & 1u)) && (best < 0 || fill[g] < fill[best])) best = g;
+      if (best >= 0) { place(best, j, slot); placed[j] = true; }
+    }
+  for (int g = NG - 1; g >= 0; --g)                 // the bias column: a lane of ones
+    if (fill[g] < 16) { place(g, G::K, G::ONES / 4); break; }
+}
+
+template <class G>
+int launch_wgrad_quad(const float* x, const float* dp, const unsigned* hit, float* dw, float* db, int accumulate, int N,
+                      void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  auto kern = conv_quad_wgrad_kernel<G>;
+  constexpr int lds = G::LDS_FLOATS * 4;
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  const int grid = N < 256 ? N : 256;
+  if (!workspace || workspace_bytes < 4ll * grid * G::OPAD * G::KCOLS) {
+    pdn_set_error("conv_quad weight gradient: workspace too small");
+    return PDN_EWORKSPACE;
+  }
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) { pdn_set_error("conv_quad: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
+  static QuadWgradPerm pm;
+  static bool built = false;
+  if (!built) { build_wgrad_perm<G>(pm); built = true; }
+  float* partial = (float*)workspace;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, x, dp, hit, partial, pm, N);
+  PDN_LAUNCH_CHECK();
+  const int total = G::O * G::KCOLS;
+  hipLaunchKernelGGL(conv_quad_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, partial, grid, G::OPAD,
+                     G::KCOLS, G::O, G::K, pm, dw, db, accumulate);
+  PDN_LAUNCH_CHECK();
+  return PDN_OK;
+}
+
 template <class G>
 int launch_fwd(const float* x, const float* w, const float* bias, float* pooled, unsigned* mask, int N, hipStream_t st) {
   auto kern = conv_quad_fwd_kernel<G>;
@@ -404,7 +669,7 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* pooled,
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { pdn_set_error("conv_quad: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   const int groups = (N + G::IPT - 1) / G::IPT;
-  const int grid = groups < 256 ? groups : 256;
+  const int grid = groups < 256 * G::WGS ? groups : 256 * G::WGS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, x, w, bias, pooled, mask, N);
   PDN_LAUNCH_CHECK();
   return PDN_OK;
@@ -432,6 +697,21 @@ int conv_quad_relu_pool_bwd_data(const float* dpooled, const unsigned* mask, con
   if (C == 20 && H == 16 && W == 16 && O == 50)
     return launch_dgrad<QuadDgradGeom<20, 16, 16, 50>>(dpooled, mask, w, dx, N, (hipStream_t)stream);
   pdn_set_error("conv_quad_relu_pool_bwd_data: no instantiation for this shape");
+  return PDN_EUNSUPPORTED;
+}
+
+bool conv_quad_wgrad_supported(int C, int H, int W, int O, int k, int stride, int pad) {
+  if (!quad_enabled() || k != 3 || stride != 1 || pad != 1) return false;
+  return C == 20 && H == 16 && W == 16 && O == 50;
+}
+
+int conv_quad_relu_pool_bwd_weight(const float* x, const float* dpooled, const unsigned* mask, float* dw, float* db,
+                                   int accumulate, int N, int C, int H, int W, int O, void* workspace,
+                                   int64_t workspace_bytes, void* stream) {
+  if (C == 20 && H == 16 && W == 16 && O == 50)
+    return launch_wgrad_quad<QuadWgradGeom<20, 16, 16, 50>>(x, dpooled, mask, dw, db, accumulate, N, workspace,
+                                                            workspace_bytes, (hipStream_t)stream);
+  pdn_set_error("conv_quad_relu_pool_bwd_weight: no instantiation for this shape");
   return PDN_EUNSUPPORTED;
 }
 
