@@ -88,7 +88,8 @@ GATE_RTOL = 1e-4
 COUNTER_SLOTS = ("rowres_chunk", "rowtile_plain", "rowtile_swiglu_fwd", "rowtile_swiglu_bwd", "rowtile_rope", "rowtile_rowmax",
                  "rowres_chunk_epilogue", "attention_p_fwd", "attention_p_bwd", "attention_resident_fwd",
                  "attention_resident_bwd", "attention_stream", "lm_head_dx_sumexp", "lm_head_dw_ce", "outres", "outres_tn",
-                 "linear_relu_fwd", "linear_dx_masked", "ce_small", "tiled_swiglu_fwd", "tiled_swiglu_bwd")
+                 "linear_relu_fwd", "linear_dx_masked", "ce_small", "tiled_swiglu_fwd", "tiled_swiglu_bwd",
+                 "conv_quad_fwd", "conv_quad_dgrad", "conv_quad_wgrad")
 
 
 def kernel_counters(lib, reset=False):

@@ -262,6 +262,11 @@ def _train_gate(which, net, X, y, step, rtol=1e-4):
         # Linear -> ReLU as one product, the relu gradient applied in the consumer's input-gradient product: a dispatch
         # that falls back to separate relu passes would keep the losses right and only show as a slower number
         raise SystemExit(f"bench.py --config mlp: the fused Linear + ReLU products were not launched ({launched})")
+    if which == "lenet" and (launched.get("conv_quad_fwd", 0) < 6 or launched.get("conv_quad_dgrad", 0) < 3 or
+                             launched.get("conv_quad_wgrad", 0) < 6):
+        # both layers' conv + relu + pool forwards and weight gradients, the second layer's data gradient, three steps:
+        # the kernels of csrc/conv_quad.hip the roofline block below prices (a fall-back to conv_direct.hip is 30 % slower)
+        raise SystemExit(f"bench.py --config lenet: the conv_quad.hip kernels were not launched ({launched})")
     return {"steps": 3, "batch": nb, "worst_loss_rel_err": worst, "rtol": rtol, "against": "oracle (NumPy port of the reference)",
             "kernel_launches": launched}
 
@@ -323,12 +328,13 @@ def _conv_roofline(lib, hp, B):
     pmc, pmc_src = _conv_pmc()
     ridge = PEAK_FP32_MFMA / PEAK_HBM
 
-    def traffic_of(prefix):
-        hits = [v for k, v in pmc.items() if k.startswith(prefix)]
+    def traffic_of(parts):                                 # kernel template + geometry arguments, as rocprofv3 prints them
+        hits = [v for k, v in pmc.items() if all(p in k for p in parts)]
         return hits[0] if len(hits) == 1 and B == (pmc_src or {}).get("batch") else None
 
     for tag, (C, H, O) in (("conv1", (3, 32, 20)), ("conv2", (20, 16, 50))):
-        if lib.query("pdn_conv2d_relu_pool_supported", C, H, H, O, 3, 1, 1) != 7:
+        sup = lib.query("pdn_conv2d_relu_pool_supported", C, H, H, O, 3, 1, 1)
+        if sup & 5 != 5 or (C != 3 and not sup & 2):
             continue
         P = H // 2
         x = hp.from_numpy(rng.standard_normal((B, C, H, H), dtype=np.float32))
@@ -368,16 +374,16 @@ def _conv_roofline(lib, hp, B):
                 "flop_per_byte": flop / nbytes, "algorithmic_flop_per_launch": flop,
                 "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": us, "traffic": None}
     # counter traffic: kernel names of the committed summary (template arguments identify layer and direction)
-    for key, prefix in (("conv1_fwd_relu_pool", "conv_direct_kernel<2, 2, 3, 8, 1, 0>"),
-                        ("conv2_fwd_relu_pool", "conv_direct_kernel<1, 4, 3, 4, 1, 0>"),
-                        ("conv2_bwd_data", "conv_direct_kernel<1, 2, 3, 16, 0, 1>"),
-                        ("conv1_bwd_weight", "conv_wgrad_lean_kernel<1, 1, 8, 16, 1>"),
-                        ("conv2_bwd_weight", "conv_wgrad_lean_kernel<6, 2, 8, 8, 1>")):
+    for key, parts in (("conv1_fwd_relu_pool", ("conv_quad_fwd_kernel", "<3, 32, 32, 20>")),
+                       ("conv2_fwd_relu_pool", ("conv_quad_fwd_kernel", "<20, 16, 16, 50>")),
+                       ("conv2_bwd_data", ("conv_quad_dgrad_kernel", "<20, 16, 16, 50>")),
+                       ("conv1_bwd_weight", ("conv_quad_wgrad_kernel", "<3, 32, 32, 20>")),
+                       ("conv2_bwd_weight", ("conv_quad_wgrad_kernel", "<20, 16, 16, 50>"))):
         if key in out:
-            out[key]["traffic"] = traffic_of(prefix)
+            out[key]["traffic"] = traffic_of(parts)
     dom_key = max(out, key=lambda k: out[k]["avg_launch_us"])
     dom = out[dom_key]
-    return {"bound": dom["bound"], "kernel": dom_key + " (conv_direct.hip)", "achieved": dom["achieved"], "peak": dom["peak"],
+    return {"bound": dom["bound"], "kernel": dom_key + " (conv_quad.hip)", "achieved": dom["achieved"], "peak": dom["peak"],
             "unit": dom["unit"], "frac": dom["frac"], "traffic": dom["traffic"], "avg_launch_us": dom["avg_launch_us"],
             "algorithmic_flop_per_launch": dom["algorithmic_flop_per_launch"],
             "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "traffic_source": pmc_src,

@@ -164,7 +164,7 @@ int pdn_qkv_rope_norm_fwd_f32(const float* x, const float* norm_w, float eps, fl
                               int64_t ldx, void* stream);
 /* Launch counters per kernel: which kernel the entry points really launched since the last reset -- bench.py's parity
  * gates and the tests assert on them (a dispatch that silently falls back to a slower kernel must not stay green).
- * Copies min(n, 21) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
+ * Copies min(n, 24) counters to `out` (may be null), clears all of them when `reset` != 0.  Slots:
  *   0 gemm_rowres_kernel (chunk kernel, any)      1 gemm_rowtile_kernel plain        2 ... + SwiGLU forward (gate | up)
  *   3 ... + SwiGLU backward (dh)                  4 ... + RoPE (q | k | v)           5 ... + row maxima (lm_head forward)
  *   6 gemm_rowres_kernel with a fused epilogue    7 attention_p forward (persistent) 8 attention_p backward (dQ + dK/dV)
@@ -172,7 +172,8 @@ int pdn_qkv_rope_norm_fwd_f32(const float* x, const float* norm_w, float eps, fl
  *  12 lm_head input gradient + sum of exponentials (gemm_outres_kernel CE 2)        13 lm_head weight gradient, CE gradient inside
  *  14 gemm_outres_kernel plain                   15 gemm_outres_tn_kernel plain
  *  16 pdn_linear_relu_fwd_f32                    17 pdn_linear_dx_masked_f32        18 cross entropy over <= 32 classes
- *  19 pdn_gateup_swiglu_tiled_fwd_f32            20 pdn_swiglu_bwd_tiled_f32 */
+ *  19 pdn_gateup_swiglu_tiled_fwd_f32            20 pdn_swiglu_bwd_tiled_f32
+ *  21 conv_quad_fwd_kernel (csrc/conv_quad.hip)  22 conv_quad_dgrad_kernel          23 conv_quad_wgrad_kernel */
 int pdn_kernel_counters(int64_t* out, int n, int reset);
 /* Round 5: which kernel the row-resident entry points below and above launch.  The tile-piece kernel
  * (csrc/gemm_rowtile.hip: one 32-column tile of B over the whole contraction per piece, rotating accumulator sets, stores

@@ -42,7 +42,10 @@ enum {
   PDN_CNT_CE_SMALL = 18,          // ce_small_kernel: cross entropy over <= 32 classes, one thread per row
   PDN_CNT_TILED_SWIGLU_FWD = 19,  // tiled kernel with SwiGLU in the store (pdn_gateup_swiglu_tiled_fwd_f32)
   PDN_CNT_TILED_SWIGLU_BWD = 20,  // ... with the SwiGLU backward in the store (pdn_swiglu_bwd_tiled_f32)
-  PDN_CNT_SLOTS = 21
+  PDN_CNT_CONV_QUAD_FWD = 21,     // conv_quad_fwd_kernel (conv + relu + max_pool of the LeNet shapes, csrc/conv_quad.hip)
+  PDN_CNT_CONV_QUAD_DGRAD = 22,   // conv_quad_dgrad_kernel (col2im-style data gradient)
+  PDN_CNT_CONV_QUAD_WGRAD = 23,   // conv_quad_wgrad_kernel (shifted image copies)
+  PDN_CNT_SLOTS = 24
 };
 void pdn_count(int slot);
 

@@ -243,7 +243,7 @@ struct QuadDgradGeom {
 
 template <class G>
 __global__ __launch_bounds__(512, 1) void conv_quad_dgrad_kernel(const float* __restrict__ dp, const unsigned* __restrict__ hit,
-                                                                 const float* __restrict__ w, float* __restrict__ dx, int N, int ablate) {
+                                                                 const float* __restrict__ w, float* __restrict__ dx, int N) {
   constexpr int C = G::C, H = G::H, W = G::W, O = G::O, PW = G::PW, P = G::P, RT = G::RT, KG = G::KG, KS = G::KS,
                 WSD = G::WSD, TILES = G::TILES, ITEMS = G::ITEMS, FROWS = G::FROWS;
   constexpr int PM = (H / 2) * (W / 2), MW = H * W / 32;
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 1) void conv_quad_dgrad_kernel(const float* __
           const bool more = t + 1 < TILES;
           const int nimg = (grp + (int)gridDim.x) * 4 + (wave >> 1);
           const bool next_round = grp + (int)gridDim.x < groups && nimg < N;
-          if (!(ablate & 2)) issue(more ? img : (next_round ? nimg : img), more ? t + 1 : 0);
+          issue(more ? img : (next_round ? nimg : img), more ? t + 1 : 0);
         }
         __builtin_amdgcn_sched_barrier(0);      // ... and issue them HERE (hipcc otherwise sinks them behind the MFMAs)
         f32x16 acc[RT];
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(512, 1) void conv_quad_dgrad_kernel(const float* __
         // alias analysis cannot see: the accesses are volatile = issued in program order, and the LDS serves one
         // wave's instructions in order.
         volatile float* ft = fl + 2 * t * PW;
-        if (!(ablate & 1)) {
+        {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) {
             float sum[C / 2], old[C / 2];
@@ -391,8 +391,9 @@ int launch_dgrad(const float* dp, const unsigned* hit, const float* w, float* dx
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) { pdn_set_error("conv_quad: LDS attribute: %s", hipGetErrorString(e)); return (int)e; }
   const int groups = (N + 3) / 4;
-  hipLaunchKernelGGL(kern, dim3(groups < 256 ? groups : 256), dim3(512), lds, st, dp, hit, w, dx, N, getenv("PDN_QUAD_ABLATE") ? atoi(getenv("PDN_QUAD_ABLATE")) : 0);
+  hipLaunchKernelGGL(kern, dim3(groups < 256 ? groups : 256), dim3(512), lds, st, dp, hit, w, dx, N);
   PDN_LAUNCH_CHECK();
+  pdn_count(PDN_CNT_CONV_QUAD_DGRAD);
   return PDN_OK;
 }
 
@@ -654,6 +655,7 @@ int launch_wgrad_quad(const float* x, const float* dp, const unsigned* hit, floa
   float* partial = (float*)workspace;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, x, dp, hit, partial, pm, N);
   PDN_LAUNCH_CHECK();
+  pdn_count(PDN_CNT_CONV_QUAD_WGRAD);
   const int total = G::O * G::KCOLS;
   hipLaunchKernelGGL(conv_quad_wgrad_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, partial, grid, G::OPAD,
                      G::KCOLS, G::O, G::K, pm, dw, db, accumulate);
@@ -672,6 +674,7 @@ int launch_fwd(const float* x, const float* w, const float* bias, float* pooled,
   const int grid = groups < 256 * G::WGS ? groups : 256 * G::WGS;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, x, w, bias, pooled, mask, N);
   PDN_LAUNCH_CHECK();
+  pdn_count(PDN_CNT_CONV_QUAD_FWD);
   return PDN_OK;
 }
 
@@ -702,7 +705,7 @@ int conv_quad_relu_pool_bwd_data(const float* dpooled, const unsigned* mask, con
 
 bool conv_quad_wgrad_supported(int C, int H, int W, int O, int k, int stride, int pad) {
   if (!quad_enabled() || k != 3 || stride != 1 || pad != 1) return false;
-  return C == 20 && H == 16 && W == 16 && O == 50;
+  return (C == 20 && H == 16 && W == 16 && O == 50) || (C == 3 && H == 32 && W == 32 && O == 20);
 }
 
 int conv_quad_relu_pool_bwd_weight(const float* x, const float* dpooled, const unsigned* mask, float* dw, float* db,
@@ -711,6 +714,9 @@ int conv_quad_relu_pool_bwd_weight(const float* x, const float* dpooled, const u
   if (C == 20 && H == 16 && W == 16 && O == 50)
     return launch_wgrad_quad<QuadWgradGeom<20, 16, 16, 50>>(x, dpooled, mask, dw, db, accumulate, N, workspace,
                                                             workspace_bytes, (hipStream_t)stream);
+  if (C == 3 && H == 32 && W == 32 && O == 20)
+    return launch_wgrad_quad<QuadWgradGeom<3, 32, 32, 20>>(x, dpooled, mask, dw, db, accumulate, N, workspace,
+                                                           workspace_bytes, (hipStream_t)stream);
   pdn_set_error("conv_quad_relu_pool_bwd_weight: no instantiation for this shape");
   return PDN_EUNSUPPORTED;
 }

@@ -246,17 +246,17 @@ class EmulatedLib:
     #    the library would have launched for the same arguments (its dispatch rules restated), so the gates of bench.py
     #    and the path assertions of the tests run without a GPU
     def _count(self, slot):
-        self._counters = getattr(self, "_counters", [0] * 21)
+        self._counters = getattr(self, "_counters", [0] * 24)
         self._counters[slot] += 1
 
     def pdn_kernel_counters(self, out, n, reset):
-        c = getattr(self, "_counters", [0] * 21)
+        c = getattr(self, "_counters", [0] * 24)
         if out:
             arr = ctypes.cast(out, ctypes.POINTER(ctypes.c_int64))
-            for i in range(min(int(n), 21)):
+            for i in range(min(int(n), 24)):
                 arr[i] = c[i]
         if reset:
-            self._counters = [0] * 21
+            self._counters = [0] * 24
         return 0
 
     @staticmethod
@@ -1575,9 +1575,20 @@ class EmulatedLib:
         up = np.repeat(np.repeat(dp, 2, -2), 2, -1)
         return np.where(bits, up, 0).astype(np.float32)
 
+    @staticmethod
+    def _conv_quad(C, H, W, O, k, s, p, which):
+        """csrc/conv_quad.hip's dispatch restated: the LeNet shapes of examples/pydynet/mnist.py:82-98 (3x3 / 1 / 1)."""
+        if (k, s, p) != (3, 1, 1):
+            return False
+        shapes = {"fwd": ((20, 16, 16, 50), (3, 32, 32, 20)), "dgrad": ((20, 16, 16, 50),),
+                  "wgrad": ((20, 16, 16, 50), (3, 32, 32, 20))}[which]
+        return (C, H, W, O) in shapes
+
     def pdn_conv2d_relu_pool_fwd_f32(self, x, w, bias, pooled, mask, N, C, H, W, O, k, s, p, stream):
         if not self.pdn_conv2d_relu_pool_supported(C, H, W, O, k, s, p) & 1:
             return -2
+        if self._conv_quad(C, H, W, O, k, s, p, "fwd"):
+            self._count(21)
         col, oh, ow = self._conv_cols(x, N, C, H, W, k, s, p)
         out = np.matmul(flat(w, O * C * k * k).reshape(O, -1), col)
         if bias:
@@ -1595,6 +1606,8 @@ class EmulatedLib:
     def pdn_conv2d_relu_pool_bwd_data_f32(self, dp, mask, w, dx, N, C, H, W, O, k, s, p, stream):
         if not self.pdn_conv2d_relu_pool_supported(C, H, W, O, k, s, p) & 2:
             return -2
+        if self._conv_quad(C, H, W, O, k, s, p, "dgrad"):
+            self._count(22)
         oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         dy = self._expanded(dp, mask, N, O, oh, ow)
         return self.pdn_conv2d_bwd_data_f32(dy.ctypes.data, w, dx, N, C, H, W, O, k, s, p, stream)
@@ -1602,6 +1615,8 @@ class EmulatedLib:
     def pdn_conv2d_relu_pool_bwd_weight_f32(self, x, dp, mask, dw, db, acc, N, C, H, W, O, k, s, p, ws, wsb, stream):
         if not self.pdn_conv2d_relu_pool_supported(C, H, W, O, k, s, p) & 4:
             return -2
+        if self._conv_quad(C, H, W, O, k, s, p, "wgrad"):
+            self._count(23)
         oh, ow = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         dy = self._expanded(dp, mask, N, O, oh, ow)
         return self.pdn_conv2d_bwd_weight_f32(x, dy.ctypes.data, dw, db, acc, N, C, H, W, O, k, s, p, ws, wsb, stream)

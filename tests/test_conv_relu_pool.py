@@ -69,6 +69,14 @@ def _run(dev, x, w, b, gp, defer, x_grad=True):
         fused.conv2d.defer = True
 
 
+def _quad_counters(reset=False):
+    import ctypes
+    from pydynet_amd import _lib
+    buf = (ctypes.c_int64 * 24)()
+    _lib.lib().call("pdn_kernel_counters", buf, 24, 1 if reset else 0)
+    return tuple(int(v) for v in buf[21:24])
+
+
 def _close(a, b, what, tol=2e-5):
     scale = max(float(np.abs(b).max()), 1e-30)
     err = float(np.abs(np.asarray(a, np.float64) - b).max())
@@ -89,8 +97,13 @@ def check_fused_chain_matches_float64_and_unfused(dev):
                 w = (0.3 * rng.standard_normal((O, C, 3, 3))).astype(np.float32)
                 b = rng.standard_normal((O,), dtype=np.float32)
             gp = rng.standard_normal((N, O, H // 2, W // 2), dtype=np.float32)
+            _quad_counters(reset=True)
             kind, out, dx, dw, db = _run(dev, x, w, b, gp, defer=True)
             assert kind == "conv2d_relu_pool", (case, kind)
+            # the LeNet shapes run on csrc/conv_quad.hip (library launch counters 21 / 22 / 23).  conv1 has no fused data
+            # gradient (it is a network's first layer): asked for dx, its node expands the pooled gradient and runs the plain kernels
+            want = {(3, 32, 32, 20): (1, 0, 0), (20, 16, 16, 50): (1, 1, 1)}.get((C, H, W, O), (0, 0, 0))
+            assert _quad_counters() == want, (case, _quad_counters(), want)
             kind0, out0, dx0, dw0, db0 = _run(dev, x, w, b, gp, defer=False)
             assert kind0 == "pool2d"
             # the LeNet shapes run the fused forward on csrc/conv_quad.hip, whose contraction order differs from the plain
@@ -106,8 +119,11 @@ def check_fused_chain_matches_float64_and_unfused(dev):
             for got, want, name in zip((dx, dw, db), (dx0, dw0, db0), ("dx", "dw", "db")):
                 _close(got, want.astype(np.float64), (case, "vs unfused", name), 2e-5)
         # the first layer of a network: no gradient for the input
+        _quad_counters(reset=True)
         kind, out, dx, dw, db = _run(dev, x, w, b, gp, defer=True, x_grad=False)
         assert kind == "conv2d_relu_pool" and dx is None
+        if (C, H, W, O) in ((3, 32, 32, 20), (20, 16, 16, 50)):
+            assert _quad_counters() == (1, 0, 1), (case, _quad_counters())
         _close(dw, ref[2], (case, "dw, no dx"), 1e-6)
 
 
