@@ -235,8 +235,10 @@ struct QuadDgradGeom {
   static constexpr int WSD = (O + 3) / 4 * 4;                          // weight row stride (13 slots for O = 50)
   static constexpr int TILES = H / 4;                                  // 32-position tiles (two rows) per half image
   static constexpr int FRAME = C * P;                                  // floats per wave
-  static constexpr int LDS_FLOATS = RT * 32 * WSD + 8 * FRAME;
+  static constexpr int STG = O * (W / 2) + 64;                          // per wave: O pooled rows of a tile + its hit words
+  static constexpr int LDS_FLOATS = RT * 32 * WSD + 8 * FRAME + 8 * STG;
   static_assert(W == 16 && (C & 1) == 0 && (H % 4) == 0, "two image rows per tile; channel pairs");
+  static_assert(O <= 64 && (STG & 3) == 0, "one lane per dy channel stages its pooled row");
   static_assert(O % 8 == 0 || O % 8 == 2, "k-steps: groups of 8 dy channels + one pair");
   static_assert(((WSD / 4) & 1) == 1, "odd slot count per weight row");
 };
@@ -266,45 +268,66 @@ __global__ __launch_bounds__(512, 1) void conv_quad_dgrad_kernel(const float* __
   const float* arow = wl + l31 * WSD + 4 * half;
   float* fl = frame + half * P + rowbit * PW + x;          // + 2 t PW per tile, + (channel pair, kh) constant
   const int groups = (N + 3) / 4;
-  float rawv[KS];
-  unsigned rawm[KS];
-  auto issue = [&](int img, int t) {                          // operands of tile t of this wave's half image
-    const int tg = TILES * hw + t;
-    const float* dpb = dp + ((int64_t)img * O + 4 * half) * PM + tg * (W / 2) + (x >> 1);
-    const unsigned* hb = hit + ((int64_t)img * O + 4 * half) * MW + tg;
-#pragma unroll
-    for (int s = 0; s < 4 * KG; ++s) {
-      const int o = 8 * (s >> 2) + (s & 3);
-      rawv[s] = dpb[o * PM];
-      rawm[s] = hb[o * MW];
-    }
-    if (KS > 4 * KG) {                                        // the last pair of dy channels: one k-step
-      rawv[KS - 1] = dp[((int64_t)img * O + 8 * KG + half) * PM + tg * (W / 2) + (x >> 1)];
-      rawm[KS - 1] = hit[((int64_t)img * O + 8 * KG + half) * MW + tg];
-    }
+  // dy operands: lane o (< O) loads the pooled row (W / 2 floats) and the hit word of channel o for one tile -- three
+  // load instructions per tile and wave; a load per operand and lane (2 KS of them) kept the texture addresser busier than
+  // the matrix pipe once the operands came from HBM instead of the cache (287 us inside the step against 224 us alone).
+  // They pass through a private staging area of the wave: written one tile ahead, read back per k-step (lane = position).
+  float* stg = frames + 8 * G::FRAME + wave * G::STG;       // [O][W / 2] pooled rows, then [64] hit words
+  unsigned* stgm = reinterpret_cast<unsigned*>(stg + O * (W / 2));
+  const int ol = lane < O ? lane : O - 1;
+  float4 g0, g1;
+  unsigned gm;
+  auto where = [&](int k, int& img, int& t) {               // tile k of this wave's sequence -> (image, tile); false: none
+    const int grp = blockIdx.x + (k / TILES) * (int)gridDim.x;
+    img = grp * 4 + (wave >> 1);
+    t = k % TILES;
+    return grp < groups && img < N;
   };
-  {
-    const int img0 = blockIdx.x * 4 + (wave >> 1);
-    if ((int)blockIdx.x < groups && img0 < N) issue(img0, 0);
-  }
+  auto issue = [&](int k) {                                 // (always issued: an invalid k re-reads tile 0 of a valid image)
+    int img, t;
+    if (!where(k, img, t)) { img = blockIdx.x * 4 + (wave >> 1); img = img < N ? img : N - 1; t = 0; }
+    const int tg = TILES * hw + t;
+    const float* src = dp + ((int64_t)img * O + ol) * PM + tg * (W / 2);
+    g0 = *reinterpret_cast<const float4*>(src);
+    g1 = *reinterpret_cast<const float4*>(src + 4);
+    gm = hit[((int64_t)img * O + ol) * MW + tg];
+  };
+  int kseq = 0;
+  issue(0);
+  if (lane < O) { *reinterpret_cast<float4*>(stg + lane * (W / 2)) = g0; *reinterpret_cast<float4*>(stg + lane * (W / 2) + 4) = g1; }
+  stgm[lane] = gm;
+  issue(1);
+  const float* bvl = stg + (4 * half) * (W / 2) + (x >> 1);  // + (8 g + j) (W / 2) per k-step
+  const unsigned* bml = stgm + 4 * half;
   for (int grp = blockIdx.x; grp < groups; grp += gridDim.x) {
     const int img = grp * 4 + (wave >> 1);
     if (img < N) {
 #pragma unroll 1
-      for (int t = 0; t < TILES; ++t) {
+      for (int t = 0; t < TILES; ++t, ++kseq) {
         float bv[KS];
-#pragma unroll
-        for (int s = 0; s < KS; ++s) bv[s] = (rawm[s] >> l31) & 1u ? rawv[s] : 0.f;
-        __builtin_amdgcn_sched_barrier(0);      // expand the landed operands BEFORE the next tile's loads are issued
         {
-          // EXACTLY one prefetch per tile, whatever comes next (a conditional issue makes the compiler wait for the
-          // prefetch itself: the vmcnt it puts in front of the first use must hold on the path that issued nothing)
-          const bool more = t + 1 < TILES;
-          const int nimg = (grp + (int)gridDim.x) * 4 + (wave >> 1);
-          const bool next_round = grp + (int)gridDim.x < groups && nimg < N;
-          issue(more ? img : (next_round ? nimg : img), more ? t + 1 : 0);
+          float rv[KS];
+          unsigned rm[KS];
+#pragma unroll
+          for (int s = 0; s < 4 * KG; ++s) {
+            const int o = 8 * (s >> 2) + (s & 3);
+            rv[s] = bvl[o * (W / 2)];
+            rm[s] = bml[o];
+          }
+          if (KS > 4 * KG) {                                  // the last pair of dy channels: one k-step
+            rv[KS - 1] = stg[(8 * KG + half) * (W / 2) + (x >> 1)];
+            rm[KS - 1] = stgm[8 * KG + half];
+          }
+#pragma unroll
+          for (int s = 0; s < KS; ++s) bv[s] = (rm[s] >> l31) & 1u ? rv[s] : 0.f;
         }
-        __builtin_amdgcn_sched_barrier(0);      // ... and issue them HERE (hipcc otherwise sinks them behind the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
+        // the next tile's rows (loaded a tile ago) take the staging area -- the LDS serves this wave's reads above first --
+        // and the tile after that is requested: EXACTLY one prefetch per tile (see the comment in the weight gradient)
+        if (lane < O) { *reinterpret_cast<float4*>(stg + lane * (W / 2)) = g0; *reinterpret_cast<float4*>(stg + lane * (W / 2) + 4) = g1; }
+        stgm[lane] = gm;
+        issue(kseq + 2);
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[RT];
 #pragma unroll
         for (int T = 0; T < RT; ++T)
