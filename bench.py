@@ -438,6 +438,23 @@ def other_configs(*release):
     except BaseException as e:
         res["llama_b256"] = {"error": f"{type(e).__name__}: {e}"}
     gc.collect()
+    try:
+        # the DROP-IN formulation: the same model written with plain operators (tests/models_plain_llama.py = what the
+        # reference's own llm/llama/model.py does: RoPE as slices + concat, attention as matmul -> softmax -> matmul),
+        # beside the fused-node model at the same batch; parity: tests/test_plain_llama.py (reference-generated vectors)
+        Graph.clear()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import plain_llama_bench
+        r = plain_llama_bench.run(64, 5)
+        res["llama_plain_ops_b64"] = {"value": r["plain"]["samples_per_s"], "unit": "samples/s", "ms_per_step": r["plain"]["ms_per_step"],
+                                      "model_flops_frac_of_fp32_mfma_peak": r["plain"]["mfma_frac"],
+                                      "fused_model_same_batch": r["fused"], "plain_over_fused": r["plain_over_fused"],
+                                      "kernel_launches_per_step": r["plain"]["kernel_launches_per_step"],
+                                      "config": {"workload": "6-layer Llama3 written with plain operators (drop-in formulation), "
+                                                             "fwd+bwd+Adam, seq 256", "per_gpu_batch": 64}}
+    except BaseException as e:
+        res["llama_plain_ops_b64"] = {"error": f"{type(e).__name__}: {e}"}
+    gc.collect()
     for key, cfg, batch, steps, warmup in runs:
         a = _ap.Namespace(config=cfg, batch=batch, steps=steps, warmup=warmup, no_graph=False, no_cpu_baseline=True, gpus=1)
         try:
