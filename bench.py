@@ -522,10 +522,11 @@ COMPACT_LIMIT = 4096
 def write_detail(full):
     """The full record next to the script (`PDN_BENCH_DETAIL` overrides the path; also under gpurun_out/ when that scratch
     directory exists, so that a gpurun call brings it back).  Returns the path the compact line names."""
-    path = os.environ.get("PDN_BENCH_DETAIL") or os.path.join(ROOT, DETAIL_FILE)
+    override = os.environ.get("PDN_BENCH_DETAIL")
+    path = override or os.path.join(ROOT, DETAIL_FILE)
     written = None
     for p in (path, os.path.join(ROOT, "gpurun_out", DETAIL_FILE)):
-        if p != path and not os.path.isdir(os.path.dirname(p)):
+        if p != path and (override or not os.path.isdir(os.path.dirname(p))):
             continue
         try:
             with open(p, "w") as f:

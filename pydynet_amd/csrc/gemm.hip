@@ -1668,7 +1668,12 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
       const double rounds = blocks >= 4 * slots ? blocks / slots : (double)cdiv64((int64_t)blocks, (int64_t)slots);
       const double wps = blocks * waves_pb / 1024.0;   // resident waves per SIMD in a round
       const double util = wps >= 1.875 ? 1.0 : (wps > 1.0 ? 0.7 + 0.3 * (wps - 1.0) / 0.875 : 0.7);
-      double cost = rounds * ((double)BM * BN * (kps * bk + 64) / waves_pb * 4.0 / (kCfgs[c].eff * util));
+      // 64 x 64 tiles for the forward product of a mid-size Linear layer (config 3's 4096 x 3200 x 500: 158 -> 140 us inside
+      // the step; tools/gemm_fc_sweep.py): what a block costs besides its MFMAs weighs most there.  Only the NN form: the
+      // transposed forms of the same layer measured slower inside the step with it (weight gradient 130 -> 183 us).
+      const double eff = (c == kScalarCfg && vec && a_kin && !b_kin && (int64_t)M * N >= (1 << 20) &&
+                          (int64_t)M * N <= (1 << 24) && K >= 1024 && K <= 4096) ? 0.95 : kCfgs[c].eff;
+      double cost = rounds * ((double)BM * BN * (kps * bk + 64) / waves_pb * 4.0 / (eff * util));
       // ... plus what a block costs besides its MFMAs (first tiles in, accumulators out: ~25k cycles = 10 us, fitted at
       // 16384 x 288 x {288, 768, 864}: 38 us for 384 blocks of 128 x 96 against 46 us for 768 of 64 x 128), paid once
       // per RESIDENCY round -- co-resident blocks overlap theirs -- which is what makes few fat blocks win on short
