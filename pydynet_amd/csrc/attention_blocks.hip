@@ -76,10 +76,19 @@ int pdn_attention_blocks_ok(int L, int head_dim) {
   return !off && L > AB_ROWS && L % AB_ROWS == 0 && L <= 1024 && pdn_attention_p_supported(AB_ROWS, head_dim);
 }
 
-struct AbTemp {               // scratch from the library's allocator (stream-ordered reuse, csrc/runtime.hip)
+// Scratch from the library's allocator.  The pool orders reuse on the COMPUTE stream only (csrc/runtime.hip): a block
+// freed here is safe for the next compute-stream user, whose kernels queue behind ours.  With the opt-in second stream
+// (PDN_TWO_STREAM=1, core/fused/_common.py) a side-stream allocation could take the block while our kernels still read
+// it, so in that mode the free waits for the stream first.
+struct AbTemp {
   void* p = nullptr;
-  int get(int64_t bytes) { return pdn_malloc(&p, bytes); }
-  ~AbTemp() { if (p) pdn_free(p); }
+  hipStream_t st = nullptr;
+  int get(int64_t bytes, void* stream) { st = (hipStream_t)stream; return pdn_malloc(&p, bytes); }
+  ~AbTemp() {
+    static const bool two_stream = getenv("PDN_TWO_STREAM") && atoi(getenv("PDN_TWO_STREAM")) != 0;
+    if (p && two_stream) (void)hipStreamSynchronize(st);
+    if (p) pdn_free(p);
+  }
 };
 
 int pdn_attention_blocks_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L,
@@ -87,9 +96,9 @@ int pdn_attention_blocks_fwd(const float* q, const float* k, const float* v, flo
   const int nb = L / AB_ROWS;
   const int64_t BH = (int64_t)B * H, lse_n = BH * AB_ROWS, on = (int64_t)B * AB_ROWS * H * hd;
   AbTemp t_o, t_l;
-  int rc = t_o.get(on * 4);
+  int rc = t_o.get(on * 4, stream);
   if (rc) return rc;
-  rc = t_l.get(3 * lse_n * 4);
+  rc = t_l.get(3 * lse_n * 4, stream);
   if (rc) return rc;
   float* On = (float*)t_o.p;
   float* la = (float*)t_l.p;

@@ -560,8 +560,10 @@ __global__ void rope_kernel(const float* __restrict__ x, const float* __restrict
 }
 // the same on rows that are `x_rs` / `y_rs` floats apart (the q | k column blocks of a packed q | k | v projection,
 // rotated in place before the persistent attention kernels read them: core/fused/attn.py)
-__global__ void rope_rows_kernel(const float* __restrict__ x, const float* __restrict__ cosT, const float* __restrict__ sinT,
-                                 float* __restrict__ y, int64_t rows, int L, int heads, int half, int64_t x_rs, int64_t y_rs,
+// (x and y may be the SAME buffer -- core/fused/attn.py rotates q | k in place -- so neither is __restrict__: every
+// thread reads its own pair before it writes it)
+__global__ void rope_rows_kernel(const float* x, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                 float* y, int64_t rows, int L, int heads, int half, int64_t x_rs, int64_t y_rs,
                                  float sign) {
   const int64_t pairs_per_row = (int64_t)heads * half;
   const int64_t total = rows * pairs_per_row;

@@ -23,6 +23,15 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Timing-ablation switches (tools/*_probe.py): read ONCE per process; a non-zero value makes kernels skip work and return
+// WRONG results, so it is announced on stderr instead of taking effect silently.
+static int pdn_ablation_switch(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v) fprintf(stderr, "[pdnhip] WARNING: %s=%d -- timing ablation active, results of the affected kernels are WRONG\n", name, v);
+  return v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct OutResParams {
@@ -506,7 +515,8 @@ static int outres_launch(const float* A, const float* B, float* C, const float* 
   }
   PDN_CHECK_ARG(((((uintptr_t)A | (uintptr_t)B) & 15) == 0), "pdn_gemm_outres_f32: 16-byte alignment required");
   OutResParams p{A, B, C, bias, residual, M, K, lda, ldb, ldc, nullptr, nullptr, nullptr, 0.f, K / OR_KP, nullptr};
-  p.ablate_rt = getenv("PDN_OUTRES_RT_ABLATE") ? atoi(getenv("PDN_OUTRES_RT_ABLATE")) : 0;
+  static const int s_pdn_outres_rt_ablate = pdn_ablation_switch("PDN_OUTRES_RT_ABLATE");
+  p.ablate_rt = s_pdn_outres_rt_ablate;
   if (kb > 0) {
     p.ppb = kb / OR_KP;
     p.ppb_magic = (unsigned)(((1ull << 32) + (unsigned)p.ppb - 1) / (unsigned)p.ppb);
@@ -523,7 +533,7 @@ static int outres_launch(const float* A, const float* B, float* C, const float* 
   if (splits > 1) { p.kps = kps; p.slab = (float*)workspace; }
   static const int nw_env = getenv("PDN_OUTRES_NW") ? atoi(getenv("PDN_OUTRES_NW")) : 0;
   static const int stage_env = getenv("PDN_OUTRES_STAGE") ? atoi(getenv("PDN_OUTRES_STAGE")) : -1;
-  static const int ablate = getenv("PDN_OUTRES_ABLATE") ? atoi(getenv("PDN_OUTRES_ABLATE")) : 0;
+  static const int ablate = pdn_ablation_switch("PDN_OUTRES_ABLATE");
   // one 8-wave workgroup per CU when that fills the chip, else 4-wave workgroups
   const int nw = nw_env ? nw_env : plan_nw;
   const int stage = stage_env >= 0 ? stage_env : 1;

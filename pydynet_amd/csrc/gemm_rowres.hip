@@ -27,6 +27,15 @@
 #include "gemm_rowtile.h"
 #include <stdlib.h>
 
+// Timing-ablation switches (tools/*_probe.py): read ONCE per process; a non-zero value makes kernels skip work and return
+// WRONG results, so it is announced on stderr instead of taking effect silently.
+static int pdn_ablation_switch(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v) fprintf(stderr, "[pdnhip] WARNING: %s=%d -- timing ablation active, results of the affected kernels are WRONG\n", name, v);
+  return v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct RowResParams {
@@ -729,7 +738,8 @@ static int rowres_launch(const float* A, const float* B, float* C, const float* 
     p.g_off = epi->g_off; p.u_off = epi->u_off;
     p.lse = epi->lse;
   }
-  p.epi_ablate = getenv("PDN_ROWRES_EPI_ABLATE") ? atoi(getenv("PDN_ROWRES_EPI_ABLATE")) : 0;
+  static const int s_pdn_rowres_epi_ablate = pdn_ablation_switch("PDN_ROWRES_EPI_ABLATE");
+  p.epi_ablate = s_pdn_rowres_epi_ablate;
   hipStream_t st = (hipStream_t)stream;
   static const int ablate = getenv("PDN_ROWRES_ABLATE") ? atoi(getenv("PDN_ROWRES_ABLATE")) : 0;
   static const int nw_env = getenv("PDN_ROWRES_NW") ? atoi(getenv("PDN_ROWRES_NW")) : 0;

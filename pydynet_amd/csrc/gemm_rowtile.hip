@@ -32,6 +32,15 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Timing-ablation switches (tools/*_probe.py): read ONCE per process; a non-zero value makes kernels skip work and return
+// WRONG results, so it is announced on stderr instead of taking effect silently.
+static int pdn_ablation_switch(const char* name) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : 0;
+  if (v) fprintf(stderr, "[pdnhip] WARNING: %s=%d -- timing ablation active, results of the affected kernels are WRONG\n", name, v);
+  return v;
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define RT_KG 36                  // k-groups of 8 (K = 288)
@@ -191,6 +200,10 @@ __global__ __launch_bounds__(512, 1) void gemm_rowtile_kernel(RowTileParams p) {
 #pragma unroll
     for (int t = 0; t < RT_KG; ++t) ss += (a[t].x * a[t].x + a[t].y * a[t].y) + (a[t].z * a[t].z + a[t].w * a[t].w);
     ss += __shfl_xor(ss, 32, 64);
+    // x * (1 / r) * w, sum of squares in-lane + one shuffle: the standalone pdn_rmsnorm_fwd_f32 (and the reference,
+    // norm.py:221-248) compute x / r * w with a wave reduction, so xn and rms of the folded form agree with the unfolded
+    // one to fp32 round-off, NOT bit for bit (tests/test_fused_epilogues.py: folded vs separate norm, 5e-6 relative,
+    // full and ragged row blocks); the backward reuses the xn / rms stored HERE, so a step is self-consistent.
     const float r = sqrtf(ss / 288.f + p.norm_eps);
     const float inv = 1.f / r;
     const bool row_ok = !GUARD || m0 + li < p.M;
@@ -554,7 +567,8 @@ int pdn_rowtile_launch(const RowTileArgs& a, void* stream) {
   p.H = a.H; p.GU = a.GU; p.rope = reinterpret_cast<const float2*>(a.rope); p.ldh = a.ldh;
   p.F = a.F; p.L = a.L > 0 ? a.L : 1; p.hd = a.hd > 0 ? a.hd : 32; p.rope_tiles = a.rope_cols / 32;
   p.g_off = a.g_off; p.u_off = a.u_off; p.lse = a.lse;
-  p.ablate = getenv("PDN_ROWTILE_ABLATE") ? atoi(getenv("PDN_ROWTILE_ABLATE")) : 0;
+  static const int s_pdn_rowtile_ablate = pdn_ablation_switch("PDN_ROWTILE_ABLATE");
+  p.ablate = s_pdn_rowtile_ablate;
   p.norm_w = a.norm_w; p.xn = a.xn; p.rms = a.rms; p.ldxn = a.ldxn; p.norm_eps = a.norm_eps;
   const bool norm = a.norm_w != nullptr;
   if (norm && !(a.epi == 1 || a.epi == 3)) { pdn_set_error("pdn_rowtile_launch: the RMSNorm fold exists for the gate | up and q | k | v projections"); return PDN_EINVAL; }
