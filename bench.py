@@ -445,13 +445,16 @@ def other_configs(*release):
         Graph.clear()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import plain_llama_bench
-        r = plain_llama_bench.run(64, 5)
-        res["llama_plain_ops_b64"] = {"value": r["plain"]["samples_per_s"], "unit": "samples/s", "ms_per_step": r["plain"]["ms_per_step"],
-                                      "model_flops_frac_of_fp32_mfma_peak": r["plain"]["mfma_frac"],
-                                      "fused_model_same_batch": r["fused"], "plain_over_fused": r["plain_over_fused"],
-                                      "kernel_launches_per_step": r["plain"]["kernel_launches_per_step"],
-                                      "config": {"workload": "6-layer Llama3 written with plain operators (drop-in formulation), "
-                                                             "fwd+bwd+Adam, seq 256", "per_gpu_batch": 64}}
+        for pb_batch, pb_steps in ((64, 5), (256, 4)):
+            r = plain_llama_bench.run(pb_batch, pb_steps)
+            res[f"llama_plain_ops_b{pb_batch}"] = {
+                "value": r["plain"]["samples_per_s"], "unit": "samples/s", "ms_per_step": r["plain"]["ms_per_step"],
+                "model_flops_frac_of_fp32_mfma_peak": r["plain"]["mfma_frac"],
+                "fused_model_same_batch": r["fused"], "plain_over_fused": r["plain_over_fused"],
+                "kernel_launches_per_step": r["plain"]["kernel_launches_per_step"],
+                "config": {"workload": "6-layer Llama3 written with plain operators (drop-in formulation: RoPE by slices + "
+                                       "concat, attention as matmul -> softmax -> matmul, recognised link by link and run as "
+                                       "one fused attention node), fwd+bwd+Adam, seq 256", "per_gpu_batch": pb_batch}}
     except BaseException as e:
         res["llama_plain_ops_b64"] = {"error": f"{type(e).__name__}: {e}"}
     gc.collect()

@@ -13,7 +13,8 @@ expression.  Reference chains replaced:
     relu            nn/functional.py:31-32          (maximum(0., x); gradient 1 at x == 0)
     softmax         nn/functional.py:43-49          (last axis)
     rope            llm/llama/model.py:23-44        (26 nodes)
-    attention       llm/llama/model.py:112-121      (transpose, matmul, /sqrt(hd), +mask, softmax, matmul)
+    attention       llm/llama/model.py:112-121      (transpose, matmul, /sqrt(hd), +mask, softmax, matmul); the same chain
+                                                    BUILT from plain operators is recognised link by link (chain.py)
     embedding       nn/functional.py:14-20 + tensor.py:937-940 (scatter-ASSIGN gradient)
     cross_entropy   nn/functional.py:364-381        (7 nodes, integer targets)
 """
@@ -25,3 +26,7 @@ from .attn import _attn_layout, _attn_mask_args, _attn_kernel, attention, qkv_at
 from .ffn import gate_up_swiglu, ffn_swiglu
 from .conv import relu, conv2d, conv2d_relu_pool, pool2d
 from .recurrent import _cell_grads, rnn_cell, lstm_cell, gru_cell, gru_sequence
+from . import chain as _chain_mod
+from .chain import attn_link
+from .. import tensor as _tensor
+_tensor._chain = _chain_mod           # Tensor.__matmul__ / __truediv__ / __add__ consult it (the attention chain of plain operators)

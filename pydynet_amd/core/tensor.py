@@ -62,11 +62,16 @@ def _is_array(x):
     return isinstance(x, np.ndarray) or type(x).__name__ == "ndarray"
 
 
+_chain = None          # core/fused/chain.py once the fused package is imported (it imports this module)
+
+
 class Tensor:
     _gid = -1
     _host_scalar = False
     _grad_owned = True
     _grad_hook = None
+    _pending_link = False   # True on the deferred links of core/fused/chain.py
+    _causal_mask = False    # True on a Tensor built from exactly the additive causal mask of llm/llama/model.py:199-203
 
     def __init__(self, data, dtype=None, copy=True, device=None, requires_grad=False) -> None:
         if isinstance(data, Tensor):
@@ -80,6 +85,12 @@ class Tensor:
                     data = data.get()          # a device array handed to a cpu Tensor
                 self.data = np.array(data, dtype=dtype, copy=copy)
             else:
+                if (isinstance(data, np.ndarray) and data.ndim == 2 and data.shape[0] == data.shape[1] > 1
+                        and data.dtype.kind == "f" and np.isneginf(data[0, -1])):
+                    # the additive causal mask, recognised on the host while it still is a NumPy array: the attention
+                    # chain built from plain operators then takes the kernels' causal schedule (core/fused/chain.py)
+                    n = data.shape[0]
+                    self._causal_mask = bool(np.array_equal(data, np.triu(np.full((n, n), -np.inf, data.dtype), k=1)))
                 self.data = xp.array(data, dtype=dtype, copy=bool(copy))
         self.requires_grad = is_grad_enable() and requires_grad
         self.last = []
@@ -163,15 +174,31 @@ class Tensor:
     def argmax(self, axis=None, keepdims=False): return argmax(self, axis, keepdims)
     def argmin(self, axis=None, keepdims=False): return argmin(self, axis, keepdims)
 
-    def __add__(self, x): return add(self, x)
+    def __add__(self, x):
+        if _chain is not None and self._pending_link:
+            r = _chain.on_add(self, x)
+            if r is not None:
+                return r
+        return add(self, x)
     def __radd__(self, x): return add(x, self)
     def __sub__(self, x): return sub(self, x)
     def __rsub__(self, x): return sub(x, self)
     def __mul__(self, x): return mul(self, x)
     def __rmul__(self, x): return mul(x, self)
-    def __matmul__(self, x): return matmul(self, x)
+    def __matmul__(self, x):
+        # (the reference's attention chain built from plain operators becomes one fused node: core/fused/chain.py)
+        if _chain is not None and (self._pending_link or type(self) is transpose) and isinstance(x, Tensor):
+            r = _chain.on_matmul(self, x)
+            if r is not None:
+                return r
+        return matmul(self, x)
     def __rmatmul__(self, x): return matmul(x, self)
-    def __truediv__(self, x): return div(self, x)
+    def __truediv__(self, x):
+        if _chain is not None and self._pending_link:
+            r = _chain.on_div(self, x)
+            if r is not None:
+                return r
+        return div(self, x)
     def __rtruediv__(self, x): return div(x, self)
     def __pow__(self, x): return pow(self, x)
     def __rpow__(self, x): return pow(x, self)
@@ -588,6 +615,7 @@ class transpose(_UnaryOperator):
         if axes is not None and len(axes) == 1 and isinstance(axes[0], (tuple, list)):
             axes = tuple(axes[0])
         self.axes = axes
+        self._src = x if isinstance(x, Tensor) else None      # (core/fused/chain.py looks through the view)
         super().__init__(x)
 
     def forward_(self, x): return x.data.transpose(self.axes)

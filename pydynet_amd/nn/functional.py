@@ -48,6 +48,10 @@ def silu(x):
 
 def softmax(x, axis=None):
     if axis is not None and x.ndim >= 1 and axis in (-1, x.ndim - 1) and x.dtype == np.float32:
+        if x._pending_link:                  # a deferred link of the plain-operator attention chain (core/fused/chain.py)
+            r = fused.chain.on_softmax(x)
+            if r is not None:
+                return r
         return fused.softmax(x)
     with no_grad():
         max_ = x.max(axis, keepdims=True)

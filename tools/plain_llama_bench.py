@@ -1,5 +1,7 @@
 """Throughput of the DROP-IN formulation: the full-size 6-layer Llama written with plain operators (tests/models_plain_llama.py =
 what a user of the reference's own llm/llama/model.py gets) beside the fused-node model the headline is quoted on.
+Measured round 6 (MI355X): batch 64: 2697 vs 4153 samples/s (0.65; the plain step is host-bound there: ~430 nodes per step);
+batch 256: 3891 vs 5139 (0.76) with the attention chain recognised (core/fused/chain.py), 3361 (0.65) without.
 usage: python tools/plain_llama_bench.py [batch=64] [steps=5]"""
 import os
 import sys
