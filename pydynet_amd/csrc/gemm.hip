@@ -37,6 +37,16 @@
 #include <mutex>
 #include <stdlib.h>
 #include <stdio.h>
+#include <type_traits>
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant
+template <int N, class F>
+__device__ __forceinline__ void gemm_static_for(F&& f) {
+  if constexpr (N > 0) {
+    gemm_static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -411,8 +421,10 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
           gm[i][ui] = p.grad_mask[(int64_t)(m0 + (wave_m * WM + i) * 32 + r) * (p.N >> 5) + (col0 >> 5) + (c4 >> 3)] >> (4 * (c4 & 7));
         }
     }
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
+    // (a compile-time band index: with the mask epilogues on the 128-accumulator tiles `#pragma unroll` gave up on this
+    //  loop and the accumulators were indexed at run time = kept in scratch: 576 B per lane, the step ran 2x slower)
+    gemm_static_for<WM>([&](auto i_c) {
+      constexpr int i = decltype(i_c)::value;
       uint32_t wd[NU];
       float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);   // MASKS + mask_colsum: this lane's columns summed over the band's rows
 #pragma unroll
@@ -520,14 +532,14 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);        // band reads done before the next band overwrites
       __builtin_amdgcn_wave_barrier();
-    }
+    });
     return;
   }
   // edge tiles / unaligned outputs: guarded scalar path
-#pragma unroll
-  for (int i = 0; i < WM; ++i) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
+  gemm_static_for<WM>([&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+    gemm_static_for<WN>([&](auto j_c) {
+      constexpr int j = decltype(j_c)::value;
       const int col = n0 + (wave_n * WN + j) * 32 + li;
       const int rbase = m0 + (wave_m * WM + i) * 32 + 4 * lh;
       if (col < p.N) {
@@ -560,8 +572,8 @@ __global__ __launch_bounds__(WAVES_M* WAVES_N * 64, (BK == 16 && WM * WN <= 3) ?
           if (lh == 0 && band_row < p.M) p.mask_colsum[(int64_t)(band_row >> 5) * p.N + col] = csum;
         }
       }
-    }
-  }
+    });
+  });
 }
 
 // C = beta*C + sum_s ws[s] + bias (+ residual), deterministic order.  Rows of the slabs are N
@@ -1639,9 +1651,12 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   static const bool no_fixed = getenv("PDN_GEMM_NO_FIXED") != nullptr;      // A/B switch for the residency-round term
   for (int c = 0; c < kNumCfgs && !use_stream; ++c) {
     if (!vec && c != kScalarCfg) continue;  // scalar staging: 64x64 only
-    if (ext_on && !(c == 0 || c == 3 || c == 8 || c == kScalarCfg)) continue;   // the tile shapes built with MASKS
+    if (ext_on && !(c == 0 || c == 3 || c == 6 || c == 7 || c == 8 || c == kScalarCfg)) continue;   // the tile shapes built with MASKS
     if (mask_colsum && c == 8) continue;    // (a lane keeps its columns over a band only when 64 % (8 WN) == 0)
-    if (c == 7 && N < 2048) continue;
+    // 128 x 256: very wide outputs -- and (round 6) the 1024-wide Linear + ReLU layers of config 2 at chip-filling row
+    // counts, where it measures 0.86 of the fp32-MFMA peak against 0.71-0.80 for 128 x 128 (tools/gemm_fc_sweep.py)
+    if (c == 7 && N < 2048 && !(ext_on && N >= 1024 && N % 256 == 0 && M >= 16384)) continue;
+    if (c == 6 && ext_on && !(N >= 1024 && M >= 16384)) continue;
     if (c == 8 && N < 768) continue;        // 256-row tiles lose on narrow outputs (one block per CU)
     const int BM = kCfgs[c].waves_m * kCfgs[c].wm * 32, BN = kCfgs[c].waves_n * kCfgs[c].wn * 32;
     const int bk = kCfgs[c].bk;
@@ -1699,7 +1714,7 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   else if (const char* e = getenv("PDN_GEMM_CFG")) {            // tuning override: "<cfg>[,<splits>]"
     int c = -1, sp = 0;
     if (sscanf(e, "%d,%d", &c, &sp) >= 1 && c >= 0 && c < kNumCfgs && vec &&
-        (!ext_on || c == 0 || c == 3 || (c == 8 && !mask_colsum) || c == kScalarCfg)) {
+        (!ext_on || c == 0 || c == 3 || c == 6 || c == 7 || (c == 8 && !mask_colsum) || c == kScalarCfg)) {
       best = c;
       if (sp >= 1 && (sp == 1 || ((int64_t)sp * M * N * nbatch <= ws_cap && !b_colsum && !ext_on))) best_splits = sp;
     }
@@ -1759,6 +1774,8 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
     else switch (best) {
       case 0: launch_layout<2, 2, 2, 2, 32, true, true>(p, a_kin, b_kin, grid, st); break;
       case 3: launch_layout<4, 1, 1, 2, 32, true, true>(p, a_kin, b_kin, grid, st); break;
+      case 6: launch_layout<2, 2, 4, 2, 16, true, true>(p, a_kin, b_kin, grid, st); break;
+      case 7: launch_layout<2, 2, 2, 4, 16, true, true>(p, a_kin, b_kin, grid, st); break;
       case 8: launch_layout<4, 1, 2, 3, 16, true, true>(p, a_kin, b_kin, grid, st); break;
       default: launch_layout<2, 2, 1, 1, 32, true, true>(p, a_kin, b_kin, grid, st); break;
     }
