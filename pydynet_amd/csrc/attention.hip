@@ -501,7 +501,17 @@ int pdn_attention_blocks_bwd(const float* q, const float* k, const float* v, con
                              int64_t o_bs, int causal, const float* rope_cos, const float* rope_sin, float* workspace,
                              void* stream);
 
+// csrc/attention_hd128.hip: head dim 128, any length up to 1024 (four head-dim tiles, 64-row chunks)
+bool pdn_attention_hd128_ok(int L, int head_dim);
+int pdn_attention_hd128_fwd(const float* q, const float* k, const float* v, float* o, float* lse, int B, int H, int L,
+                            int64_t rs, int64_t bs, int64_t ors, int64_t obs, int causal, const float* key_bias,
+                            int64_t kb_bs, void* stream);
+int pdn_attention_hd128_bwd(const float* q, const float* k, const float* v, const float* o, const float* d_o, const float* lse,
+                            float* dq, float* dk, float* dv, int B, int H, int L, int64_t rs, int64_t bs, int64_t ors,
+                            int64_t obs, int causal, const float* key_bias, int64_t kb_bs, float* delta, void* stream);
+
 static bool att_shape_ok(int L, int head_dim) {
+  if (pdn_attention_hd128_ok(L, head_dim)) return true;
   return (head_dim == 48 || head_dim == 64) && L % 32 == 0 && L >= 32 && L <= ATT_MAX_L;
 }
 static int att_groups(int L) { return (L / 32 + ATT_MAX_TILES - 1) / ATT_MAX_TILES; }
@@ -539,6 +549,11 @@ static int att_fwd_impl(const float* q, const float* k, const float* v, float* o
                     (o_batch_stride % 4) == 0 &&
                     ((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)o) & 15) == 0),
                 "pdn_attention_fwd_f32: 16-byte alignment required");
+  if (pdn_attention_hd128_ok(L, head_dim)) {
+    PDN_CHECK_ARG(!rope_cos, "pdn_attention_fwd_f32: no RoPE inside the head-dim-128 kernels");
+    return pdn_attention_hd128_fwd(q, k, v, o, lse, B, H, L, row_stride, batch_stride, o_row_stride, o_batch_stride, causal,
+                                   key_bias, kb_bs, stream);
+  }
   // rotation-free operands at the benchmark shape class: the persistent, DMA-staged kernels (csrc/attention_p.hip)
   if (!rope_cos && !key_bias && pdn_attention_p_supported(L, head_dim))
     return pdn_attention_p_fwd(q, k, v, o, lse, B, H, L, head_dim, row_stride, batch_stride, o_row_stride, o_batch_stride,
@@ -932,6 +947,11 @@ static int att_bwd_impl(const float* q, const float* k, const float* v, const fl
     return PDN_EWORKSPACE;
   }
   float* delta = (float*)workspace;
+  if (pdn_attention_hd128_ok(L, head_dim)) {
+    PDN_CHECK_ARG(!rope_cos, "pdn_attention_bwd_f32: no RoPE inside the head-dim-128 kernels");
+    return pdn_attention_hd128_bwd(q, k, v, o, d_o, lse, dq, dk, dv, B, H, L, row_stride, batch_stride, o_row_stride,
+                                   o_batch_stride, causal, key_bias, kb_bs, delta, stream);
+  }
   // operands that need no rotation on the way in (never rotated, or rotated by the projection's epilogue) at the
   // benchmark shape class: the persistent, DMA-staged kernels (csrc/attention_p.hip); dq / dk are rotated back there
   // when the tables are given

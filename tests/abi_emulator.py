@@ -834,7 +834,10 @@ class EmulatedLib:
         l = e.sum(-1, keepdims=True)
         return e / l, (m + np.log(l))[..., 0]
 
-    def pdn_attention_supported(self, L, hd): return 1 if (hd in (48, 64) and L % 32 == 0 and 32 <= L <= 1024) else 0
+    def pdn_attention_supported(self, L, hd):
+        if hd == 128 and 1 <= L <= 1024:          # csrc/attention_hd128.hip: any length (rows beyond L masked inside)
+            return 1
+        return 1 if (hd in (48, 64) and L % 32 == 0 and 32 <= L <= 1024) else 0
     def pdn_attention_lds_bytes(self, L, hd): return min(L, 256) * (hd + 4 + 64) * 4
     def pdn_attention_bwd_lds_bytes(self, L, hd): return min(L, 256) * (2 * 68 + 2) * 4
 

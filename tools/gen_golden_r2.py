@@ -422,7 +422,8 @@ def gen_generate_full():
           "logit scale", max(out["logit_max"]))
 
 
-MASKED_CASES = {"hd48": (2, 64, 2, 48, 11), "hd64": (2, 96, 1, 64, 12)}       # B, L, H, hd, seed
+MASKED_CASES = {"hd48": (2, 64, 2, 48, 11), "hd64": (2, 96, 1, 64, 12),       # B, L, H, hd, seed
+                "hd128": (2, 44, 2, 128, 13)}      # the example's own head dim and length (dim 512 / 4 heads, L = 44: csrc/attention_hd128.hip)
 
 
 def gen_masked_attention():

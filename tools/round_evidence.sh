@@ -4,7 +4,7 @@
 #   rocprofv3 kernel stats of the bench command, PMC passes (SQ / LDS / L2 / FETCH / WRITE) of the same command
 #   -- regenerated EVERY time (the summary records a hash of the kernel sources it was measured on; bench.py flags
 #   `traffic_stale` when the sources have changed since) -- the LeNet profile, attention / GEMM probes.
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 R=$PWD; O=$R/gpurun_out/$ROUND; mkdir -p $O
 timeout 1800 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; tail -3 $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log
@@ -12,6 +12,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 
 bash tools/pmc_cmd.sh ${ROUND}_bench kernel python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-gemm-prof --no-parity-gate --no-other-configs > $O/bench_pmc.txt 2>&1
 python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_bench/summary.json $O/pmc_bench_default.json 512 && cp $O/pmc_bench_default.json profiles/${ROUND}_pmc_bench_default.json
 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 400 $O/bench_default.json; echo
+cp bench_detail.json $O/bench_detail.json                     # the full record the compact line names
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2>> $O/bench_default.err   # the driver's own command line
 PDN_BENCH_FORCE_DP=1 python bench.py --no-cpu-baseline --no-other-configs > $O/bench_force_dp.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --no-other-configs --batch 256 > $O/bench_b256.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --no-other-configs --batch 1024 --steps 5 > $O/bench_b1024.json 2>> $O/bench_default.err
@@ -40,6 +42,10 @@ bash tools/pmc_cmd.sh ${ROUND}_attn attention python tools/attn_compare.py 256 2
   python bench.py --config decode --steps 900 --warmup 20 --no-cpu-baseline; } > $O/all_configs.txt 2>&1
 # phase timestamps from inside the decode kernels / the attention forward (traced builds made by the same scripts here)
 bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
+python tools/conv_quad_probe.py > $O/conv_quad_probe.txt 2>&1
+PDN_CONV_QUAD=0 python tools/conv_quad_probe.py > $O/conv_direct_probe.txt 2>&1
+{ python tools/plain_llama_bench.py 64 5; python tools/plain_llama_bench.py 256 4; } > $O/plain_llama_bench.txt 2>&1
+python tools/gemm_fc_sweep.py 4096 3200 500 > $O/gemm_fc_sweep.txt 2>&1
 python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
 python tools/lmhead_probe.py > $O/lmhead_probe.txt 2>&1
 python tools/attn_masked_probe.py > $O/attn_masked_probe.txt 2>&1
