@@ -418,7 +418,7 @@ def other_configs(*release):
     del release
     gc.collect()
     res = {}
-    runs = (("mlp_b256", "mlp", 256, 200, 20), ("mlp_b65536", "mlp", 65536, 20, 3), ("lenet_b256", "lenet", 256, 200, 20),
+    runs = (("mlp_b256", "mlp", 256, 200, 20), ("mlp_b65536", "mlp", 65536, 20, 6), ("lenet_b256", "lenet", 256, 200, 20),
             ("lenet_b4096", "lenet", 4096, 50, 5), ("gru", "gru", 0, 100, 10), ("decode", "decode", 0, 200, 20))
     try:                                                     # (first: before the graph-replayed runs below)
         Graph.clear()

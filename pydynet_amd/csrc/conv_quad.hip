@@ -449,7 +449,8 @@ struct QuadWgradGeom {
   static constexpr int SC = (H + 2) * W + 4, SK = C * SC;              // plane (+ one slot), copy
   static constexpr int BUF = 3 * SK;                                   // one image: three shifted copies
   static constexpr int ONES = 2 * BUF;                                 // plane of ones behind the two buffers
-  static constexpr int LDS_FLOATS = 2 * BUF + H * W + 16;
+  static constexpr int ONES_FLOATS = H * W + 16 + 64;                  // + 16 slots: a padding lane picks its group's free slot residue
+  static constexpr int LDS_FLOATS = 2 * BUF + ONES_FLOATS;
   static constexpr int F4 = C * H * W / 4, NV = (F4 + 511) / 512;
   static constexpr int GPR = W / 8;                                    // groups of 8 positions per image row
   static constexpr int NPR = RW / 2, NW = (W == 16 ? NPR : RW);        // pooled rows / hit words per wave and image
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(512, 1) void conv_quad_wgrad_kernel(const float* __
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
   const int ot = wave % OT, q = wave / OT, row0 = q * RW;
   for (int e = tid; e < 2 * BUF; e += 512) lds[e] = 0.f;
-  for (int e = tid; e < H * W + 16; e += 512) lds[G::ONES + e] = 1.f;
+  for (int e = tid; e < G::ONES_FLOATS; e += 512) lds[G::ONES + e] = 1.f;
   // x staging plan: piece f = (c, y, x quad) in memory order; copy kw holds x_pad[..][x' + kw], x_pad[..][x''] = x[x'' - 1]
   int dst1[NV];
 #pragma unroll
@@ -655,8 +656,21 @@ void build_wgrad_perm(QuadWgradPerm& pm) {
         if (fill[g] < 16 && (pass == 1 || !(used[g] >> (slot & 15) & 1u)) && (best < 0 || fill[g] < fill[best])) best = g;
       if (best >= 0) { place(best, j, slot); placed[j] = true; }
     }
-  for (int g = NG - 1; g >= 0; --g)                 // the bias column: a lane of ones
-    if (fill[g] < 16) { place(g, G::K, G::ONES / 4); break; }
+  // the bias column (a lane of ones) and the padding lanes: they all read the plane of ones, each group's at the 16-byte
+  // slot residue its real columns leave free (one shared address per group = a broadcast: no conflict with anybody)
+  bool bias_placed = false;
+  for (int g = NG - 1; g >= 0; --g) {
+    if (fill[g] == 16) continue;
+    int free_res = 0;
+    while (free_res < 16 && (used[g] >> free_res & 1u)) ++free_res;
+    const int base = G::ONES / 4, slot = base + ((free_res - base) % 16 + 16) % 16;
+    while (fill[g] < 16) {
+      const int ln = grp_lanes[g & 1][fill[g]++];
+      pm.col[(g >> 1) * 32 + ln] = (unsigned short)(bias_placed ? 0xFFFF : G::K);
+      pm.slot[(g >> 1) * 32 + ln] = (unsigned short)slot;
+      bias_placed = true;
+    }
+  }
 }
 
 template <class G>
