@@ -494,7 +494,9 @@ int pdn_decode_gemv_sum_f32(const float* base, int64_t base_row_stride, const fl
                             const float* bias, float* y, int64_t y_row_stride, int B, int K, int N, float* blk_max,
                             int* blk_arg, void* stream);
 /* shapes the resident (K / V of a head chunk-wise in LDS) kernels above take: head_dim 48 or 64, L a multiple of 32 up
- * to 1024 -- sequences beyond 256 pass through LDS in 256-row chunks (forward: one online rescale per chunk) */
+ * to 1024 -- sequences beyond 256 pass through LDS in 256-row chunks (forward: one online rescale per chunk) -- and
+ * (round 6, csrc/attention_hd128.hip) head_dim 128 at ANY length 1 .. 1024, no RoPE inside: the shape of
+ * examples/pydynet/transformer.py:53-130 (dim 512, 4 heads, (B, 1, 1, L) padding mask as the key bias) */
 int pdn_attention_supported(int L, int head_dim);
 int64_t pdn_attention_lds_bytes(int L, int head_dim);
 int64_t pdn_attention_bwd_lds_bytes(int L, int head_dim);
