@@ -1596,7 +1596,10 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   bool use_stream = false;
   int sshape = 0;
   if (!ext_on && !a_kin && !b_kin && a_rs == 1 && b_cs == 1 && !b_colsum && K >= 2048 &&
-      (int64_t)M * N * nbatch <= (1 << 20) && nbatch <= 64 && !getenv("PDN_GEMM_NO_STREAM")) {
+      // (outputs BELOW 2^20 elements: at 1024 x 1024 -- config 2's second layer -- the tiled kernel with its k-split measured
+      //  1065 us against 1144 us, and the MLP step 5.44 -> 5.32 ms; PDN_GEMM_STREAM_MAX overrides the bound)
+      (int64_t)M * N * nbatch <= (getenv("PDN_GEMM_STREAM_MAX") ? atol(getenv("PDN_GEMM_STREAM_MAX")) : (1 << 20) - 1) && nbatch <= 64 &&
+      !getenv("PDN_GEMM_NO_STREAM")) {
     // tile shape of the LDS-staged kernel (in 32-row / 32-column MFMA tiles): 3 x 3 unless another one pads the output
     // less (784 x 1024: 9 x 11 tiles of 96 x 96 = 912 K accumulators, 5 x 16 of 160 x 64 = 819 K)
     static const int kShapes[5][2] = {{3, 3}, {5, 2}, {2, 5}, {4, 2}, {2, 4}};
