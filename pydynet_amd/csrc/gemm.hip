@@ -1686,11 +1686,7 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
       const double rounds = blocks >= 4 * slots ? blocks / slots : (double)cdiv64((int64_t)blocks, (int64_t)slots);
       const double wps = blocks * waves_pb / 1024.0;   // resident waves per SIMD in a round
       const double util = wps >= 1.875 ? 1.0 : (wps > 1.0 ? 0.7 + 0.3 * (wps - 1.0) / 0.875 : 0.7);
-      // 64 x 64 tiles for the forward product of a mid-size Linear layer (config 3's 4096 x 3200 x 500: 158 -> 140 us inside
-      // the step; tools/gemm_fc_sweep.py): what a block costs besides its MFMAs weighs most there.  Only the NN form: the
-      // transposed forms of the same layer measured slower inside the step with it (weight gradient 130 -> 183 us).
-      const double eff = (c == kScalarCfg && vec && a_kin && !b_kin && (int64_t)M * N >= (1 << 20) &&
-                          (int64_t)M * N <= (1 << 24) && K >= 1024 && K <= 4096) ? 0.95 : kCfgs[c].eff;
+      const double eff = kCfgs[c].eff;
       double cost = rounds * ((double)BM * BN * (kps * bk + 64) / waves_pb * 4.0 / (eff * util));
       // ... plus what a block costs besides its MFMAs (first tiles in, accumulators out: ~25k cycles = 10 us, fitted at
       // 16384 x 288 x {288, 768, 864}: 38 us for 384 blocks of 128 x 96 against 46 us for 768 of 64 x 128), paid once
@@ -1712,6 +1708,17 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
     const int BMb = kCfgs[best].waves_m * kCfgs[best].wm * 32, BNb = kCfgs[best].waves_n * kCfgs[best].wn * 32;
     const int64_t blocks = cdiv64(M, BMb) * cdiv64(N, BNb) * nbatch;
     if (blocks > 512 && blocks < 1024 && (int64_t)2 * M * N * nbatch <= ws_cap) best_splits = 2;
+  }
+  // Mid-size products that 128 x 128 tiles cannot spread over the chip (fewer than 256 of them) or whose contraction is
+  // short (K <= 512): 64 x 64 tiles with a k-split.  Config 3's fully connected layers (4096 x 3200 x 500 in its three
+  // forms) measured inside the step: 1.390 -> 1.335 ms with `5,8` for all of them, every other choice in between
+  // (round 6; the cost model above prices a block's fixed cost too high for these).
+  if (!use_stream && !ext_on && !b_colsum && vec && nbatch == 1 && (int64_t)M * N >= (1 << 20) && (int64_t)M * N <= (1 << 24) &&
+      K <= 4096 && K >= 128 && (cdiv64(M, 128) * cdiv64(N, 128) < 256 || K <= 512)) {
+    int sp = 8;
+    while (sp > 1 && (K / sp < 64 || (int64_t)sp * M * N > ws_cap)) sp >>= 1;
+    best = kScalarCfg;
+    best_splits = sp;
   }
   if (use_stream) best = 0;
   else if (const char* e = getenv("PDN_GEMM_CFG")) {            // tuning override: "<cfg>[,<splits>]"
