@@ -41,7 +41,7 @@ def hip():
 
 @pytest.fixture()
 def emulated_hip(monkeypatch):
-    """hipnp running on host memory against the NumPy emulation of the C ABI (tests/abi_emulator.py)."""
+    """hipnp running on host memory against the NumPy emulation of the C ABI (tests/abi_emulator/)."""
     from tests import abi_emulator
     from pydynet_amd import hipnp
     from pydynet_amd.core.tensor import Graph

@@ -1,5 +1,5 @@
 """The WHOLE `bench.main()` with two ranks, without a GPU: the real `RcclComm` class, the TCP rendezvous and
-`DataParallel` run on the emulated C ABI (tests/abi_emulator.py: `pdn_comm_*` answered by gloo on host buffers), the
+`DataParallel` run on the emulated C ABI (tests/abi_emulator/: `pdn_comm_*` answered by gloo on host buffers), the
 model shrunk through bench.py's module constants.  Checks what the driver's multi-GPU run relies on: rank 0 prints
 exactly ONE JSON line and the other rank none, `value` is the whole job's, `per_rank_samples_per_s` has one entry per
 rank, the `comm` block describes the buckets actually reduced (the embedding table alone in the last one), and the

@@ -1,7 +1,7 @@
 """bench.py's gates say what ran: the parity gate counts the fused tape nodes it built and reads
 the library's per-kernel launch counters (`pdn_kernel_counters`), and REFUSES to go on when the step was not made of the
 nodes / kernels the roofline block prices -- a dispatch regression to the unfused composition must not stay green and
-show up only as a slower number.  Runs the real `bench.parity_gate` on the emulated C ABI (tests/abi_emulator.py, which
+show up only as a slower number.  Runs the real `bench.parity_gate` on the emulated C ABI (tests/abi_emulator/, which
 restates the library's dispatch rules for its counters) with the full-size model of BASELINE.json config 4 at one
 sequence: reference loss 11.395865 (tests/golden/llama_full.json, generated from /root/reference)."""
 import numpy as np

@@ -46,6 +46,7 @@ python tools/conv_quad_probe.py > $O/conv_quad_probe.txt 2>&1
 PDN_CONV_QUAD=0 python tools/conv_quad_probe.py > $O/conv_direct_probe.txt 2>&1
 { python tools/plain_llama_bench.py 64 5; python tools/plain_llama_bench.py 256 4; } > $O/plain_llama_bench.txt 2>&1
 python tools/gemm_fc_sweep.py 4096 3200 500 > $O/gemm_fc_sweep.txt 2>&1
+{ python tools/attn_hd128_probe.py 256 2048 1; python tools/attn_hd128_probe.py 256 2048 0; python tools/attn_hd128_probe.py 64 4096 0; python tools/attn_hd128_probe.py 1024 512 1; } > $O/attn_hd128_probe.txt 2>&1
 python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
 python tools/lmhead_probe.py > $O/lmhead_probe.txt 2>&1
 python tools/attn_masked_probe.py > $O/attn_masked_probe.txt 2>&1
