@@ -419,7 +419,8 @@ def other_configs(*release):
     gc.collect()
     res = {}
     runs = (("mlp_b256", "mlp", 256, 200, 20), ("mlp_b65536", "mlp", 65536, 20, 6), ("lenet_b256", "lenet", 256, 200, 20),
-            ("lenet_b4096", "lenet", 4096, 50, 5), ("gru", "gru", 0, 100, 10), ("decode", "decode", 0, 200, 20))
+            ("lenet_b4096", "lenet", 4096, 50, 5), ("gru", "gru", 0, 100, 10), ("decode", "decode", 0, 200, 20),
+            ("transformer", "transformer", 128, 100, 10))
     try:                                                     # (first: before the graph-replayed runs below)
         Graph.clear()
         res["llama_dim512"] = llama_other_width(512, 8, 1536)
@@ -463,7 +464,8 @@ def other_configs(*release):
         try:
             Graph.clear()
             fn = {"mlp": lambda: bench_other.run_train(a, "mlp"), "lenet": lambda: bench_other.run_train(a, "lenet"),
-                  "gru": lambda: bench_other.run_gru(a), "decode": lambda: bench_other.run_decode(a)}[cfg]
+                  "gru": lambda: bench_other.run_gru(a), "decode": lambda: bench_other.run_decode(a),
+                  "transformer": lambda: bench_other.run_transformer(a)}[cfg]
             r = fn()
             r.pop("memory", None)
             res[key] = r
@@ -604,7 +606,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=("llama", "mlp", "lenet", "gru", "decode"), default="llama",
+    ap.add_argument("--config", choices=("llama", "mlp", "lenet", "gru", "decode", "transformer"), default="llama",
                     help="llama = the headline line (BASELINE.json configs 4 / 5); mlp / lenet = configs 2 / 3; gru = "
                          "examples/pydynet/ts_prediction.py; decode = KV-cache greedy generation (bench_other.py)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "0")),

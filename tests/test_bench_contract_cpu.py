@@ -169,3 +169,14 @@ def test_gpus_n_beyond_the_visible_devices_fails_fast():
                        env=env, capture_output=True, text=True, timeout=60)
     assert r.returncode != 0 and time.monotonic() - t0 < 10
     assert "--gpus 64 but only" in r.stderr and r.stdout.strip() == ""
+
+
+def test_transformer_config_runs_on_the_emulated_device(emulated_hip):
+    """`bench.py --config transformer` (the example of the reference's third published benchmark at its own width): gate
+    against the reference-generated fixture, the plain-operator attention chain on the RESIDENT head-dim-128 kernels."""
+    import argparse
+    import bench_other
+    a = argparse.Namespace(config="transformer", batch=4, steps=2, warmup=1, no_graph=False, no_cpu_baseline=True, gpus=1)
+    r = bench_other.run_transformer(a)
+    assert r["attention_kernel"] == "resident" and r["value"] > 0 and r["unit"] == "samples/s"
+    assert r["parity_gate"]["worst_loss_rel_err"] <= 1e-4 and r["config"]["per_gpu_batch"] == 4
