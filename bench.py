@@ -611,7 +611,7 @@ def main():
                          "examples/pydynet/ts_prediction.py; decode = KV-cache greedy generation (bench_other.py)")
     ap.add_argument("--batch", type=int, default=int(os.environ.get("PDN_BENCH_BATCH", "0")),
                     help="per-GPU batch (default: 512 for llama (256 in rounds 1-4), 256 for mlp / lenet, 1568 for gru, 1 for decode)")
-    ap.add_argument("--no-graph", action="store_true", help="mlp / lenet: time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-graph", action="store_true", help="mlp / lenet / transformer: time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gemm-prof", action="store_true")
     ap.add_argument("--no-parity-gate", action="store_true",

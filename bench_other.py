@@ -468,25 +468,34 @@ def run_transformer(args):
         fused.attention.forward_ = orig
     if kinds != ["resident"]:
         raise SystemExit(f"bench.py --config transformer: the attention chain did not run on the resident kernels ({kinds})")
-    dt, nodes, g = _time_steps(hp, step, args.steps, args.warmup, False)
+    # the whole step replayed as one hipGraph, as the other small configurations (tests/test_graph_gpu.py pins the replayed
+    # steps of this model to the reference's losses); --no-graph times the eager launches: ~1.9 ms of host work for ~1.5 ms
+    # of kernels at this shape
+    use_graph = not args.no_graph
+    dt, nodes, g = _time_steps(hp, step, args.steps, args.warmup, use_graph)
+    if g is not None:
+        g.destroy()
     value = B * args.steps / dt
     # algorithmic FLOPs per sample, forward x 3: four 512 x 512 projections, two 512 x 1536 feed-forward products, scores
     flop = 3 * (L * (4 * 2 * D * D + 2 * 2 * D * E * D) + 2 * 2 * L * L * D)
-    try:
-        gcount = hp.Graph()
-        gcount.capture(step)
-        launches = int(gcount.nodes)
-        gcount.destroy()
-    except Exception:
-        launches = 0
-    roof = _latency_roof(hp, lib, launches, 1e6 * dt / args.steps, "eager launches of one training step") if launches else None
+    launches = int(nodes or 0)
+    if not launches and not os.environ.get("PDN_BENCH_NO_GRAPH_PROBE"):   # (rocprofv3 crashes on graph launches: profile runs set it)
+        try:
+            gcount = hp.Graph()
+            gcount.capture(step)
+            launches = int(gcount.nodes)
+            gcount.destroy()
+        except Exception:
+            launches = 0
+    roof = _latency_roof(hp, lib, launches, 1e6 * dt / args.steps,
+                         "whole step replayed as one hipGraph" if use_graph else "eager launches of one training step") if launches else None
     out = {"metric": "training-step samples/sec (1-layer Transformer classifier, dim 512, 4 heads, 44 positions; transformer.py)",
            "value": value, "unit": "samples/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f32", "data": "synthetic",
            "config": {"workload": "examples/pydynet/transformer.py: Transformer(512, 1 layer, 4 heads, expansion 3), vocab 6000, 44 positions, "
                                   "padding mask, logistic loss, Adam lr 5e-4, fwd+bwd+Adam; plain-operator model code",
-                      "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1", "step_launch": "eager launches"},
+                      "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1", "step_launch": f"hipGraph replay ({nodes} nodes)" if use_graph else "eager launches"},
            "algorithmic_tflops": flop * value / 1e12, "model_flops_frac_of_fp32_mfma_peak": flop * value / PEAK_FP32_MFMA,
            "attention_kernel": kinds[0], "parity_gate": gate, "roofline": roof,
            "reference_published": "README.md:153: 1.075 s per CoLA epoch (CuPy, RTX 4090), 17.5 s (NumPy) -- an epoch is 54 training "
@@ -522,7 +531,13 @@ def run_gru(args):
         return loss
 
     gate = _gru_gate(gru, head, xs_np, ys_np, Hd)
-    dt, nodes, g = _time_steps(hp, step, args.steps, args.warmup, False)
+    # the whole step replayed as one hipGraph, as the other small configurations (tests/test_graph_gpu.py pins the replayed
+    # steps of this model to the reference's losses); --no-graph times the eager launches: ~1.9 ms of host work for ~1.5 ms
+    # of kernels at this shape
+    use_graph = not args.no_graph
+    dt, nodes, g = _time_steps(hp, step, args.steps, args.warmup, use_graph)
+    if g is not None:
+        g.destroy()
     value = B * args.steps / dt
     # dominant kernel: the persistent sequence kernel (hidden state in MFMA accumulators), forward launch
     rng = np.random.default_rng(0)

@@ -494,10 +494,22 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   constexpr int SNW = 8;                                  // waves per streaming workgroup
   bool use_stream = false;
   int sshape = 0;
-  if (!ext_on && !a_kin && !b_kin && a_rs == 1 && b_cs == 1 && !b_colsum && K >= 2048 &&
-      // (outputs BELOW 2^20 elements: at 1024 x 1024 -- config 2's second layer -- the tiled kernel with its k-split measured
-      //  1065 us against 1144 us, and the MLP step 5.44 -> 5.32 ms; PDN_GEMM_STREAM_MAX overrides the bound)
-      (int64_t)M * N * nbatch <= (getenv("PDN_GEMM_STREAM_MAX") ? atol(getenv("PDN_GEMM_STREAM_MAX")) : (1 << 20) - 1) && nbatch <= 64 &&
+  // Which weight gradients it takes (tools/gemm_fc_sweep.py, same process, warm clocks, K = 4096 ... 65536):
+  //   * outputs BELOW 2^20 elements: at 1024 x 1024 -- config 2's second layer -- the tiled kernel with its k-split measured
+  //     1065 us against 1144 us, and the MLP step 5.44 -> 5.32 ms (PDN_GEMM_STREAM_MAX overrides the bound);
+  //   * from 2^18 elements on only where the tiled kernel's 128 / 96-wide tiles would PAD the output by more than 4 %:
+  //     784 x 1024 (config 2's first layer: 9 x 8 tiles of 96 x 128 = +10 %) 954 us here against 1030-1080 us tiled, but
+  //     512 x 512 and 512 x 1536 (the Transformer example, the dim-512 Llama) 38 / 85 us tiled against 45 / 109 us here at
+  //     K = 5632 and 280 / 804 against 330 / 890 us at K = 65536; below 2^18 (288 x 288, 288 x 768) this kernel wins at every K.
+  bool stream_fits = (int64_t)M * N * nbatch <= (getenv("PDN_GEMM_STREAM_MAX") ? atol(getenv("PDN_GEMM_STREAM_MAX")) : (1 << 20) - 1);
+  if (stream_fits && (int64_t)M * N * nbatch >= (1 << 18) && !getenv("PDN_GEMM_STREAM_MAX")) {
+    static const int kPadTiles[3][2] = {{128, 128}, {128, 96}, {96, 128}};
+    double pad = 1e30;
+    for (const auto& t : kPadTiles)
+      pad = std::min(pad, (double)(cdiv64(M, t[0]) * t[0]) * (double)(cdiv64(N, t[1]) * t[1]) / ((double)M * N));
+    stream_fits = pad > 1.04;
+  }
+  if (!ext_on && !a_kin && !b_kin && a_rs == 1 && b_cs == 1 && !b_colsum && K >= 2048 && stream_fits && nbatch <= 64 &&
       !getenv("PDN_GEMM_NO_STREAM")) {
     // tile shape of the LDS-staged kernel (in 32-row / 32-column MFMA tiles): 3 x 3 unless another one pads the output
     // less (784 x 1024: 9 x 11 tiles of 96 x 96 = 912 K accumulators, 5 x 16 of 160 x 64 = 819 K)
@@ -612,9 +624,13 @@ static int gemm_f32_impl(int M, int N, int K, float alpha, const float* A, int64
   // short (K <= 512): 64 x 64 tiles with a k-split.  Config 3's fully connected layers (4096 x 3200 x 500 in its three
   // forms) measured inside the step: 1.390 -> 1.335 ms with `5,8` for all of them, every other choice in between
   // (round 6; the cost model above prices a block's fixed cost too high for these).
-  if (!use_stream && !ext_on && !b_colsum && vec && nbatch == 1 && (int64_t)M * N >= (1 << 20) && (int64_t)M * N <= (1 << 24) &&
+  // The k-split pays in the weight-gradient form only (long contraction over the rows): with the rows on the output side
+  // 5632 x 512 over K = 1536 measured 85 us unsplit against 94 / 96 / 103 us split 2 / 4 / 8 ways, 8192 x 1024 over 1024
+  // 143 against 161 / 177 / 233 us (tools/gemm_fc_sweep.py) -- and the Linear + ReLU products (mask epilogues: no split) take
+  // the same tiles: 5632 x 512 -> 1536 with its ReLU 104 -> 8x us.
+  if (!use_stream && !b_colsum && vec && nbatch == 1 && (int64_t)M * N >= (1 << 20) && (int64_t)M * N <= (1 << 24) &&
       K <= 4096 && K >= 128 && (cdiv64(M, 128) * cdiv64(N, 128) < 256 || K <= 512)) {
-    int sp = 8;
+    int sp = (a_kin || ext_on) ? 1 : 8;
     while (sp > 1 && (K / sp < 64 || (int64_t)sp * M * N > ws_cap)) sp >>= 1;
     best = kScalarCfg;
     best_splits = sp;

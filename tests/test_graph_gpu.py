@@ -117,6 +117,45 @@ def test_replayed_llama_steps_equal_eager_steps(hip):
         assert np.allclose(p0[n], p1[n], rtol=1e-4, atol=2e-6), n     # (device-side double a_t vs the host scalar)
 
 
+def test_replayed_transformer_example_steps_equal_the_reference_losses(hip):
+    """examples/pydynet/transformer.py's step (plain-operator model code: embedding scatter, in-place -inf padding mask under
+    no_grad, the recognised attention chain, leading-axis LayerNorm with running statistics, logistic loss, Adam) captured
+    once and replayed: step 2 and step 3 against the losses the REAL reference produced (tests/golden/transformer_example.npz)
+    -- what `bench.py --config transformer` times by default."""
+    import os
+    import pydynet_amd as pdn
+    import pydynet_amd.nn as nn
+    import pydynet_amd.nn.functional as F
+    from pydynet_amd.optim import Adam
+    from pydynet_amd.core.tensor import Graph
+    from tests import models_transformer as mt
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transformer_example.npz"))
+    c = mt.CFG
+    Transformer, loss_fn = mt.build(pdn, nn, F)
+    ids_np, labels_np, emb = mt.make_inputs()
+    Graph.clear()
+    np.random.seed(11)
+    net = Transformer(c["embed"], c["layers"], c["heads"], c["expansion"], c["vocab"], c["max_len"])
+    net.word_embedding.weight.data[...] = emb
+    net.to("hip:0")
+    opt = Adam(net.parameters(), lr=c["lr"])
+    net.train()
+    ids, labels = pdn.Tensor(ids_np, device="hip:0"), pdn.Tensor(labels_np, device="hip:0")
+
+    def step():
+        loss = loss_fn(net, ids, labels)
+        opt.zero_grad(); loss.backward(); opt.step()
+        return loss
+    g = hip.Graph()
+    loss = g.capture(step)                                  # warm-up run = step 1, first replay = step 2
+    got = [loss.item()]
+    g.replay()
+    got.append(loss.item())
+    assert g.nodes > 20 and opt.t == 4
+    g.destroy()
+    assert np.allclose(got, d["losses"][1:3], rtol=1e-4), (got, d["losses"])
+
+
 def test_replay_survives_a_later_eager_op_that_grows_the_workspace(hip):
     """A captured step holds raw scratch addresses (split-K slabs, reductions, the embedding scatter's
     last-occurrence vector, Adam's chunk table).  The process-wide scratch buffer is replaced whenever an eager op
