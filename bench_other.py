@@ -531,9 +531,7 @@ def run_gru(args):
         return loss
 
     gate = _gru_gate(gru, head, xs_np, ys_np, Hd)
-    # the whole step replayed as one hipGraph, as the other small configurations (tests/test_graph_gpu.py pins the replayed
-    # steps of this model to the reference's losses); --no-graph times the eager launches: ~1.9 ms of host work for ~1.5 ms
-    # of kernels at this shape
+    # the whole step replayed as one hipGraph, as the other small configurations; --no-graph times the eager launches
     use_graph = not args.no_graph
     dt, nodes, g = _time_steps(hp, step, args.steps, args.warmup, use_graph)
     if g is not None:
@@ -553,20 +551,24 @@ def run_gru(args):
            "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
            "note": f"a {T_}-step recurrence ({flops / (us * 1e-6) / 1e12:.2f} TFLOP/s of recurrent MFMA work): {T_} dependent "
                    "steps of 48 MFMAs inside ONE launch -- neither an HBM nor an MFMA roof applies"}
-    try:
-        gcount = hp.Graph()
-        gcount.capture(step)
-        launches = int(gcount.nodes)
-        gcount.destroy()
-    except Exception:
-        launches = 0
-    roof = dict(_latency_roof(hp, lib, launches, 1e6 * dt / args.steps, "eager launches of one training step"),
+    launches = int(nodes or 0)
+    if not launches:
+        try:
+            gcount = hp.Graph()
+            gcount.capture(step)
+            launches = int(gcount.nodes)
+            gcount.destroy()
+        except Exception:
+            launches = 0
+    roof = dict(_latency_roof(hp, lib, launches, 1e6 * dt / args.steps,
+                              "whole step replayed as one hipGraph" if use_graph else "eager launches of one training step"),
                 sequence_kernel=seq)
     out = {"metric": "training-step sequences/sec (GRU 1->32, T=40, ts_prediction.py)", "value": value, "unit": "sequences/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "examples/pydynet/ts_prediction.py GRU(1->32), T = 40, Linear(32,1) head, MSE, Adam lr 1e-3, fwd+bwd+Adam",
-                      "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1", "step_launch": "eager launches"},
+                      "per_gpu_batch": B, "global_batch": B, "parallelism": "dp1",
+                      "step_launch": f"hipGraph replay ({nodes} nodes)" if use_graph else "eager launches"},
            "parity_gate": gate, "roofline": roof}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = _cpu_gru(T_, Hd)

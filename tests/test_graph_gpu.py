@@ -156,6 +156,49 @@ def test_replayed_transformer_example_steps_equal_the_reference_losses(hip):
     assert np.allclose(got, d["losses"][1:3], rtol=1e-4), (got, d["losses"])
 
 
+def test_replayed_gru_steps_equal_eager_steps(hip):
+    """examples/pydynet/ts_prediction.py's step (GRU over T steps on the persistent sequence kernels, Linear head, MSE, Adam)
+    replayed as one hipGraph = the same steps issued eagerly (what `bench.py --config gru` times by default)."""
+    import pydynet_amd as pdn
+    import pydynet_amd.nn as nn
+    import pydynet_amd.nn.functional as F
+    from pydynet_amd.optim import Adam
+    from pydynet_amd.core.tensor import Graph
+    rng = np.random.default_rng(5)
+    T, B, H, N = 12, 96, 32, 5
+    xs_np, ys_np = rng.random((T, B, 1), dtype=np.float32), rng.random((B, 1), dtype=np.float32)
+    results = []
+    for use_graph in (False, True):
+        Graph.clear()
+        np.random.seed(2)
+        gru = nn.GRU(1, H, dtype=np.float32).to("hip:0")
+        head = nn.Linear(H, 1, dtype=np.float32).to("hip:0")
+        params = list(gru.parameters()) + list(head.parameters())
+        opt = Adam(params, lr=1e-3)
+        xs, ys = pdn.Tensor(xs_np, device="hip:0"), pdn.Tensor(ys_np, device="hip:0")
+
+        def step():
+            out, hn = gru(xs)
+            loss = F.mse_loss(head(hn[0]), ys)
+            opt.zero_grad(); loss.backward(); opt.step()
+            return loss
+        if use_graph:
+            g = hip.Graph()
+            loss = g.capture(step)
+            losses = [loss.item()]
+            for _ in range(N - 2):
+                g.replay()
+                losses.append(loss.item())
+            g.destroy()
+        else:
+            losses = [step().item() for _ in range(N)][1:]
+        results.append((losses, [p.numpy() for p in params]))
+    (l0, p0), (l1, p1) = results
+    assert np.allclose(l0, l1, rtol=1e-6), (l0, l1)
+    for a, b in zip(p0, p1):
+        assert np.allclose(a, b, rtol=1e-4, atol=2e-6)
+
+
 def test_replay_survives_a_later_eager_op_that_grows_the_workspace(hip):
     """A captured step holds raw scratch addresses (split-K slabs, reductions, the embedding scatter's
     last-occurrence vector, Adam's chunk table).  The process-wide scratch buffer is replaced whenever an eager op
