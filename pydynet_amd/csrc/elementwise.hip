@@ -10,6 +10,7 @@
 // path; anything else (broadcast, transposed views, in-place into a slice) goes through a
 // dimension-collapsed strided index walk.
 #include "common.h"
+#include <stdlib.h>
 
 enum { PDN_F32 = 0, PDN_F64 = 1, PDN_I64 = 2, PDN_BOOL = 3, PDN_I32 = 4, PDN_F16 = 5 };
 
@@ -29,10 +30,13 @@ enum {
 
 struct EwDims {
   int ndim;
+  int fast;                        // fewer than 2^31 elements: the index walk divides by multiply-high (mg, sh), see ew_offsets
   int64_t shape[PDN_MAX_DIMS];
   int64_t sa[PDN_MAX_DIMS];
   int64_t sb[PDN_MAX_DIMS];
   int64_t so[PDN_MAX_DIMS];
+  uint32_t mg[PDN_MAX_DIMS];
+  uint32_t sh[PDN_MAX_DIMS];
 };
 
 template <typename T> __device__ __forceinline__ T t_exp(T x);
@@ -106,6 +110,25 @@ __device__ __forceinline__ T un_apply(T x) {
 __device__ __forceinline__ void ew_offsets(const EwDims& d, int64_t i, int64_t& oa, int64_t& ob,
                                            int64_t& oo) {
   oa = ob = oo = 0;
+  if (d.fast) {
+    // gfx950 has no integer divide: a 64-bit i / s is an ~80-instruction routine per dimension and element, which bounded
+    // these kernels at 1.4-2.4 TB/s (a RoPE product of the plain-operator Llama: 57 us for 113 MB; the transposed copy in
+    // front of its score product 97 us for 151 MB).  For n < 2^31 and s >= 2 (size-1 dimensions are dropped):
+    // n / s = umulhi(n, ceil(2^(31 + l) / s)) >> (l - 1), l = ceil(log2 s) -- exact, the error term n e / (s 2^p) < 1 / s.
+    // (Tried and dropped, tools/ew_strided_probe.py under rocprofv3: a walk of compile-time depth over right-aligned slots
+    // -- slower, 33 -> 44 us on a two-dimensional add -- and 24-bit multiply-adds for the offsets -- no change: past the
+    // divisions these kernels wait for memory.)
+    uint32_t n = (uint32_t)i;
+#pragma unroll 1
+    for (int k = d.ndim - 1; k > 0; --k) {
+      const uint32_t q = __umulhi(n, d.mg[k]) >> d.sh[k];
+      const uint32_t r = n - q * (uint32_t)d.shape[k];
+      oa += (int64_t)r * d.sa[k]; ob += (int64_t)r * d.sb[k]; oo += (int64_t)r * d.so[k];
+      n = q;
+    }
+    if (d.ndim > 0) { oa += (int64_t)n * d.sa[0]; ob += (int64_t)n * d.sb[0]; oo += (int64_t)n * d.so[0]; }
+    return;
+  }
 #pragma unroll 1
   for (int k = d.ndim - 1; k >= 0; --k) {
     const int64_t s = d.shape[k];
@@ -155,6 +178,23 @@ __global__ void ew_binary_contig_f32(const float* __restrict__ a, const float* _
     const float x = a[i];
     const float y = mode == 0 ? b[i] : scalar;
     out[i] = mode == 2 ? bin_apply<float, OP>(y, x) : bin_apply<float, OP>(x, y);
+  }
+}
+
+__device__ __forceinline__ float4 ew_load_quad(const float* __restrict__ p, int64_t step, int vec) {
+  if (vec) return *reinterpret_cast<const float4*>(p);
+  if (step == 0) { const float v = p[0]; return make_float4(v, v, v, v); }
+  return make_float4(p[0], p[step], p[2 * step], p[3 * step]);
+}
+
+template <int OP>
+__global__ void ew_unary_quad_f32(const float* __restrict__ a, float* out, EwDims d, int64_t total4, int64_t ia, int avec) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t oa, ob, oo;
+    ew_offsets(d, i, oa, ob, oo);
+    const float4 v = ew_load_quad(a + oa, ia, avec);
+    *reinterpret_cast<float4*>(out + oo) = make_float4(un_apply<float, OP>(v.x), un_apply<float, OP>(v.y),
+                                                       un_apply<float, OP>(v.z), un_apply<float, OP>(v.w));
   }
 }
 
@@ -216,6 +256,15 @@ static size_t dtype_size(int dt) {
   return 0;
 }
 
+// n / s for n < 2^31 by multiply-high (see ew_offsets): mg = ceil(2^(31 + l) / s), sh = l - 1, l = ceil(log2 s), s >= 2
+static void ew_set_magic(EwDims& d, int k) {
+  const uint64_t s = (uint64_t)d.shape[k];
+  int l = 0;
+  while (((uint64_t)1 << l) < s) ++l;
+  d.mg[k] = (uint32_t)((((uint64_t)1 << (31 + l)) + s - 1) / s);
+  d.sh[k] = (uint32_t)(l > 0 ? l - 1 : 0);
+}
+
 // Drop size-1 dims, merge adjacent dims that are jointly contiguous in every operand.
 static int64_t collapse(EwDims& d, int ndim, const int64_t* shape, const int64_t* sa,
                         const int64_t* sb, const int64_t* so) {
@@ -235,7 +284,45 @@ static int64_t collapse(EwDims& d, int ndim, const int64_t* shape, const int64_t
     }
   }
   d.ndim = n;
+  static const bool no_fast = getenv("PDN_EW_NO_FASTDIV") != nullptr;       // A/B switch (tools/ew_strided_probe.py)
+  d.fast = !no_fast && total > 0 && total < ((int64_t)1 << 31);
+  for (int k = 0; k < n && d.fast; ++k) ew_set_magic(d, k);
   return total;
+}
+
+// Four consecutive outputs per lane for the UNARY kernels and the strided float copy: the view of `d` whose innermost
+// dimension counts QUADS (one index walk and one 16-byte store per four elements; the operand is read as 16 bytes where its
+// innermost stride is 1 and everything is 16-byte aligned, as one value where it is 0, as four dwords otherwise).  Needs a
+// unit-stride, 16-byte aligned output whose innermost extent is a multiple of four.  Measured (rocprofv3, 75 MB operands):
+// transposed copy (B, L, H, hd) -> (B, H, L, hd) 39 -> 31 us; the BINARY kernels measured no better this way (a stride-2
+// view times a broadcast table 29 us either way, a row-broadcast add 33 -> 39 us) and keep one element per lane.
+struct EwQuad {
+  EwDims d;
+  int64_t total4, ia;
+  int avec;
+  bool ok;
+};
+static EwQuad ew_quad_view(const EwDims& d0, int64_t total, const void* a, const void* out) {
+  EwQuad q;
+  q.ok = false;
+  static const bool off = getenv("PDN_EW_NO_QUAD") != nullptr;                 // A/B switch (tools/ew_strided_probe.py)
+  const int last = d0.ndim - 1;
+  if (off || !d0.fast || last < 0 || d0.shape[last] % 4 || d0.so[last] != 1 || ((uintptr_t)out & 15)) return q;
+  if (d0.shape[last] < 8) return q;                        // (the quad count of a divided dimension must stay >= 2)
+  bool a4 = ((uintptr_t)a & 15) == 0;
+  for (int k = 0; k < last; ++k) {
+    if (d0.so[k] % 4) return q;
+    a4 = a4 && d0.sa[k] % 4 == 0;
+  }
+  q.d = d0;
+  q.ia = d0.sa[last];
+  q.avec = a4 && q.ia == 1;
+  q.d.shape[last] /= 4;
+  q.d.sa[last] *= 4; q.d.so[last] *= 4;
+  ew_set_magic(q.d, last);
+  q.total4 = total / 4;
+  q.ok = true;
+  return q;
 }
 
 static inline int grid_for(int64_t n, int per_thread = 1) {
@@ -370,7 +457,16 @@ extern "C" int pdn_ew_unary(int dtype, int op, int ndim, const int64_t* shape, c
                      (float*)out, n4, total)
       UN_CASES(float, LU_CONTIG)
     } else {
-      UN_CASES(float, LU_STRIDED)
+      const EwQuad q = ew_quad_view(d, total, a, out);
+      if (q.ok) {
+        const int gq = grid_for(q.total4, 2);
+#define LU_QUAD(T, OPC)                                                                                        \
+  hipLaunchKernelGGL((ew_unary_quad_f32<OPC>), dim3(gq), dim3(256), 0, st, (const float*)a, (float*)out, q.d, \
+                     q.total4, q.ia, q.avec)
+        UN_CASES(float, LU_QUAD)
+      } else {
+        UN_CASES(float, LU_STRIDED)
+      }
     }
   } else if (dtype == PDN_F64) {
     UN_CASES(double, LU_STRIDED)
@@ -421,6 +517,15 @@ extern "C" int pdn_cast(int src_dtype, int dst_dtype, int ndim, const int64_t* s
   if (src_dtype == dst_dtype && is_contig1(d, d.sa) && is_contig1(d, d.so)) {
     PDN_HIP(hipMemcpyAsync(out, a, total * dtype_size(src_dtype), hipMemcpyDeviceToDevice, st));
     return PDN_OK;
+  }
+  if (src_dtype == PDN_F32 && dst_dtype == PDN_F32) {       // transposed / sliced views made contiguous: 16 bytes per lane
+    const EwQuad q = ew_quad_view(d, total, a, out);
+    if (q.ok) {
+      hipLaunchKernelGGL((ew_unary_quad_f32<UOP_COPY>), dim3(grid_for(q.total4, 2)), dim3(256), 0, st, (const float*)a,
+                         (float*)out, q.d, q.total4, q.ia, q.avec);
+      PDN_LAUNCH_CHECK();
+      return PDN_OK;
+    }
   }
   int rc;
   switch (src_dtype) {

@@ -174,6 +174,57 @@ def test_elementwise_views_inplace_and_cast(hip):
     assert np.array_equal(hip.pad(A, [(0, 0), (1, 2)]).get(), np.pad(a, [(0, 0), (1, 2)]))
 
 
+def test_strided_elementwise_index_walks(hip):
+    """The strided / broadcasting kernels walk their index with multiply-high divisions (< 2^31 elements) and, where the
+    output's innermost extent is a multiple of four at unit stride, with four elements per lane (csrc/elementwise.hip):
+    bit-equal to NumPy over the eligibility edges -- innermost extents 4 / 8 / 12 / odd, stride-2 and stride-0 operands,
+    bases off the 16-byte grid, transposed views, sliced outputs, in-place forms, extents that are powers of two / one
+    more / one less -- and on the 64-bit path above 2^31 elements' worth of index (a large broadcast)."""
+    rng = np.random.default_rng(12)
+
+    def both(shape):
+        a = rng.standard_normal(shape, dtype=np.float32)
+        return a, hip.from_numpy(a)
+    # RoPE's shapes: a stride-2 view times a broadcast table (tests/models_plain_llama.py: rotate_pairs)
+    x, X = both((3, 17, 6, 24, 2))
+    c, C = both((17, 1, 24))
+    for k in (0, 1):
+        assert np.array_equal((X[..., k] * C).get(), x[..., k] * c)
+        assert np.array_equal((X[..., k] * C - X[..., 1 - k]).get(), x[..., k] * c - x[..., 1 - k])
+    for inner in (4, 8, 12, 7, 33, 64, 65, 63):
+        a, A = both((5, 3, inner))
+        b, B = both((3, 1))
+        v, V = both((inner,))
+        assert np.array_equal((A + B).get(), a + b)                       # stride-0 innermost operand
+        assert np.array_equal((A * V).get(), a * v)                       # row broadcast
+        assert np.array_equal((A.transpose(1, 0, 2) - 2.0).get(), a.transpose(1, 0, 2) - 2.0)
+        assert np.array_equal(hip.ascontiguousarray(A.transpose(1, 0, 2)).get(), np.ascontiguousarray(a.transpose(1, 0, 2)))
+        assert np.allclose(hip.exp(A.transpose(1, 0, 2)).get(), np.exp(a.transpose(1, 0, 2)), rtol=RT)
+        if inner > 4:                                                       # operand bases off the 16-byte grid
+            assert np.array_equal((A[..., 1:] + A[..., :-1]).get(), a[..., 1:] + a[..., :-1])
+            assert np.array_equal((A[:, :, 1:inner - 3] * 3.0).get(), a[:, :, 1:inner - 3] * 3.0)
+        O = hip.zeros((5, 3, inner + 4), np.float32)                        # a sliced (row-padded) output
+        O[..., :inner] = A.transpose(0, 1, 2) * 1.0
+        ref = np.zeros((5, 3, inner + 4), np.float32); ref[..., :inner] = a
+        assert np.array_equal(O.get(), ref)
+        A2 = hip.from_numpy(a.copy()); A2 += B; A2 *= V                     # in place
+        assert np.array_equal(A2.get(), (a + b) * v)
+    y, Y = both((4, 16, 6, 48))                                             # the transposed copy in front of the scores
+    assert np.array_equal(hip.ascontiguousarray(Y.transpose(0, 2, 1, 3)).get(), np.ascontiguousarray(y.transpose(0, 2, 1, 3)))
+    assert np.array_equal(hip.ascontiguousarray(Y.transpose(0, 2, 3, 1)).get(), np.ascontiguousarray(y.transpose(0, 2, 3, 1)))
+    for ext in (2, 3, 255, 256, 257, 1023, 1025):                           # divisors around powers of two
+        a, A = both((3, ext, 8))
+        assert np.array_equal((A.transpose(1, 0, 2) + 1.0).get(), a.transpose(1, 0, 2) + 1.0)
+        assert np.array_equal((A.transpose(2, 1, 0) + 1.0).get(), a.transpose(2, 1, 0) + 1.0)
+    big = hip.from_numpy(rng.standard_normal((1, 2048), dtype=np.float32))   # 2^31 + 2^21 index values: the 64-bit walk
+    col = hip.from_numpy(rng.standard_normal((1024 * 1025, 1), dtype=np.float32))
+    out = big + col
+    hb, hc = big.get(), col.get()
+    for r in (0, 1, 524287, 1024 * 1025 - 1):
+        assert np.array_equal(out[r].get(), hb[0] + hc[r, 0])
+    del out
+
+
 @pytest.mark.parametrize("shape,axis,keep", [((7, 288), -1, True), ((4, 6, 256), (0, 1), False),
                                              ((300, 1000), None, False), ((5000, 33), 0, False),
                                              ((3, 4, 5), 1, True), ((2, 3, 4, 5), (1, 3), False),

@@ -1,8 +1,9 @@
 """Throughput of the DROP-IN formulation: the full-size 6-layer Llama written with plain operators (tests/models_plain_llama.py =
 what a user of the reference's own llm/llama/model.py gets) beside the fused-node model the headline is quoted on.
 Measured round 6 (MI355X): batch 64: 2697 vs 4153 samples/s (0.65; the plain step is host-bound there: ~430 nodes per step);
-batch 256: 3891 vs 5139 (0.76) with the attention chain recognised (core/fused/chain.py), 3361 (0.65) without.
-usage: python tools/plain_llama_bench.py [batch=64] [steps=5]"""
+batch 256: 3891 vs 5139 (0.76) with the attention chain recognised (core/fused/chain.py), 3361 (0.65) without; 3983 vs 5027 (0.79)
+once the strided elementwise kernels divide by multiply-high (csrc/elementwise.hip: their share of the step 7.9 -> 5.6 ms).
+usage: python tools/plain_llama_bench.py [batch=64] [steps=5] [plain|fused: only that model, e.g. under rocprofv3]"""
 import os
 import sys
 import time
@@ -64,4 +65,5 @@ if __name__ == "__main__":
     import json
     b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     s = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    print(json.dumps(run(b, s), indent=1))
+    which = (sys.argv[3],) if len(sys.argv) > 3 else ("plain", "fused")
+    print(json.dumps(run(b, s, which=which), indent=1))
