@@ -446,6 +446,7 @@ def run_transformer(args):
     net.word_embedding.weight.data[...] = (0.1 * rng.standard_normal((V, D))).astype(np.float32)
     net.to("hip:0")
     opt = Adam(net.parameters(), lr=5e-4)
+    opt.flatten_grads()                                       # one flat gradient buffer: zero_grad is a single fill (as bench.py)
     net.train()
     ids, labels = pdn.Tensor(ids_np, dtype=np.int64, device="hip:0"), pdn.Tensor(labels_np, device="hip:0")
     kinds = []
