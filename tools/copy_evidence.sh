@@ -4,10 +4,10 @@ ROUND=${ROUND:-r06}; S=gpurun_out/$ROUND; D=profiles
 cp $S/bench_default.json $D/${ROUND}_bench_default.json
 cp $S/bench_detail.json $D/${ROUND}_bench_detail.json
 cp $S/bench_driver_cmd.json $D/${ROUND}_bench_driver_cmd.json
-for f in conv_quad_probe conv_direct_probe plain_llama_bench gemm_fc_sweep attn_hd128_probe; do [ -f $S/$f.txt ] && cp $S/$f.txt $D/${ROUND}_$f.txt; done
+for f in conv_quad_probe conv_direct_probe plain_llama_bench gemm_fc_sweep attn_hd128_probe transformer_kernel_stats ew_strided_probe ew_strided_probe_64bit_divide plain_llama_kernel_stats; do [ -f $S/$f.txt ] && cp $S/$f.txt $D/${ROUND}_$f.txt; done
 tail -1 $S/bench_force_dp.json > $D/${ROUND}_bench_force_dp.json
 for b in 1024 256 128 64; do cp $S/bench_b$b.json $D/${ROUND}_bench_b$b.json; done
-for c in mlp lenet gru decode lenet_b4096 mlp_b65536 mlp_b8192; do cp $S/bench_$c.json $D/${ROUND}_bench_$c.json; done
+for c in mlp lenet gru decode lenet_b4096 mlp_b65536 mlp_b8192 transformer transformer_eager; do cp $S/bench_$c.json $D/${ROUND}_bench_$c.json; done
 cp $S/bench_default_kernel_stats.csv $D/${ROUND}_bench_default_kernel_stats.csv
 cp $S/bench_kernel_stats.txt $D/${ROUND}_bench_default_kernel_stats.txt
 cp $S/pmc_bench_default.json $D/${ROUND}_pmc_bench_default.json

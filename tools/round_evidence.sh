@@ -20,6 +20,10 @@ python bench.py --no-cpu-baseline --no-other-configs --batch 1024 --steps 5 > $O
 python bench.py --no-cpu-baseline --no-other-configs --batch 128 > $O/bench_b128.json 2>> $O/bench_default.err
 python bench.py --no-cpu-baseline --no-other-configs --batch 64 > $O/bench_b64.json 2>> $O/bench_default.err
 for c in mlp lenet gru decode; do python bench.py --config $c --steps 200 --warmup 20 > $O/bench_$c.json 2>> $O/bench_default.err; done
+python bench.py --config transformer --steps 100 --warmup 10 > $O/bench_transformer.json 2>> $O/bench_default.err
+python bench.py --config transformer --no-graph --steps 100 --warmup 10 --no-cpu-baseline > $O/bench_transformer_eager.json 2>> $O/bench_default.err
+# (rocprofv3 crashes on hipGraph launches: the profile times the eager launches and skips the launch-floor graph)
+PDN_BENCH_NO_GRAPH_PROBE=1 bash tools/prof_cmd.sh ${ROUND}_transformer python bench.py --config transformer --no-graph --steps 20 --warmup 3 --no-cpu-baseline > $O/transformer_kernel_stats.txt 2>&1
 # (the LeNet line reads the counter summary of its own kernels: collected and stamped first)
 bash tools/pmc_cmd.sh ${ROUND}_lenet conv python tools/bench_configs.py 3 lenet:4096 > $O/lenet_pmc.txt 2>&1
 python tools/stamp_pmc.py gpurun_out/pmc_${ROUND}_lenet/summary.json $O/pmc_lenet_b4096.json && cp $O/pmc_lenet_b4096.json profiles/${ROUND}_pmc_lenet_b4096.json
@@ -45,7 +49,10 @@ bash tools/decode_trace.sh > $O/decode_trace.txt 2>&1
 python tools/conv_quad_probe.py > $O/conv_quad_probe.txt 2>&1
 PDN_CONV_QUAD=0 python tools/conv_quad_probe.py > $O/conv_direct_probe.txt 2>&1
 { python tools/plain_llama_bench.py 64 5; python tools/plain_llama_bench.py 256 4; } > $O/plain_llama_bench.txt 2>&1
-python tools/gemm_fc_sweep.py 4096 3200 500 > $O/gemm_fc_sweep.txt 2>&1
+{ for s in "4096 3200 500" "5632 512 512" "5632 512 1536" "8192 784 1024" "65536 784 1024" "65536 512 1536" "65536 288 768"; do echo "== rows, in, out: $s"; SWEEP_SHOW=1 python tools/gemm_fc_sweep.py $s; done; } > $O/gemm_fc_sweep.txt 2>&1
+bash tools/prof_cmd.sh ${ROUND}_ew python tools/ew_strided_probe.py > $O/ew_strided_probe.txt 2>&1
+PDN_EW_NO_FASTDIV=1 bash tools/prof_cmd.sh ${ROUND}_ew0 python tools/ew_strided_probe.py > $O/ew_strided_probe_64bit_divide.txt 2>&1
+bash tools/prof_cmd.sh ${ROUND}_plain python tools/plain_llama_bench.py 256 4 plain > $O/plain_llama_kernel_stats.txt 2>&1
 { python tools/attn_hd128_probe.py 256 2048 1; python tools/attn_hd128_probe.py 256 2048 0; python tools/attn_hd128_probe.py 64 4096 0; python tools/attn_hd128_probe.py 1024 512 1; } > $O/attn_hd128_probe.txt 2>&1
 python tools/epilogue_probe.py > $O/epilogue_probe.txt 2>&1
 python tools/lmhead_probe.py > $O/lmhead_probe.txt 2>&1
