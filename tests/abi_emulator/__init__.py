@@ -31,5 +31,13 @@ def install(monkeypatch):
     monkeypatch.setattr(hipnp, "_ws", {})
     monkeypatch.setattr(hipnp, "_err", {})
     monkeypatch.setattr(hipnp, "_state", {"device": 0, "stream": 0, "streams": {}})
+    # recycled handles of a PREVIOUS emulator instance (pinned read-back slots and their events, the side stream with its
+    # fork / join events) mean nothing to this one: a loss read through a stale slot returns whatever that host block
+    # held last (seen as a wrong first loss in tests/test_dropin_reference_programs.py after the bench.main() tests)
+    from pydynet_amd import _hipnp_host, _hipnp_streams
+    monkeypatch.setattr(_hipnp_host.read_later, "_free", {})
+    monkeypatch.setattr(_hipnp_streams, "_side", {})
+    from pydynet_amd.core import fused
+    monkeypatch.setattr(fused.qkv_attention, "_rope_tables", {})
     return emu
 

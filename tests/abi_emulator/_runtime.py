@@ -10,10 +10,17 @@ from ._base import _NP, _ints, view, flat  # noqa: F401
 
 
 class RuntimeMixin:
+    # address -> owning NumPy block, shared by EVERY emulator instance of the process: arrays of an earlier test that the
+    # garbage collector releases late call free() on whichever instance is installed THEN -- with a table per instance
+    # their blocks were gone with the old instance, malloc handed the same addresses to the new one, and the late free()
+    # dropped a LIVE block (seen as a wrong first loss / a segmentation fault in test_dropin_reference_programs.py after the
+    # bench.main() tests).  Shared, an address stays taken until its own owner frees it.
+    _blocks = {}
+
     def __init__(self):
         self.protos = _lib.parse_header()
         self.calls = []
-        self._blocks, self._handles = {}, 1000
+        self._handles = 1000
 
     # -- dispatch -------------------------------------------------------------------------
     def call(self, name, *args):
