@@ -35,6 +35,33 @@ def test_gemm_nn(hip, M, N, K):
     assert rel_err(c, ref) < 1e-5
 
 
+def test_gemm_mid_size_dispatch_edges(hip):
+    """The three products of a Linear layer (x W, g W^T, x^T g) around the tile-rule boundaries of csrc/gemm.hip (round 6):
+    outputs of 2^18 / 2^20 / 2^24 elements, fewer or more than 256 tiles of 128 x 128, contractions 64 / 512 / 513 / 1536 /
+    4096, weight gradients whose tiled tiles pad the output (streaming kernel) or do not (tiled + k-split), extents that
+    are not multiples of the tile or of four (scalar staging), accumulation into C -- each against float64."""
+    rng = np.random.default_rng(77)
+    shapes = [(5632, 512, 512), (5632, 512, 1536), (5632, 1536, 512), (2816, 512, 512), (4096, 3200, 500), (4096, 500, 500),
+              (8192, 784, 1024), (2048, 512, 512), (2047, 513, 511), (1024, 1024, 1024), (8200, 132, 260), (3000, 64, 520),
+              (6000, 4096, 192), (16384, 288, 768), (16390, 290, 770), (512, 4100, 2052)]
+    from pydynet_amd import _lib
+    if type(_lib.lib()).__name__ == "EmulatedLib":                          # (no dispatch to exercise: the host plumbing only)
+        shapes = [(2047, 513, 511), (3000, 64, 520)]
+    for R, I, O in shapes:
+        x = rng.standard_normal((R, I), dtype=np.float32)
+        w = rng.standard_normal((I, O), dtype=np.float32)
+        g = rng.standard_normal((R, O), dtype=np.float32)
+        X, W, G = hip.from_numpy(x), hip.from_numpy(w), hip.from_numpy(g)
+        x64, w64, g64 = x.astype(np.float64), w.astype(np.float64), g.astype(np.float64)
+        assert rel_err(hip.matmul(X, W).get(), x64 @ w64) < 2e-5, (R, I, O, "x W")
+        assert rel_err(hip.matmul(G, W.T).get(), g64 @ w64.T) < 2e-5, (R, I, O, "g W^T")
+        assert rel_err(hip.matmul(X.T, G).get(), x64.T @ g64) < 2e-5, (R, I, O, "x^T g")
+        c0 = rng.standard_normal((I, O), dtype=np.float32)
+        C = hip.from_numpy(c0.copy())
+        hip.gemm(X.T, G, C, beta=1.0)                                       # gradient accumulation through the slab pass
+        assert rel_err(C.get(), x64.T @ g64 + c0) < 2e-5, (R, I, O, "x^T g + C")
+
+
 def test_gemm_transposed_views_and_identity_check(hip):
     # asymmetric B with A = I catches swapped row/col in the MFMA C layout
     n = 96
