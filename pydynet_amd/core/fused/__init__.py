@@ -17,6 +17,9 @@ expression.  Reference chains replaced:
                                                     BUILT from plain operators is recognised link by link (chain.py)
     embedding       nn/functional.py:14-20 + tensor.py:937-940 (scatter-ASSIGN gradient)
     cross_entropy   nn/functional.py:364-381        (7 nodes, integer targets)
+    linear_cross_entropy  llm/llama/model.py:179 + :239-249 (lm_head -> reshape -> cross entropy as one node); the same
+                                                    three calls written with plain operators are taken over as they are
+                                                    built (chain.py: loss_chain)
 """
 from ._common import (_hip, _L, _contig, hip_f32, _require_f32, _foldable, two_stream, _beside, _is_leaf_f32, _Deferred, _pack_columns, _dx_of_shared_input, _gemm_raw)
 from .dense import linear, linear_relu, embedding, cross_entropy, linear_cross_entropy

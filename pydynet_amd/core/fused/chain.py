@@ -21,6 +21,7 @@ import numpy as np
 from ..tensor import Graph, Tensor, _Operator, transpose, matmul as _matmul, div as _div, add as _add
 from ._common import _Deferred
 from .attn import attention, _attn_layout
+from .dense import linear as _linear, linear_cross_entropy as _linear_ce
 from .pointwise import softmax as _softmax
 
 
@@ -123,3 +124,58 @@ def on_softmax(x):
     if _pending(x, ("scaled", "masked")):
         return attn_link("soft", (x,), x.q, x.k, mask=x.mask)
     return None
+
+
+# ---- the loss of the reference's own training step (llm/llama/model.py:239-249) ---------------------------------------
+#
+#     logits = self.forward_logits(ids)                  # ... -> nn.Linear(dim, vocab)            (model.py:179)
+#     loss = criterion(logits.reshape(B * L, V), targets)                                          (model.py:242-249)
+#
+# A projection the device could hand to a fused consumer is created without running (`fused.linear`, `_Deferred`).  While
+# it is still pending, `reshape` that only regroups its leading axes is the same projection of the regrouped input, and
+# `cross_entropy_loss` of it is ONE `linear_cross_entropy` node over (x, W, b): the (tokens x vocab) logits are written
+# once, their gradient never exists, and both backward products form it from the saved logits -- the node
+# `pydynet_amd.llm.llama.Llama.loss` builds by name.  The pending nodes that were passed over stay what they were: anybody
+# who reads `logits` (an accuracy, a second loss term) gets the ordinary product then, on the tape as before.
+class loss_chain:
+    enabled = True        # class switch: False keeps linear -> reshape -> cross entropy as three nodes (A/B and tests)
+    fused_built = 0       # chains that became a linear_cross_entropy node
+
+
+def _pending_linear(t):
+    return type(t) is _linear and t._pending is not None and not t.has_res
+
+
+def on_reshape(t, new_shape):
+    """Hook of Tensor.reshape: a pending projection whose LAST axis is kept."""
+    if not (loss_chain.enabled and _pending_linear(t)):
+        return None
+    if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
+        new_shape = tuple(new_shape[0])
+    shape = [int(v) for v in new_shape]
+    if not shape or shape[-1] != t.shape[-1] or any(v == 0 for v in shape):
+        return None
+    rows = t.size // t.shape[-1]
+    if shape.count(-1) == 1:
+        known = int(np.prod([v for v in shape[:-1] if v != -1], dtype=np.int64))
+        if known == 0 or rows % known:
+            return None
+        shape[shape.index(-1)] = rows // known
+    if any(v < 0 for v in shape) or int(np.prod(shape[:-1], dtype=np.int64)) != rows:
+        return None
+    x, w = t._pending[0], t._pending[1]
+    b = t._pending[2] if t.has_bias else None
+    return _linear(x.reshape(*shape[:-1], x.shape[-1]), w, b)
+
+
+def on_cross_entropy(y_pred, y_true, reduction):
+    """Hook of F.cross_entropy_loss (class-index targets, 2-D float32 predictions)."""
+    if not (loss_chain.enabled and _pending_linear(y_pred) and y_pred.ndim == 2):
+        return None
+    x, w = y_pred._pending[0], y_pred._pending[1]
+    b = y_pred._pending[2] if y_pred.has_bias else None
+    if not _linear_ce.applicable(x, w, b, y_true, reduction):
+        return None
+    loss_chain.fused_built += 1
+    return _linear_ce(x, w, b, y_true, reduction)
+

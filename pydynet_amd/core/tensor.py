@@ -71,6 +71,7 @@ class Tensor:
     _grad_owned = True
     _grad_hook = None
     _pending_link = False   # True on the deferred links of core/fused/chain.py
+    _lazy_linear = False    # True on core/fused/dense.py's `linear` (created without running where a consumer may take it over)
     _causal_mask = False    # True on a Tensor built from exactly the additive causal mask of llm/llama/model.py:199-203
 
     def __init__(self, data, dtype=None, copy=True, device=None, requires_grad=False) -> None:
@@ -164,7 +165,12 @@ class Tensor:
             self.grad[...] = 0.
 
     # ---- views / reductions / operators -------------------------------------------------
-    def reshape(self, *new_shape): return reshape(self, new_shape)
+    def reshape(self, *new_shape):
+        if self._lazy_linear and _chain is not None:        # a pending projection regrouped: still one projection (chain.py)
+            r = _chain.on_reshape(self, new_shape)
+            if r is not None:
+                return r
+        return reshape(self, new_shape)
     def transpose(self, *axes): return transpose(self, axes if len(axes) != 0 else None)
     def swapaxes(self, axis1, axis2): return swapaxes(self, axis1, axis2)
     def max(self, axis=None, keepdims=False): return max(self, axis, keepdims)

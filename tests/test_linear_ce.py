@@ -50,7 +50,13 @@ def _case(dev, rows, V, reduction, upstream, seed):
             assert fused.linear_cross_entropy.applicable(h, head.weight, head.bias, t, reduction)
             loss = fused.linear_cross_entropy(h, head.weight, head.bias, t, reduction)
         else:
-            loss = nn.CrossEntropyLoss(reduction=reduction)(head(h), t)
+            from pydynet_amd.core.fused import chain
+            chain.loss_chain.enabled = False            # the SEPARATE nodes (a pending projection would be taken over, chain.py)
+            try:
+                loss = nn.CrossEntropyLoss(reduction=reduction)(head(h), t)
+            finally:
+                chain.loss_chain.enabled = True
+            assert type(loss) is not fused.linear_cross_entropy
         (loss * upstream).backward()
         out[fused_on] = (host(loss), host(x.grad), host(head.weight.grad), host(head.bias.grad))
     # float64 statement
