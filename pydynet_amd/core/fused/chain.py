@@ -18,11 +18,12 @@ import math
 
 import numpy as np
 
-from ..tensor import Graph, Tensor, _Operator, transpose, matmul as _matmul, div as _div, add as _add
+from ..tensor import (Graph, Tensor, _Operator, transpose, matmul as _matmul, div as _div, add as _add, sub as _sub, mul as _mul,
+                      reshape as _reshape, concat as _concat, _get_slice)
 from ._common import _Deferred
 from .attn import attention, _attn_layout
 from .dense import linear as _linear, linear_cross_entropy as _linear_ce
-from .pointwise import softmax as _softmax
+from .pointwise import softmax as _softmax, rope as _rope
 
 
 class attn_link(_Deferred, _Operator):
@@ -147,7 +148,9 @@ def _pending_linear(t):
 
 
 def on_reshape(t, new_shape):
-    """Hook of Tensor.reshape: a pending projection whose LAST axis is kept."""
+    """Hook of Tensor.reshape: a pending projection whose LAST axis is kept; the tail of the rotary embedding."""
+    if type(t) is _concat:
+        return _rope_tail(t, new_shape)
     if not (loss_chain.enabled and _pending_linear(t)):
         return None
     if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
@@ -178,4 +181,98 @@ def on_cross_entropy(y_pred, y_true, reduction):
         return None
     loss_chain.fused_built += 1
     return _linear_ce(x, w, b, y_true, reduction)
+
+
+# ---- the backward pass of the reference's rotary embedding (llm/llama/model.py:23-44) ----------------------------------
+#
+#     xri = x.reshape(*x.shape[:-1], -1, 2);  r, i = xri[..., 0], xri[..., 1]
+#     c, s = unsqueeze(cos, -2), unsqueeze(sin, -2)
+#     out = concat([unsqueeze(r * c - i * s, -1), unsqueeze(r * s + i * c, -1)], -1).reshape(*x.shape)
+#
+# thirteen nodes per rotated tensor whose BACKWARD is what costs: four strided products, two scatter-assigns of a slice into
+# zeros, their sums, a negation (~270 us per tensor at 65536 tokens against ~35 us for the rotation by -theta that they
+# amount to).  The forward values are kept exactly as the plain operators produced them; when the final `reshape` finds
+# precisely this expression over ONE tensor x and two tables without gradient, its result is put on the tape as a single
+# node over x whose gradient is `fused.rope`'s (rotation of the upstream gradient by -theta): same mathematics, rounding
+# order of one multiply-add pair per element aside.  Anything else -- a different expression, tables that need a gradient --
+# is left alone.  An intermediate that has OTHER consumers keeps working: the thirteen nodes stay on the tape and carry
+# whatever gradient those consumers send (gradients add over paths); only the path through this result runs as one node.
+class rope_chain:
+    enabled = True        # class switch: False keeps the thirteen nodes on the tape (A/B and tests)
+    taken = 0             # expressions whose backward became one node
+
+
+class rope_taken(_rope):
+    """`fused.rope` over values somebody else already computed (the plain-operator expression above)."""
+
+    def __init__(self, x, cos, sin, data):
+        self._given = data
+        super().__init__(x, cos, sin)
+
+    def forward_(self, x):
+        d, self._given = self._given, None
+        return d
+
+
+def _unsqueezed(t, axis_from_end):
+    """x if t is `reshape(x, shape with a 1 inserted at -axis_from_end)` (pdn.unsqueeze), else None."""
+    if type(t) is not _reshape:
+        return None
+    x = getattr(t, "_src", None)
+    if x is None:
+        return None
+    want = list(x.shape)
+    want.insert(len(want) + 1 - axis_from_end, 1)
+    return x if tuple(t.shape) == tuple(want) else None
+
+
+def _pair_slice(t, which):
+    """pairs if t is `pairs[..., which]`, else None."""
+    if type(t) is _get_slice and isinstance(t.key, tuple) and len(t.key) == 2 and t.key[0] is Ellipsis and \
+            isinstance(t.key[1], (int, np.integer)) and int(t.key[1]) == which and t.last:
+        return t.last[0]
+    return None
+
+
+def _product(t):
+    return tuple(t.last) if type(t) is _mul and len(t.last) == 2 else None
+
+
+def _rope_tail(cat, new_shape):
+    if not (rope_chain.enabled and cat.requires_grad and len(cat.tensors) == 2 and cat.ndim == 5
+            and cat.axis in (-1, 4) and cat.device.is_hip and cat.dtype == np.float32):
+        return None
+    A, B = _unsqueezed(cat.tensors[0], 1), _unsqueezed(cat.tensors[1], 1)
+    if A is None or B is None or type(A) is not _sub or type(B) is not _add:
+        return None
+    pa, pb, pc, pd = _product(A.last[0]), _product(A.last[1]), _product(B.last[0]), _product(B.last[1])
+    if None in (pa, pb, pc, pd):
+        return None
+
+    def split(p):                        # (slice of pairs, table view) in either order
+        for u, v in (p, p[::-1]):
+            if type(u) is _get_slice:
+                return u, v
+        return None, None
+    (r1, c1), (i1, s1), (r2, s2), (i2, c2) = split(pa), split(pb), split(pc), split(pd)
+    if r1 is None or r1 is not r2 or i1 is None or i1 is not i2 or c1 is not c2 or s1 is not s2:
+        return None
+    pairs = _pair_slice(r1, 0)
+    if pairs is None or _pair_slice(i1, 1) is not pairs or type(pairs) is not _reshape or not pairs.last:
+        return None
+    x = pairs.last[0]
+    cos, sin = _unsqueezed(c1, 2), _unsqueezed(s1, 2)
+    if cos is None or sin is None or cos.requires_grad or sin.requires_grad or x.ndim != 4 or not x.requires_grad:
+        return None
+    Bq, Lq, H, hd = x.shape
+    if hd % 2 or tuple(pairs.shape) != (Bq, Lq, H, hd // 2, 2) or tuple(cos.shape) != (Lq, hd // 2) or \
+            tuple(sin.shape) != (Lq, hd // 2) or cos.dtype != np.float32 or sin.dtype != np.float32:
+        return None
+    if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
+        new_shape = tuple(new_shape[0])
+    shape = [int(v) for v in new_shape]
+    if len(shape) != 4 or shape[:3] != [Bq, Lq, H] or shape[3] not in (-1, hd):
+        return None
+    rope_chain.taken += 1
+    return rope_taken(x, cos, sin, cat.data.reshape(Bq, Lq, H, hd))
 

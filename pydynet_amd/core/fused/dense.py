@@ -24,7 +24,7 @@ class linear(_Deferred, _Operator):
 
     folds_existing = True      # backward adds the gradient x already holds inside the dX GEMM
     defer = True               # class switch: False runs every product at construction (no linear + relu fusion)
-    _lazy_linear = True        # Tensor.reshape asks core/fused/chain.py about pending projections
+    _reshape_hook = True       # Tensor.reshape asks core/fused/chain.py about pending projections
 
     def __init__(self, x, weight, bias=None, residual=None):
         self.has_bias, self.has_res = bias is not None, residual is not None

@@ -71,7 +71,7 @@ class Tensor:
     _grad_owned = True
     _grad_hook = None
     _pending_link = False   # True on the deferred links of core/fused/chain.py
-    _lazy_linear = False    # True on core/fused/dense.py's `linear` (created without running where a consumer may take it over)
+    _reshape_hook = False   # True where core/fused/chain.py wants to see `reshape`: pending projections, the tail of a rotary embedding
     _causal_mask = False    # True on a Tensor built from exactly the additive causal mask of llm/llama/model.py:199-203
 
     def __init__(self, data, dtype=None, copy=True, device=None, requires_grad=False) -> None:
@@ -166,7 +166,7 @@ class Tensor:
 
     # ---- views / reductions / operators -------------------------------------------------
     def reshape(self, *new_shape):
-        if self._lazy_linear and _chain is not None:        # a pending projection regrouped: still one projection (chain.py)
+        if self._reshape_hook and _chain is not None:       # a pending projection regrouped; the rotary embedding's tail (chain.py)
             r = _chain.on_reshape(self, new_shape)
             if r is not None:
                 return r
@@ -610,6 +610,7 @@ class reshape(_UnaryOperator):
         if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
             new_shape = tuple(new_shape[0])
         self.new_shape = new_shape
+        self._src = x if isinstance(x, Tensor) else None      # (core/fused/chain.py looks through the view, also without a tape)
         super().__init__(x)
 
     def forward_(self, x): return x.data.reshape(self.new_shape)
@@ -663,6 +664,8 @@ class _get_slice(_UnaryOperator):
 
 class concat(_Operator):
     """xp.concatenate; each input receives its slice of the gradient (tensor.py:943-993)."""
+
+    _reshape_hook = True
 
     def __init__(self, tensors, axis=0) -> None:
         tensors = list(tensors)

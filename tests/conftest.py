@@ -7,6 +7,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The float64 references of the GPU tests run on the box's host cores, which a GPU box shares with other tenants: with one
+# BLAS thread per core (256) a loaded host turned a 60 s run of `pytest -m gpu` into 9-12 minutes (seen three times in round
+# 6, every test uniformly slower).  32 threads are plenty for the largest reference product here.
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_v, str(min(32, os.cpu_count() or 32)))
+try:
+    import threadpoolctl
+    threadpoolctl.threadpool_limits(limits=min(32, os.cpu_count() or 32))
+except Exception:                                    # (already-imported NumPy keeps its pool size without threadpoolctl)
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
