@@ -23,7 +23,7 @@ from ..tensor import (Graph, Tensor, _Operator, transpose, matmul as _matmul, di
 from ._common import _Deferred
 from .attn import attention, _attn_layout
 from .dense import linear as _linear, linear_cross_entropy as _linear_ce
-from .pointwise import softmax as _softmax, rope as _rope
+from .pointwise import softmax as _softmax, rope as _rope, silu as _silu, swiglu as _swiglu
 
 
 class attn_link(_Deferred, _Operator):
@@ -275,4 +275,24 @@ def _rope_tail(cat, new_shape):
         return None
     rope_chain.taken += 1
     return rope_taken(x, cos, sin, cat.data.reshape(Bq, Lq, H, hd))
+
+
+# ---- silu(gate) * up (llm/llama/model.py:56-58 with nn/functional.py:39-40) --------------------------------------------
+# `F.silu` of a HIP float32 tensor is a pending node; a product with a tensor of the same shape takes it over as ONE
+# `swiglu` node (one pass forward, one backward, instead of the activation, a product and its two gradient products).
+class swiglu_chain:
+    enabled = True
+    taken = 0
+
+
+def on_mul(a, b):
+    """Hook of Tensor.__mul__ when one factor is a pending `silu`."""
+    if not (swiglu_chain.enabled and isinstance(a, Tensor) and isinstance(b, Tensor)):
+        return None
+    for act, other in ((a, b), (b, a)):
+        if type(act) is _silu and act._pending is not None and other is not act and \
+                tuple(other.shape) == tuple(act.shape) and other.dtype == np.float32 and other.device == act.device:
+            swiglu_chain.taken += 1
+            return _swiglu(act._pending[0], other)
+    return None
 

@@ -4,8 +4,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from ..tensor import _Operator
-from ._common import _hip, _L, _contig, _require_f32
+from ..tensor import Tensor, _Operator
+from ._common import _hip, _L, _contig, _require_f32, _Deferred
 
 
 class gated_sigmoid(_Operator):
@@ -63,7 +63,20 @@ class swiglu(_Operator):
         return [dg, du]
 
 
-class silu(_Operator):
+class silu(_Deferred, _Operator):
+    """x * sigmoid(x) (nn/functional.py:39-40).  On a HIP device the node is created without running (`_Deferred`): the
+    product `F.silu(gate) * up` of llm/llama/model.py:56-58 takes it over as ONE `swiglu` node (core/fused/chain.py:
+    on_mul); any other consumer reads `.data`, which runs the kernel then."""
+
+    defer = True               # class switch: False runs the activation at construction (no silu * up fusion)
+    _mul_hook = True           # Tensor.__mul__ asks core/fused/chain.py about pending activations
+
+    def __init__(self, x):
+        if silu.defer and isinstance(x, Tensor) and x.device.is_hip and x.dtype == np.float32:
+            self._init_deferred([x], x.shape, np.float32)
+        else:
+            super().__init__(x)
+
     def forward_(self, x):
         if self.xp is np:
             return x.data / (1 + np.exp(-x.data))

@@ -71,6 +71,7 @@ class Tensor:
     _grad_owned = True
     _grad_hook = None
     _pending_link = False   # True on the deferred links of core/fused/chain.py
+    _mul_hook = False       # True on core/fused/pointwise.py's `silu` (pending activation: `silu(gate) * up` becomes one node)
     _reshape_hook = False   # True where core/fused/chain.py wants to see `reshape`: pending projections, the tail of a rotary embedding
     _causal_mask = False    # True on a Tensor built from exactly the additive causal mask of llm/llama/model.py:199-203
 
@@ -189,7 +190,12 @@ class Tensor:
     def __radd__(self, x): return add(x, self)
     def __sub__(self, x): return sub(self, x)
     def __rsub__(self, x): return sub(x, self)
-    def __mul__(self, x): return mul(self, x)
+    def __mul__(self, x):
+        if _chain is not None and (self._mul_hook or getattr(x, "_mul_hook", False)):    # silu(gate) * up (chain.py)
+            r = _chain.on_mul(self, x)
+            if r is not None:
+                return r
+        return mul(self, x)
     def __rmul__(self, x): return mul(x, self)
     def __matmul__(self, x):
         # (the reference's attention chain built from plain operators becomes one fused node: core/fused/chain.py)

@@ -4,7 +4,8 @@ Measured round 6 (MI355X): batch 64: 2697 vs 4153 samples/s (0.65; the plain ste
 batch 256: 3891 vs 5139 (0.76) with the attention chain recognised (core/fused/chain.py), 3361 (0.65) without; 3983 vs 5027 (0.79)
 once the strided elementwise kernels divide by multiply-high (csrc/elementwise.hip: the strided kernels of a step 6.8 -> 4.3 ms under rocprofv3);
 4198 vs 5118 (0.82) with the loss of model.py:239-249 taken as one linear_cross_entropy node (core/fused/chain.py);
-4334 vs 5070 (0.85) with the backward of the rotary embedding as one node (chain.rope_chain).
+4334 vs 5070 (0.85) with the backward of the rotary embedding as one node (chain.rope_chain);
+4524 vs 5111 (0.885) with silu(gate) * up as one swiglu node (chain.swiglu_chain).
 usage: python tools/plain_llama_bench.py [batch=64] [steps=5] [plain|fused: only that model, e.g. under rocprofv3]"""
 import os
 import sys
