@@ -9,11 +9,12 @@ class Dropout(Module):
         assert 0 <= p < 1
         self.p = p
 
-    def forward(self, x):
-        if self._train:
-            mask = rand(*x.shape, device=x.device) < 1 - self.p
-            return x * mask.astype(x.dtype) / (1 - self.p)
-        return x
-
     def __repr__(self) -> str:
         return f"Dropout(p={self.p})"
+
+    def forward(self, x):
+        if not self._train:
+            return x
+        keep = 1 - self.p
+        kept = (rand(*x.shape, device=x.device) < keep).astype(x.dtype)      # one host draw per element, as the reference
+        return x * kept / keep

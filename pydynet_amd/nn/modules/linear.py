@@ -16,17 +16,18 @@ class Linear(Module):
     def __init__(self, in_features, out_features, bias=True, device=None, dtype=None) -> None:
         super().__init__()
         self.in_features, self.out_features = in_features, out_features
-        kw = {"device": Device(device), "dtype": dtype}
-        self.weight = Parameter(empty((in_features, out_features), **kw))
-        self.bias = Parameter(empty(out_features, **kw)) if bias else None
+        where = Device(device)
+        self.weight = Parameter(empty((in_features, out_features), device=where, dtype=dtype))
+        self.bias = Parameter(empty(out_features, device=where, dtype=dtype)) if bias else None
         self.reset_paramters()
 
-    def reset_paramters(self):
+    def reset_paramters(self):                           # (the reference's spelling; `reset_parameters` is an alias)
         init.kaiming_uniform_(self.weight, a=math.sqrt(5))
-        if self.bias is not None:
-            fan_in, _ = init._calculate_fan(self.weight)
-            bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
-            init.uniform_(self.bias, -bound, bound)
+        if self.bias is None:
+            return
+        fan_in = init._calculate_fan(self.weight)[0]
+        limit = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        init.uniform_(self.bias, -limit, limit)
 
     reset_parameters = reset_paramters
 
