@@ -149,8 +149,12 @@ def _pending_linear(t):
 
 def on_reshape(t, new_shape):
     """Hook of Tensor.reshape: a pending projection whose LAST axis is kept; the tail of the rotary embedding."""
+    if type(t) is rope_link:
+        return _rope_reshape(t, new_shape)
     if type(t) is _concat:
         return _rope_tail(t, new_shape)
+    if type(t) is not _linear:
+        return _rope_pairs(t, new_shape)
     if not (loss_chain.enabled and _pending_linear(t)):
         return None
     if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
@@ -287,12 +291,155 @@ class swiglu_chain:
 
 def on_mul(a, b):
     """Hook of Tensor.__mul__ when one factor is a pending `silu`."""
-    if not (swiglu_chain.enabled and isinstance(a, Tensor) and isinstance(b, Tensor)):
+    if not (isinstance(a, Tensor) and isinstance(b, Tensor)):
+        return None
+    if type(a) is rope_link or type(b) is rope_link:
+        return _rope_product(a, b)
+    if not swiglu_chain.enabled:
         return None
     for act, other in ((a, b), (b, a)):
         if type(act) is _silu and act._pending is not None and other is not act and \
                 tuple(other.shape) == tuple(act.shape) and other.dtype == np.float32 and other.device == act.device:
             swiglu_chain.taken += 1
             return _swiglu(act._pending[0], other)
+    return None
+
+
+# ---- the rotary embedding written with plain operators, FORWARD too (llm/llama/model.py:23-44) -------------------------
+# Every operator of the expression documented above `rope_chain` is a pending link while nobody reads it:
+#     pairs = x.reshape(..., hd/2, 2) -> comp = pairs[..., 0 | 1] -> prod = comp * unsqueeze(table, -2)
+#     -> diff = prod - prod, sum = prod + prod -> unsq = unsqueeze(., -1) -> cat = concat([unsq, unsq], -1) -> reshape(x.shape)
+# and the last reshape, finding exactly `concat([r c - i s, r s + i c])` over ONE x and two tables without gradient, builds ONE
+# `fused.rope` node (one kernel forward, one backward) instead of thirteen.  A link somebody reads builds its ordinary
+# operator then (over the previous link, which does the same) and becomes an identity over it, with a fresh place in the
+# tape -- programs that look at the pairs or the products behave as before.
+class rope_link(_Deferred, _Operator):
+    _rope_link = True
+    _mul_hook = True
+    _reshape_hook = True
+    enabled = True        # class switch: False runs the plain operators (the backward-only node of `rope_chain` still applies)
+    fused_built = 0       # expressions that became one fused.rope node
+
+    def __init__(self, stage, inputs, shape, **info):
+        self.stage, self.info = stage, info
+        self._init_deferred(inputs, shape, np.float32)
+
+    def forward_(self, *ins):
+        st = self.stage
+        if st == "pairs" or st == "unsq":
+            inner = _reshape(ins[0], self._shape)
+        elif st == "comp":
+            inner = _get_slice(ins[0], (Ellipsis, self.info["which"]))
+        elif st == "prod":
+            inner = _mul(ins[0], ins[1])
+        elif st == "diff":
+            inner = _sub(ins[0], ins[1])
+        elif st == "sum":
+            inner = _add(ins[0], ins[1])
+        else:                                            # "cat" (constructed past concat.__new__'s own hook)
+            inner = object.__new__(_concat)
+            inner.__init__(list(ins), axis=-1)
+        if self.requires_grad and inner.requires_grad:
+            self.last = [inner]                          # (see attn_link.forward_: a fresh place in the registry)
+            Graph._free_node(self)
+            self.last = [inner]
+            Graph._add_node(self)
+        return inner.data
+
+    def grad_fn(self, x, grad):
+        return grad
+
+
+def _link(t, stage):
+    return type(t) is rope_link and t._pending is not None and t.stage == stage
+
+
+def _resolve(shape, size):
+    shape = [int(v) for v in shape]
+    if shape.count(-1) == 1:
+        known = int(np.prod([v for v in shape if v != -1], dtype=np.int64))
+        if known == 0 or size % known:
+            return None
+        shape[shape.index(-1)] = size // known
+    return shape if all(v >= 0 for v in shape) and int(np.prod(shape, dtype=np.int64)) == size else None
+
+
+def _rope_pairs(x, new_shape):
+    """x.reshape(*x.shape[:-1], -1, 2) of a 4-D float32 HIP tensor."""
+    if not (rope_link.enabled and x.ndim == 4 and x.device.is_hip and x.dtype == np.float32):
+        return None
+    if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
+        new_shape = tuple(new_shape[0])
+    if len(new_shape) != 5 or new_shape[-1] != 2:
+        return None
+    shape = _resolve(new_shape, x.size)
+    if shape is None or tuple(shape[:3]) != tuple(x.shape[:3]) or x.shape[3] % 2 or shape[3] != x.shape[3] // 2:
+        return None
+    return rope_link("pairs", (x,), shape)
+
+
+def on_getitem(t, key):
+    """Hook of Tensor.__getitem__ on a pending link: pairs[..., 0] / pairs[..., 1]."""
+    if _link(t, "pairs") and isinstance(key, tuple) and len(key) == 2 and key[0] is Ellipsis and \
+            isinstance(key[1], (int, np.integer)) and int(key[1]) in (0, 1):
+        return rope_link("comp", (t,), t.shape[:-1], which=int(key[1]))
+    return None
+
+
+def _rope_product(a, b):
+    for comp, view in ((a, b), (b, a)):
+        if _link(comp, "comp") and type(view) is _reshape:
+            table = _unsqueezed(view, 2)
+            L, half = comp.shape[1], comp.shape[3]
+            if table is not None and not table.requires_grad and tuple(table.shape) == (L, half) and \
+                    table.dtype == np.float32 and table.device == comp.device:
+                return rope_link("prod", (a, b), comp.shape, comp=comp, table=table)
+    return None
+
+
+def on_addsub(a, b, op):
+    """Hook of Tensor.__sub__ / __add__ on a pending link: prod - prod, prod + prod."""
+    if _link(a, "prod") and _link(b, "prod") and a is not b:
+        return rope_link("diff" if op == "sub" else "sum", (a, b), a.shape)
+    return None
+
+
+def _rope_reshape(t, new_shape):
+    if len(new_shape) == 1 and isinstance(new_shape[0], (tuple, list)):
+        new_shape = tuple(new_shape[0])
+    if (_link(t, "diff") or _link(t, "sum")) and len(new_shape) == 5:            # pdn.unsqueeze(., -1)
+        shape = _resolve(new_shape, t.size)
+        if shape is not None and tuple(shape) == tuple(t.shape) + (1,):
+            return rope_link("unsq", (t,), shape)
+        return None
+    if not (_link(t, "cat") and len(new_shape) == 4):
+        return None
+    shape = _resolve(new_shape, t.size)
+    u_re, u_im = t._pending
+    d, a = u_re._pending[0], u_im._pending[0]                                     # (all links of a pending cat are pending)
+    if shape is None or d.stage != "diff" or a.stage != "sum":
+        return None
+    (rc, is_), (rs, ic) = d._pending, a._pending
+    r, i = rc.info["comp"], is_.info["comp"]
+    cos, sin = rc.info["table"], is_.info["table"]
+    if not (rs.info["comp"] is r and ic.info["comp"] is i and rs.info["table"] is sin and ic.info["table"] is cos and
+            cos is not sin and r.info["which"] == 0 and i.info["which"] == 1 and r._pending[0] is i._pending[0]):
+        return None
+    x = r._pending[0]._pending[0]
+    if tuple(shape) != tuple(x.shape):
+        return None
+    rope_link.fused_built += 1
+    return _rope(x, cos, sin)
+
+
+def on_concat(tensors, axis):
+    """Hook of concat.__new__: two pending unsqueezed combinations joined on the last axis."""
+    tensors = list(tensors)
+    if len(tensors) == 2 and _link(tensors[0], "unsq") and _link(tensors[1], "unsq") and tensors[0] is not tensors[1] and \
+            axis in (-1, 4) and tuple(tensors[0].shape) == tuple(tensors[1].shape):
+        links = [tensors[0], tensors[1], tensors[0]._pending[0], tensors[1]._pending[0]]
+        links += list(links[2]._pending) + list(links[3]._pending)
+        if all(type(k) is rope_link and k._pending is not None for k in links):
+            return rope_link("cat", tuple(tensors), tuple(tensors[0].shape[:-1]) + (2,))
     return None
 

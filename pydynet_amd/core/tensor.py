@@ -71,6 +71,7 @@ class Tensor:
     _grad_owned = True
     _grad_hook = None
     _pending_link = False   # True on the deferred links of core/fused/chain.py
+    _rope_link = False      # True on the pending links of a rotary embedding written with plain operators (chain.py: rope_link)
     _mul_hook = False       # True on core/fused/pointwise.py's `silu` (pending activation: `silu(gate) * up` becomes one node)
     _reshape_hook = False   # True where core/fused/chain.py wants to see `reshape`: pending projections, the tail of a rotary embedding
     _causal_mask = False    # True on a Tensor built from exactly the additive causal mask of llm/llama/model.py:199-203
@@ -167,7 +168,8 @@ class Tensor:
 
     # ---- views / reductions / operators -------------------------------------------------
     def reshape(self, *new_shape):
-        if self._reshape_hook and _chain is not None:       # a pending projection regrouped; the rotary embedding's tail (chain.py)
+        # a pending projection regrouped; the rotary embedding: its first reshape (to pairs), its unsqueezes, its tail (chain.py)
+        if _chain is not None and (self._reshape_hook or (len(new_shape) == 5 and new_shape[-1] == 2)):
             r = _chain.on_reshape(self, new_shape)
             if r is not None:
                 return r
@@ -186,9 +188,18 @@ class Tensor:
             r = _chain.on_add(self, x)
             if r is not None:
                 return r
+        if self._rope_link and _chain is not None:
+            r = _chain.on_addsub(self, x, "add")
+            if r is not None:
+                return r
         return add(self, x)
     def __radd__(self, x): return add(x, self)
-    def __sub__(self, x): return sub(self, x)
+    def __sub__(self, x):
+        if self._rope_link and _chain is not None:
+            r = _chain.on_addsub(self, x, "sub")
+            if r is not None:
+                return r
+        return sub(self, x)
     def __rsub__(self, x): return sub(x, self)
     def __mul__(self, x):
         if _chain is not None and (self._mul_hook or getattr(x, "_mul_hook", False)):    # silu(gate) * up (chain.py)
@@ -217,7 +228,12 @@ class Tensor:
     def __pos__(self): return 1 * self
     def __neg__(self): return -1 * self
     def __abs__(self): return abs(self)
-    def __getitem__(self, key): return _get_slice(self, key)
+    def __getitem__(self, key):
+        if self._rope_link and _chain is not None:
+            r = _chain.on_getitem(self, key)
+            if r is not None:
+                return r
+        return _get_slice(self, key)
 
     def _inplace(self, *others, func):
         if self.requires_grad and is_grad_enable():
@@ -672,6 +688,15 @@ class concat(_Operator):
     """xp.concatenate; each input receives its slice of the gradient (tensor.py:943-993)."""
 
     _reshape_hook = True
+
+    def __new__(cls, tensors=(), axis=0):
+        if cls is concat and _chain is not None:         # two pending halves of a rotary embedding (chain.py: on_concat)
+            tensors = list(tensors)
+            if len(tensors) == 2 and tensors[0]._rope_link:
+                r = _chain.on_concat(tensors, axis)
+                if r is not None:
+                    return r
+        return object.__new__(cls)
 
     def __init__(self, tensors, axis=0) -> None:
         tensors = list(tensors)

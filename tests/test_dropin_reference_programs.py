@@ -63,7 +63,7 @@ def test_reference_llama_file_runs_on_emulated_hip(emulated_hip):
 
 def test_reference_llama_file_at_the_benchmark_width_takes_every_chain(emulated_hip):
     """The reference's model file at width 288 (the width the fused loss node serves) with the row thresholds lowered: its
-    `finetune_step` (model.py:226-252) must run the attention chain, `silu(gate) * up`, the rotary embedding's backward and
+    `finetune_step` (model.py:226-252) must run the attention chain, `silu(gate) * up`, the rotary embedding and
     the `Linear -> reshape -> CrossEntropyLoss` loss as ONE node each (core/fused/chain.py) and reproduce the trajectory of
     the same file on the NumPy device."""
     from pydynet_amd.optim import Adam
@@ -76,7 +76,7 @@ def test_reference_llama_file_at_the_benchmark_width_takes_every_chain(emulated_
     ids, tgt = rng.integers(0, V, (B, L)), rng.integers(0, V, (B, L))
     saved = (fused.linear_relu.min_rows, fused.linear_cross_entropy.min_rows)
     fused.linear_relu.min_rows, fused.linear_cross_entropy.min_rows = 1, 32
-    counts0 = (chain.attn_link.fused_built, chain.swiglu_chain.taken, chain.rope_chain.taken, chain.loss_chain.fused_built)
+    counts0 = (chain.attn_link.fused_built, chain.swiglu_chain.taken, chain.rope_link.fused_built, chain.loss_chain.fused_built)
     out = {}
     try:
         for dev in ("cpu", "hip:0"):
@@ -89,7 +89,7 @@ def test_reference_llama_file_at_the_benchmark_width_takes_every_chain(emulated_
             out[dev] = [m.finetune_step(ids, tgt, opt) for _ in range(3)]
     finally:
         fused.linear_relu.min_rows, fused.linear_cross_entropy.min_rows = saved
-    taken = [b - a for a, b in zip(counts0, (chain.attn_link.fused_built, chain.swiglu_chain.taken, chain.rope_chain.taken,
+    taken = [b - a for a, b in zip(counts0, (chain.attn_link.fused_built, chain.swiglu_chain.taken, chain.rope_link.fused_built,
                                               chain.loss_chain.fused_built))]
     assert taken == [2 * 3, 2 * 3, 2 * 2 * 3, 3], taken          # per step: 2 layers x (attention, swiglu, q and k rotations), 1 loss
     assert np.allclose(out["hip:0"], out["cpu"], rtol=1e-4), out

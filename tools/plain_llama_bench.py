@@ -5,7 +5,8 @@ batch 256: 3891 vs 5139 (0.76) with the attention chain recognised (core/fused/c
 once the strided elementwise kernels divide by multiply-high (csrc/elementwise.hip: the strided kernels of a step 6.8 -> 4.3 ms under rocprofv3);
 4198 vs 5118 (0.82) with the loss of model.py:239-249 taken as one linear_cross_entropy node (core/fused/chain.py);
 4334 vs 5070 (0.85) with the backward of the rotary embedding as one node (chain.rope_chain);
-4524 vs 5111 (0.885) with silu(gate) * up as one swiglu node (chain.swiglu_chain).
+4524 vs 5111 (0.885) with silu(gate) * up as one swiglu node (chain.swiglu_chain); 4663 vs 5018-5130 (0.91-0.93) with the rotary
+embedding's operators as pending links that end in one fused.rope node (chain.rope_link); batch 64: 3346 vs 4163 (0.80).
 usage: python tools/plain_llama_bench.py [batch=64] [steps=5] [plain|fused: only that model, e.g. under rocprofv3]"""
 import os
 import sys
