@@ -690,12 +690,13 @@ class concat(_Operator):
     _reshape_hook = True
 
     def __new__(cls, tensors=(), axis=0):
-        if cls is concat and _chain is not None:         # two pending halves of a rotary embedding (chain.py: on_concat)
-            tensors = list(tensors)
-            if len(tensors) == 2 and tensors[0]._rope_link:
-                r = _chain.on_concat(tensors, axis)
-                if r is not None:
-                    return r
+        # two pending halves of a rotary embedding (chain.py: on_concat); anything else -- other sequences, iterators that
+        # __init__ must still be able to walk -- goes straight on
+        if cls is concat and _chain is not None and isinstance(tensors, (list, tuple)) and len(tensors) == 2 and \
+                getattr(tensors[0], "_rope_link", False):
+            r = _chain.on_concat(tensors, axis)
+            if r is not None:
+                return r
         return object.__new__(cls)
 
     def __init__(self, tensors, axis=0) -> None:
